@@ -1,0 +1,273 @@
+#!/usr/bin/env python3
+"""bench.py -- forward+likelihood evaluations/s of the HIP hot path on N MI355X.
+
+One "step" = one batched pass of the hot path (rf_eval_batch_device: spectra ->
+trace -> logL) over every walker resident on the rank, inputs already in HBM, logL
+read back to pinned host memory.  Walkers shard across ranks with no data-path
+collective (weak scaling: per-GPU work fixed); workloads with tempered chains add the
+parallel-tempering swap exchange (one all_gather of (T, logL) per step over RCCL).
+
+Workloads (BASELINE.json configs):
+  c2  (default) 1024 walkers/GPU, 1 P trace (p 0.06), nfft 4096, k_max 15 (<= 15 layers)
+  c4            8192 walkers/GPU, 3 traces (P .06, P .08, S .10), k_max 30, PT swap
+  c1            sample_syn shape: nfft 256, 2 traces, ocean, k_max 10 (plumbing size)
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector == matrix peak (datasheet)
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+WORKLOADS = {
+    "c2": dict(walkers=1024, nfft=4096, rayps=[0.06], ipha=[1], k_max=15, sdep=0.0, deconv=0, temps=1,
+               desc="c2: 1024 walkers/GPU x 1 P trace (p=0.06) x nfft 4096 (2049 bins) x <=15 layers, T=1"),
+    "c4": dict(walkers=8192, nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], k_max=30, sdep=0.0, deconv=0,
+               temps=8,
+               desc="c4: 8192 walkers/GPU (1024 chains x 8 temperatures) x 3 traces (P .06, P .08, S .10) x nfft 4096 "
+                    "x <=30 layers, PT swap"),
+    "c1": dict(walkers=1024, nfft=256, rayps=[0.06, 0.08], ipha=[1, 1], k_max=10, sdep=2.0, deconv=0, temps=1,
+               desc="c1-shape: 1024 walkers/GPU x 2 P traces x nfft 256 x ocean x <=11 layers"),
+}
+
+
+def make_params(w):
+    """sample_syn-shaped params (tests/golden/sample_syn/params.in) with the workload's
+    geometry; obs filled later."""
+    from rf_inv_amd import get_params
+
+    p = get_params(os.path.join(ROOT, "tests", "golden", "sample_syn", "params.in"))
+    n = len(w["rayps"])
+    p.ntrc, p.nfft = n, w["nfft"]
+    p.rayps = np.array(w["rayps"], dtype=np.float64)
+    p.ipha = np.array(w["ipha"], dtype=np.int32)
+    p.a_gus = np.full(n, 4.0)
+    p.sig_min = np.full(n, 0.01); p.sig_max = np.full(n, 0.01); p.sig_mode = np.zeros(n, dtype=np.int32)
+    p.k_min, p.k_max, p.sdep, p.deconv_mode = 1, w["k_max"], w["sdep"], w["deconv"]
+    p.delta = float(np.float32(0.05))
+    p.t_start, p.t_end, p.nsmp = 0.0, 5.0, 101
+    return p
+
+
+def draw_walkers(p, ref, first_id, count, seed=12345678):
+    """Walker models drawn like init_model (reference src/model.f90:66-95) from a
+    counter-based RNG keyed by seed + global walker id, re-drawn until valid."""
+    from rf_inv_amd import format_model
+
+    pad = p.k_max + 2
+    layers = np.ones((count, 4, pad))
+    nlay = np.zeros(count, dtype=np.int32)
+    for i in range(count):
+        g = np.random.Generator(np.random.Philox(key=seed + first_id + i))
+        while True:
+            k = p.k_min + int(g.random() * (p.k_max - p.k_min))
+            z = np.zeros(max(p.k_max - 1, 1)); dvp = np.zeros(p.k_max); dvs = np.zeros(p.k_max)
+            z[:k] = p.z_min + g.random(k) * (p.z_max - p.z_min)
+            dvs[:k] = g.standard_normal(k) * p.dvs_prior
+            dvs[p.k_max - 1] = g.standard_normal() * p.dvs_prior
+            nl, a, b, r, h, ok = format_model(p, ref, k, z, dvp, dvs)
+            if ok:
+                break
+        nlay[i] = nl
+        layers[i, 0, :nl], layers[i, 1, :nl], layers[i, 2, :nl], layers[i, 3, :nl] = a, b, r, h
+    return nlay, layers
+
+
+def alg_work(p, nlay, common):
+    """Algorithmic flops / bytes per evaluation in the REFERENCE's arithmetic
+    (SURVEY.md section 8d): returns (F_spectra[nb], F_total[nb], B_alg[nb])."""
+    nh = p.nfft // 2 + 1
+    sea = 1 if p.sdep > 0 else 0
+    nfwd = 1 if common else p.ntrc
+    n_ifft = 2 if p.deconv_mode == 0 else 1
+    f_spec = nfwd * nh * ((nlay - 1 - sea) * 570.0 + 580.0)
+    f_rest = p.ntrc * (n_ifft * 2.5 * p.nfft * math.log2(p.nfft) + 2.0 * p.nsmp ** 2 + 4.0 * p.nsmp + 3.0 * p.nfft)
+    b = 8.0 * (4 * nlay + p.ntrc) + 8.0 * p.nfft * p.ntrc + 8.0
+    return f_spec, f_spec + f_rest, b
+
+
+def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
+    """Oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded
+    sample of the same workload.  The reference itself cannot be built in this image
+    (needs FFTW3 + LAPACK), see DESIGN.md."""
+    from oracle import rf_oracle as orc
+
+    orc.build()
+    cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep,
+               rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha)
+    cores = max(1, min(orc.max_threads(), os.cpu_count() or 1))
+    probe = min(len(nlay), 2 * cores)
+    t0 = time.perf_counter()
+    orc.eval_batch(cfg, obs, r_inv, nlay[:probe], layers[:probe], sig[:probe], p.nsmp, nthreads=cores)
+    dt = time.perf_counter() - t0
+    n = int(min(len(nlay), max(probe, budget_s / max(dt / probe, 1e-6))))
+    n = max(cores, n - n % cores)
+    t0 = time.perf_counter()
+    ll = orc.eval_batch(cfg, obs, r_inv, nlay[:n], layers[:n], sig[:n], p.nsmp, nthreads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} walkers of the same workload, oracle/rf_oracle.c (gcc -O2, OpenMP x{cores}), "
+                      f"{dt:.1f} s wall"}, ll, n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default=os.environ.get("RFGPU_BENCH_WORKLOAD", "c2"), choices=sorted(WORKLOADS))
+    ap.add_argument("--walkers", type=int, default=0, help="override walkers per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--also", default="", help="comma list of extra workloads measured briefly into 'also'")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    def run(workload, steps, warmup, with_cpu):
+        from rf_inv_amd import RFEngine, read_ref_model
+        from rf_inv_amd.likelihood import init_r_inv
+        from rf_inv_amd.pt import PTSwap
+
+        w = dict(WORKLOADS[workload])
+        if args.walkers:
+            w["walkers"] = args.walkers
+        p = make_params(w)
+        ref = read_ref_model(os.path.join(ROOT, "tests", "golden", "sample_syn", "model", "sample.velmod"))
+        nb = w["walkers"]
+        nlay, layers = draw_walkers(p, ref, rank * nb, nb)
+        sig = np.full((nb, p.ntrc), 0.01)
+        r_inv = init_r_inv(p.nsmp, p.a_gus, p.delta)
+        # observed traces: noise-free synthetic of a fixed 3-interface model, produced by the
+        # HIP path itself
+        from rf_inv_amd import format_model
+        zt = np.zeros(max(p.k_max - 1, 1)); dvt = np.zeros(p.k_max); dst = np.zeros(p.k_max)
+        zt[:3] = [3.1 + p.sdep, 7.7 + p.sdep, 14.2 + p.sdep]; dst[:3] = [-0.6, 0.2, 0.5]; dst[p.k_max - 1] = 0.9
+        nl_t, a_t, b_t, r_t, h_t, ok = format_model(p, ref, 3, zt, dvt, dst)
+        assert ok
+        kw = dict(nfft=p.nfft, delta=p.delta, t_start=p.t_start, deconv_mode=p.deconv_mode, sdep=p.sdep,
+                  rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha, nsmp=p.nsmp, nlay_max=p.k_max + 2,
+                  device=local_rank)
+        with RFEngine(obs=np.zeros((p.ntrc, p.nsmp)), r_inv=r_inv, max_walkers=1, **kw) as e0:
+            obs = np.ascontiguousarray(e0.calc_rf(nl_t, a_t, b_t, r_t, h_t)[:p.nsmp].T)
+        eng = RFEngine(obs=obs, r_inv=r_inv, max_walkers=nb, **kw)
+
+        stream = torch.cuda.Stream(device=dev)
+        d_ids = torch.arange(nb, dtype=torch.int32, device=dev)
+        d_nlay = torch.from_numpy(nlay).to(dev)
+        d_layers = torch.from_numpy(layers).to(dev)
+        d_sig = torch.from_numpy(sig).to(dev)
+        d_logl = torch.empty(nb, dtype=torch.float64, device=dev)
+        h_logl = torch.empty(nb, dtype=torch.float64).pin_memory()
+        swap = PTSwap(eng, nb, w["temps"], dev, seed=1234, t_high=15.0) if w["temps"] > 1 else None
+
+        def step():
+            with torch.cuda.stream(stream):
+                eng.eval_batch_device(d_ids, d_nlay, d_layers, d_sig, d_logl, stream=stream)
+                if swap is not None:
+                    swap.step(d_logl, stream)
+                h_logl.copy_(d_logl, non_blocking=True)
+
+        def barrier():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
+
+        for _ in range(warmup):
+            step()
+        barrier()
+        eng.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        barrier()
+        dt = time.perf_counter() - t0
+        eng.profile_enable(False)
+        prof = eng.profile_read()
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        ll_gpu = h_logl.numpy().copy()
+        assert np.all(np.isfinite(ll_gpu)), "non-finite logL in the benchmark batch"
+
+        f_spec, f_tot, b_alg = alg_work(p, nlay.astype(np.float64), eng.is_ray_common)
+        n_l = max(prof["launches"], 1)
+        spectra_ms = prof["spectra_ms"] / n_l
+        res = {
+            "value": world * nb * steps / dt,
+            "ms_per_step": 1e3 * dt / steps,
+            "config": {"workload": w["desc"], "walkers_per_gpu": nb, "nfft": p.nfft, "ntrc": p.ntrc,
+                       "nsmp": p.nsmp, "k_max": p.k_max, "mean_nlay": float(nlay.mean()),
+                       "max_nlay": int(nlay.max()), "deconv_mode": p.deconv_mode, "sdep": p.sdep,
+                       "temperatures": w["temps"], "parallelism": f"walkers sharded x{world}"},
+            "roofline": {
+                "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
+                "achieved": float(f_spec.sum()) / (spectra_ms * 1e-3) / 1e12 if spectra_ms > 0 else None,
+                "frac": float(f_spec.sum()) / (spectra_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if spectra_ms > 0 else None,
+                "traffic": None,
+                "kernel": "rfgpu::spectra_kernel", "kernel_ms": spectra_ms,
+                "note": "fp64: MI355X matrix (MFMA) peak == vector peak = 78.6 TF; the kernel issues fp64 VALU FMA, "
+                        "MFMA not used (no rate advantage). achieved = reference-arithmetic flops (SURVEY 8d: "
+                        "570/(bin*layer)+580/bin) per launch / live HIP-event kernel time.",
+            },
+            "roofline_hbm": {
+                "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                "achieved": float(b_alg.sum()) * steps / dt / 1e9,
+                "frac": float(b_alg.sum()) * steps / dt / 1e9 / HBM_PEAK_GBS,
+                "note": "algorithmic bytes/eval (layers+sigma in, prop_rft(nfft,ntrc)+logL out) x evals/s of this rank",
+            },
+            "kernel_ms": {"spectra": spectra_ms, "trace": prof["trace_ms"] / n_l, "logl": prof["logl_ms"] / n_l},
+            "alg_gflop_per_step": float(f_tot.sum()) / 1e9,
+        }
+        if with_cpu and rank == 0:
+            base, ll_cpu, n = cpu_baseline(p, obs, r_inv, nlay, layers, sig)
+            res["cpu_baseline"] = base
+            d = np.abs(ll_gpu[:n] - ll_cpu)
+            res["parity_in_bench"] = {"n": n, "max_abs_dlogl": float(d.max()),
+                                      "max_rel_dlogl": float((d / np.abs(ll_cpu)).max())}
+        eng.close()
+        return res
+
+    main_res = run(args.workload, args.steps, args.warmup, not args.no_cpu_baseline and world == 1)
+    also = {}
+    for wl in [x for x in args.also.split(",") if x]:
+        r = run(wl, max(5, args.steps // 10), max(2, args.warmup // 4), False)
+        also[wl] = {k: r[k] for k in ("value", "ms_per_step", "config", "roofline", "kernel_ms")}
+    if rank == 0:
+        out = {"metric": "forward+likelihood evals/sec (whole node)", "value": main_res["value"], "unit": "evals/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic"}
+        out.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
+        if also:
+            out["also"] = also
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+/*
+ * rfgpu.h -- C ABI of librfgpu: the MI355X (gfx950) forward + likelihood engine
+ * that replaces RF_INV's src/forward.f90 + src/likelihood.f90.
+ *
+ * The reference has no FFI for this path: the boundary is two Fortran module
+ * interfaces (`module forward`, `module likelihood`).  The entry points below
+ * are exactly what a bind(C) replacement of those two modules binds; each one
+ * cites the reference interface it replaces.  The Fortran shim modules that do
+ * the binding live in rf_inv_amd/fortran/ and INTEGRATION.md shows the build
+ * change a maintainer makes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all reals are IEEE binary64;
+ *   - arrays are Fortran column-major exactly as the reference passes them;
+ *   - every call returns 0 on success, non-zero on error (rf_last_error()
+ *     returns the message); evaluations never trap on out-of-domain physics,
+ *     they propagate NaN like the reference;
+ *   - "walker" = one chain slot owned by the context, 0-based;
+ *   - host-buffer calls are synchronous at return; *_device calls take device
+ *     pointers + a hipStream_t (as void*) and are asynchronous on that stream.
+ *   - there is NO CPU fallback: if no gfx950 device is usable rf_ctx_create
+ *     fails.
+ */
+#ifndef RFGPU_H
+#define RFGPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RFGPU_ABI_VERSION 1
+
+typedef struct rf_ctx rf_ctx;
+
+/* Everything `init_forward` / `init_likelihood` read from `module params`
+ * (reference src/params.f90:34-96) plus capacity hints. */
+typedef struct rf_config {
+    int32_t nfft;        /* params nfft; power of two, >= 8                      */
+    int32_t ntrc;        /* params ntrc                                         */
+    int32_t nsmp;        /* params nsmp (src/params.f90:449-451)                */
+    int32_t deconv_mode; /* params deconv_mode: 0 = normalise by vertical, 1 = water-level decon */
+    double delta;        /* params delta = dble(float32 SAC delta) (src/params.f90:452) */
+    double t_start;      /* params t_start                                      */
+    double sdep;         /* params sdep (> 0: ocean layer; keys direct_arrival, src/forward.f90:484) */
+    const double *rayps; /* [ntrc] params rayps                                 */
+    const double *a_gus; /* [ntrc] params a_gus                                 */
+    const int32_t *ipha; /* [ntrc] params ipha: +1 P, -1 S                      */
+    const double *obs;   /* obs(ldobs, ntrc) column-major, rows 1..nsmp used (src/params.f90:413,458) */
+    int32_t ldobs;       /* leading dimension of obs (reference: npts_max = 2000) */
+    const double *r_inv; /* r_inv(nsmp, nsmp, ntrc) column-major as built by src/likelihood.f90:168-222,
+                            or NULL: the library builds it (rf_compute_r_inv)    */
+    int32_t max_walkers; /* chain slots to allocate (reference: nchains)        */
+    int32_t nlay_max;    /* max layers incl. ocean + half-space (reference nlay_max = 200, src/params.f90:44) */
+    int32_t device;      /* HIP device ordinal                                  */
+} rf_config;
+
+/* ---- lifecycle ------------------------------------------------------- */
+/* replaces init_fftw (src/fftw.f90:41-48) + init_forward (src/forward.f90:47-55)
+ * + init_r_inv (src/likelihood.f90:168-241) + allocation of rft/log_likelihood
+ * state (src/likelihood.f90:150-151). */
+int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out);
+int rf_ctx_destroy(rf_ctx *ctx);
+const char *rf_last_error(void);
+int rf_abi_version(void);
+
+/* ---- tables the reference exports ------------------------------------ */
+/* `flt(nh, ntrc)` public array of module forward (src/forward.f90:30,95-119) */
+int rf_get_flt(const rf_ctx *ctx, double *flt);
+/* `is_ray_common` of module forward (src/forward.f90:36,59-91) */
+int rf_get_is_ray_common(const rf_ctx *ctx, int32_t *flag);
+/* private r_inv(nsmp, nsmp, ntrc) of module likelihood (src/likelihood.f90:34) */
+int rf_get_r_inv(const rf_ctx *ctx, double *r_inv);
+/* init_r_inv for one trace (src/likelihood.f90:183-222): Gaussian-correlated
+ * noise matrix, SVD, pseudo-inverse with cut-off s > 1e-3.  Host-only helper
+ * (one-sided Jacobi SVD, fp64); r_inv is (nsmp, nsmp) column-major. */
+int rf_compute_r_inv(int32_t nsmp, double a_gus, double delta, double *r_inv, int32_t *rank_out);
+
+/* ---- single-evaluation drop-ins --------------------------------------- */
+/* subroutine calc_rf(chain_id, nlay, n, ntrc, rayps, alpha, beta, rho, h, rft)
+ * (src/forward.f90:123-208).  n, ntrc, rayps come from the context.
+ * rft is rft(nfft, ntrc), filled completely. */
+int rf_calc_rf(rf_ctx *ctx, int32_t nlay, const double *alpha, const double *beta,
+               const double *rho, const double *h, double *rft);
+
+/* subroutine calc_likelihood(chain_id, fwd_flag, prop_k, prop_z, prop_dvp, prop_dvs,
+ *                            sig, prop_log_likelihood, prop_rft)
+ * (src/likelihood.f90:56-101) with the layer stack already formatted by the
+ * host's format_model (src/likelihood.f90:75-76 stays on the Fortran side).
+ * fwd_flag = 0 re-uses the walker's stored trace (src/likelihood.f90:81).
+ * prop_rft(nfft, ntrc) may be NULL (trace stays device-resident). */
+int rf_calc_likelihood(rf_ctx *ctx, int32_t walker, int32_t fwd_flag, int32_t nlay,
+                       const double *alpha, const double *beta, const double *rho,
+                       const double *h, const double *sig, double *prop_log_likelihood,
+                       double *prop_rft);
+
+/* ---- batched evaluation (the throughput path) ------------------------- */
+/* nb independent calc_likelihood calls (the sequential chain loop of
+ * src/pt_mcmc.f90:493-496 turned into one launch).
+ *   walker_ids[nb]  distinct walker slots
+ *   fwd_flag[nb]    or NULL (= all 1)
+ *   nlay[nb]        layers of each proposed model
+ *   layers          [nb][4][nlay_pad]: alpha, beta, rho, h rows (C order)
+ *   sig             [nb][ntrc]
+ *   logl            [nb] out
+ * The proposed traces stay on the device until rf_commit / rf_get_rft. */
+int rf_eval_batch(rf_ctx *ctx, int32_t nb, const int32_t *walker_ids, const int32_t *fwd_flag,
+                  const int32_t *nlay, int32_t nlay_pad, const double *layers,
+                  const double *sig, double *logl);
+/* same with every pointer a device pointer; asynchronous on `stream`. */
+int rf_eval_batch_device(rf_ctx *ctx, int32_t nb, const int32_t *d_walker_ids,
+                         const int32_t *d_fwd_flag, const int32_t *d_nlay, int32_t nlay_pad,
+                         const double *d_layers, const double *d_sig, double *d_logl,
+                         void *stream);
+
+/* accept step of src/pt_mcmc.f90:182-191: for accept[i] != 0 the proposed trace
+ * of walker_ids[i] becomes its current trace (`rft(:,:,ichain) = prop_rft`). */
+int rf_commit(rf_ctx *ctx, int32_t nb, const int32_t *walker_ids, const int32_t *accept);
+int rf_commit_device(rf_ctx *ctx, int32_t nb, const int32_t *d_walker_ids,
+                     const int32_t *d_accept, void *stream);
+
+/* read back `rft(1:n, 1:ntrc, walker)` (which = 0) or the last proposed trace
+ * (which = 1); out is out(n, ntrc) column-major.  Used for histogram recording
+ * (src/pt_mcmc.f90:272-285). */
+int rf_get_rft(rf_ctx *ctx, int32_t walker, int32_t which, int32_t n, double *out);
+
+/* ---- parallel tempering ------------------------------------------------ */
+/* judge_pt (src/pt_mcmc.f90:580-595) for npairs DISJOINT chain pairs: swap
+ * temps[i1] <-> temps[i2] iff log(u) <= (L2-L1)(1/T1-1/T2).  temps/logl are device
+ * arrays indexed by (local or gathered-global) walker; pairs [npairs][2]; no walker
+ * may appear twice (the reference proposes a single pair per iteration,
+ * src/pt_mcmc.f90:501-506).  log_u[npairs] are the host-drawn log(grnd()) values
+ * (the RNG stays on the host; temperatures move, states stay: src/pt_mcmc.f90:532-535). */
+int rf_pt_swap_device(rf_ctx *ctx, int32_t npairs, const int32_t *d_pairs, const double *d_log_u,
+                      double *d_temps, const double *d_logl, int32_t *d_accepted, void *stream);
+
+/* ---- instrumentation ----------------------------------------------------- */
+/* HIP-event timing of the three kernels of rf_eval_batch*, accumulated while
+ * enabled.  ms[3] = spectra, trace, logl totals; launches = batches timed. */
+int rf_profile_enable(rf_ctx *ctx, int32_t on);
+int rf_profile_read(rf_ctx *ctx, double *ms, int64_t *launches, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFGPU_H */

@@ -1,0 +1,69 @@
+"""ctypes binding of librfgpu.so (include/rfgpu.h).  Fails loudly when the HIP
+library has not been built: there is no other implementation behind it."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "librfgpu.so")
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int32)
+
+
+class RFConfig(C.Structure):
+    """struct rf_config of include/rfgpu.h"""
+    _fields_ = [
+        ("nfft", C.c_int32), ("ntrc", C.c_int32), ("nsmp", C.c_int32), ("deconv_mode", C.c_int32),
+        ("delta", C.c_double), ("t_start", C.c_double), ("sdep", C.c_double),
+        ("rayps", dp), ("a_gus", dp), ("ipha", ip),
+        ("obs", dp), ("ldobs", C.c_int32),
+        ("r_inv", dp),
+        ("max_walkers", C.c_int32), ("nlay_max", C.c_int32), ("device", C.c_int32),
+    ]
+
+
+# every symbol include/rfgpu.h declares: name -> (restype, argtypes)
+_vp = C.c_void_p
+SYMBOLS = {
+    "rf_ctx_create": (C.c_int, [C.POINTER(RFConfig), C.POINTER(_vp)]),
+    "rf_ctx_destroy": (C.c_int, [_vp]),
+    "rf_last_error": (C.c_char_p, []),
+    "rf_abi_version": (C.c_int, []),
+    "rf_get_flt": (C.c_int, [_vp, dp]),
+    "rf_get_is_ray_common": (C.c_int, [_vp, ip]),
+    "rf_get_r_inv": (C.c_int, [_vp, dp]),
+    "rf_compute_r_inv": (C.c_int, [C.c_int32, C.c_double, C.c_double, dp, ip]),
+    "rf_calc_rf": (C.c_int, [_vp, C.c_int32, dp, dp, dp, dp, dp]),
+    "rf_calc_likelihood": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, dp, dp, dp, dp]),
+    "rf_eval_batch": (C.c_int, [_vp, C.c_int32, ip, ip, ip, C.c_int32, dp, dp, dp]),
+    "rf_eval_batch_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp]),
+    "rf_commit": (C.c_int, [_vp, C.c_int32, ip, ip]),
+    "rf_commit_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
+    "rf_get_rft": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, dp]),
+    "rf_pt_swap_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rf_profile_enable": (C.c_int, [_vp, C.c_int32]),
+    "rf_profile_read": (C.c_int, [_vp, dp, C.POINTER(C.c_int64), C.c_int32]),
+}
+
+_lib = None
+
+
+def load():
+    """Load librfgpu.so and type every entry point.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build the HIP extension first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C rf_inv_amd/csrc). "
+            "rf_inv_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,548 @@
+// rfgpu_api.cpp -- host side of the C ABI declared in include/rfgpu.h.
+// Context management, init-time tables (filter, twiddles, R^-1), staging of host
+// buffers and kernel launches.  No CPU fallback: every evaluation runs the gfx950
+// kernels of rfgpu_kernels.hip.
+#include "rfgpu_internal.h"
+#include "../../include/rfgpu.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace rfgpu;
+
+static thread_local std::string g_err;
+
+static int fail(const std::string &msg)
+{
+    g_err = msg;
+    return 1;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(std::string(#expr) + ": " + hipGetErrorString(e_));                    \
+    } while (0)
+
+struct rf_ctx {
+    rf_config cfg{};
+    int device = 0;
+    int nh = 0, nfwd = 1, ray_common = 1, nslots = 0;
+    DeviceTables tab{};
+    WalkerState ws{};
+    hipStream_t stream = nullptr;
+    // owned device allocations
+    std::vector<void *> owned;
+    double2 *spec = nullptr; // [nslots][nfwd][2][nh]
+    // staging for host-buffer calls
+    int *d_ids = nullptr, *d_fwd = nullptr, *d_nlay = nullptr, *d_acc = nullptr;
+    double *d_layers = nullptr, *d_sig = nullptr, *d_logl = nullptr;
+    int stage_nb = 0, stage_pad = 0;
+    // host copies of tables
+    std::vector<double> flt, r_inv;
+    // launch policy
+    int bins_per_lane = 1;
+    int num_cu = 256;
+    // profiling
+    // profiling: a pool of event quads so that timing never synchronises inside a
+    // timed loop (flushed lazily / when the pool is exhausted)
+    bool prof = false;
+    struct EvQuad { hipEvent_t e[4]; };
+    std::vector<EvQuad> ev_pool;
+    size_t ev_used = 0;
+    double prof_ms[3] = {0, 0, 0};
+    int64_t prof_n = 0;
+};
+
+extern "C" const char *rf_last_error(void) { return g_err.c_str(); }
+extern "C" int rf_abi_version(void) { return RFGPU_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------
+// init_r_inv for one trace (reference src/likelihood.f90:183-222) with a one-sided
+// Jacobi SVD (Hestenes) in fp64.  r_inv(i,j) column-major.
+// ---------------------------------------------------------------------------
+extern "C" int rf_compute_r_inv(int32_t nsmp, double a_gus, double delta, double *r_inv, int32_t *rank_out)
+{
+    if (nsmp <= 0 || !r_inv) return fail("rf_compute_r_inv: bad arguments");
+    const int n = nsmp;
+    const double r = std::exp(-(a_gus * a_gus) * (delta * delta)); // :183
+    // U holds the working columns (starts as R), V accumulates the rotations
+    std::vector<double> U((size_t)n * n), V((size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const int d = (i - j) * (i - j);
+            U[(size_t)j + (size_t)n * i] = std::pow(r, (double)d); // :185-190
+        }
+    for (int i = 0; i < n; ++i) V[(size_t)i + (size_t)n * i] = 1.0;
+    const double eps = 1e-15;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                double *up = &U[(size_t)n * p], *uq = &U[(size_t)n * q];
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < n; ++i) {
+                    alpha += up[i] * up[i];
+                    beta += uq[i] * uq[i];
+                    gamma += up[i] * uq[i];
+                }
+                if (gamma == 0.0) continue;
+                const double lim = eps * std::sqrt(alpha * beta);
+                if (std::fabs(gamma) <= lim) continue;
+                off = std::max(off, std::fabs(gamma) / std::sqrt(alpha * beta));
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), s = c * t;
+                double *vp = &V[(size_t)n * p], *vq = &V[(size_t)n * q];
+                for (int i = 0; i < n; ++i) {
+                    const double a = up[i], b = uq[i];
+                    up[i] = c * a - s * b;
+                    uq[i] = s * a + c * b;
+                    const double va = vp[i], vb = vq[i];
+                    vp[i] = c * va - s * vb;
+                    vq[i] = s * va + c * vb;
+                }
+            }
+        if (off < 1e-14) break;
+    }
+    // singular values = column norms; R+ = sum_{s_k > 1e-3} v_k u_k^T / s_k  (:212-222)
+    std::fill(r_inv, r_inv + (size_t)n * n, 0.0);
+    int rank = 0;
+    // process in descending singular-value order for a deterministic summation order
+    std::vector<std::pair<double, int>> sv(n);
+    for (int k = 0; k < n; ++k) {
+        double nn = 0;
+        for (int i = 0; i < n; ++i) nn += U[(size_t)n * k + i] * U[(size_t)n * k + i];
+        sv[k] = {std::sqrt(nn), k};
+    }
+    std::sort(sv.begin(), sv.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) {
+        return a.first > b.first;
+    });
+    for (int kk = 0; kk < n; ++kk) {
+        const double s = sv[kk].first;
+        const int k = sv[kk].second;
+        if (!(s > 1.0e-3)) continue; // :214
+        ++rank;
+        const double *uk = &U[(size_t)n * k], *vk = &V[(size_t)n * k];
+        const double inv = 1.0 / (s * s); // u_k (unit) = U[:,k] / s, times 1/s
+        for (int j = 0; j < n; ++j) {
+            const double uj = uk[j] * inv;
+            for (int i = 0; i < n; ++i) r_inv[(size_t)i + (size_t)n * j] += vk[i] * uj;
+        }
+    }
+    if (rank_out) *rank_out = rank;
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+static int dev_alloc(rf_ctx *c, void **p, size_t bytes)
+{
+    HIP_TRY(hipMalloc(p, bytes ? bytes : 8));
+    c->owned.push_back(*p);
+    return 0;
+}
+
+template <class T>
+static int upload(rf_ctx *c, const std::vector<T> &h, const T **d)
+{
+    void *p = nullptr;
+    if (dev_alloc(c, &p, h.size() * sizeof(T))) return 1;
+    HIP_TRY(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    *d = static_cast<const T *>(p);
+    return 0;
+}
+
+static int ensure_stage(rf_ctx *c, int nb, int pad)
+{
+    if (nb <= c->stage_nb && pad <= c->stage_pad) return 0;
+    const int nnb = std::max(nb, c->stage_nb), npad = std::max(pad, c->stage_pad);
+    // (old staging buffers stay owned by the context until destroy; growth is rare)
+    void *p;
+    if (dev_alloc(c, &p, sizeof(int) * nnb)) return 1;
+    c->d_ids = (int *)p;
+    if (dev_alloc(c, &p, sizeof(int) * nnb)) return 1;
+    c->d_fwd = (int *)p;
+    if (dev_alloc(c, &p, sizeof(int) * nnb)) return 1;
+    c->d_nlay = (int *)p;
+    if (dev_alloc(c, &p, sizeof(int) * nnb)) return 1;
+    c->d_acc = (int *)p;
+    if (dev_alloc(c, &p, sizeof(double) * (size_t)nnb * 4 * npad)) return 1;
+    c->d_layers = (double *)p;
+    if (dev_alloc(c, &p, sizeof(double) * (size_t)nnb * c->cfg.ntrc)) return 1;
+    c->d_sig = (double *)p;
+    if (dev_alloc(c, &p, sizeof(double) * nnb)) return 1;
+    c->d_logl = (double *)p;
+    c->stage_nb = nnb;
+    c->stage_pad = npad;
+    return 0;
+}
+
+extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
+{
+    if (!cfg || !ctx_out) return fail("rf_ctx_create: null argument");
+    *ctx_out = nullptr;
+    const int n = cfg->nfft;
+    if (n < 8 || (n & (n - 1))) return fail("rf_ctx_create: nfft must be a power of two >= 8");
+    if (cfg->ntrc < 1 || cfg->nsmp < 1 || cfg->nsmp > n) return fail("rf_ctx_create: bad ntrc / nsmp");
+    if (cfg->deconv_mode != 0 && cfg->deconv_mode != 1) return fail("rf_ctx_create: deconv_mode must be 0 or 1");
+    if (!cfg->rayps || !cfg->a_gus || !cfg->ipha || !cfg->obs) return fail("rf_ctx_create: null table");
+    if (cfg->ldobs < cfg->nsmp) return fail("rf_ctx_create: ldobs < nsmp");
+    if (cfg->max_walkers < 1 || cfg->nlay_max < 2) return fail("rf_ctx_create: bad capacity");
+    for (int i = 0; i < cfg->ntrc; ++i)
+        if (cfg->ipha[i] != 1 && cfg->ipha[i] != -1) return fail("rf_ctx_create: ipha must be +1 or -1");
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail("rf_ctx_create: no HIP device available (librfgpu has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("rf_ctx_create: device ordinal out of range");
+    HIP_TRY(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+        return fail(std::string("rf_ctx_create: kernels are built for gfx950 only, device is ") + prop.gcnArchName);
+
+    rf_ctx *c = new rf_ctx();
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    c->num_cu = prop.multiProcessorCount;
+    const int ntrc = cfg->ntrc, nsmp = cfg->nsmp, nh = n / 2 + 1;
+    c->nh = nh;
+    // check_ray (forward.f90:59-91)
+    c->ray_common = 1;
+    for (int i = 1; i < ntrc; ++i)
+        if (cfg->rayps[i] != cfg->rayps[0] || cfg->ipha[i] != cfg->ipha[0]) c->ray_common = 0;
+    c->nfwd = c->ray_common ? 1 : ntrc;
+    c->nslots = cfg->max_walkers + 1; // last slot: scratch walker of rf_calc_rf
+
+    auto cleanup = [&](int rc) {
+        rf_ctx_destroy(c);
+        return rc;
+    };
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess)
+        return cleanup(fail("hipStreamCreate failed"));
+
+    // init_filter (forward.f90:95-119), fp64 on the host, same expression order
+    const double pi = 3.1415926535897931;
+    c->flt.resize((size_t)nh * ntrc);
+    {
+        const double df = 1.0 / (cfg->delta * n);
+        for (int t = 0; t < ntrc; ++t) {
+            const double fac_norm = n * cfg->a_gus[t] * cfg->delta / std::sqrt(pi);
+            for (int i = 1; i <= nh; ++i) {
+                const double omega = (i - 1) * 2.0 * pi * df;
+                const double q = omega / (2.0 * cfg->a_gus[t]);
+                c->flt[(size_t)(i - 1) + (size_t)nh * t] = std::exp(-(q * q)) / fac_norm;
+            }
+        }
+    }
+    // r_inv: supplied (host dgesvd, bit-identical to the reference build) or built here
+    c->r_inv.resize((size_t)nsmp * nsmp * ntrc);
+    if (cfg->r_inv) {
+        std::memcpy(c->r_inv.data(), cfg->r_inv, sizeof(double) * c->r_inv.size());
+    } else {
+        for (int t = 0; t < ntrc; ++t) {
+            int same = -1;
+            for (int u = 0; u < t; ++u)
+                if (cfg->a_gus[u] == cfg->a_gus[t]) same = u;
+            double *dst = c->r_inv.data() + (size_t)nsmp * nsmp * t;
+            if (same >= 0)
+                std::memcpy(dst, c->r_inv.data() + (size_t)nsmp * nsmp * same, sizeof(double) * nsmp * nsmp);
+            else if (rf_compute_r_inv(nsmp, cfg->a_gus[t], cfg->delta, dst, nullptr))
+                return cleanup(1);
+        }
+    }
+    std::vector<double> obs((size_t)nsmp * ntrc);
+    for (int t = 0; t < ntrc; ++t)
+        for (int i = 0; i < nsmp; ++i) obs[(size_t)i + (size_t)nsmp * t] = cfg->obs[(size_t)i + (size_t)cfg->ldobs * t];
+    std::vector<double2> tw((size_t)n / 2);
+    for (int k = 0; k < n / 2; ++k) {
+        const long double a = 2.0L * 3.14159265358979323846264338327950288L * k / n;
+        tw[k] = make_double2((double)cosl(a), (double)sinl(a));
+    }
+    std::vector<double> rayps(cfg->rayps, cfg->rayps + ntrc);
+    std::vector<int> ipha(cfg->ipha, cfg->ipha + ntrc);
+
+    DeviceTables &T = c->tab;
+    T.nfft = n; T.nh = nh; T.ntrc = ntrc; T.nfwd = c->nfwd; T.nsmp = nsmp;
+    T.deconv_mode = cfg->deconv_mode; T.ray_common = c->ray_common;
+    T.delta = cfg->delta; T.t_start = cfg->t_start; T.sdep = cfg->sdep;
+    T.domg = 2.0 * pi / (n * cfg->delta);   // forward.f90:241
+    T.omg_dc = (double)1.0e-5f;             // forward.f90:247 single-precision literal
+    if (upload(c, c->flt, &T.flt) || upload(c, obs, &T.obs) || upload(c, c->r_inv, &T.r_inv) ||
+        upload(c, rayps, &T.rayps) || upload(c, ipha, &T.ipha) || upload(c, tw, &T.twiddle))
+        return cleanup(1);
+
+    // walker state
+    void *p;
+    const size_t rft_elems = 2 * (size_t)c->nslots * ntrc * n;
+    if (dev_alloc(c, &p, sizeof(double) * rft_elems)) return cleanup(1);
+    c->ws.rft = (double *)p;
+    if (hipMemset(p, 0, sizeof(double) * rft_elems) != hipSuccess) return cleanup(fail("hipMemset failed"));
+    if (dev_alloc(c, &p, sizeof(double) * 2 * (size_t)c->nslots * ntrc)) return cleanup(1);
+    c->ws.phi = (double *)p;
+    hipMemset(p, 0, sizeof(double) * 2 * (size_t)c->nslots * ntrc);
+    if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
+    c->ws.cur_slot = (int *)p;
+    hipMemset(p, 0, sizeof(int) * c->nslots);
+    if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
+    c->ws.prop_fwd = (int *)p;
+    hipMemset(p, 0, sizeof(int) * c->nslots);
+    c->ws.nslots = c->nslots;
+    if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * c->nfwd * 2 * nh)) return cleanup(1);
+    c->spec = (double2 *)p;
+
+    if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || trace_lds_bytes(n, nsmp) > 160 * 1024)
+        return cleanup(fail("rf_ctx_create: nfft / nsmp / nlay_max exceed the 160 KiB LDS of a gfx950 CU"));
+    const char *env = getenv("RFGPU_BINS_PER_LANE");
+    if (env) c->bins_per_lane = atoi(env) == 2 ? 2 : 1;
+    *ctx_out = c;
+    return 0;
+}
+
+extern "C" int rf_ctx_destroy(rf_ctx *c)
+{
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (void *p : c->owned) hipFree(p);
+    for (auto &q : c->ev_pool)
+        for (int i = 0; i < 4; ++i) hipEventDestroy(q.e[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" int rf_get_flt(const rf_ctx *c, double *flt)
+{
+    if (!c || !flt) return fail("rf_get_flt: null argument");
+    std::memcpy(flt, c->flt.data(), sizeof(double) * c->flt.size());
+    return 0;
+}
+extern "C" int rf_get_is_ray_common(const rf_ctx *c, int32_t *flag)
+{
+    if (!c || !flag) return fail("rf_get_is_ray_common: null argument");
+    *flag = c->ray_common;
+    return 0;
+}
+extern "C" int rf_get_r_inv(const rf_ctx *c, double *r_inv)
+{
+    if (!c || !r_inv) return fail("rf_get_r_inv: null argument");
+    std::memcpy(r_inv, c->r_inv.data(), sizeof(double) * c->r_inv.size());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+static void flush_profile(rf_ctx *c)
+{
+    for (size_t u = 0; u < c->ev_used; ++u) {
+        rf_ctx::EvQuad &q = c->ev_pool[u];
+        hipEventSynchronize(q.e[3]);
+        for (int i = 0; i < 3; ++i) {
+            float ms = 0;
+            hipEventElapsedTime(&ms, q.e[i], q.e[i + 1]);
+            c->prof_ms[i] += ms;
+        }
+        c->prof_n += 1;
+    }
+    c->ev_used = 0;
+}
+
+static rf_ctx::EvQuad *next_quad(rf_ctx *c)
+{
+    constexpr size_t kMaxPool = 1024;
+    if (c->ev_used == c->ev_pool.size()) {
+        if (c->ev_pool.size() >= kMaxPool) {
+            flush_profile(c);
+        } else {
+            rf_ctx::EvQuad q;
+            for (int i = 0; i < 4; ++i)
+                if (hipEventCreate(&q.e[i]) != hipSuccess) return nullptr;
+            c->ev_pool.push_back(q);
+        }
+    }
+    return &c->ev_pool[c->ev_used++];
+}
+
+static int pick_nsplit(const rf_ctx *c, int nb)
+{
+    // fill >= ~8 waves per CU; never split below one 64-bin iteration per wave
+    const int per_iter = 64 * c->bins_per_lane;
+    const int niter = (c->nh + per_iter - 1) / per_iter;
+    const long waves = (long)nb * c->nfwd;
+    const long want = 8L * c->num_cu;
+    int ns = (int)std::min<long>(niter, std::max<long>(1, (want + waves - 1) / waves));
+    const char *env = getenv("RFGPU_NSPLIT");
+    if (env && atoi(env) > 0) ns = std::min(niter, atoi(env));
+    return ns;
+}
+
+static int run_batch(rf_ctx *c, const BatchArgs &b, hipStream_t s)
+{
+    if (b.nb <= 0) return 0;
+    if (b.nb > c->nslots) return fail("batch larger than max_walkers + 1");
+    if (b.nlay_pad > c->cfg.nlay_max) return fail("nlay_pad exceeds nlay_max of the context");
+    HIP_TRY(hipSetDevice(c->device));
+    rf_ctx::EvQuad *q = c->prof ? next_quad(c) : nullptr;
+    if (q) hipEventRecord(q->e[0], s);
+    launch_spectra(c->tab, b, c->spec, pick_nsplit(c, b.nb), c->bins_per_lane, s);
+    if (q) hipEventRecord(q->e[1], s);
+    launch_trace(c->tab, b, c->spec, c->ws, s);
+    if (q) hipEventRecord(q->e[2], s);
+    launch_logl(c->tab, b, c->ws, s);
+    if (q) hipEventRecord(q->e[3], s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rf_eval_batch_device(rf_ctx *c, int32_t nb, const int32_t *d_walker_ids,
+                                    const int32_t *d_fwd_flag, const int32_t *d_nlay, int32_t nlay_pad,
+                                    const double *d_layers, const double *d_sig, double *d_logl, void *stream)
+{
+    if (!c || !d_walker_ids || !d_nlay || !d_layers || !d_sig || !d_logl)
+        return fail("rf_eval_batch_device: null argument");
+    BatchArgs b{nb, nlay_pad, d_walker_ids, d_fwd_flag, d_nlay, d_layers, d_sig, d_logl};
+    return run_batch(c, b, (hipStream_t)stream);
+}
+
+extern "C" int rf_eval_batch(rf_ctx *c, int32_t nb, const int32_t *walker_ids, const int32_t *fwd_flag,
+                             const int32_t *nlay, int32_t nlay_pad, const double *layers, const double *sig,
+                             double *logl)
+{
+    if (!c || !walker_ids || !nlay || !layers || !sig || !logl) return fail("rf_eval_batch: null argument");
+    if (nb <= 0) return 0;
+    for (int i = 0; i < nb; ++i) {
+        if (walker_ids[i] < 0 || walker_ids[i] >= c->nslots) return fail("rf_eval_batch: walker id out of range");
+        if (nlay[i] < 2 || nlay[i] > nlay_pad) return fail("rf_eval_batch: nlay out of range");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if (ensure_stage(c, nb, nlay_pad)) return 1;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_ids, walker_ids, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+    if (fwd_flag) HIP_TRY(hipMemcpyAsync(c->d_fwd, fwd_flag, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_nlay, nlay, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_layers, layers, sizeof(double) * (size_t)nb * 4 * nlay_pad, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_sig, sig, sizeof(double) * (size_t)nb * c->cfg.ntrc, hipMemcpyHostToDevice, s));
+    BatchArgs b{nb, nlay_pad, c->d_ids, fwd_flag ? c->d_fwd : nullptr, c->d_nlay, c->d_layers, c->d_sig, c->d_logl};
+    if (run_batch(c, b, s)) return 1;
+    HIP_TRY(hipMemcpyAsync(logl, c->d_logl, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int rf_get_rft(rf_ctx *c, int32_t walker, int32_t which, int32_t nout, double *out)
+{
+    if (!c || !out) return fail("rf_get_rft: null argument");
+    if (walker < 0 || walker >= c->nslots) return fail("rf_get_rft: walker out of range");
+    if (nout < 1 || nout > c->cfg.nfft) return fail("rf_get_rft: n out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    int cur = 0, pf = 0;
+    HIP_TRY(hipMemcpy(&cur, c->ws.cur_slot + walker, sizeof(int), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(&pf, c->ws.prop_fwd + walker, sizeof(int), hipMemcpyDeviceToHost));
+    const int slot = (which == 1 && pf) ? 1 - cur : cur;
+    const int n = c->cfg.nfft, ntrc = c->cfg.ntrc;
+    const double *src = c->ws.rft + (((size_t)slot * c->nslots + walker) * ntrc) * (size_t)n;
+    HIP_TRY(hipMemcpy2D(out, sizeof(double) * nout, src, sizeof(double) * n, sizeof(double) * nout, ntrc,
+                        hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int rf_calc_likelihood(rf_ctx *c, int32_t walker, int32_t fwd_flag, int32_t nlay,
+                                  const double *alpha, const double *beta, const double *rho, const double *h,
+                                  const double *sig, double *prop_log_likelihood, double *prop_rft)
+{
+    if (!c || !sig || !prop_log_likelihood) return fail("rf_calc_likelihood: null argument");
+    if (walker < 0 || walker >= c->nslots) return fail("rf_calc_likelihood: walker out of range");
+    int nl = nlay;
+    std::vector<double> layers;
+    if (fwd_flag) {
+        if (!alpha || !beta || !rho || !h) return fail("rf_calc_likelihood: null layer arrays");
+        if (nlay < 2 || nlay > c->cfg.nlay_max) return fail("rf_calc_likelihood: nlay out of range");
+        layers.resize((size_t)4 * nlay);
+        std::memcpy(&layers[0], alpha, sizeof(double) * nlay);
+        std::memcpy(&layers[nlay], beta, sizeof(double) * nlay);
+        std::memcpy(&layers[2 * (size_t)nlay], rho, sizeof(double) * nlay);
+        std::memcpy(&layers[3 * (size_t)nlay], h, sizeof(double) * nlay);
+    } else {
+        nl = 2;
+        layers.assign(8, 1.0);
+    }
+    const int32_t ids[1] = {walker}, ff[1] = {fwd_flag ? 1 : 0}, nls[1] = {nl};
+    if (rf_eval_batch(c, 1, ids, ff, nls, nl, layers.data(), sig, prop_log_likelihood)) return 1;
+    if (prop_rft) return rf_get_rft(c, walker, 1, c->cfg.nfft, prop_rft);
+    return 0;
+}
+
+extern "C" int rf_calc_rf(rf_ctx *c, int32_t nlay, const double *alpha, const double *beta, const double *rho,
+                          const double *h, double *rft)
+{
+    if (!c || !rft) return fail("rf_calc_rf: null argument");
+    std::vector<double> sig((size_t)c->cfg.ntrc, 1.0);
+    double ll;
+    return rf_calc_likelihood(c, c->nslots - 1, 1, nlay, alpha, beta, rho, h, sig.data(), &ll, rft);
+}
+
+extern "C" int rf_commit_device(rf_ctx *c, int32_t nb, const int32_t *d_walker_ids, const int32_t *d_accept,
+                                void *stream)
+{
+    if (!c || !d_walker_ids || !d_accept) return fail("rf_commit_device: null argument");
+    if (nb <= 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    launch_commit(c->ws, nb, d_walker_ids, d_accept, c->cfg.ntrc, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rf_commit(rf_ctx *c, int32_t nb, const int32_t *walker_ids, const int32_t *accept)
+{
+    if (!c || !walker_ids || !accept) return fail("rf_commit: null argument");
+    if (nb <= 0) return 0;
+    for (int i = 0; i < nb; ++i)
+        if (walker_ids[i] < 0 || walker_ids[i] >= c->nslots) return fail("rf_commit: walker id out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    if (ensure_stage(c, nb, 2)) return 1;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_ids, walker_ids, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_acc, accept, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+    launch_commit(c->ws, nb, c->d_ids, c->d_acc, c->cfg.ntrc, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
+}
+
+extern "C" int rf_pt_swap_device(rf_ctx *c, int32_t npairs, const int32_t *d_pairs, const double *d_log_u,
+                                 double *d_temps, const double *d_logl, int32_t *d_accepted, void *stream)
+{
+    if (!c || !d_pairs || !d_log_u || !d_temps || !d_logl) return fail("rf_pt_swap_device: null argument");
+    if (npairs <= 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    launch_pt_swap(npairs, d_pairs, d_log_u, d_temps, d_logl, d_accepted, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rf_profile_enable(rf_ctx *c, int32_t on)
+{
+    if (!c) return fail("rf_profile_enable: null context");
+    if (!on) flush_profile(c);
+    c->prof = on != 0;
+    return 0;
+}
+
+extern "C" int rf_profile_read(rf_ctx *c, double *ms, int64_t *launches, int32_t reset)
+{
+    if (!c || !ms || !launches) return fail("rf_profile_read: null argument");
+    flush_profile(c);
+    for (int i = 0; i < 3; ++i) ms[i] = c->prof_ms[i];
+    *launches = c->prof_n;
+    if (reset) {
+        c->prof_ms[0] = c->prof_ms[1] = c->prof_ms[2] = 0;
+        c->prof_n = 0;
+    }
+    return 0;
+}

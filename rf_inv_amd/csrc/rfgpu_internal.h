@@ -1,0 +1,58 @@
+// Internal launcher interface between the C-ABI host layer (rfgpu_api.cpp) and the
+// gfx950 kernels (rfgpu_kernels.hip).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rfgpu {
+
+// doubles of per-layer coefficients staged in LDS (see stage_layer_coef)
+constexpr int NCOEF = 20;
+
+struct DeviceTables {
+    int nfft, nh, ntrc, nfwd, nsmp, deconv_mode, ray_common;
+    double delta, t_start, sdep, domg, omg_dc;
+    const double *flt;      // [ntrc][nh]
+    const double *obs;      // [ntrc][nsmp]
+    const double *r_inv;    // [ntrc][nsmp*nsmp]  column-major blocks
+    const double *rayps;    // [ntrc]
+    const int *ipha;        // [ntrc]
+    const double2 *twiddle; // [nfft/2]  exp(+2 pi i k / nfft)
+};
+
+struct BatchArgs {
+    int nb, nlay_pad;
+    const int *walker_ids; // [nb]
+    const int *fwd_flag;   // [nb] or nullptr
+    const int *nlay;       // [nb]
+    const double *layers;  // [nb][4][nlay_pad]
+    const double *sig;     // [nb][ntrc]
+    double *logl;          // [nb]
+};
+
+struct WalkerState {
+    double *rft;      // [2][nslots][ntrc][nfft]
+    double *phi;      // [2][nslots][ntrc]
+    int *cur_slot;    // [nslots] 0/1: which half holds the current trace
+    int *prop_fwd;    // [nslots] last proposal ran the forward model
+    int nslots;
+};
+
+// K1: propagator-matrix spectra  -> spec[nb][nfwd][2][nh] (freq_r, freq_v after
+// the conj / -conj of forward.f90:145-146)
+void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit,
+                    int bins_per_lane, hipStream_t s);
+// K2: decon / filter / c2r / shift / normalise / write trace / quadratic form
+void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec,
+                  const WalkerState &w, hipStream_t s);
+// K3: log-likelihood from the per-trace quadratic forms
+void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
+void launch_commit(const WalkerState &w, int nb, const int *walker_ids, const int *accept,
+                   int ntrc, hipStream_t s);
+void launch_pt_swap(int npairs, const int *pairs, const double *log_u, double *temps,
+                    const double *logl, int *accepted, hipStream_t s);
+
+size_t spectra_lds_bytes(int nlay_pad);
+size_t trace_lds_bytes(int nfft, int nsmp);
+
+} // namespace rfgpu

@@ -1,0 +1,616 @@
+// rfgpu_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the RF_INV
+// forward + likelihood hot path.  All arithmetic is IEEE fp64 on the vector ALU.
+//
+// Reference behaviour restated (file:line under /root/reference):
+//   K1 spectra_kernel   src/forward.f90:212-287 (calc_seis) with :350-380 (e_inverse),
+//                       :385-421 (layer_matrix_sol), :424-442 (layer_matrix_liq) and the
+//                       conj / -conj of :145-146
+//   K2 trace_kernel     src/forward.f90:148-203 (water_level_decon :447-470, direct_arrival
+//                       :474-519, filter, c2r, time shift, vertical normalisation) and
+//                       src/likelihood.f90:87-93 (misfit, misfit . R^-1 . misfit)
+//   K3 logl_kernel      src/likelihood.f90:86,94-96
+//
+// Formulation of K1: every solid-layer propagator P has the
+// checkerboard pattern "real where i+j even, imaginary otherwise" and an explicit
+// omega / 1/omega in its off-diagonal 2x2 blocks, i.e.  P = T A T^-1 with
+// T = diag(1, i, w, i w) and A REAL with no explicit omega.  The chain
+// prod P_l = T (prod A_l) T^-1 is therefore a chain of real 4x4 products, E^-1 T is
+// omega-independent, and only the columns of the product that the boundary condition
+// consumes (1, 2 and, under an ocean, 4) are propagated.
+#include "rfgpu_internal.h"
+#include <math.h>
+
+namespace rfgpu {
+
+// ---------------------------------------------------------------------------
+// small complex helpers (same operation order as the oracle's c_mul / c_div)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ double2 cmul(double2 a, double2 b)
+{
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 cneg(double2 a) { return make_double2(-a.x, -a.y); }
+// Smith's complex division, as Fortran compilers emit for complex(8) a / b
+__device__ __forceinline__ double2 cdiv(double2 a, double2 b)
+{
+    double r, d;
+    if (fabs(b.x) >= fabs(b.y)) {
+        r = b.y / b.x;
+        d = b.x + b.y * r;
+        return make_double2((a.x + a.y * r) / d, (a.y - a.x * r) / d);
+    }
+    r = b.x / b.y;
+    d = b.y + b.x * r;
+    return make_double2((a.x * r + a.y) / d, (a.y * r - a.x) / d);
+}
+
+// ---------------------------------------------------------------------------
+// K1  spectra
+// ---------------------------------------------------------------------------
+// LDS image per (walker, forward-trace), staged once per wave:
+//   coef[l][0..19]  per solid layer l (0-based, l < nlay-1):
+//      0 xi   1 eta   2 h
+//      3 k1 = 2 b2 p2          4 k2 = bp
+//      5 k5 = 2 b2 rho p bp    6 k6 = -p / rho
+//      7 k7 = p 2 b2 xi        8 k8n = -p bp / eta
+//      9 k9 = p bp / xi       10 k10n = -p 2 b2 eta
+//     11 k11n = -rho 4 b2^2 p2 xi   12 k12n = -rho bp^2 / eta
+//     13 k13n = -rho bp^2 / xi      14 k14n = -rho 4 b2^2 p2 eta
+//     15 k15 = p2 / (xi rho)        16 k16 = eta / rho
+//     17 k17 = xi / rho             18 k18 = p2 / (eta rho)       19 pad
+//   tail[0..7]  g1..g8 : rows 3,4 of E^-1 T of the half-space
+//   tail[8..10] water layer: xi_w, h_w, rho_w / xi_w
+__device__ __forceinline__ void stage_layer_coef(double *c, double alpha, double beta, double rho,
+                                                 double h, double p)
+{
+    const double b2 = beta * beta;
+    const double p2 = p * p;
+    const double bp = 1.0 - 2.0 * b2 * p2;
+    const double eta = sqrt(1.0 / b2 - p2);
+    const double xi = sqrt(1.0 / (alpha * alpha) - p2);
+    const double b4p2 = 4.0 * b2 * b2 * p2;
+    c[0] = xi;
+    c[1] = eta;
+    c[2] = h;
+    c[3] = 2.0 * b2 * p2;
+    c[4] = bp;
+    c[5] = 2.0 * b2 * rho * p * bp;
+    c[6] = -p / rho;
+    c[7] = p * (2.0 * b2 * xi);
+    c[8] = -p * (bp / eta);
+    c[9] = p * (bp / xi);
+    c[10] = -p * (2.0 * b2 * eta);
+    c[11] = -rho * (b4p2 * xi);
+    c[12] = -rho * (bp * bp / eta);
+    c[13] = -rho * (bp * bp / xi);
+    c[14] = -rho * (b4p2 * eta);
+    c[15] = p2 / xi / rho;
+    c[16] = eta / rho;
+    c[17] = xi / rho;
+    c[18] = p2 / eta / rho;
+    c[19] = 0.0;
+}
+
+__device__ __forceinline__ void stage_halfspace(double *g, double alpha, double beta, double rho, double p)
+{
+    // rows 3 and 4 of E^-1 (forward.f90:370-377) times T = diag(1, i, w, i w)
+    const double eta = sqrt(1.0 / (beta * beta) - p * p);
+    const double xi = sqrt(1.0 / (alpha * alpha) - p * p);
+    const double bp = 1.0 - 2.0 * beta * beta * p * p;
+    g[0] = beta * beta * p / alpha;        // re: B1
+    g[1] = 1.0 / (2.0 * rho * alpha);      // re: B4
+    g[2] = -bp / (2.0 * alpha * xi);       // im: B2
+    g[3] = p / (2.0 * rho * alpha * xi);   // im: B3
+    g[4] = bp / (2.0 * beta * eta);        // re: B1
+    g[5] = -p / (2.0 * rho * beta * eta);  // re: B4
+    g[6] = beta * p;                       // im: B2
+    g[7] = 1.0 / (2.0 * rho * beta);       // im: B3
+}
+
+template <int NCOL>
+struct ColState {
+    double v[NCOL][4];
+};
+
+// one layer applied to NCOL real column vectors:  v <- A v
+template <int NCOL>
+__device__ __forceinline__ void apply_layer(ColState<NCOL> &s, const double *__restrict__ c, double omg)
+{
+    double sx, cx, se, ce;
+    // argument formed exactly like the reference: (omega * xi) * z  (forward.f90:397-400)
+    sincos((omg * c[0]) * c[2], &sx, &cx);
+    sincos((omg * c[1]) * c[2], &se, &ce);
+    const double a = fma(c[3], cx, c[4] * ce);    // A11 = A33
+    const double e = fma(c[4], cx, c[3] * ce);    // A22 = A44
+    const double d = cx - ce;
+    const double x41 = c[5] * d;                  // A41 = -A32
+    const double x23 = c[6] * d;                  // A23 = -A14
+    const double x21 = fma(c[7], sx, c[8] * se);  // A21 = -A34
+    const double x12 = fma(c[9], sx, c[10] * se); // A43 = -A12
+    const double p31 = fma(c[11], sx, c[12] * se);
+    const double p42 = fma(c[13], sx, c[14] * se);
+    const double p13 = fma(c[15], sx, c[16] * se);
+    const double p24 = fma(c[17], sx, c[18] * se);
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) {
+        const double v1 = s.v[j][0], v2 = s.v[j][1], v3 = s.v[j][2], v4 = s.v[j][3];
+        // sum over k = 1..4 in order, like matmul (forward.f90:262)
+        s.v[j][0] = fma(-x23, v4, fma(p13, v3, fma(-x12, v2, a * v1)));
+        s.v[j][1] = fma(p24, v4, fma(x23, v3, fma(e, v2, x21 * v1)));
+        s.v[j][2] = fma(-x21, v4, fma(a, v3, fma(-x41, v2, p31 * v1)));
+        s.v[j][3] = fma(e, v4, fma(x12, v3, fma(p42, v2, x41 * v1)));
+    }
+}
+
+// T_rj = sum_k (E^-1 T)(r,k) B_kj  for r = 3 (g[0..3]) or 4 (g[4..7])
+__device__ __forceinline__ double2 halfspace_row(const double *g, const double *v)
+{
+    return make_double2(fma(g[1], v[3], g[0] * v[0]), fma(g[3], v[2], g[2] * v[1]));
+}
+
+template <int NCOL>
+__device__ __forceinline__ void finish_bin(const ColState<NCOL> &s, const double *tail, double omg,
+                                           int ipha, double2 &ur, double2 &uz)
+{
+    const double2 t31 = halfspace_row(tail, s.v[0]);
+    const double2 t41 = halfspace_row(tail + 4, s.v[0]);
+    const double2 t32 = halfspace_row(tail, s.v[1]);
+    const double2 t42 = halfspace_row(tail + 4, s.v[1]);
+    // sl(r,1) = T_r1 ; sl(r,2) = -i T_r2
+    const double2 sl31 = t31, sl41 = t41;
+    const double2 sl32 = make_double2(t32.y, -t32.x);
+    const double2 sl42 = make_double2(t42.y, -t42.x);
+    if (NCOL == 2) {
+        // free surface (forward.f90:267-275)
+        const double2 denom = csub(cmul(sl31, sl42), cmul(sl32, sl41));
+        if (ipha >= 0) {
+            ur = cdiv(sl42, denom);
+            uz = cdiv(cneg(sl41), denom);
+        } else {
+            ur = cdiv(cneg(sl32), denom);
+            uz = cdiv(sl31, denom);
+        }
+    } else {
+        // sea floor (forward.f90:276-287).  sl(r,4) = -(i/w) T_r4 and
+        // lq21 = -(rho_w w / xi_w) sin: the w cancels in sl(r,4) * lq21.
+        const double2 t34 = halfspace_row(tail, s.v[NCOL - 1]);
+        const double2 t44 = halfspace_row(tail + 4, s.v[NCOL - 1]);
+        double sw, cw;
+        sincos((omg * tail[8]) * tail[9], &sw, &cw);
+        const double q = tail[10] * sw;                       // (rho_w / xi_w) sin
+        const double2 s44l = make_double2(-t44.y * q, t44.x * q); // i T44 q
+        const double2 s34l = make_double2(-t34.y * q, t34.x * q);
+        const double2 a = cadd(make_double2(sl42.x * cw, sl42.y * cw), s44l);
+        const double2 b = cadd(make_double2(sl32.x * cw, sl32.y * cw), s34l);
+        const double2 d1 = csub(cmul(a, sl31), cmul(b, sl41));
+        const double2 d2 = csub(cmul(b, sl41), cmul(a, sl31));
+        if (ipha >= 0) {
+            ur = cdiv(a, d1);
+            uz = cdiv(make_double2(cw * sl41.x, cw * sl41.y), d2);
+        } else {
+            ur = cdiv(cneg(b), d1);
+            uz = cdiv(make_double2(-cw * sl31.x, -cw * sl31.y), d2);
+        }
+    }
+}
+
+struct SpectraParams {
+    DeviceTables t;
+    BatchArgs b;
+    double2 *spec;
+    int nsplit;
+};
+
+// One wave (64 lanes) per (walker, forward-trace, bin-split).  Lanes own frequency
+// bins (coalesced 16-B stores of the spectra); the layer stack of the walker is staged
+// in LDS as precomputed coefficients and broadcast to all lanes; the 4x4 chain runs in
+// registers, BINS bins per lane at a time for instruction-level parallelism.
+template <int BINS, int NCOL>
+__device__ __forceinline__ void spectra_body(const SpectraParams &P, const double *coef,
+                                             const double *tail, int nl, int ilay0, int ipha,
+                                             double2 *__restrict__ out_r, double2 *__restrict__ out_v,
+                                             int split)
+{
+    const int lane = threadIdx.x;
+    const int nh = P.t.nh;
+    const int per_iter = 64 * BINS;
+    const int niter = (nh + per_iter - 1) / per_iter;
+    for (int it = split; it < niter; it += P.nsplit) {
+        ColState<NCOL> st[BINS];
+        double omg[BINS];
+        int kbin[BINS];
+#pragma unroll
+        for (int q = 0; q < BINS; ++q) {
+            kbin[q] = it * per_iter + q * 64 + lane;
+            // forward.f90:245-248: omega = (iomg-1) * domg, DC bin uses the single literal 1.0e-5
+            omg[q] = kbin[q] == 0 ? P.t.omg_dc : (double)kbin[q] * P.t.domg;
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[q].v[j][r] = 0.0;
+            st[q].v[0][0] = 1.0;
+            st[q].v[1][1] = 1.0;
+            if (NCOL == 3) st[q].v[2][3] = 1.0;
+        }
+        for (int l = ilay0; l < nl - 1; ++l) {
+            const double *c = coef + l * NCOEF;
+#pragma unroll
+            for (int q = 0; q < BINS; ++q) apply_layer<NCOL>(st[q], c, omg[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < BINS; ++q) {
+            double2 ur, uz;
+            finish_bin<NCOL>(st[q], tail, omg[q], ipha, ur, uz);
+            if (kbin[q] < nh) {
+                out_r[kbin[q]] = make_double2(ur.x, -ur.y);  // freq_r = conjg(ur)   forward.f90:145
+                out_v[kbin[q]] = make_double2(-uz.x, uz.y);  // freq_v = -conjg(uz)  forward.f90:146
+            }
+        }
+    }
+}
+
+template <int BINS>
+__global__ __launch_bounds__(64) void spectra_kernel(SpectraParams P)
+{
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int split = blockIdx.x % P.nsplit;
+    const int bf = blockIdx.x / P.nsplit;
+    const int f = bf % P.t.nfwd;
+    const int ib = bf / P.t.nfwd;
+    if (P.b.fwd_flag && !P.b.fwd_flag[ib]) return;
+
+    const int nl = P.b.nlay[ib];
+    const int pad = P.b.nlay_pad;
+    const double *L = P.b.layers + (size_t)ib * 4 * pad;
+    const double p = P.t.rayps[f];
+    const int ipha = P.t.ipha[f];
+    const bool sea = L[pad] < 0.0;          // beta(1) < 0  (forward.f90:229)
+    const int ilay0 = sea ? 1 : 0;
+
+    double *coef = lds;
+    double *tail = lds + (size_t)pad * NCOEF;
+    for (int l = lane; l < nl - 1; l += 64)
+        if (l >= ilay0) stage_layer_coef(coef + l * NCOEF, L[l], L[pad + l], L[2 * pad + l], L[3 * pad + l], p);
+    if (lane == 0) {
+        stage_halfspace(tail, L[nl - 1], L[pad + nl - 1], L[2 * pad + nl - 1], p);
+        if (sea) {
+            const double xiw = sqrt(1.0 / (L[0] * L[0]) - p * p);   // forward.f90:431
+            tail[8] = xiw;
+            tail[9] = L[3 * pad];
+            tail[10] = L[2 * pad] / xiw;
+        }
+    }
+    __syncthreads();
+
+    double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
+    double2 *out_v = out_r + P.t.nh;
+    if (sea)
+        spectra_body<BINS, 3>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
+    else
+        spectra_body<BINS, 2>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
+}
+
+size_t spectra_lds_bytes(int nlay_pad) { return sizeof(double) * ((size_t)nlay_pad * NCOEF + 16); }
+
+void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit,
+                    int bins_per_lane, hipStream_t s)
+{
+    SpectraParams P{t, b, spec, nsplit};
+    const dim3 grid((unsigned)(b.nb * t.nfwd * nsplit));
+    const size_t lds = spectra_lds_bytes(b.nlay_pad);
+    if (bins_per_lane == 2)
+        hipLaunchKernelGGL(spectra_kernel<2>, grid, dim3(64), lds, s, P);
+    else
+        hipLaunchKernelGGL(spectra_kernel<1>, grid, dim3(64), lds, s, P);
+}
+
+// ---------------------------------------------------------------------------
+// K2  trace: decon / filter / c2r / shift / normalise / misfit quadratic form
+// ---------------------------------------------------------------------------
+constexpr int TRACE_THREADS = 256;
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// block-wide max over TRACE_THREADS threads; red needs >= 4 doubles
+__device__ __forceinline__ double block_max(double v, double *red)
+{
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+}
+
+// Fortran nint: round half away from zero
+__device__ __forceinline__ int f_nint(double x) { return (int)(x >= 0.0 ? floor(x + 0.5) : -floor(0.5 - x)); }
+
+// direct_arrival (forward.f90:474-519): strictly sequential, no FMA contraction --
+// its result feeds nint() (integer bookkeeping must be bit-exact).
+__device__ __noinline__ double direct_arrival(int nlay, const double *h, const double *v, double rayp,
+                                              double sdep)
+{
+#pragma clang fp contract(off)
+    double t = 0.0;
+    const int i0 = sdep > 0.0 ? 1 : 0;
+    for (int i = i0; i < nlay - 1; ++i) {
+        const double vv = v[i] * v[i];
+        const double inv = 1.0 / vv;
+        const double pp = rayp * rayp;
+        const double rad = inv - pp;
+        const double term = h[i] * sqrt(rad);
+        t = t + term;
+    }
+    return t;
+}
+
+__device__ __noinline__ int calc_npre(double t_start, double tp, double delta, int ipha)
+{
+#pragma clang fp contract(off)
+    // forward.f90:177 / :186
+    const double num = ipha == 1 ? (-t_start - tp) : (-t_start + tp);
+    return f_nint(num / delta);
+}
+
+struct TraceParams {
+    DeviceTables t;
+    BatchArgs b;
+    const double2 *spec;
+    WalkerState w;
+    int log2n;
+};
+
+__global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
+{
+    extern __shared__ double2 lds2[];
+    const DeviceTables &t = P.t;
+    const int n = t.nfft, nh = t.nh, nsmp = t.nsmp;
+    double2 *a = lds2;                                   // [n] FFT work array
+    double *mis = reinterpret_cast<double *>(a + n);     // [nsmp] misfits
+    double *red = mis + ((nsmp + 1) & ~1);               // [8] reductions / broadcasts
+
+    const int tid = threadIdx.x;
+    const int itrc = blockIdx.x % t.ntrc;
+    const int ib = blockIdx.x / t.ntrc;
+    if (P.b.fwd_flag && !P.b.fwd_flag[ib]) return;
+    const int walker = P.b.walker_ids[ib];
+    const int f = t.ray_common ? 0 : itrc;
+    const int ipha = t.ipha[itrc];
+    const double2 *__restrict__ sr = P.spec + ((size_t)(ib * t.nfwd + f) * 2) * nh; // freq_r
+    const double2 *__restrict__ sv = sr + nh;                                        // freq_v
+    const double *__restrict__ flt = t.flt + (size_t)itrc * nh;
+
+    // ---- which spectrum becomes the RF, and the direct-arrival time ------------
+    const bool decon = t.deconv_mode == 1;
+    double wlvl = 0.0;
+    const double2 *num = (ipha == 1) ? sr : sv;      // forward.f90:148-163
+    const double2 *den = (ipha == 1) ? sv : sr;      // decon only
+    if (decon) {
+        double m = -HUGE_VAL;
+        for (int k = tid; k < nh; k += TRACE_THREADS) {
+            const double2 x = den[k];
+            m = fmax(m, x.x * x.x + x.y * x.y);      // forward.f90:458
+        }
+        wlvl = 0.001 * block_max(m, red);            // forward.f90:460, pcnt = 0.001 (:149)
+    } else if (tid == 0) {
+        const int nl = P.b.nlay[ib];
+        const int pad = P.b.nlay_pad;
+        const double *L = P.b.layers + (size_t)ib * 4 * pad;
+        const double *vel = (ipha == 1) ? L : L + pad;   // alpha for P, beta for S (:157,161)
+        red[4] = direct_arrival(nl, L + 3 * pad, vel, t.rayps[itrc], t.sdep);
+    }
+    __syncthreads();
+    const double tp = decon ? 0.0 : red[4];
+
+    // ---- Z = RF*flt + i * (V*flt), Hermitian-extended, written bit-reversed ------
+    const int shift = 32 - P.log2n;
+    for (int k = tid; k < nh; k += TRACE_THREADS) {
+        double2 r = num[k];
+        if (decon) {
+            const double2 x = den[k];
+            const double amp = x.x * x.x + x.y * x.y;
+            const double dd = fmax(amp, wlvl);                       // forward.f90:464
+            const double2 yx = cmul(r, make_double2(x.x, -x.y));
+            r = make_double2(yx.x / dd, yx.y / dd);
+        }
+        const double fk = flt[k];
+        const double2 R = make_double2(r.x * fk, r.y * fk);          // forward.f90:168
+        double2 V = make_double2(0.0, 0.0);
+        if (!decon) {
+            const double2 v = sv[k];
+            V = make_double2(v.x * fk, v.y * fk);                    // forward.f90:198
+        }
+        if (k == 0 || 2 * k == n) {
+            // c2r ignores Im of the DC and Nyquist bins
+            a[__brev((unsigned)k) >> shift] = make_double2(R.x, V.x);
+        } else {
+            a[__brev((unsigned)k) >> shift] = make_double2(R.x - V.y, R.y + V.x);
+            a[__brev((unsigned)(n - k)) >> shift] = make_double2(R.x + V.y, V.x - R.y);
+        }
+    }
+    __syncthreads();
+
+    // ---- in-place radix-2 DIT, sign +, unnormalised (FFTW c2r definition) --------
+    const double2 *__restrict__ tw = t.twiddle;
+    for (int len = 2, lg = 1; len <= n; len <<= 1, ++lg) {
+        const int half = len >> 1;
+        const int step = n >> lg;
+        for (int q = tid; q < (n >> 1); q += TRACE_THREADS) {
+            const int k = q & (half - 1);
+            const int i0 = ((q >> (lg - 1)) << lg) + k;
+            const int i1 = i0 + half;
+            const double2 w = tw[k * step];
+            const double2 u = a[i0];
+            const double2 v = cmul(a[i1], w);
+            a[i0] = cadd(u, v);
+            a[i1] = csub(u, v);
+        }
+        __syncthreads();
+    }
+    // a[j].x = rx (RF trace), a[j].y = vertical trace
+
+    double fac = 1.0;
+    if (!decon) {
+        double m = -HUGE_VAL;
+        for (int j = tid; j < n; j += TRACE_THREADS) m = fmax(m, a[j].y);
+        fac = block_max(m, red);                                     // maxval(rx) forward.f90:201
+    }
+
+    // ---- time shift (+ reverse/negate for S), normalise, store, misfit ----------
+    const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
+    const int slot = 1 - P.w.cur_slot[walker];
+    double *__restrict__ dst =
+        P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
+    const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
+    for (int i = tid + 1; i <= n; i += TRACE_THREADS) {
+        int j;
+        double val;
+        if (ipha == 1) {
+            j = (n - npre + i) % n;                                  // forward.f90:179
+            if (j < 0) j += n;
+            if (j == 0) j = n;
+            val = a[j - 1].x;
+        } else {
+            j = (n + npre - i + 1) % n;                              // forward.f90:188
+            if (j < 0) j += n;
+            if (j == 0) j = n;
+            val = -a[j - 1].x;
+        }
+        if (!decon) val = val / fac;                                 // forward.f90:202
+        dst[i - 1] = val;
+        if (i <= nsmp) mis[i - 1] = val - obs[i - 1];                // likelihood.f90:88
+    }
+    __syncthreads();
+
+    // ---- phi = (misfit . R^-1) . misfit   (likelihood.f90:92-93) -----------------
+    // wave w takes columns j = w, w+4, ...; lanes stride the rows of column j
+    // (column-major: coalesced), wave-level shuffle reduction.
+    const double *__restrict__ R = t.r_inv + (size_t)itrc * nsmp * nsmp;
+    const int wv = tid >> 6, lane = tid & 63;
+    double acc = 0.0;
+    for (int j = wv; j < nsmp; j += TRACE_THREADS / 64) {
+        const double *col = R + (size_t)j * nsmp;
+        double part = 0.0;
+        for (int i = lane; i < nsmp; i += 64) part = fma(mis[i], col[i], part);
+        part = wave_sum(part);                                       // phi1(j)
+        acc = fma(part, mis[j], acc);
+    }
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    if (tid == 0)
+        P.w.phi[((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+size_t trace_lds_bytes(int nfft, int nsmp)
+{
+    return sizeof(double2) * (size_t)nfft + sizeof(double) * (size_t)(((nsmp + 1) & ~1) + 8);
+}
+
+void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec, const WalkerState &w,
+                  hipStream_t s)
+{
+    TraceParams P{t, b, spec, w, 0};
+    while ((1 << P.log2n) < t.nfft) ++P.log2n;
+    const size_t lds = trace_lds_bytes(t.nfft, t.nsmp);
+    hipLaunchKernelGGL(trace_kernel, dim3((unsigned)(b.nb * t.ntrc)), dim3(TRACE_THREADS), lds, s, P);
+}
+
+// ---------------------------------------------------------------------------
+// K3  log-likelihood (likelihood.f90:86,94-96), one thread per batch item
+// ---------------------------------------------------------------------------
+struct LoglParams {
+    DeviceTables t;
+    BatchArgs b;
+    WalkerState w;
+};
+
+__global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
+{
+#pragma clang fp contract(off)
+    const int ib = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ib >= P.b.nb) return;
+    const int walker = P.b.walker_ids[ib];
+    const int fwd = P.b.fwd_flag ? P.b.fwd_flag[ib] : 1;
+    const int cur = P.w.cur_slot[walker];
+    // fwd_flag = .false. re-uses the stored trace (likelihood.f90:81): same phi
+    const int slot = fwd ? 1 - cur : cur;
+    const double *phi = P.w.phi + ((size_t)slot * P.w.nslots + walker) * P.t.ntrc;
+    double ll = 0.0;
+    for (int it = 0; it < P.t.ntrc; ++it) {
+        const double sg = P.b.sig[(size_t)ib * P.t.ntrc + it];
+        const double q = 0.5 * phi[it] / (sg * sg);
+        const double r = (double)P.t.nsmp * log(sg);
+        ll = ll - q - r;
+    }
+    P.b.logl[ib] = ll;
+    P.w.prop_fwd[walker] = fwd;
+}
+
+void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
+{
+    LoglParams P{t, b, w};
+    hipLaunchKernelGGL(logl_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P);
+}
+
+// ---------------------------------------------------------------------------
+// accept step (pt_mcmc.f90:190): flip the walker's current-trace slot
+// ---------------------------------------------------------------------------
+__global__ void commit_kernel(WalkerState w, int nb, const int *walker_ids, const int *accept)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int wk = walker_ids[i];
+    if (accept[i] && w.prop_fwd[wk]) w.cur_slot[wk] = 1 - w.cur_slot[wk];
+    w.prop_fwd[wk] = 0;
+}
+
+void launch_commit(const WalkerState &w, int nb, const int *walker_ids, const int *accept, int ntrc,
+                   hipStream_t s)
+{
+    (void)ntrc;
+    hipLaunchKernelGGL(commit_kernel, dim3((unsigned)((nb + 255) / 256)), dim3(256), 0, s, w, nb,
+                       walker_ids, accept);
+}
+
+// ---------------------------------------------------------------------------
+// judge_pt (pt_mcmc.f90:580-595) for a list of DISJOINT pairs, one thread per pair
+// (the reference proposes one pair per iteration; the batched schedule draws a
+// random partial matching, so no walker appears twice and pairs commute).
+// ---------------------------------------------------------------------------
+__global__ void pt_swap_kernel(int npairs, const int *pairs, const double *log_u, double *temps,
+                               const double *logl, int *accepted)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs) return;
+    const int c1 = pairs[2 * i], c2 = pairs[2 * i + 1];
+    const double t1 = temps[c1], t2 = temps[c2];
+    const double del_s = (logl[c2] - logl[c1]) * (1.0 / t1 - 1.0 / t2);
+    const int yn = log_u[i] <= del_s;
+    if (yn) {
+        temps[c2] = t1;
+        temps[c1] = t2;
+    }
+    if (accepted) accepted[i] = yn;
+}
+
+void launch_pt_swap(int npairs, const int *pairs, const double *log_u, double *temps, const double *logl,
+                    int *accepted, hipStream_t s)
+{
+    hipLaunchKernelGGL(pt_swap_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, npairs, pairs,
+                       log_u, temps, logl, accepted);
+}
+
+} // namespace rfgpu

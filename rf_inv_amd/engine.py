@@ -1,0 +1,203 @@
+"""RFEngine: one librfgpu context (one GPU), the object both interface mirrors
+(`Forward`, `Likelihood`) and the batched drivers talk to.  Thin: every method is
+one C-ABI call (include/rfgpu.h).  torch is used only for device buffers/streams
+in the *_device entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .params import NLAY_MAX, Params
+
+
+class RFGPUError(RuntimeError):
+    pass
+
+
+def _dptr(a):
+    return a.ctypes.data_as(_lib.dp)
+
+
+def _iptr(a):
+    return a.ctypes.data_as(_lib.ip)
+
+
+class RFEngine:
+    def __init__(self, *, nfft, delta, t_start, deconv_mode, sdep, rayps, a_gus, ipha, obs, nsmp,
+                 r_inv=None, max_walkers=1, nlay_max=NLAY_MAX, device=0):
+        """obs[ntrc, >= nsmp] (row t = trace t, the reference's obs(:, t));
+        r_inv[ntrc, nsmp, nsmp] with r_inv[t].ravel() == Fortran r_inv(:, :, t) or None."""
+        self._lib = _lib.load()
+        self.nfft, self.nsmp = int(nfft), int(nsmp)
+        self.nh = self.nfft // 2 + 1
+        self._rayps = np.ascontiguousarray(rayps, dtype=np.float64)
+        self._a_gus = np.ascontiguousarray(a_gus, dtype=np.float64)
+        self._ipha = np.ascontiguousarray(ipha, dtype=np.int32)
+        self.ntrc = int(self._rayps.size)
+        self._obs = np.ascontiguousarray(obs, dtype=np.float64)
+        if self._obs.ndim != 2 or self._obs.shape[0] != self.ntrc or self._obs.shape[1] < self.nsmp:
+            raise ValueError("obs must be [ntrc, >= nsmp]")
+        self._r_inv = None if r_inv is None else np.ascontiguousarray(r_inv, dtype=np.float64)
+        if self._r_inv is not None and self._r_inv.shape != (self.ntrc, self.nsmp, self.nsmp):
+            raise ValueError("r_inv must be [ntrc, nsmp, nsmp]")
+        self.max_walkers, self.nlay_max, self.device = int(max_walkers), int(nlay_max), int(device)
+        cfg = _lib.RFConfig(self.nfft, self.ntrc, self.nsmp, int(deconv_mode), float(delta), float(t_start),
+                            float(sdep), _dptr(self._rayps), _dptr(self._a_gus), _iptr(self._ipha),
+                            _dptr(self._obs), int(self._obs.shape[1]),
+                            _dptr(self._r_inv) if self._r_inv is not None else None,
+                            self.max_walkers, self.nlay_max, self.device)
+        self._ctx = C.c_void_p()
+        self._chk(self._lib.rf_ctx_create(C.byref(cfg), C.byref(self._ctx)))
+
+    @classmethod
+    def from_params(cls, p: Params, r_inv=None, max_walkers=None, nlay_max=None, device=0):
+        return cls(nfft=p.nfft, delta=p.delta, t_start=p.t_start, deconv_mode=p.deconv_mode, sdep=p.sdep,
+                   rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha, obs=p.obs, nsmp=p.nsmp, r_inv=r_inv,
+                   max_walkers=max_walkers or p.nchains,
+                   nlay_max=nlay_max or (p.k_max + 2), device=device)
+
+    # ------------------------------------------------------------------
+    def _chk(self, rc):
+        if rc != 0:
+            raise RFGPUError(self._lib.rf_last_error().decode())
+
+    def close(self):
+        if getattr(self, "_ctx", None) is not None and self._ctx:
+            self._lib.rf_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- tables --------------------------------------------------------
+    @property
+    def flt(self):
+        """flt(nh, ntrc) of module forward, Fortran-ordered (src/forward.f90:30)."""
+        out = np.empty((self.ntrc, self.nh))
+        self._chk(self._lib.rf_get_flt(self._ctx, _dptr(out)))
+        return out.T
+
+    @property
+    def is_ray_common(self):
+        f = C.c_int32()
+        self._chk(self._lib.rf_get_is_ray_common(self._ctx, C.byref(f)))
+        return bool(f.value)
+
+    @property
+    def r_inv(self):
+        out = np.empty((self.ntrc, self.nsmp, self.nsmp))
+        self._chk(self._lib.rf_get_r_inv(self._ctx, _dptr(out)))
+        return out
+
+    # ---- single evaluations ---------------------------------------------
+    def calc_rf(self, nlay, alpha, beta, rho, h):
+        """rft(nfft, ntrc) -- src/forward.f90:123-208."""
+        a, b, r, hh = (np.ascontiguousarray(x, dtype=np.float64) for x in (alpha, beta, rho, h))
+        out = np.empty((self.ntrc, self.nfft))
+        self._chk(self._lib.rf_calc_rf(self._ctx, int(nlay), _dptr(a), _dptr(b), _dptr(r), _dptr(hh), _dptr(out)))
+        return out.T
+
+    def calc_likelihood(self, walker, fwd_flag, nlay, alpha, beta, rho, h, sig, want_rft=True):
+        """(prop_log_likelihood, prop_rft(nfft, ntrc) or None) -- src/likelihood.f90:56-101
+        after format_model."""
+        a, b, r, hh = (np.ascontiguousarray(x, dtype=np.float64) for x in (alpha, beta, rho, h))
+        s = np.ascontiguousarray(sig, dtype=np.float64)
+        ll = C.c_double()
+        out = np.empty((self.ntrc, self.nfft)) if want_rft else None
+        self._chk(self._lib.rf_calc_likelihood(self._ctx, int(walker), int(bool(fwd_flag)), int(nlay), _dptr(a),
+                                               _dptr(b), _dptr(r), _dptr(hh), _dptr(s), C.byref(ll),
+                                               _dptr(out) if want_rft else None))
+        return ll.value, (out.T if want_rft else None)
+
+    # ---- batched -----------------------------------------------------------
+    def eval_batch(self, walker_ids, nlay, layers, sig, fwd_flag=None):
+        """layers[nb, 4, nlay_pad] (alpha, beta, rho, h), sig[nb, ntrc] -> logL[nb]."""
+        ids = np.ascontiguousarray(walker_ids, dtype=np.int32)
+        nl = np.ascontiguousarray(nlay, dtype=np.int32)
+        L = np.ascontiguousarray(layers, dtype=np.float64)
+        s = np.ascontiguousarray(sig, dtype=np.float64)
+        ff = None if fwd_flag is None else np.ascontiguousarray(fwd_flag, dtype=np.int32)
+        nb = ids.size
+        if L.shape[:2] != (nb, 4) or s.shape != (nb, self.ntrc) or nl.size != nb:
+            raise ValueError("bad batch shapes")
+        out = np.empty(nb)
+        self._chk(self._lib.rf_eval_batch(self._ctx, nb, _iptr(ids), _iptr(ff) if ff is not None else None,
+                                          _iptr(nl), int(L.shape[2]), _dptr(L), _dptr(s), _dptr(out)))
+        return out
+
+    def eval_batch_device(self, walker_ids, nlay, layers, sig, logl, fwd_flag=None, stream=None):
+        """Same with torch CUDA tensors (int32 / float64, contiguous); asynchronous on
+        `stream` (default: torch's current stream)."""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(layers.device)
+        nb = walker_ids.numel()
+        assert layers.dtype == torch.float64 and layers.is_contiguous() and layers.shape[:2] == (nb, 4)
+        assert sig.dtype == torch.float64 and sig.is_contiguous() and logl.dtype == torch.float64
+        assert walker_ids.dtype == torch.int32 and nlay.dtype == torch.int32
+        self._chk(self._lib.rf_eval_batch_device(
+            self._ctx, nb, walker_ids.data_ptr(), fwd_flag.data_ptr() if fwd_flag is not None else None,
+            nlay.data_ptr(), int(layers.shape[2]), layers.data_ptr(), sig.data_ptr(), logl.data_ptr(),
+            st.cuda_stream))
+
+    def commit(self, walker_ids, accept):
+        ids = np.ascontiguousarray(walker_ids, dtype=np.int32)
+        acc = np.ascontiguousarray(accept, dtype=np.int32)
+        self._chk(self._lib.rf_commit(self._ctx, ids.size, _iptr(ids), _iptr(acc)))
+
+    def commit_device(self, walker_ids, accept, stream=None):
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(walker_ids.device)
+        self._chk(self._lib.rf_commit_device(self._ctx, walker_ids.numel(), walker_ids.data_ptr(),
+                                             accept.data_ptr(), st.cuda_stream))
+
+    def get_rft(self, walker, which=0, n=None):
+        """rft(1:n, 1:ntrc, walker) (which=0) or the last proposal (which=1)."""
+        n = self.nfft if n is None else int(n)
+        out = np.empty((self.ntrc, n))
+        self._chk(self._lib.rf_get_rft(self._ctx, int(walker), int(which), n, _dptr(out)))
+        return out.T
+
+    def pt_swap_device(self, pairs, log_u, temps, logl, accepted=None, stream=None):
+        """judge_pt over pairs[npairs, 2] (torch int32), applied in order."""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(temps.device)
+        self._chk(self._lib.rf_pt_swap_device(self._ctx, pairs.shape[0], pairs.data_ptr(), log_u.data_ptr(),
+                                              temps.data_ptr(), logl.data_ptr(),
+                                              accepted.data_ptr() if accepted is not None else None,
+                                              st.cuda_stream))
+
+    # ---- instrumentation -----------------------------------------------------
+    def profile_enable(self, on=True):
+        self._chk(self._lib.rf_profile_enable(self._ctx, int(on)))
+
+    def profile_read(self, reset=True):
+        ms = np.zeros(3)
+        n = C.c_int64()
+        self._chk(self._lib.rf_profile_read(self._ctx, _dptr(ms), C.byref(n), int(reset)))
+        return {"spectra_ms": ms[0], "trace_ms": ms[1], "logl_ms": ms[2], "launches": n.value}
+
+
+def compute_r_inv(nsmp, a_gus, delta):
+    """librfgpu's own init_r_inv (one-sided Jacobi SVD): returns (r_inv[nsmp, nsmp]
+    with .ravel() == Fortran column-major r_inv(:, :), rank)."""
+    lib = _lib.load()
+    out = np.empty((nsmp, nsmp))
+    rank = C.c_int32()
+    if lib.rf_compute_r_inv(int(nsmp), float(a_gus), float(delta), _dptr(out), C.byref(rank)):
+        raise RFGPUError(lib.rf_last_error().decode())
+    return out, rank.value

@@ -1,0 +1,178 @@
+"""Parallel-tempering temperature exchange (reference src/pt_mcmc.f90:498-571).
+
+Walkers shard across ranks in contiguous blocks exactly like the reference's
+`global id -> (rank = id / nchains, chain = mod(id, nchains) + 1)` (:508-511);
+per-walker state never migrates, only temperatures move (:532-535, :551-554, :570).
+
+Two exchange protocols over torch.distributed (backend "nccl" = RCCL over xGMI on the
+GPU box, "gloo" in the CPU tests):
+
+  * mode="p2p"   -- the reference's protocol, one pair per iteration: the pair is drawn
+    by a replicated RNG (replacing rank 0's draw + mpi_bcast, :501-519); if it spans two
+    ranks, rank2 sends (T2, L2) to rank1 (:564-567), rank1 judges and returns the
+    temperature rank2 must hold (:544-556, :568-570).
+  * mode="allgather" -- throughput generalisation: K disjoint pairs per iteration; one
+    all_gather of every rank's (T, logL) (16 B / walker), after which every rank applies
+    the same decisions locally (device kernel rf_pt_swap_device) and keeps its own slice.
+    One collective per iteration whatever K is; xGMI is latency- not bandwidth-bound here.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def judge_pt(temp1, temp2, l1, l2, log_u):
+    """subroutine judge_pt (src/pt_mcmc.f90:580-595): accept iff log(u) <= del_s."""
+    return log_u <= (l2 - l1) * (1.0 / temp1 - 1.0 / temp2)
+
+
+def init_temps(nchains, ncool, t_high, rng):
+    """src/pt_mcmc.f90:444-452: first ncool chains at T = 1, the rest exp(u ln T_high)."""
+    t = np.ones(nchains)
+    for c in range(ncool, nchains):
+        t[c] = np.exp(rng.random() * np.log(t_high))
+    return t
+
+
+class PairSchedule:
+    """Replicated pair draws: every rank constructs it with the same seed and obtains the
+    same sequence, which replaces the reference's rank-0 draw + mpi_bcast (:501-519).
+    pairs_per_step = 1 reproduces the reference (two distinct global ids); more pairs
+    are drawn as a random partial matching (disjoint)."""
+
+    def __init__(self, n_all, seed, pairs_per_step=1):
+        if n_all < 2:
+            raise ValueError("need at least two walkers to swap")
+        self.n_all = n_all
+        self.k = min(int(pairs_per_step), n_all // 2)
+        self.rng = np.random.Generator(np.random.Philox(key=seed))
+
+    def draw(self):
+        if self.k == 1:
+            i1 = int(self.rng.random() * self.n_all)                 # :502
+            while True:
+                i2 = int(self.rng.random() * self.n_all)             # :503-506
+                if i2 != i1:
+                    break
+            pairs = np.array([[i1, i2]], dtype=np.int32)
+        else:
+            perm = self.rng.permutation(self.n_all)[: 2 * self.k]
+            pairs = perm.reshape(self.k, 2).astype(np.int32)
+        u = self.rng.random(self.k)
+        u = np.where(u <= 0.0, np.finfo(np.float64).tiny, u)
+        return pairs, np.log(u)
+
+
+class PTSwap:
+    """Temperature state of this rank's walkers + the exchange step."""
+
+    def __init__(self, engine, nchains, ntemps, device, seed=0, t_high=15.0, pairs_per_step=None,
+                 mode="allgather", cache_steps=256):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.engine = engine
+        self.nchains = int(nchains)
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.rank = dist.get_rank() if self.world > 1 else 0
+        self.device = torch.device(device)
+        self.mode = mode
+        n_all = self.world * self.nchains
+        ncool = max(1, self.nchains // max(1, int(ntemps)))
+        trng = np.random.Generator(np.random.Philox(key=seed + 7919 * (self.rank + 1)))
+        self.temps = torch.from_numpy(init_temps(self.nchains, ncool, t_high, trng)).to(self.device)
+        if pairs_per_step is None:
+            pairs_per_step = 1 if mode == "p2p" else max(1, n_all // 16)
+        self.sched = PairSchedule(n_all, seed, pairs_per_step)
+        self.k = self.sched.k
+        # pre-drawn schedule (replicated) so the step needs no host->device copy
+        self._cache = []
+        self._cache_steps = cache_steps
+        self._cursor = 0
+        self.n_accept = 0
+        if self.device.type == "cuda":
+            self._fill_cache()
+            self._gather = torch.empty((self.world, 2, self.nchains), dtype=torch.float64, device=self.device)
+            self._local = torch.empty((2, self.nchains), dtype=torch.float64, device=self.device)
+
+    def _fill_cache(self):
+        torch = self.torch
+        ps, us = zip(*(self.sched.draw() for _ in range(self._cache_steps)))
+        self._pairs = torch.from_numpy(np.stack(ps)).to(self.device)       # [S, K, 2] global ids
+        self._logu = torch.from_numpy(np.stack(us)).to(self.device)        # [S, K]
+        self._cursor = 0
+
+    # -- device, throughput mode ------------------------------------------------
+    def step(self, logl, stream=None):
+        """One exchange step on device tensors (logl[nchains] float64 on self.device)."""
+        torch, dist = self.torch, self.dist
+        if self.device.type != "cuda":
+            return self.step_host(logl)
+        if self._cursor >= self._cache_steps:
+            self._fill_cache()
+        pairs = self._pairs[self._cursor]
+        logu = self._logu[self._cursor]
+        self._cursor += 1
+        if self.world == 1:
+            self.engine.pt_swap_device(pairs, logu, self.temps, logl, None, stream)
+            return
+        self._local[0].copy_(self.temps)
+        self._local[1].copy_(logl)
+        dist.all_gather_into_tensor(self._gather, self._local)
+        # global id = rank * nchains + chain  (src/pt_mcmc.f90:508-511)
+        g_t = self._gather[:, 0, :].reshape(-1).contiguous()
+        g_l = self._gather[:, 1, :].reshape(-1).contiguous()
+        self.engine.pt_swap_device(pairs, logu, g_t, g_l, None, stream)
+        self.temps.copy_(g_t[self.rank * self.nchains:(self.rank + 1) * self.nchains])
+
+    # -- host tensors: the reference's p2p protocol and a host all_gather (gloo tests) ---
+    def step_host(self, logl):
+        """Host-resident variant (temps/logl CPU tensors or numpy): used by the Fortran-like
+        sequential host driver and by the gloo tests.  Returns the number of accepted
+        swaps that involved this rank."""
+        torch, dist = self.torch, self.dist
+        pairs, logu = self.sched.draw()
+        temps = self.temps.numpy() if hasattr(self.temps, "numpy") else self.temps
+        ll = logl.numpy() if hasattr(logl, "numpy") else np.asarray(logl)
+        nacc = 0
+        if self.mode == "allgather" and self.world > 1:
+            loc = torch.from_numpy(np.stack([temps, ll]))
+            out = [torch.empty_like(loc) for _ in range(self.world)]
+            dist.all_gather(out, loc)
+            g = torch.stack(out).numpy()
+            g_t = g[:, 0, :].reshape(-1).copy()
+            g_l = g[:, 1, :].reshape(-1)
+            for (i1, i2), lu in zip(pairs, logu):
+                if judge_pt(g_t[i1], g_t[i2], g_l[i1], g_l[i2], lu):
+                    g_t[i1], g_t[i2] = g_t[i2], g_t[i1]
+                    nacc += 1
+            temps[:] = g_t[self.rank * self.nchains:(self.rank + 1) * self.nchains]
+            self.n_accept += nacc
+            return nacc
+        for (i1, i2), lu in zip(pairs, logu):
+            r1, r2 = int(i1) // self.nchains, int(i2) // self.nchains       # :508-509
+            c1, c2 = int(i1) % self.nchains, int(i2) % self.nchains         # :510-511 (0-based)
+            if r1 == self.rank and r2 == self.rank:                         # :525-535
+                if judge_pt(temps[c1], temps[c2], ll[c1], ll[c2], lu):
+                    temps[c1], temps[c2] = temps[c2], temps[c1]
+                    nacc += 1
+            elif r1 == self.rank:                                           # :542-556
+                rp = torch.empty(2, dtype=torch.float64)
+                dist.recv(rp, src=r2, tag=2018)
+                t1, t2, e1, e2 = temps[c1], float(rp[0]), ll[c1], float(rp[1])
+                back = torch.tensor([t2], dtype=torch.float64)
+                if judge_pt(t1, t2, e1, e2, lu):
+                    temps[c1] = t2
+                    back[0] = t1
+                    nacc += 1
+                dist.send(back, dst=r2, tag=1988)
+            elif r2 == self.rank:                                           # :564-570
+                dist.send(torch.tensor([temps[c2], ll[c2]], dtype=torch.float64), dst=r1, tag=2018)
+                back = torch.empty(1, dtype=torch.float64)
+                dist.recv(back, src=r1, tag=1988)
+                if back[0] != temps[c2]:
+                    nacc += 1
+                temps[c2] = float(back[0])
+        self.n_accept += nacc
+        return nacc

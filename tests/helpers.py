@@ -1,0 +1,56 @@
+"""Shared synthetic-input builders for the parity tests (seeded, deterministic)."""
+import os
+
+import numpy as np
+
+DELTA = float(np.float32(0.05))
+
+
+def load_true_model(golden_dir):
+    return np.loadtxt(os.path.join(golden_dir, "sample_syn", "true", "true.velmod")).T
+
+
+def random_stack(rng, nlay, ocean=False, sdep=2.0):
+    """A physically valid layer stack (alpha, beta, rho, h); ocean prepends the
+    reference's water layer (model.f90:203-206)."""
+    alpha = rng.uniform(4.0, 7.5, nlay)
+    beta = alpha / rng.uniform(1.6, 1.9, nlay)
+    rho = 0.77 + 0.32 * alpha
+    h = rng.uniform(0.3, 4.0, nlay)
+    h[-1] = 999.0
+    if ocean:
+        alpha[0], beta[0], rho[0], h[0] = 1.5, -999.0, 1.0, sdep
+    return alpha, beta, rho, h
+
+
+def pack_layers(stacks, nlay_pad):
+    """list of (alpha, beta, rho, h) -> (nlay[nb], layers[nb, 4, nlay_pad])."""
+    nb = len(stacks)
+    layers = np.ones((nb, 4, nlay_pad))
+    nlay = np.zeros(nb, dtype=np.int32)
+    for i, st in enumerate(stacks):
+        n = len(st[0])
+        nlay[i] = n
+        for r in range(4):
+            layers[i, r, :n] = st[r]
+    return nlay, layers
+
+
+def make_cfg(nfft=256, deconv_mode=0, t_start=0.0, sdep=0.0, rayps=(0.06,), a_gus=None, ipha=None):
+    rayps = np.asarray(rayps, dtype=np.float64)
+    n = rayps.size
+    return dict(nfft=nfft, deconv_mode=deconv_mode, delta=DELTA, t_start=t_start, sdep=sdep,
+                rayps=rayps, a_gus=np.full(n, 4.0) if a_gus is None else np.asarray(a_gus, float),
+                ipha=np.ones(n, dtype=np.int32) if ipha is None else np.asarray(ipha, dtype=np.int32))
+
+
+def synth_obs(oracle, cfg, stack, nsmp):
+    """Noise-free observed traces of a fixed model, through the oracle."""
+    rft = oracle.calc_rf(cfg, *stack)
+    return np.ascontiguousarray(rft[:, :nsmp])
+
+
+def logl_tol(ref):
+    """|dlogL| bound: 1e-9 absolute (north star, stated at sigma = 0.01 and |logL| <~ 1e3),
+    relaxed to 1e-12 relative for large |logL|."""
+    return np.maximum(1e-9, 1e-12 * np.abs(ref))

@@ -1,0 +1,194 @@
+"""HIP path vs CPU oracle through the C ABI (include/rfgpu.h).  -m gpu only."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from helpers import DELTA, load_true_model, logl_tol, make_cfg, pack_layers, random_stack, synth_obs
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(cfg, obs, nsmp, r_inv, max_walkers=8, nlay_max=40):
+    from rf_inv_amd import RFEngine
+
+    return RFEngine(nfft=cfg["nfft"], delta=cfg["delta"], t_start=cfg["t_start"], deconv_mode=cfg["deconv_mode"],
+                    sdep=cfg["sdep"], rayps=cfg["rayps"], a_gus=cfg["a_gus"], ipha=cfg["ipha"], obs=obs,
+                    nsmp=nsmp, r_inv=r_inv, max_walkers=max_walkers, nlay_max=nlay_max)
+
+
+def test_library_is_the_hip_one():
+    from rf_inv_amd import _lib
+
+    lib = _lib.load()
+    assert lib.rf_abi_version() == 1
+    assert os.path.basename(_lib.LIB_PATH) == "librfgpu.so"
+
+
+@pytest.mark.parametrize("fname,rayp", [("sample_1.trc", 0.06), ("sample_2.trc", 0.08)])
+def test_kat_sample_syn_on_gpu(oracle, golden_dir, fname, rayp):
+    """The reference's own fixture, straight through the HIP path: every sample rounds to
+    the shipped float32 value."""
+    alpha, beta, rho, h = load_true_model(golden_dir)
+    obs, delta, nsmp = oracle.read_sac(os.path.join(golden_dir, "sample_syn", "data", fname), 0.0, 5.0)
+    cfg = make_cfg(rayps=[rayp])
+    with _engine(cfg, obs[None, :], nsmp, None) as eng:
+        rft = eng.calc_rf(3, alpha, beta, rho, h)
+    assert np.array_equal(rft[:nsmp, 0].astype(np.float32), obs.astype(np.float32))
+    ref = oracle.calc_rf(cfg, alpha, beta, rho, h)
+    assert np.abs(rft[:, 0] - ref[0]).max() < 1e-13
+
+
+CASES = [
+    # (name, nfft, deconv, sdep, rayps, ipha, t_start, nlays)
+    ("land_P", 256, 0, 0.0, (0.06,), (1,), 0.0, (2, 3, 9)),
+    ("land_P_decon", 256, 1, 0.0, (0.06,), (1,), -1.0, (2, 5)),
+    ("land_S", 256, 0, 0.0, (0.10,), (-1,), -2.0, (3, 9)),
+    ("land_S_decon", 256, 1, 0.0, (0.10,), (-1,), -1.0, (4,)),
+    ("land_PPS", 512, 0, 0.0, (0.06, 0.08, 0.10), (1, 1, -1), -1.0, (3, 15, 30)),
+    ("land_common", 256, 0, 0.0, (0.06, 0.06), (1, 1), 0.0, (3, 7)),
+    ("ocean_P", 256, 0, 2.0, (0.06, 0.08), (1, 1), 0.0, (3, 5, 11)),
+    ("ocean_PS_decon", 256, 1, 2.0, (0.06, 0.10), (1, -1), -1.0, (4, 8)),
+    ("ocean_S", 256, 0, 2.0, (0.10,), (-1,), -2.0, (5,)),
+    ("big_fft", 4096, 0, 0.0, (0.06,), (1,), 0.0, (15,)),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_batch_parity(oracle, case):
+    """rf_eval_batch: traces within 1e-12 of max|trace|, integer shifts identical by
+    construction of the trace equality, logL within the north-star tolerance."""
+    name, nfft, deconv, sdep, rayps, ipha, t_start, nlays = case
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
+    cfg = make_cfg(nfft=nfft, deconv_mode=deconv, t_start=t_start, sdep=sdep, rayps=rayps,
+                   a_gus=[4.0 if i % 2 == 0 else 2.5 for i in range(len(rayps))], ipha=ipha)
+    ocean = sdep > 0
+    nsmp = 101
+    true = random_stack(rng, 4, ocean, sdep)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = []
+    for nl in nlays:
+        for _ in range(3):
+            stacks.append(random_stack(rng, nl, ocean, sdep))
+    stacks.append(true)  # logL near its maximum: the 1e-9 absolute regime
+    nlay, layers = pack_layers(stacks, max(nlays) + 2)
+    nb = len(stacks)
+    sig = np.full((nb, len(rayps)), 0.01)
+    sig[:, -1] = 0.02
+    ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb) as eng:
+        ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+        for i in range(nb):
+            got = eng.get_rft(i, which=1).T  # [ntrc, nfft]
+            scale = np.abs(ref_rft[i]).max()
+            assert np.abs(got - ref_rft[i]).max() <= 1e-12 * scale, (name, i)
+    assert np.all(np.isfinite(ll))
+    assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), np.abs(ll - ref_ll).max()
+
+
+def test_single_call_dropins_and_state(oracle, golden_dir):
+    """rf_calc_likelihood (fwd / sigma-only), rf_commit, rf_get_rft follow
+    likelihood.f90:75-81 and pt_mcmc.f90:182-191."""
+    rng = np.random.default_rng(5)
+    cfg = make_cfg(rayps=[0.06, 0.08])
+    nsmp = 101
+    true = load_true_model(golden_dir)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    m1, m2 = random_stack(rng, 4), random_stack(rng, 6)
+    sig = np.array([0.01, 0.03])
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=2) as eng:
+        ll1, rft1 = eng.calc_likelihood(0, True, 4, *m1, sig)
+        ref1 = oracle.calc_rf(cfg, *m1)
+        assert np.abs(rft1.T - ref1).max() < 1e-12 * np.abs(ref1).max()
+        o1 = oracle.log_likelihood(ref1, obs, r_inv, sig, nsmp)
+        assert abs(ll1 - o1) <= logl_tol(o1)
+        eng.commit([0], [1])                       # accept: proposal becomes current
+        assert np.array_equal(eng.get_rft(0, 0), rft1)
+        # sigma-only proposal re-uses the stored trace
+        sig2 = np.array([0.02, 0.03])
+        ll1b, rft1b = eng.calc_likelihood(0, False, 2, np.ones(2), np.ones(2), np.ones(2), np.ones(2), sig2)
+        o1b = oracle.log_likelihood(ref1, obs, r_inv, sig2, nsmp)
+        assert abs(ll1b - o1b) <= logl_tol(o1b)
+        assert np.array_equal(rft1b, rft1)
+        # rejected forward proposal leaves the current trace untouched
+        ll2, rft2 = eng.calc_likelihood(0, True, 6, *m2, sig)
+        eng.commit([0], [0])
+        assert np.array_equal(eng.get_rft(0, 0), rft1)
+        assert not np.array_equal(rft2, rft1)
+        # first nsmp samples only
+        assert np.array_equal(eng.get_rft(0, 0, n=nsmp), rft1[:nsmp])
+
+
+def test_nan_propagates_not_traps(oracle, golden_dir):
+    cfg = make_cfg(rayps=[0.25])  # p > 1/alpha: evanescent
+    nsmp = 101
+    true = load_true_model(golden_dir)
+    obs = np.zeros((1, nsmp))
+    with _engine(cfg, obs, nsmp, None, max_walkers=1) as eng:
+        ll, rft = eng.calc_likelihood(0, True, 3, *true, np.array([0.01]))
+    assert np.isnan(ll) and np.isnan(rft).all()
+
+
+def test_nsplit_and_bins_variants_agree(oracle, monkeypatch):
+    """Launch-shape knobs must not change results beyond rounding (they only re-partition bins)."""
+    rng = np.random.default_rng(11)
+    cfg = make_cfg(nfft=1024, rayps=[0.06])
+    nsmp = 101
+    true = random_stack(rng, 5)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    stacks = [random_stack(rng, 12) for _ in range(4)]
+    nlay, layers = pack_layers(stacks, 14)
+    sig = np.full((4, 1), 0.01)
+    outs = []
+    for ns, bins in [("1", "1"), ("3", "1"), ("1", "2"), ("4", "2")]:
+        monkeypatch.setenv("RFGPU_NSPLIT", ns)
+        monkeypatch.setenv("RFGPU_BINS_PER_LANE", bins)
+        with _engine(cfg, obs, nsmp, None, max_walkers=4) as eng:
+            outs.append((eng.eval_batch(np.arange(4), nlay, layers, sig), eng.get_rft(2, 1)))
+    for ll, rft in outs[1:]:
+        assert np.array_equal(ll, outs[0][0])
+        assert np.array_equal(rft, outs[0][1])
+
+
+def test_full_size_properties(oracle):
+    """BASELINE config-2 shape (nfft 4096, 15 layers, 1024 walkers): properties that do
+    not need the oracle at full size + a sampled oracle check."""
+    rng = np.random.default_rng(2)
+    cfg = make_cfg(nfft=4096, rayps=[0.06])
+    nsmp = 101
+    true = random_stack(rng, 4)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    nb = 1024
+    stacks = [random_stack(rng, int(rng.integers(2, 16))) for _ in range(nb - 1)] + [true]
+    nlay, layers = pack_layers(stacks, 16)
+    sig = np.full((nb, 1), 0.01)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb) as eng:
+        ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+        # (1) permutation invariance: walkers are independent
+        perm = rng.permutation(nb)
+        ll_p = eng.eval_batch(np.arange(nb), nlay[perm], layers[perm], sig)
+        assert np.array_equal(ll_p, ll[perm])
+        # (2) the true model maximises logL: misfit is ~0 so logL = -nsmp log(sigma)
+        assert abs(ll[-1] - (-nsmp * np.log(0.01))) < 1e-6
+        assert np.all(ll[:-1] < ll[-1])
+        # (3) sigma rescaling identity: phi is sigma-independent
+        ll2 = eng.eval_batch(np.arange(nb), nlay, layers, 2 * sig)
+        phi = -2 * (ll + nsmp * np.log(0.01)) * 0.01 ** 2
+        assert np.allclose(ll2, -0.5 * phi / 0.02 ** 2 - nsmp * np.log(0.02), rtol=1e-12, atol=1e-9)
+    # (4) sampled oracle parity
+    idx = rng.choice(nb, 16, replace=False)
+    ref = oracle.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], nsmp)
+    assert np.all(np.abs(ll[idx] - ref) <= logl_tol(ref))
+
+
+def test_r_inv_builtin_matches_lapack(oracle):
+    from rf_inv_amd.engine import compute_r_inv
+
+    r, rank = compute_r_inv(101, 4.0, DELTA)
+    ref, ranks = oracle.build_r_inv(101, [4.0], DELTA, return_rank=True)
+    assert rank == ranks[0] == 40
+    assert np.abs(r - ref[0]).max() <= 1e-11 * np.abs(ref[0]).max()
