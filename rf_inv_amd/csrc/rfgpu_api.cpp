@@ -39,6 +39,7 @@ struct rf_ctx {
     // owned device allocations
     std::vector<void *> owned;
     double2 *spec = nullptr; // [nslots][nfwd][2][nh]
+    int *slow_list = nullptr, *slow_count = nullptr; // walkers deferred to the generic-sincos kernel
     // staging for host-buffer calls
     int *d_ids = nullptr, *d_fwd = nullptr, *d_nlay = nullptr, *d_acc = nullptr;
     double *d_layers = nullptr, *d_sig = nullptr, *d_logl = nullptr;
@@ -273,7 +274,12 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     T.delta = cfg->delta; T.t_start = cfg->t_start; T.sdep = cfg->sdep;
     T.domg = 2.0 * pi / (n * cfg->delta);   // forward.f90:241
     T.omg_dc = (double)1.0e-5f;             // forward.f90:247 single-precision literal
-    if (upload(c, c->flt, &T.flt) || upload(c, obs, &T.obs) || upload(c, c->r_inv, &T.r_inv) ||
+    std::vector<double> r_inv_t(c->r_inv.size());
+    for (int t = 0; t < ntrc; ++t)
+        for (int j = 0; j < nsmp; ++j)
+            for (int i = 0; i < nsmp; ++i)
+                r_inv_t[((size_t)t * nsmp + i) * nsmp + j] = c->r_inv[((size_t)t * nsmp + j) * nsmp + i];
+    if (upload(c, c->flt, &T.flt) || upload(c, obs, &T.obs) || upload(c, r_inv_t, &T.r_inv_t) ||
         upload(c, rayps, &T.rayps) || upload(c, ipha, &T.ipha) || upload(c, tw, &T.twiddle))
         return cleanup(1);
 
@@ -295,6 +301,10 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     c->ws.nslots = c->nslots;
     if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * c->nfwd * 2 * nh)) return cleanup(1);
     c->spec = (double2 *)p;
+    if (dev_alloc(c, &p, sizeof(int) * ((size_t)c->nslots * c->nfwd + 1))) return cleanup(1);
+    c->slow_list = (int *)p + 1;
+    c->slow_count = (int *)p;
+    hipMemset(p, 0, sizeof(int));
 
     if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || trace_lds_bytes(n, nsmp) > 160 * 1024)
         return cleanup(fail("rf_ctx_create: nfft / nsmp / nlay_max exceed the 160 KiB LDS of a gfx950 CU"));
@@ -370,11 +380,15 @@ static rf_ctx::EvQuad *next_quad(rf_ctx *c)
 
 static int pick_nsplit(const rf_ctx *c, int nb)
 {
-    // fill >= ~8 waves per CU; never split below one 64-bin iteration per wave
+    // Walkers differ in depth (2..k_max layers), so one wave per walker leaves a long
+    // tail; splitting the bin iterations of a walker over several waves (interleaved, so
+    // every split sees the same layer count) evens it out.  Aim at >= 32 waves per CU
+    // (measured on MI355X: c2 1024 walkers 2.6 -> 4.1 M evals/s from 1 -> 8 splits; c4 with
+    // 24576 (walker, trace) waves is best unsplit); never below one 64-bin iteration per wave.
     const int per_iter = 64 * c->bins_per_lane;
     const int niter = (c->nh + per_iter - 1) / per_iter;
     const long waves = (long)nb * c->nfwd;
-    const long want = 8L * c->num_cu;
+    const long want = 32L * c->num_cu;
     int ns = (int)std::min<long>(niter, std::max<long>(1, (want + waves - 1) / waves));
     const char *env = getenv("RFGPU_NSPLIT");
     if (env && atoi(env) > 0) ns = std::min(niter, atoi(env));
@@ -389,11 +403,11 @@ static int run_batch(rf_ctx *c, const BatchArgs &b, hipStream_t s)
     HIP_TRY(hipSetDevice(c->device));
     rf_ctx::EvQuad *q = c->prof ? next_quad(c) : nullptr;
     if (q) hipEventRecord(q->e[0], s);
-    launch_spectra(c->tab, b, c->spec, pick_nsplit(c, b.nb), c->bins_per_lane, s);
+    launch_spectra(c->tab, b, c->spec, pick_nsplit(c, b.nb), c->bins_per_lane, c->slow_list, c->slow_count, s);
     if (q) hipEventRecord(q->e[1], s);
     launch_trace(c->tab, b, c->spec, c->ws, s);
     if (q) hipEventRecord(q->e[2], s);
-    launch_logl(c->tab, b, c->ws, s);
+    launch_logl(c->tab, b, c->ws, c->slow_count, s);
     if (q) hipEventRecord(q->e[3], s);
     HIP_TRY(hipGetLastError());
     return 0;

@@ -14,7 +14,7 @@ struct DeviceTables {
     double delta, t_start, sdep, domg, omg_dc;
     const double *flt;      // [ntrc][nh]
     const double *obs;      // [ntrc][nsmp]
-    const double *r_inv;    // [ntrc][nsmp*nsmp]  column-major blocks
+    const double *r_inv_t;  // [ntrc][nsmp*nsmp]  r_inv(i,j) at [i*nsmp + j] (transposed image)
     const double *rayps;    // [ntrc]
     const int *ipha;        // [ntrc]
     const double2 *twiddle; // [nfft/2]  exp(+2 pi i k / nfft)
@@ -41,12 +41,13 @@ struct WalkerState {
 // K1: propagator-matrix spectra  -> spec[nb][nfwd][2][nh] (freq_r, freq_v after
 // the conj / -conj of forward.f90:145-146)
 void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit,
-                    int bins_per_lane, hipStream_t s);
+                    int bins_per_lane, int *slow_list, int *slow_count, hipStream_t s);
 // K2: decon / filter / c2r / shift / normalise / write trace / quadratic form
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec,
                   const WalkerState &w, hipStream_t s);
 // K3: log-likelihood from the per-trace quadratic forms
-void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
+void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count,
+                 hipStream_t s);
 void launch_commit(const WalkerState &w, int nb, const int *walker_ids, const int *accept,
                    int ntrc, hipStream_t s);
 void launch_pt_swap(int npairs, const int *pairs, const double *log_u, double *temps,

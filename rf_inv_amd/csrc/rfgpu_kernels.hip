@@ -109,19 +109,76 @@ __device__ __forceinline__ void stage_halfspace(double *g, double alpha, double 
     g[7] = 1.0 / (2.0 * rho * beta);       // im: B3
 }
 
+// ---------------------------------------------------------------------------
+// sincos for the propagator phases.  The reference calls libm sin/cos on the double
+// (omega*xi)*z (forward.f90:397-400); arguments reach a few hundred radians.  ocml's
+// sincos reduces EVERY argument with the Payne-Hanek v_trig_preop path (~150
+// instructions); this one uses a 3-term Cody-Waite reduction with FMA, exact for
+// |n| < 2^20, and minimax kernels on [-pi/4, pi/4] (the classic fdlibm k_sin/k_cos
+// coefficient sets), ~40 instructions, abs. error <= 1.4 ulp(1) (glibc: 0.5).  Valid
+// for |x| < 2^20 * pi/2; the kernel checks the largest phase of a walker once, while
+// staging its layers, and sends walkers beyond 1e6 rad (never seen with physical
+// inputs) through an out-of-line ocml-sincos body instead.  NaN / Inf propagate.
+// ---------------------------------------------------------------------------
+constexpr double SINCOS_CW_LIMIT = 1.0e6;
+
+__device__ __forceinline__ void sincos_cw(double x, double &sn, double &cs)
+{
+    constexpr double INV_PIO2 = 6.36619772367581382433e-01;
+    constexpr double PIO2_1 = 1.57079632673412561417e+00;  // first 33 bits of pi/2
+    constexpr double PIO2_2 = 6.07710050630396597660e-11;  // next 33 bits
+    constexpr double PIO2_3 = 2.02226624879595063154e-21;  // pi/2 - PIO2_1 - PIO2_2
+    const double fn = rint(x * INV_PIO2);
+    const int q = (int)fn;
+    const double r0 = fma(-fn, PIO2_1, x);       // exact: fn * PIO2_1 has <= 53 bits
+    const double r = fma(-fn, PIO2_2, r0);       // one rounding, captured below
+    double lo = fma(-fn, PIO2_2, r0 - r);
+    lo = fma(-fn, PIO2_3, lo);
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    double s0 = fma(r * z, ps, r);               // sin(r)
+    double c0 = fma(z, fma(z, pc, -0.5), 1.0);   // cos(r)
+    const double s1 = fma(lo, c0, s0);           // sin(r + lo)
+    const double c1 = fma(-lo, s0, c0);          // cos(r + lo)
+    // quadrant: q&1 swaps, signs from q&2 / (q+1)&2
+    const bool sw = q & 1;
+    double ss = sw ? c1 : s1;
+    double cc = sw ? s1 : c1;
+    sn = (q & 2) ? -ss : ss;
+    cs = ((q + 1) & 2) ? -cc : cc;
+}
+
 template <int NCOL>
 struct ColState {
     double v[NCOL][4];
 };
 
 // one layer applied to NCOL real column vectors:  v <- A v
-template <int NCOL>
+template <bool FAST>
+__device__ __forceinline__ void phase_sincos(double x, double &sn, double &cs)
+{
+    if (FAST)
+        sincos_cw(x, sn, cs);
+    else
+        sincos(x, &sn, &cs);
+}
+
+template <int NCOL, bool FAST>
 __device__ __forceinline__ void apply_layer(ColState<NCOL> &s, const double *__restrict__ c, double omg)
 {
     double sx, cx, se, ce;
     // argument formed exactly like the reference: (omega * xi) * z  (forward.f90:397-400)
-    sincos((omg * c[0]) * c[2], &sx, &cx);
-    sincos((omg * c[1]) * c[2], &se, &ce);
+    phase_sincos<FAST>((omg * c[0]) * c[2], sx, cx);
+    phase_sincos<FAST>((omg * c[1]) * c[2], se, ce);
     const double a = fma(c[3], cx, c[4] * ce);    // A11 = A33
     const double e = fma(c[4], cx, c[3] * ce);    // A22 = A44
     const double d = cx - ce;
@@ -150,7 +207,7 @@ __device__ __forceinline__ double2 halfspace_row(const double *g, const double *
     return make_double2(fma(g[1], v[3], g[0] * v[0]), fma(g[3], v[2], g[2] * v[1]));
 }
 
-template <int NCOL>
+template <int NCOL, bool FAST>
 __device__ __forceinline__ void finish_bin(const ColState<NCOL> &s, const double *tail, double omg,
                                            int ipha, double2 &ur, double2 &uz)
 {
@@ -178,7 +235,7 @@ __device__ __forceinline__ void finish_bin(const ColState<NCOL> &s, const double
         const double2 t34 = halfspace_row(tail, s.v[NCOL - 1]);
         const double2 t44 = halfspace_row(tail + 4, s.v[NCOL - 1]);
         double sw, cw;
-        sincos((omg * tail[8]) * tail[9], &sw, &cw);
+        phase_sincos<FAST>((omg * tail[8]) * tail[9], sw, cw);
         const double q = tail[10] * sw;                       // (rho_w / xi_w) sin
         const double2 s44l = make_double2(-t44.y * q, t44.x * q); // i T44 q
         const double2 s34l = make_double2(-t34.y * q, t34.x * q);
@@ -201,13 +258,15 @@ struct SpectraParams {
     BatchArgs b;
     double2 *spec;
     int nsplit;
+    int *slow_list;   // [nslots * nfwd] (walker, trace) pairs deferred to spectra_slow_kernel
+    int *slow_count;  // [1] reset by logl_kernel
 };
 
 // One wave (64 lanes) per (walker, forward-trace, bin-split).  Lanes own frequency
 // bins (coalesced 16-B stores of the spectra); the layer stack of the walker is staged
 // in LDS as precomputed coefficients and broadcast to all lanes; the 4x4 chain runs in
 // registers, BINS bins per lane at a time for instruction-level parallelism.
-template <int BINS, int NCOL>
+template <int BINS, int NCOL, bool FAST>
 __device__ __forceinline__ void spectra_body(const SpectraParams &P, const double *coef,
                                              const double *tail, int nl, int ilay0, int ipha,
                                              double2 *__restrict__ out_r, double2 *__restrict__ out_v,
@@ -237,12 +296,12 @@ __device__ __forceinline__ void spectra_body(const SpectraParams &P, const doubl
         for (int l = ilay0; l < nl - 1; ++l) {
             const double *c = coef + l * NCOEF;
 #pragma unroll
-            for (int q = 0; q < BINS; ++q) apply_layer<NCOL>(st[q], c, omg[q]);
+            for (int q = 0; q < BINS; ++q) apply_layer<NCOL, FAST>(st[q], c, omg[q]);
         }
 #pragma unroll
         for (int q = 0; q < BINS; ++q) {
             double2 ur, uz;
-            finish_bin<NCOL>(st[q], tail, omg[q], ipha, ur, uz);
+            finish_bin<NCOL, FAST>(st[q], tail, omg[q], ipha, ur, uz);
             if (kbin[q] < nh) {
                 out_r[kbin[q]] = make_double2(ur.x, -ur.y);  // freq_r = conjg(ur)   forward.f90:145
                 out_v[kbin[q]] = make_double2(-uz.x, uz.y);  // freq_v = -conjg(uz)  forward.f90:146
@@ -251,29 +310,26 @@ __device__ __forceinline__ void spectra_body(const SpectraParams &P, const doubl
     }
 }
 
-template <int BINS>
-__global__ __launch_bounds__(64) void spectra_kernel(SpectraParams P)
+// Stages the layer stack of (walker ib, forward-trace f) into LDS; returns true when some
+// phase of the walker leaves the Cody-Waite range of sincos_cw.
+__device__ __forceinline__ bool stage_walker(const SpectraParams &P, int ib, int f, double *coef, double *tail,
+                                             int &nl, int &ilay0, bool &sea)
 {
-    extern __shared__ double lds[];
     const int lane = threadIdx.x;
-    const int split = blockIdx.x % P.nsplit;
-    const int bf = blockIdx.x / P.nsplit;
-    const int f = bf % P.t.nfwd;
-    const int ib = bf / P.t.nfwd;
-    if (P.b.fwd_flag && !P.b.fwd_flag[ib]) return;
-
-    const int nl = P.b.nlay[ib];
+    nl = P.b.nlay[ib];
     const int pad = P.b.nlay_pad;
     const double *L = P.b.layers + (size_t)ib * 4 * pad;
     const double p = P.t.rayps[f];
-    const int ipha = P.t.ipha[f];
-    const bool sea = L[pad] < 0.0;          // beta(1) < 0  (forward.f90:229)
-    const int ilay0 = sea ? 1 : 0;
-
-    double *coef = lds;
-    double *tail = lds + (size_t)pad * NCOEF;
+    sea = L[pad] < 0.0;          // beta(1) < 0  (forward.f90:229)
+    ilay0 = sea ? 1 : 0;
+    const double omg_max = (double)(P.t.nh - 1) * P.t.domg;
+    bool big = false;
     for (int l = lane; l < nl - 1; l += 64)
-        if (l >= ilay0) stage_layer_coef(coef + l * NCOEF, L[l], L[pad + l], L[2 * pad + l], L[3 * pad + l], p);
+        if (l >= ilay0) {
+            double *c = coef + l * NCOEF;
+            stage_layer_coef(c, L[l], L[pad + l], L[2 * pad + l], L[3 * pad + l], p);
+            big |= fabs(omg_max * fmax(c[0], c[1]) * c[2]) >= SINCOS_CW_LIMIT;
+        }
     if (lane == 0) {
         stage_halfspace(tail, L[nl - 1], L[pad + nl - 1], L[2 * pad + nl - 1], p);
         if (sea) {
@@ -281,30 +337,87 @@ __global__ __launch_bounds__(64) void spectra_kernel(SpectraParams P)
             tail[8] = xiw;
             tail[9] = L[3 * pad];
             tail[10] = L[2 * pad] / xiw;
+            big |= fabs(omg_max * xiw * L[3 * pad]) >= SINCOS_CW_LIMIT;
         }
     }
+    big = __any(big);
     __syncthreads();
+    return big;
+}
 
+template <int BINS>
+__global__ __launch_bounds__(64) void spectra_kernel(SpectraParams P)
+{
+    extern __shared__ double lds[];
+    const int split = blockIdx.x % P.nsplit;
+    const int bf = blockIdx.x / P.nsplit;
+    const int f = bf % P.t.nfwd;
+    const int ib = bf / P.t.nfwd;
+    if (P.b.fwd_flag && !P.b.fwd_flag[ib]) return;
+
+    double *coef = lds;
+    double *tail = lds + (size_t)P.b.nlay_pad * NCOEF;
+    int nl, ilay0;
+    bool sea;
+    const bool big = stage_walker(P, ib, f, coef, tail, nl, ilay0, sea);
+    if (big) {
+        // rare: hand the walker to spectra_slow_kernel (generic sincos) via the list
+        if (split == 0 && threadIdx.x == 0) P.slow_list[atomicAdd(P.slow_count, 1)] = bf;
+        return;
+    }
+    const int ipha = P.t.ipha[f];
     double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
     double2 *out_v = out_r + P.t.nh;
     if (sea)
-        spectra_body<BINS, 3>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
+        spectra_body<BINS, 3, true>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
     else
-        spectra_body<BINS, 2>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
+        spectra_body<BINS, 2, true>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
+}
+
+// walkers whose phases exceed the Cody-Waite range (|x| >= 1e6 rad): same body with ocml's
+// generic sincos, in its own kernel so its registers do not burden the fast path.  Fixed
+// small grid striding over the (normally empty) list.
+__global__ __launch_bounds__(64) void spectra_slow_kernel(SpectraParams P)
+{
+    extern __shared__ double lds[];
+    const int count = *P.slow_count;
+    for (int e = blockIdx.x; e < count * P.nsplit; e += gridDim.x) {
+        const int bf = P.slow_list[e / P.nsplit];
+        const int split = e % P.nsplit;
+        const int f = bf % P.t.nfwd;
+        const int ib = bf / P.t.nfwd;
+        double *coef = lds;
+        double *tail = lds + (size_t)P.b.nlay_pad * NCOEF;
+        int nl, ilay0;
+        bool sea;
+        __syncthreads();
+        stage_walker(P, ib, f, coef, tail, nl, ilay0, sea);
+        const int ipha = P.t.ipha[f];
+        double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
+        double2 *out_v = out_r + P.t.nh;
+        if (sea)
+            spectra_body<1, 3, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
+        else
+            spectra_body<1, 2, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
+    }
 }
 
 size_t spectra_lds_bytes(int nlay_pad) { return sizeof(double) * ((size_t)nlay_pad * NCOEF + 16); }
 
 void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit,
-                    int bins_per_lane, hipStream_t s)
+                    int bins_per_lane, int *slow_list, int *slow_count, hipStream_t s)
 {
-    SpectraParams P{t, b, spec, nsplit};
+    SpectraParams P{t, b, spec, nsplit, slow_list, slow_count};
     const dim3 grid((unsigned)(b.nb * t.nfwd * nsplit));
     const size_t lds = spectra_lds_bytes(b.nlay_pad);
     if (bins_per_lane == 2)
         hipLaunchKernelGGL(spectra_kernel<2>, grid, dim3(64), lds, s, P);
     else
         hipLaunchKernelGGL(spectra_kernel<1>, grid, dim3(64), lds, s, P);
+    // the slow kernel partitions bins by 64 per iteration (BINS = 1)
+    const int niter1 = (t.nh + 63) / 64;
+    P.nsplit = nsplit < niter1 ? nsplit : niter1;
+    hipLaunchKernelGGL(spectra_slow_kernel, dim3(512), dim3(64), lds, s, P);
 }
 
 // ---------------------------------------------------------------------------
@@ -495,18 +608,19 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
     __syncthreads();
 
     // ---- phi = (misfit . R^-1) . misfit   (likelihood.f90:92-93) -----------------
-    // wave w takes columns j = w, w+4, ...; lanes stride the rows of column j
-    // (column-major: coalesced), wave-level shuffle reduction.
-    const double *__restrict__ R = t.r_inv + (size_t)itrc * nsmp * nsmp;
-    const int wv = tid >> 6, lane = tid & 63;
+    // thread j owns column j: phi1(j) = sum_i misfit(i) r_inv(i,j), i ascending exactly
+    // like the reference's matmul.  r_inv_t holds r_inv transposed (row-major image), so
+    // for a fixed i consecutive threads read consecutive addresses (coalesced, L2-resident);
+    // misfit(i) is an LDS broadcast.
+    const double *__restrict__ RT = t.r_inv_t + (size_t)itrc * nsmp * nsmp;
     double acc = 0.0;
-    for (int j = wv; j < nsmp; j += TRACE_THREADS / 64) {
-        const double *col = R + (size_t)j * nsmp;
-        double part = 0.0;
-        for (int i = lane; i < nsmp; i += 64) part = fma(mis[i], col[i], part);
-        part = wave_sum(part);                                       // phi1(j)
-        acc = fma(part, mis[j], acc);
+    for (int j = tid; j < nsmp; j += TRACE_THREADS) {
+        double phi1 = 0.0;
+        for (int i = 0; i < nsmp; ++i) phi1 = fma(mis[i], RT[(size_t)i * nsmp + j], phi1);
+        acc = fma(phi1, mis[j], acc);
     }
+    acc = wave_sum(acc);
+    const int wv = tid >> 6, lane = tid & 63;
     if (lane == 0) red[wv] = acc;
     __syncthreads();
     if (tid == 0)
@@ -534,12 +648,14 @@ struct LoglParams {
     DeviceTables t;
     BatchArgs b;
     WalkerState w;
+    int *slow_count;
 };
 
 __global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
 {
 #pragma clang fp contract(off)
     const int ib = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ib == 0) *P.slow_count = 0;   // re-arm the deferred-walker list for the next batch
     if (ib >= P.b.nb) return;
     const int walker = P.b.walker_ids[ib];
     const int fwd = P.b.fwd_flag ? P.b.fwd_flag[ib] : 1;
@@ -558,9 +674,10 @@ __global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
     P.w.prop_fwd[walker] = fwd;
 }
 
-void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
+void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count,
+                 hipStream_t s)
 {
-    LoglParams P{t, b, w};
+    LoglParams P{t, b, w, slow_count};
     hipLaunchKernelGGL(logl_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P);
 }
 

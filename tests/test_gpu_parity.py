@@ -192,3 +192,28 @@ def test_r_inv_builtin_matches_lapack(oracle):
     ref, ranks = oracle.build_r_inv(101, [4.0], DELTA, return_rank=True)
     assert rank == ranks[0] == 40
     assert np.abs(r - ref[0]).max() <= 1e-11 * np.abs(ref[0]).max()
+
+
+def test_huge_phase_takes_generic_sincos_kernel(oracle):
+    """A layer so thick that omega*eta*h > 1e6 rad leaves the Cody-Waite range: the
+    walker is deferred to spectra_slow_kernel (ocml sincos).  Mixed batch: the other
+    walkers stay on the fast path; results of both agree with the oracle."""
+    rng = np.random.default_rng(21)
+    cfg = make_cfg(nfft=256, rayps=[0.06, 0.08])
+    nsmp = 101
+    true = random_stack(rng, 4)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, 5) for _ in range(6)]
+    for i in (1, 4):
+        stacks[i][3][2] = 2.0e5  # km
+    nlay, layers = pack_layers(stacks, 7)
+    sig = np.full((6, 2), 0.05)
+    ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=6) as eng:
+        for rep in range(2):  # twice: the deferred list must re-arm between batches
+            ll = eng.eval_batch(np.arange(6), nlay, layers, sig)
+            assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (rep, np.abs(ll - ref_ll))
+        for i in range(6):
+            got = eng.get_rft(i, which=1).T
+            assert np.abs(got - ref_rft[i]).max() <= 1e-11 * np.abs(ref_rft[i]).max(), i
