@@ -234,8 +234,8 @@ def main():
         assert np.all(np.isfinite(ll_gpu)), "non-finite logL in the benchmark batch"
 
         f_spec, f_tot, b_alg = alg_work(p, nlay.astype(np.float64), eng.is_ray_common)
-        n_l = max(prof["launches"], 1)
-        spectra_ms = prof["spectra_ms"] / n_l
+        n_l = max(prof["launches"], 1)          # batches timed
+        spectra_ms = prof["spectra_ms"] / n_l   # spectra kernel time per batch (one launch per batch)
         res = {
             "value": world * nb * steps / dt,
             "ms_per_step": 1e3 * dt / steps,

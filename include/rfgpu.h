@@ -136,8 +136,10 @@ int rf_pt_swap_device(rf_ctx *ctx, int32_t npairs, const int32_t *d_pairs, const
                       double *d_temps, const double *d_logl, int32_t *d_accepted, void *stream);
 
 /* ---- instrumentation ----------------------------------------------------- */
-/* HIP-event timing of the three kernels of rf_eval_batch*, accumulated while
- * enabled.  ms[3] = spectra, trace, logl totals; launches = batches timed. */
+/* HIP-event timing (on the streams the kernels are launched on) of the three kernels
+ * of rf_eval_batch*, accumulated while enabled.  ms[3] = spectra, trace, logl totals;
+ * launches[4] = batches timed, then spectra / trace / logl kernel launches (a batch is
+ * pipelined in chunks, so there can be several spectra / trace launches per batch). */
 int rf_profile_enable(rf_ctx *ctx, int32_t on);
 int rf_profile_read(rf_ctx *ctx, double *ms, int64_t *launches, int32_t reset);
 

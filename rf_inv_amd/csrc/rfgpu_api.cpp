@@ -53,11 +53,11 @@ struct rf_ctx {
     // profiling: a pool of event quads so that timing never synchronises inside a
     // timed loop (flushed lazily / when the pool is exhausted)
     bool prof = false;
-    struct EvQuad { hipEvent_t e[4]; };
-    std::vector<EvQuad> ev_pool;
+    struct Timed { int kind; hipEvent_t e0, e1; };
+    std::vector<Timed> ev_pool;
     size_t ev_used = 0;
     double prof_ms[3] = {0, 0, 0};
-    int64_t prof_n = 0;
+    int64_t prof_n[4] = {0, 0, 0, 0};   // batches, spectra / trace / logl kernel launches
 };
 
 extern "C" const char *rf_last_error(void) { return g_err.c_str(); }
@@ -291,22 +291,22 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (hipMemset(p, 0, sizeof(double) * rft_elems) != hipSuccess) return cleanup(fail("hipMemset failed"));
     if (dev_alloc(c, &p, sizeof(double) * 2 * (size_t)c->nslots * ntrc)) return cleanup(1);
     c->ws.phi = (double *)p;
-    hipMemset(p, 0, sizeof(double) * 2 * (size_t)c->nslots * ntrc);
+    (void)hipMemset(p, 0, sizeof(double) * 2 * (size_t)c->nslots * ntrc);
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->ws.cur_slot = (int *)p;
-    hipMemset(p, 0, sizeof(int) * c->nslots);
+    (void)hipMemset(p, 0, sizeof(int) * c->nslots);
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->ws.prop_fwd = (int *)p;
-    hipMemset(p, 0, sizeof(int) * c->nslots);
+    (void)hipMemset(p, 0, sizeof(int) * c->nslots);
     c->ws.nslots = c->nslots;
     if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * c->nfwd * 2 * nh)) return cleanup(1);
     c->spec = (double2 *)p;
     if (dev_alloc(c, &p, sizeof(int) * ((size_t)c->nslots * c->nfwd + 1))) return cleanup(1);
-    c->slow_list = (int *)p + 1;
-    c->slow_count = (int *)p;
-    hipMemset(p, 0, sizeof(int));
+    c->slow_count = (int *)p;      // [1]
+    c->slow_list = (int *)p + 1;   // [nslots * nfwd]
+    (void)hipMemset(p, 0, sizeof(int));
 
-    if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || trace_lds_bytes(n, nsmp) > 160 * 1024)
+    if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || trace_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024)
         return cleanup(fail("rf_ctx_create: nfft / nsmp / nlay_max exceed the 160 KiB LDS of a gfx950 CU"));
     const char *env = getenv("RFGPU_BINS_PER_LANE");
     if (env) c->bins_per_lane = atoi(env) == 2 ? 2 : 1;
@@ -317,12 +317,14 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
 extern "C" int rf_ctx_destroy(rf_ctx *c)
 {
     if (!c) return 0;
-    hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    for (void *p : c->owned) hipFree(p);
-    for (auto &q : c->ev_pool)
-        for (int i = 0; i < 4; ++i) hipEventDestroy(q.e[i]);
-    if (c->stream) hipStreamDestroy(c->stream);
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (void *p : c->owned) (void)hipFree(p);
+    for (auto &q : c->ev_pool) {
+        (void)hipEventDestroy(q.e0);
+        (void)hipEventDestroy(q.e1);
+    }
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return 0;
 }
@@ -350,32 +352,35 @@ extern "C" int rf_get_r_inv(const rf_ctx *c, double *r_inv)
 static void flush_profile(rf_ctx *c)
 {
     for (size_t u = 0; u < c->ev_used; ++u) {
-        rf_ctx::EvQuad &q = c->ev_pool[u];
-        hipEventSynchronize(q.e[3]);
-        for (int i = 0; i < 3; ++i) {
-            float ms = 0;
-            hipEventElapsedTime(&ms, q.e[i], q.e[i + 1]);
-            c->prof_ms[i] += ms;
-        }
-        c->prof_n += 1;
+        rf_ctx::Timed &q = c->ev_pool[u];
+        (void)hipEventSynchronize(q.e1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, q.e0, q.e1);
+        c->prof_ms[q.kind] += ms;
+        c->prof_n[1 + q.kind] += 1;
     }
     c->ev_used = 0;
 }
 
-static rf_ctx::EvQuad *next_quad(rf_ctx *c)
+// begin timing one kernel launch of `kind` on stream s; returns the stop event to
+// record after the launch (nullptr when profiling is off)
+static hipEvent_t prof_begin(rf_ctx *c, int kind, hipStream_t s)
 {
-    constexpr size_t kMaxPool = 1024;
+    if (!c->prof) return nullptr;
+    constexpr size_t kMaxPool = 4096;
     if (c->ev_used == c->ev_pool.size()) {
         if (c->ev_pool.size() >= kMaxPool) {
             flush_profile(c);
         } else {
-            rf_ctx::EvQuad q;
-            for (int i = 0; i < 4; ++i)
-                if (hipEventCreate(&q.e[i]) != hipSuccess) return nullptr;
+            rf_ctx::Timed q{};
+            if (hipEventCreate(&q.e0) != hipSuccess || hipEventCreate(&q.e1) != hipSuccess) return nullptr;
             c->ev_pool.push_back(q);
         }
     }
-    return &c->ev_pool[c->ev_used++];
+    rf_ctx::Timed &q = c->ev_pool[c->ev_used++];
+    q.kind = kind;
+    (void)hipEventRecord(q.e0, s);
+    return q.e1;
 }
 
 static int pick_nsplit(const rf_ctx *c, int nb)
@@ -401,14 +406,16 @@ static int run_batch(rf_ctx *c, const BatchArgs &b, hipStream_t s)
     if (b.nb > c->nslots) return fail("batch larger than max_walkers + 1");
     if (b.nlay_pad > c->cfg.nlay_max) return fail("nlay_pad exceeds nlay_max of the context");
     HIP_TRY(hipSetDevice(c->device));
-    rf_ctx::EvQuad *q = c->prof ? next_quad(c) : nullptr;
-    if (q) hipEventRecord(q->e[0], s);
+    hipEvent_t e = prof_begin(c, 0, s);
     launch_spectra(c->tab, b, c->spec, pick_nsplit(c, b.nb), c->bins_per_lane, c->slow_list, c->slow_count, s);
-    if (q) hipEventRecord(q->e[1], s);
+    if (e) (void)hipEventRecord(e, s);
+    e = prof_begin(c, 1, s);
     launch_trace(c->tab, b, c->spec, c->ws, s);
-    if (q) hipEventRecord(q->e[2], s);
-    launch_logl(c->tab, b, c->ws, c->slow_count, s);
-    if (q) hipEventRecord(q->e[3], s);
+    if (e) (void)hipEventRecord(e, s);
+    e = prof_begin(c, 2, s);
+    launch_logl(c->tab, b, c->ws, c->slow_count, 1, s);
+    if (e) (void)hipEventRecord(e, s);
+    if (c->prof) c->prof_n[0] += 1;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -553,10 +560,10 @@ extern "C" int rf_profile_read(rf_ctx *c, double *ms, int64_t *launches, int32_t
     if (!c || !ms || !launches) return fail("rf_profile_read: null argument");
     flush_profile(c);
     for (int i = 0; i < 3; ++i) ms[i] = c->prof_ms[i];
-    *launches = c->prof_n;
+    for (int i = 0; i < 4; ++i) launches[i] = c->prof_n[i];
     if (reset) {
         c->prof_ms[0] = c->prof_ms[1] = c->prof_ms[2] = 0;
-        c->prof_n = 0;
+        c->prof_n[0] = c->prof_n[1] = c->prof_n[2] = c->prof_n[3] = 0;
     }
     return 0;
 }

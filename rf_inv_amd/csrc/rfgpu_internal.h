@@ -47,13 +47,13 @@ void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec
                   const WalkerState &w, hipStream_t s);
 // K3: log-likelihood from the per-trace quadratic forms
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count,
-                 hipStream_t s);
+                 int nslow, hipStream_t s);
 void launch_commit(const WalkerState &w, int nb, const int *walker_ids, const int *accept,
                    int ntrc, hipStream_t s);
 void launch_pt_swap(int npairs, const int *pairs, const double *log_u, double *temps,
                     const double *logl, int *accepted, hipStream_t s);
 
 size_t spectra_lds_bytes(int nlay_pad);
-size_t trace_lds_bytes(int nfft, int nsmp);
+size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad);
 
 } // namespace rfgpu

@@ -450,22 +450,25 @@ __device__ __forceinline__ double block_max(double v, double *red)
 // Fortran nint: round half away from zero
 __device__ __forceinline__ int f_nint(double x) { return (int)(x >= 0.0 ? floor(x + 0.5) : -floor(0.5 - x)); }
 
-// direct_arrival (forward.f90:474-519): strictly sequential, no FMA contraction --
-// its result feeds nint() (integer bookkeeping must be bit-exact).
-__device__ __noinline__ double direct_arrival(int nlay, const double *h, const double *v, double rayp,
-                                              double sdep)
+// direct_arrival (forward.f90:474-519).  Its result feeds nint() (integer bookkeeping
+// must be bit-exact), so no FMA contraction anywhere and the SUM stays strictly
+// sequential in layer order; only the independent per-layer terms h(i)*sqrt(1/v(i)^2-p^2)
+// are evaluated by separate lanes (each one the same IEEE operations as the reference).
+__device__ __noinline__ double arrival_term(double h, double v, double rayp)
+{
+#pragma clang fp contract(off)
+    const double vv = v * v;
+    const double inv = 1.0 / vv;
+    const double pp = rayp * rayp;
+    const double rad = inv - pp;
+    return h * sqrt(rad);
+}
+
+__device__ __noinline__ double arrival_sum(int n, const double *terms)
 {
 #pragma clang fp contract(off)
     double t = 0.0;
-    const int i0 = sdep > 0.0 ? 1 : 0;
-    for (int i = i0; i < nlay - 1; ++i) {
-        const double vv = v[i] * v[i];
-        const double inv = 1.0 / vv;
-        const double pp = rayp * rayp;
-        const double rad = inv - pp;
-        const double term = h[i] * sqrt(rad);
-        t = t + term;
-    }
+    for (int i = 0; i < n; ++i) t = t + terms[i];
     return t;
 }
 
@@ -477,12 +480,177 @@ __device__ __noinline__ int calc_npre(double t_start, double tp, double delta, i
     return f_nint(num / delta);
 }
 
+// ---------------------------------------------------------------------------
+// In-LDS inverse complex FFT (sign +, unnormalised) used for the c2r step.
+// Mixed radix, decimation in time, in place: the input is written in digit-reversed
+// order, pass p (radix R_p, stride s_p = R_0 ... R_{p-1}) combines R_p sub-transforms
+// of length s_p; every pass is one register-resident radix-R butterfly per thread
+// (R <= 16), so n = 4096 needs 3 passes / 3 barriers instead of the 12 of radix 2.
+// LDS index i is padded to i + (i >> 4) so that the stride-1 pass (16 contiguous
+// elements per lane) does not put a whole wave on one bank.
+// ---------------------------------------------------------------------------
+constexpr int FFT_MAX_PASSES = 4;
+
+struct FftPlan {
+    int npass;
+    int radix_log2[FFT_MAX_PASSES];  // execution order; stride of pass p = prod of earlier radices
+};
+
+__host__ __device__ inline int fft_pad(int i) { return i + (i >> 4); }
+
+// position (unpadded) of input bin k in the digit-reversed DIT layout
+__device__ __forceinline__ int fft_input_pos(const FftPlan &pl, int log2n, int k)
+{
+    int pos = 0, span_log2 = log2n;
+#pragma unroll
+    for (int p = FFT_MAX_PASSES - 1; p >= 0; --p) {
+        if (p < pl.npass) {
+            const int rl = pl.radix_log2[p];
+            const int d = k & ((1 << rl) - 1);
+            k >>= rl;
+            span_log2 -= rl;
+            pos += d << span_log2;
+        }
+    }
+    return pos;
+}
+
+// v *= exp(+2 pi i e / 16), e = 0..7 compile-time after unrolling
+__device__ __forceinline__ double2 mul_w16(double2 v, int e)
+{
+    constexpr double C = 0.92387953251128673848;  // cos(pi/8)
+    constexpr double S = 0.38268343236508978178;  // sin(pi/8)
+    constexpr double H = 0.70710678118654752440;  // sqrt(1/2)
+    switch (e) {
+    case 0: return v;
+    case 1: return make_double2(v.x * C - v.y * S, v.x * S + v.y * C);
+    case 2: return make_double2((v.x - v.y) * H, (v.x + v.y) * H);
+    case 3: return make_double2(v.x * S - v.y * C, v.x * C + v.y * S);
+    case 4: return make_double2(-v.y, v.x);
+    case 5: return make_double2(-v.x * S - v.y * C, v.x * C - v.y * S);
+    case 6: return make_double2((-v.x - v.y) * H, (v.x - v.y) * H);
+    default: return make_double2(-v.x * C - v.y * S, v.x * S - v.y * C);
+    }
+}
+
+template <int LOG2R>
+__device__ __forceinline__ int bitrev_small(int i)
+{
+    int r = 0;
+#pragma unroll
+    for (int b = 0; b < LOG2R; ++b) r |= ((i >> b) & 1) << (LOG2R - 1 - b);
+    return r;
+}
+
+// radix-R inverse DFT of v[0..R) in registers (decimation in frequency); the result
+// for output index j sits in v[bitrev(j)].
+template <int LOG2R>
+__device__ __forceinline__ void dft_regs(double2 (&v)[1 << LOG2R])
+{
+    constexpr int R = 1 << LOG2R;
+#pragma unroll
+    for (int sl = LOG2R - 1; sl >= 0; --sl) {
+        const int sz = 1 << sl;
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            if ((i & sz) == 0) {
+                const int j = i + sz;
+                const double2 a0 = v[i], a1 = v[j];
+                v[i] = cadd(a0, a1);
+                v[j] = mul_w16(csub(a0, a1), (i & (sz - 1)) * (8 >> sl));
+            }
+        }
+    }
+}
+
+// twiddle exp(+2 pi i t / n) for 0 <= t < n from the half table tw[0 .. n/2)
+__device__ __forceinline__ double2 tw_full(const double2 *__restrict__ tw, int t, int half_n)
+{
+    const double2 w = tw[t & (half_n - 1)];
+    return t >= half_n ? make_double2(-w.x, -w.y) : w;
+}
+
+template <int LOG2R, int THREADS>
+__device__ __forceinline__ void fft_pass(double2 *a, int log2n, int stride_log2, const double2 *__restrict__ tw,
+                                         int tid)
+{
+    constexpr int R = 1 << LOG2R;
+    const int n = 1 << log2n;
+    const int stride = 1 << stride_log2;
+    const int tw_mul_log2 = log2n - stride_log2 - LOG2R;  // n / (stride * R)
+    for (int b = tid; b < (n >> LOG2R); b += THREADS) {
+        const int jp = b & (stride - 1);
+        const int base = ((b >> stride_log2) << (stride_log2 + LOG2R)) + jp;
+        double2 v[R], w[R];
+        // issue every twiddle load (L2-resident table) before the LDS reads so that the
+        // whole pass pays one global round trip, not R-1 of them
+        if (stride_log2 > 0) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) w[k] = tw[((jp * k) << tw_mul_log2) & ((n >> 1) - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = a[fft_pad(base + (k << stride_log2))];
+        if (stride_log2 > 0) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) {
+                const bool neg = ((jp * k) << tw_mul_log2) >= (n >> 1);   // exp(i(t + pi)) = -exp(it)
+                const double2 wk = neg ? make_double2(-w[k].x, -w[k].y) : w[k];
+                v[k] = cmul(v[k], wk);
+            }
+        }
+        dft_regs<LOG2R>(v);
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[fft_pad(base + (bitrev_small<LOG2R>(k) << stride_log2))] = v[k];
+    }
+}
+
+template <int THREADS>
+__device__ __forceinline__ void fft_inverse_lds(double2 *a, const FftPlan &pl, int log2n,
+                                                const double2 *__restrict__ tw, int tid)
+{
+    int stride_log2 = 0;
+    for (int p = 0; p < pl.npass; ++p) {
+        switch (pl.radix_log2[p]) {
+        case 4: fft_pass<4, THREADS>(a, log2n, stride_log2, tw, tid); break;
+        case 3: fft_pass<3, THREADS>(a, log2n, stride_log2, tw, tid); break;
+        case 2: fft_pass<2, THREADS>(a, log2n, stride_log2, tw, tid); break;
+        default: fft_pass<1, THREADS>(a, log2n, stride_log2, tw, tid); break;
+        }
+        stride_log2 += pl.radix_log2[p];
+        __syncthreads();
+    }
+}
+
+static FftPlan make_fft_plan(int log2n)
+{
+    FftPlan pl{};
+    int rem = log2n;
+    pl.npass = 0;
+    while (rem > 0) {
+        const int r = rem >= 4 ? 4 : rem;
+        pl.radix_log2[pl.npass++] = r;
+        rem -= r;
+    }
+    return pl;
+}
+
+// the work region holds, at different times, the padded FFT array, the per-layer
+// direct-arrival terms and the 4 x nsmp quarter sums of the quadratic form
+__host__ __device__ inline size_t trace_work_doubles(int nfft, int nsmp, int nlay_pad)
+{
+    size_t d = 2 * (size_t)fft_pad(nfft);
+    if ((size_t)4 * nsmp > d) d = (size_t)4 * nsmp;
+    if ((size_t)nlay_pad > d) d = (size_t)nlay_pad;
+    return (d + 1) & ~(size_t)1;
+}
+
 struct TraceParams {
     DeviceTables t;
     BatchArgs b;
     const double2 *spec;
     WalkerState w;
     int log2n;
+    FftPlan plan;
 };
 
 __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
@@ -490,8 +658,8 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
     extern __shared__ double2 lds2[];
     const DeviceTables &t = P.t;
     const int n = t.nfft, nh = t.nh, nsmp = t.nsmp;
-    double2 *a = lds2;                                   // [n] FFT work array
-    double *mis = reinterpret_cast<double *>(a + n);     // [nsmp] misfits
+    double2 *a = lds2;                                   // [fft_pad(n)] FFT work array (padded index)
+    double *mis = reinterpret_cast<double *>(a) + trace_work_doubles(n, nsmp, P.b.nlay_pad); // [nsmp] misfits
     double *red = mis + ((nsmp + 1) & ~1);               // [8] reductions / broadcasts
 
     const int tid = threadIdx.x;
@@ -512,72 +680,82 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
     const double2 *den = (ipha == 1) ? sv : sr;      // decon only
     if (decon) {
         double m = -HUGE_VAL;
+#pragma unroll 4
         for (int k = tid; k < nh; k += TRACE_THREADS) {
             const double2 x = den[k];
             m = fmax(m, x.x * x.x + x.y * x.y);      // forward.f90:458
         }
         wlvl = 0.001 * block_max(m, red);            // forward.f90:460, pcnt = 0.001 (:149)
-    } else if (tid == 0) {
+    } else {
         const int nl = P.b.nlay[ib];
         const int pad = P.b.nlay_pad;
         const double *L = P.b.layers + (size_t)ib * 4 * pad;
         const double *vel = (ipha == 1) ? L : L + pad;   // alpha for P, beta for S (:157,161)
-        red[4] = direct_arrival(nl, L + 3 * pad, vel, t.rayps[itrc], t.sdep);
+        const int i0 = t.sdep > 0.0 ? 1 : 0;             // keyed on sdep (:484)
+        double *terms = reinterpret_cast<double *>(a);   // FFT array not yet in use
+        for (int i = i0 + tid; i < nl - 1; i += TRACE_THREADS)
+            terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], t.rayps[itrc]);
+        __syncthreads();
+        if (tid == 0) red[4] = arrival_sum(nl - 1 - i0, terms);
     }
     __syncthreads();
     const double tp = decon ? 0.0 : red[4];
+    __syncthreads();
 
-    // ---- Z = RF*flt + i * (V*flt), Hermitian-extended, written bit-reversed ------
-    const int shift = 32 - P.log2n;
-    for (int k = tid; k < nh; k += TRACE_THREADS) {
-        double2 r = num[k];
-        if (decon) {
-            const double2 x = den[k];
-            const double amp = x.x * x.x + x.y * x.y;
-            const double dd = fmax(amp, wlvl);                       // forward.f90:464
-            const double2 yx = cmul(r, make_double2(x.x, -x.y));
-            r = make_double2(yx.x / dd, yx.y / dd);
+    // ---- Z = RF*flt + i * (V*flt), Hermitian-extended, written digit-reversed ----
+    // The spectra come from HBM: each thread first issues the loads of FILL_CHUNK bins
+    // (coalesced, 16 B per lane) and only then touches LDS, so a chunk costs one memory
+    // round trip instead of one per bin.
+    constexpr int FILL_CHUNK = 4;
+    for (int k0 = tid; k0 < nh; k0 += TRACE_THREADS * FILL_CHUNK) {
+        double2 rr[FILL_CHUNK], xx[FILL_CHUNK];
+        double ff[FILL_CHUNK];
+#pragma unroll
+        for (int c = 0; c < FILL_CHUNK; ++c) {
+            const int k = k0 + c * TRACE_THREADS;
+            const int kc = k < nh ? k : nh - 1;
+            rr[c] = num[kc];
+            xx[c] = decon ? den[kc] : sv[kc];   // decon: denominator; else: vertical spectrum
+            ff[c] = flt[kc];
         }
-        const double fk = flt[k];
-        const double2 R = make_double2(r.x * fk, r.y * fk);          // forward.f90:168
-        double2 V = make_double2(0.0, 0.0);
-        if (!decon) {
-            const double2 v = sv[k];
-            V = make_double2(v.x * fk, v.y * fk);                    // forward.f90:198
-        }
-        if (k == 0 || 2 * k == n) {
-            // c2r ignores Im of the DC and Nyquist bins
-            a[__brev((unsigned)k) >> shift] = make_double2(R.x, V.x);
-        } else {
-            a[__brev((unsigned)k) >> shift] = make_double2(R.x - V.y, R.y + V.x);
-            a[__brev((unsigned)(n - k)) >> shift] = make_double2(R.x + V.y, V.x - R.y);
+#pragma unroll
+        for (int c = 0; c < FILL_CHUNK; ++c) {
+            const int k = k0 + c * TRACE_THREADS;
+            if (k < nh) {
+                double2 r = rr[c];
+                double2 V = make_double2(0.0, 0.0);
+                const double fk = ff[c];
+                if (decon) {
+                    const double2 x = xx[c];
+                    const double amp = x.x * x.x + x.y * x.y;
+                    const double dd = fmax(amp, wlvl);                   // forward.f90:464
+                    const double2 yx = cmul(r, make_double2(x.x, -x.y));
+                    r = make_double2(yx.x / dd, yx.y / dd);
+                } else {
+                    V = make_double2(xx[c].x * fk, xx[c].y * fk);        // forward.f90:198
+                }
+                const double2 R = make_double2(r.x * fk, r.y * fk);      // forward.f90:168
+                const int pk = fft_pad(fft_input_pos(P.plan, P.log2n, k));
+                if (k == 0 || 2 * k == n) {
+                    // c2r ignores Im of the DC and Nyquist bins
+                    a[pk] = make_double2(R.x, V.x);
+                } else {
+                    a[pk] = make_double2(R.x - V.y, R.y + V.x);
+                    a[fft_pad(fft_input_pos(P.plan, P.log2n, n - k))] = make_double2(R.x + V.y, V.x - R.y);
+                }
+            }
         }
     }
     __syncthreads();
 
-    // ---- in-place radix-2 DIT, sign +, unnormalised (FFTW c2r definition) --------
-    const double2 *__restrict__ tw = t.twiddle;
-    for (int len = 2, lg = 1; len <= n; len <<= 1, ++lg) {
-        const int half = len >> 1;
-        const int step = n >> lg;
-        for (int q = tid; q < (n >> 1); q += TRACE_THREADS) {
-            const int k = q & (half - 1);
-            const int i0 = ((q >> (lg - 1)) << lg) + k;
-            const int i1 = i0 + half;
-            const double2 w = tw[k * step];
-            const double2 u = a[i0];
-            const double2 v = cmul(a[i1], w);
-            a[i0] = cadd(u, v);
-            a[i1] = csub(u, v);
-        }
-        __syncthreads();
-    }
-    // a[j].x = rx (RF trace), a[j].y = vertical trace
+    // ---- in-place mixed-radix inverse FFT, sign +, unnormalised (FFTW c2r definition) ---
+    fft_inverse_lds<TRACE_THREADS>(a, P.plan, P.log2n, t.twiddle, tid);
+    // a[fft_pad(j)].x = rx (RF trace), .y = vertical trace
 
     double fac = 1.0;
     if (!decon) {
         double m = -HUGE_VAL;
-        for (int j = tid; j < n; j += TRACE_THREADS) m = fmax(m, a[j].y);
+        for (int j = tid; j < n; j += TRACE_THREADS) m = fmax(m, a[fft_pad(j)].y);
         fac = block_max(m, red);                                     // maxval(rx) forward.f90:201
     }
 
@@ -594,12 +772,12 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
             j = (n - npre + i) % n;                                  // forward.f90:179
             if (j < 0) j += n;
             if (j == 0) j = n;
-            val = a[j - 1].x;
+            val = a[fft_pad(j - 1)].x;
         } else {
             j = (n + npre - i + 1) % n;                              // forward.f90:188
             if (j < 0) j += n;
             if (j == 0) j = n;
-            val = -a[j - 1].x;
+            val = -a[fft_pad(j - 1)].x;
         }
         if (!decon) val = val / fac;                                 // forward.f90:202
         dst[i - 1] = val;
@@ -608,36 +786,54 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
     __syncthreads();
 
     // ---- phi = (misfit . R^-1) . misfit   (likelihood.f90:92-93) -----------------
-    // thread j owns column j: phi1(j) = sum_i misfit(i) r_inv(i,j), i ascending exactly
-    // like the reference's matmul.  r_inv_t holds r_inv transposed (row-major image), so
-    // for a fixed i consecutive threads read consecutive addresses (coalesced, L2-resident);
-    // misfit(i) is an LDS broadcast.
+    // phi1(j) = sum_i misfit(i) r_inv(i,j).  r_inv_t is the transposed image, so for a
+    // fixed row i consecutive lanes (columns j) read consecutive addresses (coalesced,
+    // L2-resident) and misfit(i) is an LDS broadcast.  The 4 waves take contiguous
+    // quarters of the rows (ascending i inside each, like the reference's matmul); the
+    // quarter sums are combined in wave order through LDS (the FFT array is free now).
     const double *__restrict__ RT = t.r_inv_t + (size_t)itrc * nsmp * nsmp;
+    const int wv = tid >> 6, lane = tid & 63;
+    const int rows = (nsmp + 3) >> 2;
+    const int r0 = wv * rows, r1 = min(nsmp, r0 + rows);
+    double *part = reinterpret_cast<double *>(a);            // [4][nsmp]
+    __syncthreads();                                          // all reads of a[] are done
+    for (int j = lane; j < nsmp; j += 64) {
+        double acc = 0.0;
+#pragma unroll 8
+        for (int i = r0; i < r1; ++i) acc = fma(mis[i], RT[(size_t)i * nsmp + j], acc);
+        part[wv * nsmp + j] = acc;
+    }
+    __syncthreads();
     double acc = 0.0;
     for (int j = tid; j < nsmp; j += TRACE_THREADS) {
-        double phi1 = 0.0;
-        for (int i = 0; i < nsmp; ++i) phi1 = fma(mis[i], RT[(size_t)i * nsmp + j], phi1);
+        const double phi1 = ((part[j] + part[nsmp + j]) + part[2 * nsmp + j]) + part[3 * nsmp + j];
         acc = fma(phi1, mis[j], acc);
     }
     acc = wave_sum(acc);
-    const int wv = tid >> 6, lane = tid & 63;
     if (lane == 0) red[wv] = acc;
     __syncthreads();
     if (tid == 0)
         P.w.phi[((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-size_t trace_lds_bytes(int nfft, int nsmp)
+size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad)
 {
-    return sizeof(double2) * (size_t)nfft + sizeof(double) * (size_t)(((nsmp + 1) & ~1) + 8);
+    return sizeof(double) * (trace_work_doubles(nfft, nsmp, nlay_pad) + (size_t)(((nsmp + 1) & ~1) + 8));
 }
 
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec, const WalkerState &w,
                   hipStream_t s)
 {
-    TraceParams P{t, b, spec, w, 0};
+    TraceParams P{t, b, spec, w, 0, {}};
     while ((1 << P.log2n) < t.nfft) ++P.log2n;
-    const size_t lds = trace_lds_bytes(t.nfft, t.nsmp);
+    P.plan = make_fft_plan(P.log2n);
+    const size_t lds = trace_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
+    static size_t lds_set = 0;
+    if (lds > lds_set) {  // dynamic LDS beyond 64 KiB must be opted into
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set = lds;
+    }
     hipLaunchKernelGGL(trace_kernel, dim3((unsigned)(b.nb * t.ntrc)), dim3(TRACE_THREADS), lds, s, P);
 }
 
@@ -649,13 +845,14 @@ struct LoglParams {
     BatchArgs b;
     WalkerState w;
     int *slow_count;
+    int nslow;
 };
 
 __global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
 {
 #pragma clang fp contract(off)
     const int ib = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ib == 0) *P.slow_count = 0;   // re-arm the deferred-walker list for the next batch
+    if (ib < P.nslow) P.slow_count[ib] = 0;   // re-arm the deferred-walker lists for the next batch
     if (ib >= P.b.nb) return;
     const int walker = P.b.walker_ids[ib];
     const int fwd = P.b.fwd_flag ? P.b.fwd_flag[ib] : 1;
@@ -675,9 +872,9 @@ __global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
 }
 
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count,
-                 hipStream_t s)
+                 int nslow, hipStream_t s)
 {
-    LoglParams P{t, b, w, slow_count};
+    LoglParams P{t, b, w, slow_count, nslow};
     hipLaunchKernelGGL(logl_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P);
 }
 

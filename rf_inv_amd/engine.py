@@ -187,9 +187,10 @@ class RFEngine:
 
     def profile_read(self, reset=True):
         ms = np.zeros(3)
-        n = C.c_int64()
-        self._chk(self._lib.rf_profile_read(self._ctx, _dptr(ms), C.byref(n), int(reset)))
-        return {"spectra_ms": ms[0], "trace_ms": ms[1], "logl_ms": ms[2], "launches": n.value}
+        n = (C.c_int64 * 4)()
+        self._chk(self._lib.rf_profile_read(self._ctx, _dptr(ms), n, int(reset)))
+        return {"spectra_ms": ms[0], "trace_ms": ms[1], "logl_ms": ms[2], "launches": n[0],
+                "spectra_launches": n[1], "trace_launches": n[2], "logl_launches": n[3]}
 
 
 def compute_r_inv(nsmp, a_gus, delta):
