@@ -77,6 +77,11 @@ int rf_get_r_inv(const rf_ctx *ctx, double *r_inv);
  * (one-sided Jacobi SVD, fp64); r_inv is (nsmp, nsmp) column-major. */
 int rf_compute_r_inv(int32_t nsmp, double a_gus, double delta, double *r_inv, int32_t *rank_out);
 
+/* replace the noise-covariance pseudo-inverse after creation, e.g. with the one the
+ * host built through its own LAPACK dgesvd exactly as src/likelihood.f90:183-222
+ * (r_inv(nsmp, nsmp, ntrc) column-major). */
+int rf_set_r_inv(rf_ctx *ctx, const double *r_inv);
+
 /* ---- single-evaluation drop-ins --------------------------------------- */
 /* subroutine calc_rf(chain_id, nlay, n, ntrc, rayps, alpha, beta, rho, h, rft)
  * (src/forward.f90:123-208).  n, ntrc, rayps come from the context.
@@ -94,6 +99,13 @@ int rf_calc_likelihood(rf_ctx *ctx, int32_t walker, int32_t fwd_flag, int32_t nl
                        const double *alpha, const double *beta, const double *rho,
                        const double *h, const double *sig, double *prop_log_likelihood,
                        double *prop_rft);
+
+/* the fwd_flag = .false. branch of calc_likelihood for a trace the HOST owns
+ * (src/likelihood.f90:81-98: prop_rft = rft(:,:,chain_id), then the misfit loop).
+ * In the per-call drop-in the Fortran host keeps `rft(nfft, ntrc, nchains)` itself
+ * (src/pt_mcmc.f90:190 writes it without calling into this module), so the shim
+ * passes the stored trace in: rft is rft(nfft, ntrc), sig(ntrc). */
+int rf_calc_likelihood_of_trace(rf_ctx *ctx, const double *rft, const double *sig, double *logl);
 
 /* ---- batched evaluation (the throughput path) ------------------------- */
 /* nb independent calc_likelihood calls (the sequential chain loop of

@@ -35,6 +35,8 @@ SYMBOLS = {
     "rf_get_is_ray_common": (C.c_int, [_vp, ip]),
     "rf_get_r_inv": (C.c_int, [_vp, dp]),
     "rf_compute_r_inv": (C.c_int, [C.c_int32, C.c_double, C.c_double, dp, ip]),
+    "rf_set_r_inv": (C.c_int, [_vp, dp]),
+    "rf_calc_likelihood_of_trace": (C.c_int, [_vp, dp, dp, dp]),
     "rf_calc_rf": (C.c_int, [_vp, C.c_int32, dp, dp, dp, dp, dp]),
     "rf_calc_likelihood": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, dp, dp, dp, dp, dp, dp, dp]),
     "rf_eval_batch": (C.c_int, [_vp, C.c_int32, ip, ip, ip, C.c_int32, dp, dp, dp]),

@@ -158,6 +158,17 @@ static int upload(rf_ctx *c, const std::vector<T> &h, const T **d)
     return 0;
 }
 
+// device image of r_inv: r_inv(i,j,t) at [(t*nsmp + i)*nsmp + j] (row-major per trace)
+static std::vector<double> transpose_r_inv(const std::vector<double> &r, int ntrc, int nsmp)
+{
+    std::vector<double> out(r.size());
+    for (int t = 0; t < ntrc; ++t)
+        for (int j = 0; j < nsmp; ++j)
+            for (int i = 0; i < nsmp; ++i)
+                out[((size_t)t * nsmp + i) * nsmp + j] = r[((size_t)t * nsmp + j) * nsmp + i];
+    return out;
+}
+
 static int ensure_stage(rf_ctx *c, int nb, int pad)
 {
     if (nb <= c->stage_nb && pad <= c->stage_pad) return 0;
@@ -274,11 +285,7 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     T.delta = cfg->delta; T.t_start = cfg->t_start; T.sdep = cfg->sdep;
     T.domg = 2.0 * pi / (n * cfg->delta);   // forward.f90:241
     T.omg_dc = (double)1.0e-5f;             // forward.f90:247 single-precision literal
-    std::vector<double> r_inv_t(c->r_inv.size());
-    for (int t = 0; t < ntrc; ++t)
-        for (int j = 0; j < nsmp; ++j)
-            for (int i = 0; i < nsmp; ++i)
-                r_inv_t[((size_t)t * nsmp + i) * nsmp + j] = c->r_inv[((size_t)t * nsmp + j) * nsmp + i];
+    std::vector<double> r_inv_t = transpose_r_inv(c->r_inv, ntrc, nsmp);
     if (upload(c, c->flt, &T.flt) || upload(c, obs, &T.obs) || upload(c, r_inv_t, &T.r_inv_t) ||
         upload(c, rayps, &T.rayps) || upload(c, ipha, &T.ipha) || upload(c, tw, &T.twiddle))
         return cleanup(1);
@@ -506,6 +513,43 @@ extern "C" int rf_calc_rf(rf_ctx *c, int32_t nlay, const double *alpha, const do
     std::vector<double> sig((size_t)c->cfg.ntrc, 1.0);
     double ll;
     return rf_calc_likelihood(c, c->nslots - 1, 1, nlay, alpha, beta, rho, h, sig.data(), &ll, rft);
+}
+
+extern "C" int rf_set_r_inv(rf_ctx *c, const double *r_inv)
+{
+    if (!c || !r_inv) return fail("rf_set_r_inv: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    std::memcpy(c->r_inv.data(), r_inv, sizeof(double) * c->r_inv.size());
+    const std::vector<double> t = transpose_r_inv(c->r_inv, c->cfg.ntrc, c->cfg.nsmp);
+    HIP_TRY(hipMemcpy(const_cast<double *>(c->tab.r_inv_t), t.data(), sizeof(double) * t.size(),
+                      hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int rf_calc_likelihood_of_trace(rf_ctx *c, const double *rft, const double *sig, double *logl)
+{
+    if (!c || !rft || !sig || !logl) return fail("rf_calc_likelihood_of_trace: null argument");
+    HIP_TRY(hipSetDevice(c->device));
+    const int n = c->cfg.nfft, ntrc = c->cfg.ntrc, wk = c->nslots - 1;   // scratch walker
+    if (ensure_stage(c, 1, 2)) return 1;
+    hipStream_t s = c->stream;
+    HIP_TRY(hipStreamSynchronize(s));
+    int cur = 0;
+    HIP_TRY(hipMemcpy(&cur, c->ws.cur_slot + wk, sizeof(int), hipMemcpyDeviceToHost));
+    double *dst = c->ws.rft + (((size_t)(1 - cur) * c->nslots + wk) * ntrc) * (size_t)n;
+    HIP_TRY(hipMemcpyAsync(dst, rft, sizeof(double) * (size_t)n * ntrc, hipMemcpyHostToDevice, s));
+    const int one = 1;
+    HIP_TRY(hipMemcpyAsync(c->d_ids, &wk, sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_fwd, &one, sizeof(int), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_sig, sig, sizeof(double) * ntrc, hipMemcpyHostToDevice, s));
+    launch_phi(c->tab, c->ws, wk, s);
+    BatchArgs b{1, 2, c->d_ids, c->d_fwd, c->d_nlay, c->d_layers, c->d_sig, c->d_logl};
+    launch_logl(c->tab, b, c->ws, c->slow_count, 1, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(logl, c->d_logl, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return 0;
 }
 
 extern "C" int rf_commit_device(rf_ctx *c, int32_t nb, const int32_t *d_walker_ids, const int32_t *d_accept,

@@ -48,6 +48,7 @@ void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec
 // K3: log-likelihood from the per-trace quadratic forms
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count,
                  int nslow, hipStream_t s);
+void launch_phi(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s);
 void launch_commit(const WalkerState &w, int nb, const int *walker_ids, const int *accept,
                    int ntrc, hipStream_t s);
 void launch_pt_swap(int npairs, const int *pairs, const double *log_u, double *temps,

@@ -634,6 +634,39 @@ static FftPlan make_fft_plan(int log2n)
     return pl;
 }
 
+// phi = (misfit . R^-1) . misfit (likelihood.f90:92-93), block-wide (TRACE_THREADS).
+// phi1(j) = sum_i misfit(i) r_inv(i,j).  r_inv_t is the transposed image, so for a fixed
+// row i consecutive lanes (columns j) read consecutive addresses (coalesced, L2-resident)
+// and misfit(i) is an LDS broadcast.  The 4 waves take contiguous quarters of the rows
+// (ascending i inside each, like the reference's matmul); the quarter sums are combined
+// in wave order through `part` ([4][nsmp] doubles of LDS).  Result valid in thread 0.
+__device__ __forceinline__ double quad_form(const DeviceTables &t, int itrc, const double *mis, double *part,
+                                            double *red, int tid)
+{
+    const int nsmp = t.nsmp;
+    const double *__restrict__ RT = t.r_inv_t + (size_t)itrc * nsmp * nsmp;
+    const int wv = tid >> 6, lane = tid & 63;
+    const int rows = (nsmp + 3) >> 2;
+    const int r0 = wv * rows, r1 = min(nsmp, r0 + rows);
+    __syncthreads();                                          // `part` may alias a buffer still being read
+    for (int j = lane; j < nsmp; j += 64) {
+        double acc = 0.0;
+#pragma unroll 8
+        for (int i = r0; i < r1; ++i) acc = fma(mis[i], RT[(size_t)i * nsmp + j], acc);
+        part[wv * nsmp + j] = acc;
+    }
+    __syncthreads();
+    double acc = 0.0;
+    for (int j = tid; j < nsmp; j += TRACE_THREADS) {
+        const double phi1 = ((part[j] + part[nsmp + j]) + part[2 * nsmp + j]) + part[3 * nsmp + j];
+        acc = fma(phi1, mis[j], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) red[wv] = acc;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // the work region holds, at different times, the padded FFT array, the per-layer
 // direct-arrival terms and the 4 x nsmp quarter sums of the quadratic form
 __host__ __device__ inline size_t trace_work_doubles(int nfft, int nsmp, int nlay_pad)
@@ -786,34 +819,34 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
     __syncthreads();
 
     // ---- phi = (misfit . R^-1) . misfit   (likelihood.f90:92-93) -----------------
-    // phi1(j) = sum_i misfit(i) r_inv(i,j).  r_inv_t is the transposed image, so for a
-    // fixed row i consecutive lanes (columns j) read consecutive addresses (coalesced,
-    // L2-resident) and misfit(i) is an LDS broadcast.  The 4 waves take contiguous
-    // quarters of the rows (ascending i inside each, like the reference's matmul); the
-    // quarter sums are combined in wave order through LDS (the FFT array is free now).
-    const double *__restrict__ RT = t.r_inv_t + (size_t)itrc * nsmp * nsmp;
-    const int wv = tid >> 6, lane = tid & 63;
-    const int rows = (nsmp + 3) >> 2;
-    const int r0 = wv * rows, r1 = min(nsmp, r0 + rows);
-    double *part = reinterpret_cast<double *>(a);            // [4][nsmp]
-    __syncthreads();                                          // all reads of a[] are done
-    for (int j = lane; j < nsmp; j += 64) {
-        double acc = 0.0;
-#pragma unroll 8
-        for (int i = r0; i < r1; ++i) acc = fma(mis[i], RT[(size_t)i * nsmp + j], acc);
-        part[wv * nsmp + j] = acc;
-    }
+    const double phi = quad_form(t, itrc, mis, reinterpret_cast<double *>(a), red, tid);
+    if (tid == 0) P.w.phi[((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc] = phi;
+}
+
+// likelihood.f90:81-93 for a trace supplied by the host (the fwd_flag = .false. branch
+// of the single-call drop-in: the Fortran host owns rft(:,:,chain)): one block per trace
+// reads the first nsmp samples of the scratch walker's proposal slot.
+__global__ __launch_bounds__(TRACE_THREADS) void phi_kernel(DeviceTables t, WalkerState w, int walker)
+{
+    extern __shared__ double2 lds2[];
+    const int nsmp = t.nsmp, n = t.nfft;
+    double *work = reinterpret_cast<double *>(lds2);                  // [4 * nsmp]
+    double *mis = work + 4 * (size_t)((nsmp + 1) & ~1);
+    double *red = mis + ((nsmp + 1) & ~1);
+    const int tid = threadIdx.x, itrc = blockIdx.x;
+    const int slot = 1 - w.cur_slot[walker];
+    const double *src = w.rft + (((size_t)slot * w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
+    const double *obs = t.obs + (size_t)itrc * nsmp;
+    for (int i = tid; i < nsmp; i += TRACE_THREADS) mis[i] = src[i] - obs[i];   // likelihood.f90:88
     __syncthreads();
-    double acc = 0.0;
-    for (int j = tid; j < nsmp; j += TRACE_THREADS) {
-        const double phi1 = ((part[j] + part[nsmp + j]) + part[2 * nsmp + j]) + part[3 * nsmp + j];
-        acc = fma(phi1, mis[j], acc);
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) red[wv] = acc;
-    __syncthreads();
-    if (tid == 0)
-        P.w.phi[((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc] = (red[0] + red[1]) + (red[2] + red[3]);
+    const double phi = quad_form(t, itrc, mis, work, red, tid);
+    if (tid == 0) w.phi[((size_t)slot * w.nslots + walker) * t.ntrc + itrc] = phi;
+}
+
+void launch_phi(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s)
+{
+    const size_t lds = sizeof(double) * (size_t)(5 * ((t.nsmp + 1) & ~1) + 8);
+    hipLaunchKernelGGL(phi_kernel, dim3((unsigned)t.ntrc), dim3(TRACE_THREADS), lds, s, t, w, walker);
 }
 
 size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad)

@@ -121,6 +121,22 @@ class RFEngine:
                                                _dptr(out) if want_rft else None))
         return ll.value, (out.T if want_rft else None)
 
+    def set_r_inv(self, r_inv):
+        r = np.ascontiguousarray(r_inv, dtype=np.float64)
+        if r.shape != (self.ntrc, self.nsmp, self.nsmp):
+            raise ValueError("r_inv must be [ntrc, nsmp, nsmp]")
+        self._chk(self._lib.rf_set_r_inv(self._ctx, _dptr(r)))
+
+    def calc_likelihood_of_trace(self, rft, sig):
+        """logL of a host-owned trace rft(nfft, ntrc) -- src/likelihood.f90:81-98."""
+        r = np.ascontiguousarray(np.asarray(rft, dtype=np.float64).T)
+        s = np.ascontiguousarray(sig, dtype=np.float64)
+        if r.shape != (self.ntrc, self.nfft):
+            raise ValueError("rft must be (nfft, ntrc)")
+        ll = C.c_double()
+        self._chk(self._lib.rf_calc_likelihood_of_trace(self._ctx, _dptr(r), _dptr(s), C.byref(ll)))
+        return ll.value
+
     # ---- batched -----------------------------------------------------------
     def eval_batch(self, walker_ids, nlay, layers, sig, fwd_flag=None):
         """layers[nb, 4, nlay_pad] (alpha, beta, rho, h), sig[nb, ntrc] -> logL[nb]."""

@@ -1,0 +1,98 @@
+!=======================================================================
+! module forward -- drop-in replacement of RF_INV's src/forward.f90.
+!
+! Same public interface as the reference module (src/forward.f90:28-41):
+!     real(8), allocatable, public :: flt(:,:)
+!     logical :: is_ray_common
+!     subroutine init_forward(verb)
+!     subroutine calc_rf(chain_id, nlay, n, ntrc, rayps, alpha, beta, rho, h, rft)
+! but every evaluation is delegated to librfgpu (hand-written HIP kernels for
+! gfx950) through the C ABI of include/rfgpu.h.  Written from scratch; nothing
+! here is taken from the reference implementation.  The host keeps using its
+! own `params` module; `fftw` is no longer needed by this module.
+!=======================================================================
+module forward
+  use iso_c_binding
+  use rfgpu_c
+  implicit none
+
+  real(8), allocatable, public :: flt(:,:)
+  logical :: is_ray_common
+
+  ! the engine context, shared with module likelihood
+  type(c_ptr), public :: rf_ctx = c_null_ptr
+  ! HIP device ordinal; a host that runs several MPI ranks per node sets it
+  ! (e.g. rank modulo GPUs per node) before init_forward.
+  integer, public :: rf_device = 0
+
+  public init_forward, calc_rf
+
+contains
+
+  !---------------------------------------------------------------------
+  subroutine init_forward(verb)
+    use params, only: nfft, ntrc, nsmp, deconv_mode, delta, t_start, sdep, &
+         & rayps, a_gus, ipha, obs, npts_max, nchains, k_max
+    logical, intent(in) :: verb
+    type(rf_config) :: cfg
+    integer(c_int32_t), allocatable, target, save :: ipha_c(:)
+    real(c_double), allocatable, target, save :: rayps_c(:), a_gus_c(:), obs_c(:,:)
+    integer(c_int32_t) :: flag
+    integer :: nh
+
+    allocate(ipha_c(ntrc), rayps_c(ntrc), a_gus_c(ntrc), obs_c(npts_max, ntrc))
+    ipha_c = int(ipha, c_int32_t)
+    rayps_c = rayps
+    a_gus_c = a_gus
+    obs_c = obs
+
+    cfg%nfft = nfft
+    cfg%ntrc = ntrc
+    cfg%nsmp = nsmp
+    cfg%deconv_mode = deconv_mode
+    cfg%delta = delta
+    cfg%t_start = t_start
+    cfg%sdep = sdep
+    cfg%rayps = c_loc(rayps_c)
+    cfg%a_gus = c_loc(a_gus_c)
+    cfg%ipha = c_loc(ipha_c)
+    cfg%obs = c_loc(obs_c)
+    cfg%ldobs = npts_max
+    cfg%r_inv = c_null_ptr          ! library default; init_likelihood may override
+    cfg%max_walkers = nchains
+    cfg%nlay_max = k_max + 2        ! ocean + k_max - 1 interfaces + half-space
+    cfg%device = rf_device
+    call rfgpu_check(rf_ctx_create(cfg, rf_ctx), "rf_ctx_create")
+
+    nh = nfft / 2 + 1
+    allocate(flt(nh, ntrc))
+    call rfgpu_check(rf_get_flt(rf_ctx, flt), "rf_get_flt")
+    call rfgpu_check(rf_get_is_ray_common(rf_ctx, flag), "rf_get_is_ray_common")
+    is_ray_common = (flag /= 0)
+
+    if (verb .and. ntrc > 1) then
+       write(*,*) "--- check ray parameters ---"
+       if (is_ray_common) then
+          write(*,*) "Ray geometries are common among traces"
+          write(*,*) "-> Single FWD mode"
+       else
+          write(*,*) "Ray geometries are not common among traces"
+          write(*,*) "-> Multiple FWD mode"
+       end if
+       write(*,*)
+    end if
+  end subroutine init_forward
+
+  !---------------------------------------------------------------------
+  ! n, ntrc and rayps are accepted for interface compatibility; like every
+  ! call site of the reference they must be params' nfft, ntrc, rayps.
+  subroutine calc_rf(chain_id, nlay, n, ntrc, rayps, alpha, beta, rho, h, rft)
+    integer, intent(in) :: nlay, n, ntrc, chain_id
+    real(8), intent(in) :: rayps(ntrc)
+    real(8), intent(in) :: alpha(nlay), beta(nlay), rho(nlay), h(nlay)
+    real(8), intent(out) :: rft(n, ntrc)
+
+    call rfgpu_check(rf_calc_rf(rf_ctx, int(nlay, c_int32_t), alpha, beta, rho, h, rft), "rf_calc_rf")
+  end subroutine calc_rf
+
+end module forward

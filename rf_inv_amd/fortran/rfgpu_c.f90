@@ -1,0 +1,108 @@
+!=======================================================================
+! rfgpu_c -- ISO_C_BINDING view of include/rfgpu.h (librfgpu C ABI).
+! Written from scratch for the rf_inv_amd project; mirrors the header
+! one-to-one (same names, same argument order).
+!=======================================================================
+module rfgpu_c
+  use iso_c_binding
+  implicit none
+  public
+
+  ! struct rf_config (include/rfgpu.h)
+  type, bind(C) :: rf_config
+     integer(c_int32_t) :: nfft, ntrc, nsmp, deconv_mode
+     real(c_double)     :: delta, t_start, sdep
+     type(c_ptr)        :: rayps, a_gus, ipha
+     type(c_ptr)        :: obs
+     integer(c_int32_t) :: ldobs
+     type(c_ptr)        :: r_inv
+     integer(c_int32_t) :: max_walkers, nlay_max, device
+  end type rf_config
+
+  interface
+     integer(c_int) function rf_ctx_create(cfg, ctx_out) bind(C, name="rf_ctx_create")
+       import :: c_int, c_ptr, rf_config
+       type(rf_config), intent(in) :: cfg
+       type(c_ptr), intent(out) :: ctx_out
+     end function rf_ctx_create
+
+     integer(c_int) function rf_ctx_destroy(ctx) bind(C, name="rf_ctx_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function rf_ctx_destroy
+
+     type(c_ptr) function rf_last_error() bind(C, name="rf_last_error")
+       import :: c_ptr
+     end function rf_last_error
+
+     integer(c_int) function rf_get_flt(ctx, flt) bind(C, name="rf_get_flt")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: flt(*)
+     end function rf_get_flt
+
+     integer(c_int) function rf_get_is_ray_common(ctx, flag) bind(C, name="rf_get_is_ray_common")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), intent(out) :: flag
+     end function rf_get_is_ray_common
+
+     integer(c_int) function rf_set_r_inv(ctx, r_inv) bind(C, name="rf_set_r_inv")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: r_inv(*)
+     end function rf_set_r_inv
+
+     integer(c_int) function rf_calc_rf(ctx, nlay, alpha, beta, rho, h, rft) bind(C, name="rf_calc_rf")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: nlay
+       real(c_double), intent(in) :: alpha(*), beta(*), rho(*), h(*)
+       real(c_double), intent(out) :: rft(*)
+     end function rf_calc_rf
+
+     integer(c_int) function rf_calc_likelihood(ctx, walker, fwd_flag, nlay, alpha, beta, rho, h, &
+          & sig, prop_log_likelihood, prop_rft) bind(C, name="rf_calc_likelihood")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: walker, fwd_flag, nlay
+       real(c_double), intent(in) :: alpha(*), beta(*), rho(*), h(*), sig(*)
+       real(c_double), intent(out) :: prop_log_likelihood
+       real(c_double), intent(out) :: prop_rft(*)
+     end function rf_calc_likelihood
+
+     integer(c_int) function rf_calc_likelihood_of_trace(ctx, rft, sig, logl) &
+          & bind(C, name="rf_calc_likelihood_of_trace")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(in) :: rft(*), sig(*)
+       real(c_double), intent(out) :: logl
+     end function rf_calc_likelihood_of_trace
+  end interface
+
+contains
+
+  ! Print-finalize-stop, the reference's convention for fatal errors
+  ! (e.g. /root/reference/src/likelihood.f90:206-210).
+  subroutine rfgpu_check(ierr, where)
+    integer(c_int), intent(in) :: ierr
+    character(*), intent(in) :: where
+    character(kind=c_char), pointer :: msg(:)
+    type(c_ptr) :: p
+    integer :: i, ierr2
+    if (ierr == 0) return
+    p = rf_last_error()
+    write(0, '(3a)', advance='no') "ERROR: librfgpu ", where, ": "
+    if (c_associated(p)) then
+       call c_f_pointer(p, msg, [512])
+       do i = 1, 512
+          if (msg(i) == c_null_char) exit
+          write(0, '(a)', advance='no') msg(i)
+       end do
+    end if
+    write(0, *)
+    call mpi_finalize(ierr2)
+    stop
+  end subroutine rfgpu_check
+
+end module rfgpu_c

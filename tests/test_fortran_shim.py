@@ -1,0 +1,83 @@
+"""The bind(C) Fortran shim modules `forward` / `likelihood` (rf_inv_amd/fortran) driven by
+the reference's own host modules (params, mt19937, model ... compiled unmodified into
+oracle/_ref/ by rf_inv_amd/fortran/Makefile) on the shipped sample_syn params.in."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import logl_tol
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DRIVER = os.path.join(ROOT, "oracle", "_ref", "drive_shim")
+
+
+def test_shim_sources_cite_and_export_the_reference_interface():
+    """Static check (no GPU): the shim modules export exactly the reference's public names."""
+    fwd = open(os.path.join(ROOT, "rf_inv_amd", "fortran", "forward.f90")).read()
+    lik = open(os.path.join(ROOT, "rf_inv_amd", "fortran", "likelihood.F90")).read()
+    for name in ("module forward", "flt(:,:)", "is_ray_common", "subroutine init_forward(verb)",
+                 "subroutine calc_rf(chain_id, nlay, n, ntrc, rayps, alpha, beta, rho, h, rft)"):
+        assert name in fwd, name
+    for name in ("module likelihood", "sig(:,:)", "rft(:,:,:)", "log_likelihood(:)",
+                 "subroutine init_likelihood(verb)", "subroutine calc_likelihood(chain_id, fwd_flag, prop_k, prop_z"):
+        assert name in lik, name
+
+
+def _parse_dump(path):
+    tok = open(path).read().split()
+    it = iter(tok)
+    nx = lambda: next(it)
+    nchains, ntrc, nfft, nsmp, k_max = (int(nx()) for _ in range(5))
+    delta = float(nx())
+    common = int(nx())
+    chains = []
+    for _ in range(nchains):
+        nlay = int(nx())
+        lay = np.array([[float(nx()) for _ in range(4)] for _ in range(nlay)])
+        sig = np.array([float(nx()) for _ in range(ntrc)])
+        ll = float(nx())
+        rft = np.array([[float(nx()) for _ in range(nfft)] for _ in range(ntrc)])
+        ll2 = float(nx())
+        same_trace = int(nx())
+        same_rf = int(nx())
+        chains.append(dict(nlay=nlay, lay=lay, sig=sig, ll=ll, rft=rft, ll2=ll2, same_trace=same_trace, same_rf=same_rf))
+    flt = np.array([float(nx()) for _ in range(nfft // 2 + 1)])
+    return dict(nchains=nchains, ntrc=ntrc, nfft=nfft, nsmp=nsmp, delta=delta, common=common, chains=chains, flt=flt)
+
+
+@pytest.mark.gpu
+def test_fortran_dropin_modules_on_sample_syn(oracle, golden_dir, tmp_path):
+    if not os.path.exists(DRIVER):
+        pytest.skip("oracle/_ref/drive_shim not built (no Fortran compiler / reference tree at build time)")
+    work = tmp_path / "sample_syn"
+    shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
+    os.makedirs(work / "rslt")
+    env = dict(os.environ)   # the driver carries rpaths for librfgpu and MPICH; keep the environment as is
+    r = subprocess.run([DRIVER, "params.in"], cwd=work, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "drive_shim: ok" in r.stdout, r.stdout + r.stderr
+    d = _parse_dump(work / "shim_dump.txt")
+    assert (d["nchains"], d["ntrc"], d["nfft"], d["nsmp"]) == (5, 2, 256, 101)
+    assert d["delta"] == float(np.float32(0.05)) and d["common"] == 0
+
+    from rf_inv_amd.engine import compute_r_inv
+
+    cfg = dict(nfft=256, deconv_mode=0, delta=d["delta"], t_start=0.0, sdep=2.0,
+               rayps=np.array([0.06, 0.08]), a_gus=np.array([4.0, 4.0]), ipha=np.array([1, 1], dtype=np.int32))
+    obs = np.stack([oracle.read_sac(os.path.join(golden_dir, "sample_syn", "data", f), 0.0, 5.0)[0]
+                    for f in ("sample_1.trc", "sample_2.trc")])
+    r1, rank = compute_r_inv(101, 4.0, d["delta"])   # the shim's default: librfgpu's own init_r_inv
+    r_inv = np.stack([r1, r1])
+    assert np.allclose(d["flt"], oracle.init_filter(256, d["delta"], [4.0])[0], rtol=1e-15, atol=0)
+    for c in d["chains"]:
+        a, b, rho, h = c["lay"].T
+        assert b[0] == -999.0 and a[0] == 1.5 and h[0] == 2.0       # ocean layer from the host's format_model
+        ref = oracle.calc_rf(cfg, a, b, rho, h)
+        assert np.abs(c["rft"] - ref).max() <= 1e-12 * np.abs(ref).max()
+        ll = oracle.log_likelihood(ref, obs, r_inv, c["sig"], 101)
+        assert abs(c["ll"] - ll) <= logl_tol(ll), (c["ll"], ll)
+        ll2 = oracle.log_likelihood(ref, obs, r_inv, 2 * c["sig"], 101)
+        assert abs(c["ll2"] - ll2) <= logl_tol(ll2)
+        assert c["same_trace"] == 1 and c["same_rf"] == 1
