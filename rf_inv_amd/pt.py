@@ -93,8 +93,10 @@ class PTSwap:
         self.n_accept = 0
         if self.device.type == "cuda":
             self._fill_cache()
-            self._gather = torch.empty((self.world, 2, self.nchains), dtype=torch.float64, device=self.device)
-            self._local = torch.empty((2, self.nchains), dtype=torch.float64, device=self.device)
+        # all_gather buffers: (T, logL) of every rank, concatenated along dim 0 (the layout both
+        # RCCL and gloo accept for all_gather_into_tensor)
+        self._gather = torch.empty((self.world * 2, self.nchains), dtype=torch.float64, device=self.device)
+        self._local = torch.empty((2, self.nchains), dtype=torch.float64, device=self.device)
 
     def _fill_cache(self):
         torch = self.torch
@@ -117,14 +119,18 @@ class PTSwap:
         if self.world == 1:
             self.engine.pt_swap_device(pairs, logu, self.temps, logl, None, stream)
             return
-        self._local[0].copy_(self.temps)
-        self._local[1].copy_(logl)
-        dist.all_gather_into_tensor(self._gather, self._local)
-        # global id = rank * nchains + chain  (src/pt_mcmc.f90:508-511)
-        g_t = self._gather[:, 0, :].reshape(-1).contiguous()
-        g_l = self._gather[:, 1, :].reshape(-1).contiguous()
+        g_t, g_l = self._gather_global(logl)
         self.engine.pt_swap_device(pairs, logu, g_t, g_l, None, stream)
         self.temps.copy_(g_t[self.rank * self.nchains:(self.rank + 1) * self.nchains])
+
+    def _gather_global(self, logl):
+        """One collective: every rank's (T, logL) -> global arrays indexed by
+        global id = rank * nchains + chain (src/pt_mcmc.f90:508-511)."""
+        self._local[0].copy_(self.temps)
+        self._local[1].copy_(logl)
+        self.dist.all_gather_into_tensor(self._gather, self._local)
+        g = self._gather.view(self.world, 2, self.nchains)
+        return g[:, 0, :].reshape(-1).contiguous(), g[:, 1, :].reshape(-1).contiguous()
 
     # -- host tensors: the reference's p2p protocol and a host all_gather (gloo tests) ---
     def step_host(self, logl):
@@ -137,12 +143,8 @@ class PTSwap:
         ll = logl.numpy() if hasattr(logl, "numpy") else np.asarray(logl)
         nacc = 0
         if self.mode == "allgather" and self.world > 1:
-            loc = torch.from_numpy(np.stack([temps, ll]))
-            out = [torch.empty_like(loc) for _ in range(self.world)]
-            dist.all_gather(out, loc)
-            g = torch.stack(out).numpy()
-            g_t = g[:, 0, :].reshape(-1).copy()
-            g_l = g[:, 1, :].reshape(-1)
+            gt, gl = self._gather_global(torch.as_tensor(ll))
+            g_t, g_l = gt.numpy(), gl.numpy()
             for (i1, i2), lu in zip(pairs, logu):
                 if judge_pt(g_t[i1], g_t[i2], g_l[i1], g_l[i2], lu):
                     g_t[i1], g_t[i2] = g_t[i2], g_t[i1]

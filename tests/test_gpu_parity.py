@@ -217,3 +217,30 @@ def test_huge_phase_takes_generic_sincos_kernel(oracle):
         for i in range(6):
             got = eng.get_rft(i, which=1).T
             assert np.abs(got - ref_rft[i]).max() <= 1e-11 * np.abs(ref_rft[i]).max(), i
+
+
+def test_pt_swap_device_matches_serial_replay(oracle):
+    """rf_pt_swap_device (judge_pt, pt_mcmc.f90:580-595) on one GPU vs a serial replay of the
+    same replicated schedule."""
+    import torch
+
+    from rf_inv_amd.pt import PairSchedule, PTSwap, init_temps, judge_pt
+
+    cfg = make_cfg(rayps=[0.06])
+    nch = 64
+    with _engine(cfg, np.zeros((1, 101)), 101, None, max_walkers=nch) as eng:
+        dev = torch.device("cuda", 0)
+        sw = PTSwap(eng, nch, 8, dev, seed=5, t_high=15.0, pairs_per_step=8, mode="allgather", cache_steps=16)
+        temps = init_temps(nch, 8, 15.0, np.random.Generator(np.random.Philox(key=5 + 7919)))
+        assert np.array_equal(sw.temps.cpu().numpy(), temps)
+        sched = PairSchedule(nch, 5, 8)
+        rng = np.random.default_rng(0)
+        for step in range(40):  # crosses a schedule-cache refill
+            ll = -100.0 * rng.random(nch)
+            sw.step(torch.from_numpy(ll).to(dev))
+            pairs, logu = sched.draw()
+            for (i1, i2), lu in zip(pairs, logu):
+                if judge_pt(temps[i1], temps[i2], ll[i1], ll[i2], lu):
+                    temps[i1], temps[i2] = temps[i2], temps[i1]
+            torch.cuda.synchronize()
+            assert np.array_equal(sw.temps.cpu().numpy(), temps), step
