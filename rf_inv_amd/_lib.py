@@ -62,6 +62,13 @@ def load():
             f"{LIB_PATH} is missing: build the HIP extension first "
             "(python -c 'import __graft_entry__ as g; g.build()' or make -C rf_inv_amd/csrc). "
             "rf_inv_amd has no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+    # /opt/rocm's).  Whichever is loaded first serves both; torch does not find its GPUs on
+    # the system runtime, while librfgpu runs on either -- so let torch load first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the .so lacks a declared symbol

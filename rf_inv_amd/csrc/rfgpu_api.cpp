@@ -47,7 +47,8 @@ struct rf_ctx {
     // host copies of tables
     std::vector<double> flt, r_inv;
     // launch policy
-    int bins_per_lane = 1;
+    int chain = 0;            // bins per phase chain in the spectra kernel (0: direct sincos)
+    int waves_per_block = 4;  // waves of one walker sharing a staged layer stack
     int num_cu = 256;
     // profiling
     // profiling: a pool of event quads so that timing never synchronises inside a
@@ -315,8 +316,14 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
 
     if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || trace_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024)
         return cleanup(fail("rf_ctx_create: nfft / nsmp / nlay_max exceed the 160 KiB LDS of a gfx950 CU"));
-    const char *env = getenv("RFGPU_BINS_PER_LANE");
-    if (env) c->bins_per_lane = atoi(env) == 2 ? 2 : 1;
+    // chained phases pay off when a wave owns many 64-bin iterations (nfft 4096: 33); with
+    // few iterations (nfft 256: 3) the direct path with more bin-splits is faster
+    // (measured on MI355X: c4 spectra 4.18 -> 3.17 ms, c2 0.133 -> 0.119 ms, c1 0.035 vs 0.058 ms)
+    c->chain = (c->nh + 63) / 64 >= 16 ? 4 : 0;
+    const char *env = getenv("RFGPU_CHAIN");
+    if (env) c->chain = atoi(env);
+    env = getenv("RFGPU_WPB");
+    if (env) c->waves_per_block = atoi(env);
     *ctx_out = c;
     return 0;
 }
@@ -397,8 +404,8 @@ static int pick_nsplit(const rf_ctx *c, int nb)
     // every split sees the same layer count) evens it out.  Aim at >= 32 waves per CU
     // (measured on MI355X: c2 1024 walkers 2.6 -> 4.1 M evals/s from 1 -> 8 splits; c4 with
     // 24576 (walker, trace) waves is best unsplit); never below one 64-bin iteration per wave.
-    const int per_iter = 64 * c->bins_per_lane;
-    const int niter = (c->nh + per_iter - 1) / per_iter;
+    // (with chained phases the unit of splitting is a chunk of `chain` iterations)
+    const int niter = c->chain > 1 ? std::max(1, ((c->nh + 63) / 64) / c->chain) : (c->nh + 63) / 64;
     const long waves = (long)nb * c->nfwd;
     const long want = 32L * c->num_cu;
     int ns = (int)std::min<long>(niter, std::max<long>(1, (want + waves - 1) / waves));
@@ -414,7 +421,8 @@ static int run_batch(rf_ctx *c, const BatchArgs &b, hipStream_t s)
     if (b.nlay_pad > c->cfg.nlay_max) return fail("nlay_pad exceeds nlay_max of the context");
     HIP_TRY(hipSetDevice(c->device));
     hipEvent_t e = prof_begin(c, 0, s);
-    launch_spectra(c->tab, b, c->spec, pick_nsplit(c, b.nb), c->bins_per_lane, c->slow_list, c->slow_count, s);
+    launch_spectra(c->tab, b, c->spec, pick_nsplit(c, b.nb), c->chain, c->waves_per_block, c->slow_list,
+                   c->slow_count, s);
     if (e) (void)hipEventRecord(e, s);
     e = prof_begin(c, 1, s);
     launch_trace(c->tab, b, c->spec, c->ws, s);

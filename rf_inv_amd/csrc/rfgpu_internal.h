@@ -7,7 +7,7 @@
 namespace rfgpu {
 
 // doubles of per-layer coefficients staged in LDS (see stage_layer_coef)
-constexpr int NCOEF = 20;
+constexpr int NCOEF = 28;
 
 struct DeviceTables {
     int nfft, nh, ntrc, nfwd, nsmp, deconv_mode, ray_common;
@@ -40,8 +40,8 @@ struct WalkerState {
 
 // K1: propagator-matrix spectra  -> spec[nb][nfwd][2][nh] (freq_r, freq_v after
 // the conj / -conj of forward.f90:145-146)
-void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit,
-                    int bins_per_lane, int *slow_list, int *slow_count, hipStream_t s);
+void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit, int chain,
+                    int waves_per_block, int *slow_list, int *slow_count, hipStream_t s);
 // K2: decon / filter / c2r / shift / normalise / write trace / quadratic form
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec,
                   const WalkerState &w, hipStream_t s);

@@ -59,11 +59,34 @@ __device__ __forceinline__ double2 cdiv(double2 a, double2 b)
 //     11 k11n = -rho 4 b2^2 p2 xi   12 k12n = -rho bp^2 / eta
 //     13 k13n = -rho bp^2 / xi      14 k14n = -rho 4 b2^2 p2 eta
 //     15 k15 = p2 / (xi rho)        16 k16 = eta / rho
-//     17 k17 = xi / rho             18 k18 = p2 / (eta rho)       19 pad
+//     17 k17 = xi / rho             18 k18 = p2 / (eta rho)
+//     19,20 phi_xi  = domg*xi*h  as a double-double (hi, lo)   } phase per bin of the layer and
+//     21,22 phi_eta = domg*eta*h as a double-double            } cos/sin of 64 bins of phase:
+//     23,24 cos, sin(64 phi_xi)   25,26 cos, sin(64 phi_eta)   } the chained-phase path (below)
+//     27 pad
 //   tail[0..7]  g1..g8 : rows 3,4 of E^-1 T of the half-space
 //   tail[8..10] water layer: xi_w, h_w, rho_w / xi_w
+__device__ __forceinline__ void sincos_cw(double x, double &sn, double &cs);
+
+__device__ __forceinline__ void stage_phase(double *c4, double *cs2, double domg, double slow, double h)
+{
+    // phi = domg * slow * h as hi + lo (error-free products), then cos/sin(64 phi)
+    const double t_hi = domg * slow;
+    const double t_lo = fma(domg, slow, -t_hi);
+    const double ph = t_hi * h;
+    double pl = fma(t_hi, h, -ph);
+    pl = fma(t_lo, h, pl);
+    c4[0] = ph;
+    c4[1] = pl;
+    double s, c;
+    sincos_cw(64.0 * ph, s, c);
+    const double d = 64.0 * pl;
+    cs2[0] = fma(-s, d, c);
+    cs2[1] = fma(c, d, s);
+}
+
 __device__ __forceinline__ void stage_layer_coef(double *c, double alpha, double beta, double rho,
-                                                 double h, double p)
+                                                 double h, double p, double domg)
 {
     const double b2 = beta * beta;
     const double p2 = p * p;
@@ -90,7 +113,9 @@ __device__ __forceinline__ void stage_layer_coef(double *c, double alpha, double
     c[16] = eta / rho;
     c[17] = xi / rho;
     c[18] = p2 / eta / rho;
-    c[19] = 0.0;
+    stage_phase(c + 19, c + 23, domg, xi, h);
+    stage_phase(c + 21, c + 25, domg, eta, h);
+    c[27] = 0.0;
 }
 
 __device__ __forceinline__ void stage_halfspace(double *g, double alpha, double beta, double rho, double p)
@@ -172,13 +197,11 @@ __device__ __forceinline__ void phase_sincos(double x, double &sn, double &cs)
         sincos(x, &sn, &cs);
 }
 
-template <int NCOL, bool FAST>
-__device__ __forceinline__ void apply_layer(ColState<NCOL> &s, const double *__restrict__ c, double omg)
+// one layer applied to NCOL real column vectors, v <- A v, given the layer's phases
+template <int NCOL>
+__device__ __forceinline__ void apply_layer_trig(ColState<NCOL> &s, const double *__restrict__ c, double sx,
+                                                 double cx, double se, double ce)
 {
-    double sx, cx, se, ce;
-    // argument formed exactly like the reference: (omega * xi) * z  (forward.f90:397-400)
-    phase_sincos<FAST>((omg * c[0]) * c[2], sx, cx);
-    phase_sincos<FAST>((omg * c[1]) * c[2], se, ce);
     const double a = fma(c[3], cx, c[4] * ce);    // A11 = A33
     const double e = fma(c[4], cx, c[3] * ce);    // A22 = A44
     const double d = cx - ce;
@@ -199,6 +222,16 @@ __device__ __forceinline__ void apply_layer(ColState<NCOL> &s, const double *__r
         s.v[j][2] = fma(-x21, v4, fma(a, v3, fma(-x41, v2, p31 * v1)));
         s.v[j][3] = fma(e, v4, fma(x12, v3, fma(p42, v2, x41 * v1)));
     }
+}
+
+template <int NCOL, bool FAST>
+__device__ __forceinline__ void apply_layer(ColState<NCOL> &s, const double *__restrict__ c, double omg)
+{
+    double sx, cx, se, ce;
+    // argument formed exactly like the reference: (omega * xi) * z  (forward.f90:397-400)
+    phase_sincos<FAST>((omg * c[0]) * c[2], sx, cx);
+    phase_sincos<FAST>((omg * c[1]) * c[2], se, ce);
+    apply_layer_trig<NCOL>(s, c, sx, cx, se, ce);
 }
 
 // T_rj = sum_k (E^-1 T)(r,k) B_kj  for r = 3 (g[0..3]) or 4 (g[4..7])
@@ -265,57 +298,147 @@ struct SpectraParams {
 // One wave (64 lanes) per (walker, forward-trace, bin-split).  Lanes own frequency
 // bins (coalesced 16-B stores of the spectra); the layer stack of the walker is staged
 // in LDS as precomputed coefficients and broadcast to all lanes; the 4x4 chain runs in
-// registers, BINS bins per lane at a time for instruction-level parallelism.
-template <int BINS, int NCOL, bool FAST>
-__device__ __forceinline__ void spectra_body(const SpectraParams &P, const double *coef,
-                                             const double *tail, int nl, int ilay0, int ipha,
-                                             double2 *__restrict__ out_r, double2 *__restrict__ out_v,
-                                             int split)
+// registers.
+
+template <int NCOL>
+__device__ __forceinline__ void init_cols(ColState<NCOL> &st)
 {
-    const int lane = threadIdx.x;
-    const int nh = P.t.nh;
-    const int per_iter = 64 * BINS;
-    const int niter = (nh + per_iter - 1) / per_iter;
-    for (int it = split; it < niter; it += P.nsplit) {
-        ColState<NCOL> st[BINS];
-        double omg[BINS];
-        int kbin[BINS];
 #pragma unroll
-        for (int q = 0; q < BINS; ++q) {
-            kbin[q] = it * per_iter + q * 64 + lane;
-            // forward.f90:245-248: omega = (iomg-1) * domg, DC bin uses the single literal 1.0e-5
-            omg[q] = kbin[q] == 0 ? P.t.omg_dc : (double)kbin[q] * P.t.domg;
+    for (int j = 0; j < NCOL; ++j)
 #pragma unroll
-            for (int j = 0; j < NCOL; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) st[q].v[j][r] = 0.0;
-            st[q].v[0][0] = 1.0;
-            st[q].v[1][1] = 1.0;
-            if (NCOL == 3) st[q].v[2][3] = 1.0;
-        }
-        for (int l = ilay0; l < nl - 1; ++l) {
-            const double *c = coef + l * NCOEF;
-#pragma unroll
-            for (int q = 0; q < BINS; ++q) apply_layer<NCOL, FAST>(st[q], c, omg[q]);
-        }
-#pragma unroll
-        for (int q = 0; q < BINS; ++q) {
-            double2 ur, uz;
-            finish_bin<NCOL, FAST>(st[q], tail, omg[q], ipha, ur, uz);
-            if (kbin[q] < nh) {
-                out_r[kbin[q]] = make_double2(ur.x, -ur.y);  // freq_r = conjg(ur)   forward.f90:145
-                out_v[kbin[q]] = make_double2(-uz.x, uz.y);  // freq_v = -conjg(uz)  forward.f90:146
-            }
-        }
+        for (int r = 0; r < 4; ++r) st.v[j][r] = 0.0;
+    st.v[0][0] = 1.0;
+    st.v[1][1] = 1.0;
+    if (NCOL == 3) st.v[2][3] = 1.0;
+}
+
+__device__ __forceinline__ void store_bin(double2 *__restrict__ out_r, double2 *__restrict__ out_v, int k, int nh,
+                                          double2 ur, double2 uz)
+{
+    if (k < nh) {
+        out_r[k] = make_double2(ur.x, -ur.y);  // freq_r = conjg(ur)   forward.f90:145
+        out_v[k] = make_double2(-uz.x, uz.y);  // freq_v = -conjg(uz)  forward.f90:146
     }
 }
 
-// Stages the layer stack of (walker ib, forward-trace f) into LDS; returns true when some
-// phase of the walker leaves the Cody-Waite range of sincos_cw.
+// one 64-bin iteration, every phase by a full sincos evaluation
+template <int NCOL, bool FAST>
+__device__ __forceinline__ void spectra_iter_direct(const SpectraParams &P, const double *coef, const double *tail,
+                                                    int nl, int ilay0, int ipha, double2 *__restrict__ out_r,
+                                                    double2 *__restrict__ out_v, int it, int lane)
+{
+    const int k = it * 64 + lane;
+    // forward.f90:245-248: omega = (iomg-1) * domg, DC bin uses the single literal 1.0e-5
+    const double omg = k == 0 ? P.t.omg_dc : (double)k * P.t.domg;
+    ColState<NCOL> st;
+    init_cols<NCOL>(st);
+    for (int l = ilay0; l < nl - 1; ++l) apply_layer<NCOL, FAST>(st, coef + l * NCOEF, omg);
+    double2 ur, uz;
+    finish_bin<NCOL, FAST>(st, tail, omg, ipha, ur, uz);
+    store_bin(out_r, out_v, k, P.t.nh, ur, uz);
+}
+
+// eps = arg - k * phi, phi = (hi, lo): the rounding perturbation of the reference's
+// argument (omega*xi)*z relative to the exact multiple k*phi.  (arg - k*phi_hi) is exact
+// (Sterbenz), the product k*phi is error-free through fma.
+__device__ __forceinline__ double phase_eps(double arg, double kd, double phi_hi, double phi_lo)
+{
+    const double p = kd * phi_hi;
+    double e = fma(kd, phi_hi, -p);
+    e = fma(kd, phi_lo, e);
+    return (arg - p) - e;
+}
+
+// BK consecutive 64-bin iterations per lane (bins k0, k0+64, ...): "chained phases".
+// For each layer only the first bin pays a full sincos; the exact-angle pair
+// (cos, sin)(k phi) then advances by the wave-uniform rotation (cos, sin)(64 phi) of the
+// layer, and each bin's actual phase -- the reference's rounded double (omega*xi)*z, whose
+// rounding is part of the reference result -- is recovered to first order from
+// eps = arg - k phi (|eps| < 1e-9, second order < 1e-18).  ~13 instructions per extra
+// sincos instead of ~45.  Chain length <= BK-1 rotations (error growth ~1 ulp per step).
+template <int BK, int NCOL>
+__device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, const double *coef, const double *tail,
+                                                    int nl, int ilay0, int ipha, double2 *__restrict__ out_r,
+                                                    double2 *__restrict__ out_v, int it0, int lane)
+{
+    ColState<NCOL> st[BK];
+    double omg[BK], kd[BK];
+    int kbin[BK];
+#pragma unroll
+    for (int m = 0; m < BK; ++m) {
+        kbin[m] = (it0 + m) * 64 + lane;
+        kd[m] = (double)kbin[m];
+        omg[m] = kbin[m] == 0 ? P.t.omg_dc : kd[m] * P.t.domg;
+        init_cols<NCOL>(st[m]);
+    }
+    const bool dc = kbin[0] == 0;
+    for (int l = ilay0; l < nl - 1; ++l) {
+        const double *c = coef + l * NCOEF;
+        const double xi = c[0], eta = c[1], h = c[2];
+        const double Cx = c[23], Sx = c[24], Ce = c[25], Se = c[26];
+        double sx, cx, se, ce;
+        // first bin: direct evaluation of the reference's argument
+        const double ax0 = (omg[0] * xi) * h, ae0 = (omg[0] * eta) * h;
+        sincos_cw(ax0, sx, cx);
+        sincos_cw(ae0, se, ce);
+        apply_layer_trig<NCOL>(st[0], c, sx, cx, se, ce);
+        // exact-angle start of the chain: remove the first bin's own perturbation.  The DC
+        // bin's omega is the literal 1e-5 (not 0 * domg): its chain starts from angle 0.
+        const double ex0 = phase_eps(ax0, kd[0], c[19], c[20]);
+        const double ee0 = phase_eps(ae0, kd[0], c[21], c[22]);
+        double cEx = dc ? 1.0 : fma(sx, ex0, cx);
+        double sEx = dc ? 0.0 : fma(-cx, ex0, sx);
+        double cEe = dc ? 1.0 : fma(se, ee0, ce);
+        double sEe = dc ? 0.0 : fma(-ce, ee0, se);
+#pragma unroll
+        for (int m = 1; m < BK; ++m) {
+            const double tx = cEx, te = cEe;
+            cEx = fma(tx, Cx, -(sEx * Sx));
+            sEx = fma(sEx, Cx, tx * Sx);
+            cEe = fma(te, Ce, -(sEe * Se));
+            sEe = fma(sEe, Ce, te * Se);
+            const double ex = phase_eps((omg[m] * xi) * h, kd[m], c[19], c[20]);
+            const double ee = phase_eps((omg[m] * eta) * h, kd[m], c[21], c[22]);
+            apply_layer_trig<NCOL>(st[m], c, fma(cEx, ex, sEx), fma(-sEx, ex, cEx), fma(cEe, ee, sEe),
+                                   fma(-sEe, ee, cEe));
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < BK; ++m) {
+        double2 ur, uz;
+        finish_bin<NCOL, true>(st[m], tail, omg[m], ipha, ur, uz);
+        store_bin(out_r, out_v, kbin[m], P.t.nh, ur, uz);
+    }
+}
+
+// the bins of one (walker, forward-trace) assigned to `split` of P.nsplit:
+// full chunks of BK iterations go through the chained-phase path, the remaining
+// iterations (and everything when BK == 0) through the direct path.
+template <int BK, int NCOL, bool FAST>
+__device__ __forceinline__ void spectra_body(const SpectraParams &P, const double *coef, const double *tail,
+                                             int nl, int ilay0, int ipha, double2 *__restrict__ out_r,
+                                             double2 *__restrict__ out_v, int split, int lane)
+{
+    const int niter = (P.t.nh + 63) / 64;
+    int it_direct0 = 0;
+    if (BK > 1 && FAST) {
+        const int nchunk = niter / BK;
+        for (int ch = split; ch < nchunk; ch += P.nsplit)
+            spectra_chunk_chain<(BK > 1 ? BK : 2), NCOL>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, ch * BK, lane);
+        it_direct0 = nchunk * BK;
+    }
+    // leftover iterations: spread from the last split downwards (the chunk loop loads
+    // the low splits first)
+    for (int it = it_direct0 + (P.nsplit - 1 - split); it < niter; it += P.nsplit)
+        spectra_iter_direct<NCOL, FAST>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, it, lane);
+}
+
+// Stages the layer stack of (walker ib, forward-trace f) into LDS (all threads of the
+// block); returns true (block-uniform) when some phase of the walker leaves the
+// Cody-Waite range of sincos_cw.
 __device__ __forceinline__ bool stage_walker(const SpectraParams &P, int ib, int f, double *coef, double *tail,
                                              int &nl, int &ilay0, bool &sea)
 {
-    const int lane = threadIdx.x;
     nl = P.b.nlay[ib];
     const int pad = P.b.nlay_pad;
     const double *L = P.b.layers + (size_t)ib * 4 * pad;
@@ -324,13 +447,13 @@ __device__ __forceinline__ bool stage_walker(const SpectraParams &P, int ib, int
     ilay0 = sea ? 1 : 0;
     const double omg_max = (double)(P.t.nh - 1) * P.t.domg;
     bool big = false;
-    for (int l = lane; l < nl - 1; l += 64)
+    for (int l = threadIdx.x; l < nl - 1; l += blockDim.x)
         if (l >= ilay0) {
             double *c = coef + l * NCOEF;
-            stage_layer_coef(c, L[l], L[pad + l], L[2 * pad + l], L[3 * pad + l], p);
+            stage_layer_coef(c, L[l], L[pad + l], L[2 * pad + l], L[3 * pad + l], p, P.t.domg);
             big |= fabs(omg_max * fmax(c[0], c[1]) * c[2]) >= SINCOS_CW_LIMIT;
         }
-    if (lane == 0) {
+    if (threadIdx.x == 0) {
         stage_halfspace(tail, L[nl - 1], L[pad + nl - 1], L[2 * pad + nl - 1], p);
         if (sea) {
             const double xiw = sqrt(1.0 / (L[0] * L[0]) - p * p);   // forward.f90:431
@@ -340,17 +463,23 @@ __device__ __forceinline__ bool stage_walker(const SpectraParams &P, int ib, int
             big |= fabs(omg_max * xiw * L[3 * pad]) >= SINCOS_CW_LIMIT;
         }
     }
-    big = __any(big);
-    __syncthreads();
-    return big;
+    return __syncthreads_or(big);
 }
 
-template <int BINS>
-__global__ __launch_bounds__(64) void spectra_kernel(SpectraParams P)
+// WPB waves per block share one staged layer stack; wave w of block b works on split
+// (b % nblk) * WPB + w of the walker.  NCOL = 2 is the land kernel, NCOL = 3 the ocean
+// kernel (one more column of the product is propagated); the host launches the one that
+// matches params' sdep, and a walker whose own beta(1) < 0 test (forward.f90:229)
+// disagrees with it is deferred like an out-of-range one.
+template <int BK, int NCOL>
+__global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
 {
     extern __shared__ double lds[];
-    const int split = blockIdx.x % P.nsplit;
-    const int bf = blockIdx.x / P.nsplit;
+    const int wpb = blockDim.x >> 6;
+    const int nblk = (P.nsplit + wpb - 1) / wpb;       // blocks per (walker, forward-trace)
+    const int bf = blockIdx.x / nblk;
+    const int split = (blockIdx.x % nblk) * wpb + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     const int f = bf % P.t.nfwd;
     const int ib = bf / P.t.nfwd;
     if (P.b.fwd_flag && !P.b.fwd_flag[ib]) return;
@@ -360,18 +489,16 @@ __global__ __launch_bounds__(64) void spectra_kernel(SpectraParams P)
     int nl, ilay0;
     bool sea;
     const bool big = stage_walker(P, ib, f, coef, tail, nl, ilay0, sea);
-    if (big) {
-        // rare: hand the walker to spectra_slow_kernel (generic sincos) via the list
-        if (split == 0 && threadIdx.x == 0) P.slow_list[atomicAdd(P.slow_count, 1)] = bf;
+    if (big || sea != (NCOL == 3)) {
+        // rare: hand the walker to spectra_slow_kernel (generic path) via the list
+        if (blockIdx.x % nblk == 0 && threadIdx.x == 0) P.slow_list[atomicAdd(P.slow_count, 1)] = bf;
         return;
     }
+    if (split >= P.nsplit) return;
     const int ipha = P.t.ipha[f];
     double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
     double2 *out_v = out_r + P.t.nh;
-    if (sea)
-        spectra_body<BINS, 3, true>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
-    else
-        spectra_body<BINS, 2, true>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
+    spectra_body<BK, NCOL, true>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split, lane);
 }
 
 // walkers whose phases exceed the Cody-Waite range (|x| >= 1e6 rad): same body with ocml's
@@ -396,27 +523,40 @@ __global__ __launch_bounds__(64) void spectra_slow_kernel(SpectraParams P)
         double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
         double2 *out_v = out_r + P.t.nh;
         if (sea)
-            spectra_body<1, 3, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
+            spectra_body<0, 3, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split, threadIdx.x);
         else
-            spectra_body<1, 2, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split);
+            spectra_body<0, 2, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split, threadIdx.x);
     }
 }
 
 size_t spectra_lds_bytes(int nlay_pad) { return sizeof(double) * ((size_t)nlay_pad * NCOEF + 16); }
 
-void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit,
-                    int bins_per_lane, int *slow_list, int *slow_count, hipStream_t s)
+template <int NCOL>
+static void launch_spectra_ncol(int chain, dim3 grid, dim3 block, size_t lds, hipStream_t s, const SpectraParams &P)
+{
+    switch (chain) {
+    case 2: hipLaunchKernelGGL((spectra_kernel<2, NCOL>), grid, block, lds, s, P); break;
+    case 3: hipLaunchKernelGGL((spectra_kernel<3, NCOL>), grid, block, lds, s, P); break;
+    case 4: hipLaunchKernelGGL((spectra_kernel<4, NCOL>), grid, block, lds, s, P); break;
+    case 8: hipLaunchKernelGGL((spectra_kernel<8, NCOL>), grid, block, lds, s, P); break;
+    default: hipLaunchKernelGGL((spectra_kernel<0, NCOL>), grid, block, lds, s, P); break;
+    }
+}
+
+// chain = bins per phase chain (0 / 1: every phase by a full sincos; 2, 3, 4, 8)
+void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit, int chain,
+                    int waves_per_block, int *slow_list, int *slow_count, hipStream_t s)
 {
     SpectraParams P{t, b, spec, nsplit, slow_list, slow_count};
-    const dim3 grid((unsigned)(b.nb * t.nfwd * nsplit));
+    int wpb = waves_per_block < 1 ? 1 : (waves_per_block > 4 ? 4 : waves_per_block);
+    if (wpb > nsplit) wpb = nsplit;
+    const int nblk = (nsplit + wpb - 1) / wpb;
+    const dim3 grid((unsigned)(b.nb * t.nfwd * nblk)), block(64 * wpb);
     const size_t lds = spectra_lds_bytes(b.nlay_pad);
-    if (bins_per_lane == 2)
-        hipLaunchKernelGGL(spectra_kernel<2>, grid, dim3(64), lds, s, P);
+    if (t.sdep > 0.0)
+        launch_spectra_ncol<3>(chain, grid, block, lds, s, P);
     else
-        hipLaunchKernelGGL(spectra_kernel<1>, grid, dim3(64), lds, s, P);
-    // the slow kernel partitions bins by 64 per iteration (BINS = 1)
-    const int niter1 = (t.nh + 63) / 64;
-    P.nsplit = nsplit < niter1 ? nsplit : niter1;
+        launch_spectra_ncol<2>(chain, grid, block, lds, s, P);
     hipLaunchKernelGGL(spectra_slow_kernel, dim3(512), dim3(64), lds, s, P);
 }
 

@@ -132,8 +132,8 @@ def test_nan_propagates_not_traps(oracle, golden_dir):
     assert np.isnan(ll) and np.isnan(rft).all()
 
 
-def test_nsplit_and_bins_variants_agree(oracle, monkeypatch):
-    """Launch-shape knobs must not change results beyond rounding (they only re-partition bins)."""
+def test_nsplit_and_block_shape_variants_agree(oracle, monkeypatch):
+    """Launch-shape knobs must not change results at all (they only re-partition bins)."""
     rng = np.random.default_rng(11)
     cfg = make_cfg(nfft=1024, rayps=[0.06])
     nsmp = 101
@@ -143,9 +143,10 @@ def test_nsplit_and_bins_variants_agree(oracle, monkeypatch):
     nlay, layers = pack_layers(stacks, 14)
     sig = np.full((4, 1), 0.01)
     outs = []
-    for ns, bins in [("1", "1"), ("3", "1"), ("1", "2"), ("4", "2")]:
+    for ns, wpb in [("1", "1"), ("3", "1"), ("3", "4"), ("4", "2")]:
         monkeypatch.setenv("RFGPU_NSPLIT", ns)
-        monkeypatch.setenv("RFGPU_BINS_PER_LANE", bins)
+        monkeypatch.setenv("RFGPU_WPB", wpb)
+        monkeypatch.setenv("RFGPU_CHAIN", "0")
         with _engine(cfg, obs, nsmp, None, max_walkers=4) as eng:
             outs.append((eng.eval_batch(np.arange(4), nlay, layers, sig), eng.get_rft(2, 1)))
     for ll, rft in outs[1:]:
@@ -244,3 +245,29 @@ def test_pt_swap_device_matches_serial_replay(oracle):
                     temps[i1], temps[i2] = temps[i2], temps[i1]
             torch.cuda.synchronize()
             assert np.array_equal(sw.temps.cpu().numpy(), temps), step
+
+
+@pytest.mark.parametrize("chain", ["0", "2", "3", "4", "8"])
+def test_chained_phase_variants_parity(oracle, monkeypatch, chain):
+    """Every phase-chain length of the spectra kernel (0 = a full sincos per phase) meets the
+    same tolerances, on land and under an ocean, including the DC bin whose omega is the
+    literal 1e-5 (forward.f90:247) and a bin count that leaves leftover iterations."""
+    monkeypatch.setenv("RFGPU_CHAIN", chain)
+    for sdep, nfft in [(0.0, 2048), (2.0, 1024)]:
+        rng = np.random.default_rng(77)
+        cfg = make_cfg(nfft=nfft, sdep=sdep, rayps=[0.06, 0.10], ipha=[1, -1], t_start=-1.0)
+        nsmp = 101
+        ocean = sdep > 0
+        true = random_stack(rng, 5, ocean, sdep)
+        obs = synth_obs(oracle, cfg, true, nsmp)
+        r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+        stacks = [random_stack(rng, int(n), ocean, sdep) for n in (3, 9, 17, 30)] + [true]
+        nlay, layers = pack_layers(stacks, 32)
+        sig = np.full((5, 2), 0.01)
+        ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
+        with _engine(cfg, obs, nsmp, r_inv, max_walkers=5) as eng:
+            ll = eng.eval_batch(np.arange(5), nlay, layers, sig)
+            for i in range(5):
+                got = eng.get_rft(i, which=1).T
+                assert np.abs(got - ref_rft[i]).max() <= 1e-12 * np.abs(ref_rft[i]).max(), (chain, sdep, i)
+        assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (chain, sdep, np.abs(ll - ref_ll).max())
