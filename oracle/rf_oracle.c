@@ -44,12 +44,22 @@
  *       normalisation (deconv_mode = 0, P phase).
  *   (2) true.velmod row 1 (Vp 5.0 -> rho 2.5347508187769563): pins
  *       vp_to_rho's single-precision literals bit-exactly.
- * Branches with NO reference-held known answers in /root/reference: the
- * ocean boundary condition (layer_matrix_liq), S-phase traces, water-level
- * deconvolution and the log-likelihood value.  They are restated from the
- * cited lines and cross-checked by an independent numpy restatement
- * (oracle/rf_oracle.py: calc_seis_numpy) and by physical identities in
- * tests/, but are "parity unpinned" by reference outputs -- see DESIGN.md.
+ *   (3) tests/test_mcmc_driver.py: the end-to-end value recorded in SURVEY.md
+ *       section 8c(4) from a run of the unmodified reference (rslt/likelihood,
+ *       iteration 1 = -1044.33907794324; shipped sample_syn params.in: ocean
+ *       layer, 2 traces, 5 chains, seed 12345678, 1 rank).  Driving this oracle
+ *       with the reference-order RNG restatement (rf_inv_amd/mcmc.py, itself
+ *       checked bit-for-bit against the reference's compiled mt19937/model
+ *       modules) reproduces it to 2.7e-11: pins the ocean boundary condition
+ *       (layer_matrix_liq), the 2-trace non-common-ray path, R^-1 and the
+ *       log-likelihood.  Provenance caveat: that number comes from the
+ *       surveyor's probe build (FFT/LAPACK link shims), not from a fixture the
+ *       reference ships.
+ * Branches with NO reference-derived known answers: S-phase traces and
+ * water-level deconvolution.  They are restated from the cited lines and
+ * cross-checked by an independent numpy restatement (oracle/rf_oracle.py:
+ * calc_seis_numpy) and by identities in tests/, but are "parity unpinned" by
+ * reference outputs -- see DESIGN.md.
  */
 #include <math.h>
 #include <stdlib.h>

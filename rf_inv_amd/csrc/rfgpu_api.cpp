@@ -306,6 +306,10 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->ws.prop_fwd = (int *)p;
     (void)hipMemset(p, 0, sizeof(int) * c->nslots);
+    if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * c->nfwd)) return cleanup(1);
+    c->ws.meta_tp = (double *)p;
+    if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
+    c->ws.meta_slot = (int *)p;
     c->ws.nslots = c->nslots;
     if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * c->nfwd * 2 * nh)) return cleanup(1);
     c->spec = (double2 *)p;
@@ -422,7 +426,7 @@ static int run_batch(rf_ctx *c, const BatchArgs &b, hipStream_t s)
     HIP_TRY(hipSetDevice(c->device));
     hipEvent_t e = prof_begin(c, 0, s);
     launch_spectra(c->tab, b, c->spec, pick_nsplit(c, b.nb), c->chain, c->waves_per_block, c->slow_list,
-                   c->slow_count, s);
+                   c->slow_count, c->ws, s);
     if (e) (void)hipEventRecord(e, s);
     e = prof_begin(c, 1, s);
     launch_trace(c->tab, b, c->spec, c->ws, s);

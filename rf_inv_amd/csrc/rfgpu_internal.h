@@ -35,13 +35,15 @@ struct WalkerState {
     double *phi;      // [2][nslots][ntrc]
     int *cur_slot;    // [nslots] 0/1: which half holds the current trace
     int *prop_fwd;    // [nslots] last proposal ran the forward model
+    double *meta_tp;  // [nslots * nfwd] per batch item: direct-arrival time (spectra -> trace kernel)
+    int *meta_slot;   // [nslots] per batch item: destination half of the proposal
     int nslots;
 };
 
 // K1: propagator-matrix spectra  -> spec[nb][nfwd][2][nh] (freq_r, freq_v after
 // the conj / -conj of forward.f90:145-146)
 void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit, int chain,
-                    int waves_per_block, int *slow_list, int *slow_count, hipStream_t s);
+                    int waves_per_block, int *slow_list, int *slow_count, const WalkerState &w, hipStream_t s);
 // K2: decon / filter / c2r / shift / normalise / write trace / quadratic form
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec,
                   const WalkerState &w, hipStream_t s);

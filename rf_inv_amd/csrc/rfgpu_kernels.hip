@@ -46,6 +46,28 @@ __device__ __forceinline__ double2 cdiv(double2 a, double2 b)
     return make_double2((a.x * r + a.y) / d, (a.y * r - a.x) / d);
 }
 
+// direct_arrival (forward.f90:474-519).  Its result feeds nint() (integer bookkeeping
+// must be bit-exact), so no FMA contraction anywhere and the SUM stays strictly
+// sequential in layer order; only the independent per-layer terms h(i)*sqrt(1/v(i)^2-p^2)
+// are evaluated by separate lanes (each one the same IEEE operations as the reference).
+__device__ __noinline__ double arrival_term(double h, double v, double rayp)
+{
+#pragma clang fp contract(off)
+    const double vv = v * v;
+    const double inv = 1.0 / vv;
+    const double pp = rayp * rayp;
+    const double rad = inv - pp;
+    return h * sqrt(rad);
+}
+
+__device__ __noinline__ double arrival_sum(int n, const double *terms)
+{
+#pragma clang fp contract(off)
+    double t = 0.0;
+    for (int i = 0; i < n; ++i) t = t + terms[i];
+    return t;
+}
+
 // ---------------------------------------------------------------------------
 // K1  spectra
 // ---------------------------------------------------------------------------
@@ -293,6 +315,11 @@ struct SpectraParams {
     int nsplit;
     int *slow_list;   // [nslots * nfwd] (walker, trace) pairs deferred to spectra_slow_kernel
     int *slow_count;  // [1] reset by logl_kernel
+    // per-batch-item scalars prepared for trace_kernel so that it starts with one memory
+    // round trip instead of a dependent chain of them
+    double *meta_tp;  // [nb * nfwd] direct-arrival time of the forward trace
+    int *meta_slot;   // [nb] which half of the walker's trace buffer receives the proposal
+    const int *cur_slot;
 };
 
 // One wave (64 lanes) per (walker, forward-trace, bin-split).  Lanes own frequency
@@ -489,6 +516,22 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
     int nl, ilay0;
     bool sea;
     const bool big = stage_walker(P, ib, f, coef, tail, nl, ilay0, sea);
+    if (blockIdx.x % nblk == 0) {
+        // direct_arrival (forward.f90:474-519) for trace_kernel: per-layer terms by separate
+        // threads, strictly sequential in-order sum (it feeds nint(): bit-exact bookkeeping)
+        const int pad = P.b.nlay_pad;
+        const double *L = P.b.layers + (size_t)ib * 4 * pad;
+        const double *vel = (P.t.ipha[f] == 1) ? L : L + pad;   // alpha for P, beta for S (:157,161)
+        const int i0 = P.t.sdep > 0.0 ? 1 : 0;                  // keyed on sdep (:484)
+        double *terms = tail + 16;
+        for (int i = i0 + (int)threadIdx.x; i < nl - 1; i += blockDim.x)
+            terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], P.t.rayps[f]);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            P.meta_tp[bf] = arrival_sum(nl - 1 - i0, terms);
+            if (f == 0) P.meta_slot[ib] = 1 - P.cur_slot[P.b.walker_ids[ib]];
+        }
+    }
     if (big || sea != (NCOL == 3)) {
         // rare: hand the walker to spectra_slow_kernel (generic path) via the list
         if (blockIdx.x % nblk == 0 && threadIdx.x == 0) P.slow_list[atomicAdd(P.slow_count, 1)] = bf;
@@ -529,7 +572,7 @@ __global__ __launch_bounds__(64) void spectra_slow_kernel(SpectraParams P)
     }
 }
 
-size_t spectra_lds_bytes(int nlay_pad) { return sizeof(double) * ((size_t)nlay_pad * NCOEF + 16); }
+size_t spectra_lds_bytes(int nlay_pad) { return sizeof(double) * ((size_t)nlay_pad * (NCOEF + 1) + 16); }
 
 template <int NCOL>
 static void launch_spectra_ncol(int chain, dim3 grid, dim3 block, size_t lds, hipStream_t s, const SpectraParams &P)
@@ -545,9 +588,9 @@ static void launch_spectra_ncol(int chain, dim3 grid, dim3 block, size_t lds, hi
 
 // chain = bins per phase chain (0 / 1: every phase by a full sincos; 2, 3, 4, 8)
 void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit, int chain,
-                    int waves_per_block, int *slow_list, int *slow_count, hipStream_t s)
+                    int waves_per_block, int *slow_list, int *slow_count, const WalkerState &w, hipStream_t s)
 {
-    SpectraParams P{t, b, spec, nsplit, slow_list, slow_count};
+    SpectraParams P{t, b, spec, nsplit, slow_list, slow_count, w.meta_tp, w.meta_slot, w.cur_slot};
     int wpb = waves_per_block < 1 ? 1 : (waves_per_block > 4 ? 4 : waves_per_block);
     if (wpb > nsplit) wpb = nsplit;
     const int nblk = (nsplit + wpb - 1) / wpb;
@@ -590,28 +633,6 @@ __device__ __forceinline__ double block_max(double v, double *red)
 // Fortran nint: round half away from zero
 __device__ __forceinline__ int f_nint(double x) { return (int)(x >= 0.0 ? floor(x + 0.5) : -floor(0.5 - x)); }
 
-// direct_arrival (forward.f90:474-519).  Its result feeds nint() (integer bookkeeping
-// must be bit-exact), so no FMA contraction anywhere and the SUM stays strictly
-// sequential in layer order; only the independent per-layer terms h(i)*sqrt(1/v(i)^2-p^2)
-// are evaluated by separate lanes (each one the same IEEE operations as the reference).
-__device__ __noinline__ double arrival_term(double h, double v, double rayp)
-{
-#pragma clang fp contract(off)
-    const double vv = v * v;
-    const double inv = 1.0 / vv;
-    const double pp = rayp * rayp;
-    const double rad = inv - pp;
-    return h * sqrt(rad);
-}
-
-__device__ __noinline__ double arrival_sum(int n, const double *terms)
-{
-#pragma clang fp contract(off)
-    double t = 0.0;
-    for (int i = 0; i < n; ++i) t = t + terms[i];
-    return t;
-}
-
 __device__ __noinline__ int calc_npre(double t_start, double tp, double delta, int ipha)
 {
 #pragma clang fp contract(off)
@@ -626,8 +647,10 @@ __device__ __noinline__ int calc_npre(double t_start, double tp, double delta, i
 // order, pass p (radix R_p, stride s_p = R_0 ... R_{p-1}) combines R_p sub-transforms
 // of length s_p; every pass is one register-resident radix-R butterfly per thread
 // (R <= 16), so n = 4096 needs 3 passes / 3 barriers instead of the 12 of radix 2.
-// LDS index i is padded to i + (i >> 4) so that the stride-1 pass (16 contiguous
-// elements per lane) does not put a whole wave on one bank.
+// LDS index i is padded to i + (i >> 4) + (i >> 8): the (i >> 4) term keeps the stride-1
+// pass (16 contiguous elements per lane) off a single bank, the (i >> 8) term does the
+// same for the digit-reversed fill (consecutive bins land 256 elements apart; without it
+// rocprof showed 57 % of the kernel's LDS cycles as bank conflicts, all from those writes).
 // ---------------------------------------------------------------------------
 constexpr int FFT_MAX_PASSES = 4;
 
@@ -636,7 +659,7 @@ struct FftPlan {
     int radix_log2[FFT_MAX_PASSES];  // execution order; stride of pass p = prod of earlier radices
 };
 
-__host__ __device__ inline int fft_pad(int i) { return i + (i >> 4); }
+__host__ __device__ inline int fft_pad(int i) { return i + (i >> 4) + (i >> 8); }
 
 // position (unpadded) of input bin k in the digit-reversed DIT layout
 __device__ __forceinline__ int fft_input_pos(const FftPlan &pl, int log2n, int k)
@@ -859,21 +882,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
             m = fmax(m, x.x * x.x + x.y * x.y);      // forward.f90:458
         }
         wlvl = 0.001 * block_max(m, red);            // forward.f90:460, pcnt = 0.001 (:149)
-    } else {
-        const int nl = P.b.nlay[ib];
-        const int pad = P.b.nlay_pad;
-        const double *L = P.b.layers + (size_t)ib * 4 * pad;
-        const double *vel = (ipha == 1) ? L : L + pad;   // alpha for P, beta for S (:157,161)
-        const int i0 = t.sdep > 0.0 ? 1 : 0;             // keyed on sdep (:484)
-        double *terms = reinterpret_cast<double *>(a);   // FFT array not yet in use
-        for (int i = i0 + tid; i < nl - 1; i += TRACE_THREADS)
-            terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], t.rayps[itrc]);
-        __syncthreads();
-        if (tid == 0) red[4] = arrival_sum(nl - 1 - i0, terms);
     }
-    __syncthreads();
-    const double tp = decon ? 0.0 : red[4];
-    __syncthreads();
+    // direct-arrival time and destination half were prepared by spectra_kernel
+    const double tp = decon ? 0.0 : P.w.meta_tp[ib * t.nfwd + f];
+    const int slot = P.w.meta_slot[ib];
 
     // ---- Z = RF*flt + i * (V*flt), Hermitian-extended, written digit-reversed ----
     // The spectra come from HBM: each thread first issues the loads of FILL_CHUNK bins
@@ -934,7 +946,6 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
 
     // ---- time shift (+ reverse/negate for S), normalise, store, misfit ----------
     const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
-    const int slot = 1 - P.w.cur_slot[walker];
     double *__restrict__ dst =
         P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;

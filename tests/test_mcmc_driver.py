@@ -1,0 +1,123 @@
+"""Batched RJ-MCMC driver (rf_inv_amd/mcmc.py) and MT19937 mirror against (a) the reference's
+own compiled host modules (oracle/_ref/dump_init, built by rf_inv_amd/fortran/Makefile) and
+(b) the end-to-end trajectory value recorded from a pure-reference run in SURVEY.md section 8c(4):
+rslt/likelihood, iteration 1 = -1044.33907794324 (seed 12345678, 1 rank, shipped sample_syn
+params.in)."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from rf_inv_amd import get_params, read_obs, read_ref_model
+from rf_inv_amd.mcmc import RJMCMC, EngineEvaluator
+from rf_inv_amd.mt19937 import MT19937
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DUMP = os.path.join(ROOT, "oracle", "_ref", "dump_init")
+SURVEY_IT1 = -1044.33907794324
+
+
+def _setup(golden_dir):
+    p = get_params(os.path.join(golden_dir, "sample_syn", "params.in"))
+    read_obs(p)
+    ref = read_ref_model(os.path.join(p.base_dir, p.vel_file))
+    return p, ref
+
+
+class OracleEvaluator:
+    """CPU stand-in for the engine in the CPU tests (tests/ only): same two methods."""
+
+    def __init__(self, oracle, p):
+        self.o, self.p = oracle, p
+        self.cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep,
+                        rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha)
+        self.r_inv = oracle.build_r_inv(p.nsmp, p.a_gus, p.delta)
+        self.obs = np.ascontiguousarray(p.obs[:, :p.nsmp])
+        self.cur, self.prop = {}, {}
+
+    def eval_batch(self, chains, fwd_flags, stacks, sigs):
+        out = []
+        for c, f, st, sg in zip(chains, fwd_flags, stacks, sigs):
+            rft = self.o.calc_rf(self.cfg, *st) if f else self.cur[c]
+            self.prop[c] = rft
+            out.append(self.o.log_likelihood(rft, self.obs, self.r_inv, sg, self.p.nsmp))
+        return np.array(out)
+
+    def commit(self, chains, accepts):
+        for c, a in zip(chains, accepts):
+            if a:
+                self.cur[c] = self.prop[c]
+
+
+def test_mt19937_known_state():
+    g = MT19937(12345678)
+    x = [g.grnd() for _ in range(1300)]  # crosses two regenerations
+    assert x[0] == 0.5835216229315847 and all(0.0 <= v < 1.0 for v in x)
+    # default seed when sgrnd was never called (mt19937.f90:96-100)
+    assert MT19937().grnd() == MT19937(4357).grnd()
+
+
+def test_init_model_and_rng_match_reference_modules(golden_dir, tmp_path):
+    """Bit-for-bit against the reference's own mt19937 + model + params object code."""
+    if not os.path.exists(DUMP):
+        pytest.skip("oracle/_ref/dump_init not built (no Fortran compiler / reference tree at build time)")
+    work = tmp_path / "sample_syn"
+    shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
+    os.makedirs(work / "rslt")
+    r = subprocess.run([DUMP, "params.in"], cwd=work, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "dump_init: ok" in r.stdout, r.stdout + r.stderr
+    tok = iter(open(work / "init_dump.txt").read().split())
+    nchains, k_max = int(next(tok)), int(next(tok))
+    p, ref = _setup(golden_dir)
+    assert (nchains, k_max) == (p.nchains, p.k_max)
+    g = MT19937(p.iseed)
+    m = RJMCMC(p, ref, None, g)
+    m.init_model()
+    for c in range(nchains):
+        assert int(next(tok)) == m.k[c]
+        z = np.array([float(next(tok)) for _ in range(k_max - 1)])
+        dvp = np.array([float(next(tok)) for _ in range(k_max)])
+        dvs = np.array([float(next(tok)) for _ in range(k_max)])
+        assert np.array_equal(z, m.z[c]) and np.array_equal(dvp, m.dvp[c]) and np.array_equal(dvs, m.dvs[c])
+    nxt = [float(next(tok)) for _ in range(8)]
+    assert nxt == [g.grnd() for _ in range(8)]
+
+
+def _run_first_iterations(p, ref, ev, niter):
+    g = MT19937(p.iseed)           # rank 0: iseed + 0 (rf_inv.f90:75)
+    m = RJMCMC(p, ref, ev, g)
+    m.init_model()
+    m.init_likelihood()
+    m.init_pt_mcmc()
+    vals = []
+    for it in range(1, niter + 1):
+        m.iterate(it)
+        vals.append(m.mean_t1_likelihood(it))
+    return m, vals
+
+
+def test_trajectory_pin_with_oracle(oracle, golden_dir):
+    """End-to-end pin of the ORACLE (ocean boundary condition, 2 traces, R^-1, logL) and of the
+    driver's RNG order on a value produced by the reference itself."""
+    p, ref = _setup(golden_dir)
+    m, vals = _run_first_iterations(p, ref, OracleEvaluator(oracle, p), 3)
+    assert abs(vals[0] - SURVEY_IT1) < 5e-9, vals[0]
+    assert m.counters.nprop.sum() == 3 * p.ncool
+
+
+@pytest.mark.gpu
+def test_trajectory_pin_on_gpu(oracle, golden_dir):
+    from rf_inv_amd import RFEngine
+    from rf_inv_amd.likelihood import init_r_inv
+
+    p, ref = _setup(golden_dir)
+    eng = RFEngine.from_params(p, r_inv=init_r_inv(p.nsmp, p.a_gus, p.delta))
+    m, vals = _run_first_iterations(p, ref, EngineEvaluator(eng, p.k_max + 2), 200)
+    assert abs(vals[0] - SURVEY_IT1) < 5e-9, vals[0]
+    # same trajectory as the oracle-driven run over 200 iterations (accept decisions included)
+    m2, vals2 = _run_first_iterations(p, ref, OracleEvaluator(oracle, p), 200)
+    assert np.array_equal(m.k, m2.k) and np.array_equal(m.counters.naccept, m2.counters.naccept)
+    assert np.allclose(vals, vals2, rtol=1e-11, atol=1e-8)
+    eng.close()
