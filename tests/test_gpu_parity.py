@@ -271,3 +271,58 @@ def test_chained_phase_variants_parity(oracle, monkeypatch, chain):
                 got = eng.get_rft(i, which=1).T
                 assert np.abs(got - ref_rft[i]).max() <= 1e-12 * np.abs(ref_rft[i]).max(), (chain, sdep, i)
         assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (chain, sdep, np.abs(ll - ref_ll).max())
+
+
+@pytest.mark.parametrize("nfft", [16, 32, 64, 128, 8192])
+def test_fft_sizes(oracle, nfft):
+    """Every mixed-radix plan of the in-LDS c2r (radix 16 passes + a 2/4/8 remainder), from the
+    smallest sizes to the LDS-filling 8192."""
+    rng = np.random.default_rng(nfft)
+    nsmp = min(101, nfft // 2)
+    cfg = make_cfg(nfft=nfft, rayps=[0.06, 0.09], ipha=[1, -1], t_start=0.0)
+    true = random_stack(rng, 4)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, 3), random_stack(rng, 7), true]
+    nlay, layers = pack_layers(stacks, 9)
+    sig = np.full((3, 2), 0.02)
+    ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=3) as eng:
+        ll = eng.eval_batch(np.arange(3), nlay, layers, sig)
+        for i in range(3):
+            got = eng.get_rft(i, which=1).T
+            assert np.abs(got - ref_rft[i]).max() <= 1e-12 * np.abs(ref_rft[i]).max(), (nfft, i)
+    assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (nfft, np.abs(ll - ref_ll).max())
+
+
+def test_edge_shapes(oracle):
+    """Ragged / extreme batches: a single walker, a 2-layer model (no propagator at all), the
+    deepest stack the context allows (reference nlay_max = 200), a long time window (nsmp 401),
+    mixed fwd_flag, and re-evaluation of a subset of walkers in a different order."""
+    rng = np.random.default_rng(9)
+    nsmp = 401
+    cfg = make_cfg(nfft=1024, rayps=[0.05], t_start=-2.0)
+    true = random_stack(rng, 6)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    deep = random_stack(rng, 200)
+    deep[3][:-1] *= 0.05  # 199 thin layers
+    stacks = [random_stack(rng, 2), deep, true, random_stack(rng, 11)]
+    nlay, layers = pack_layers(stacks, 200)
+    sig = np.full((4, 1), 0.03)
+    ref = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=4, nlay_max=200) as eng:
+        one = eng.eval_batch([2], nlay[2:3], layers[2:3], sig[2:3])           # nb = 1
+        assert abs(one[0] - ref[2]) <= logl_tol(ref[2])
+        ll = eng.eval_batch(np.arange(4), nlay, layers, sig)
+        assert np.all(np.abs(ll - ref) <= logl_tol(ref)), np.abs(ll - ref)
+        eng.commit(np.arange(4), [1, 1, 0, 1])
+        # subset, permuted, one of them sigma-only (re-uses its committed trace)
+        ids = np.array([3, 0, 1], dtype=np.int32)
+        ff = np.array([1, 0, 1], dtype=np.int32)
+        sig2 = np.full((3, 1), 0.05)
+        ll2 = eng.eval_batch(ids, nlay[ids], layers[ids], sig2, fwd_flag=ff)
+        ref2 = oracle.eval_batch(cfg, obs, r_inv, nlay[ids], layers[ids], sig2, nsmp)
+        assert np.all(np.abs(ll2 - ref2) <= logl_tol(ref2)), np.abs(ll2 - ref2)
+        # walker 2 was rejected: its current trace is still the zero-initialised slot
+        assert np.all(eng.get_rft(2, 0) == 0.0)
