@@ -310,6 +310,9 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     c->ws.meta_tp = (double *)p;
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->ws.meta_slot = (int *)p;
+    if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
+    c->ws.done = (int *)p;
+    (void)hipMemset(p, 0, sizeof(int) * c->nslots);
     c->ws.nslots = c->nslots;
     if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * c->nfwd * 2 * nh)) return cleanup(1);
     c->spec = (double2 *)p;
@@ -429,10 +432,7 @@ static int run_batch(rf_ctx *c, const BatchArgs &b, hipStream_t s)
                    c->slow_count, c->ws, s);
     if (e) (void)hipEventRecord(e, s);
     e = prof_begin(c, 1, s);
-    launch_trace(c->tab, b, c->spec, c->ws, s);
-    if (e) (void)hipEventRecord(e, s);
-    e = prof_begin(c, 2, s);
-    launch_logl(c->tab, b, c->ws, c->slow_count, 1, s);
+    launch_trace(c->tab, b, c->spec, c->ws, c->slow_count, s);   // also forms logL
     if (e) (void)hipEventRecord(e, s);
     if (c->prof) c->prof_n[0] += 1;
     HIP_TRY(hipGetLastError());

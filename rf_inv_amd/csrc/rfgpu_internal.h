@@ -37,6 +37,7 @@ struct WalkerState {
     int *prop_fwd;    // [nslots] last proposal ran the forward model
     double *meta_tp;  // [nslots * nfwd] per batch item: direct-arrival time (spectra -> trace kernel)
     int *meta_slot;   // [nslots] per batch item: destination half of the proposal
+    int *done;        // [nslots] per batch item: traces finished (last one forms logL), self-resetting
     int nslots;
 };
 
@@ -46,8 +47,9 @@ void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, in
                     int waves_per_block, int *slow_list, int *slow_count, const WalkerState &w, hipStream_t s);
 // K2: decon / filter / c2r / shift / normalise / write trace / quadratic form
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec,
-                  const WalkerState &w, hipStream_t s);
-// K3: log-likelihood from the per-trace quadratic forms
+                  const WalkerState &w, int *slow_count, hipStream_t s);
+// log-likelihood from cached quadratic forms (used for host-owned traces; the batched path
+// forms logL inside trace_kernel)
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count,
                  int nslow, hipStream_t s);
 void launch_phi(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s);
