@@ -532,15 +532,25 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
             if (f == 0) P.meta_slot[ib] = 1 - P.cur_slot[P.b.walker_ids[ib]];
         }
     }
-    if (big || sea != (NCOL == 3)) {
-        // rare: hand the walker to spectra_slow_kernel (generic path) via the list
-        if (blockIdx.x % nblk == 0 && threadIdx.x == 0) P.slow_list[atomicAdd(P.slow_count, 1)] = bf;
-        return;
-    }
-    if (split >= P.nsplit) return;
     const int ipha = P.t.ipha[f];
     double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
     double2 *out_v = out_r + P.t.nh;
+    if (big || sea != (NCOL == 3)) {
+        // rare: out-of-range phases or a layer stack of the other kind (land / ocean)
+        if (BK > 1) {
+            // the chained-phase kernels have the registers to spare: generic path in place
+            if (split >= P.nsplit) return;
+            if (sea)
+                spectra_body<0, 3, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split, lane);
+            else
+                spectra_body<0, 2, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split, lane);
+        } else if (blockIdx.x % nblk == 0 && threadIdx.x == 0) {
+            // the lean direct kernel (4 waves/SIMD) defers to spectra_slow_kernel via the list
+            P.slow_list[atomicAdd(P.slow_count, 1)] = bf;
+        }
+        return;
+    }
+    if (split >= P.nsplit) return;
     spectra_body<BK, NCOL, true>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split, lane);
 }
 
@@ -600,6 +610,7 @@ void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, in
         launch_spectra_ncol<3>(chain, grid, block, lds, s, P);
     else
         launch_spectra_ncol<2>(chain, grid, block, lds, s, P);
+    if (chain == 2 || chain == 3 || chain == 4 || chain == 8) return;   // generic path handled in place
     hipLaunchKernelGGL(spectra_slow_kernel, dim3(512), dim3(64), lds, s, P);
 }
 

@@ -326,3 +326,31 @@ def test_edge_shapes(oracle):
         assert np.all(np.abs(ll2 - ref2) <= logl_tol(ref2)), np.abs(ll2 - ref2)
         # walker 2 was rejected: its current trace is still the zero-initialised slot
         assert np.all(eng.get_rft(2, 0) == 0.0)
+
+
+@pytest.mark.parametrize("chain", ["0", "4"])
+def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, monkeypatch, chain):
+    """In ONE batch: ordinary walkers, one with out-of-range phases (|x| > 1e6 rad) and one whose
+    stack is of the other kind than the context (a water layer, beta(1) < 0, with sdep = 0:
+    calc_seis keys on beta(1), forward.f90:229, direct_arrival on sdep, :484).  Both the
+    in-place generic path of the chained-phase kernels and the deferred-list kernel."""
+    monkeypatch.setenv("RFGPU_CHAIN", chain)
+    rng = np.random.default_rng(31)
+    cfg = make_cfg(nfft=2048, rayps=[0.06, 0.07], t_start=-1.0)
+    nsmp = 101
+    true = random_stack(rng, 4)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, 6) for _ in range(5)]
+    stacks[1][3][2] = 3.0e5                      # huge phase
+    stacks[3] = random_stack(rng, 6, ocean=True)  # water layer in a land context
+    nlay, layers = pack_layers(stacks, 8)
+    sig = np.full((5, 2), 0.05)
+    ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=5) as eng:
+        for rep in range(2):
+            ll = eng.eval_batch(np.arange(5), nlay, layers, sig)
+            assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (rep, np.abs(ll - ref_ll))
+        for i in range(5):
+            got = eng.get_rft(i, which=1).T
+            assert np.abs(got - ref_rft[i]).max() <= 1e-11 * np.abs(ref_rft[i]).max(), i
