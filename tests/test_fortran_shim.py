@@ -81,3 +81,50 @@ def test_fortran_dropin_modules_on_sample_syn(oracle, golden_dir, tmp_path):
         ll2 = oracle.log_likelihood(ref, obs, r_inv, 2 * c["sig"], 101)
         assert abs(c["ll2"] - ll2) <= logl_tol(ll2)
         assert c["same_trace"] == 1 and c["same_rf"] == 1
+
+
+RFINV = os.path.join(ROOT, "oracle", "_ref", "drive_rfinv")
+
+
+@pytest.mark.gpu
+def test_reference_sampler_on_top_of_the_dropin_modules(oracle, golden_dir, tmp_path):
+    """The reference's OWN pt_mcmc.f90 (compiled unmodified) running its sequential PT RJ-MCMC
+    loop on top of our forward / likelihood modules on the GPU, shipped sample_syn params.in.
+    Checked against (a) the value SURVEY.md section 8c(4) records from a pure-reference run and
+    (b) the batched Python driver (rf_inv_amd/mcmc.py) on the same engine: identical
+    trajectory (every accept/reject decision) over 300 iterations."""
+    if not os.path.exists(RFINV):
+        pytest.skip("oracle/_ref/drive_rfinv not built (no Fortran compiler / reference tree at build time)")
+    n_it = 300
+    work = tmp_path / "sample_syn"
+    shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
+    os.makedirs(work / "rslt")
+    r = subprocess.run([RFINV, "params.in", str(n_it)], cwd=work, env=dict(os.environ), capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "drive_rfinv: ok" in r.stdout, r.stdout + r.stderr
+    tok = iter(open(work / "rfinv_dump.txt").read().split())
+    n, ntype, ncool = int(next(tok)), int(next(tok)), int(next(tok))
+    hist = np.array([float(next(tok)) for _ in range(n)])
+    nprop = np.array([int(next(tok)) for _ in range(ntype)])
+    nacc = np.array([int(next(tok)) for _ in range(ntype)])
+    assert (n, ntype, ncool) == (n_it, 4, 1)
+    assert abs(hist[0] - (-1044.33907794324)) < 1e-7     # R^-1 here is librfgpu's own SVD, not LAPACK
+
+    from rf_inv_amd import RFEngine, get_params, read_obs, read_ref_model
+    from rf_inv_amd.mcmc import RJMCMC, EngineEvaluator
+    from rf_inv_amd.mt19937 import MT19937
+
+    p = get_params(os.path.join(golden_dir, "sample_syn", "params.in"))
+    read_obs(p)
+    p.nburn, p.niter = 0, n_it
+    ref = read_ref_model(os.path.join(p.base_dir, p.vel_file))
+    with RFEngine.from_params(p) as eng:               # same default R^-1 as the Fortran shim
+        m = RJMCMC(p, ref, EngineEvaluator(eng, p.k_max + 2), MT19937(p.iseed))
+        m.init_model(); m.init_likelihood(); m.init_pt_mcmc()
+        vals = []
+        for it in range(1, n_it + 1):
+            m.iterate(it)
+            vals.append(m.mean_t1_likelihood(it))
+    assert np.array_equal(m.counters.nprop[1:ntype + 1], nprop)
+    assert np.array_equal(m.counters.naccept[1:ntype + 1], nacc)
+    assert np.allclose(hist, vals, rtol=1e-12, atol=1e-9)
