@@ -1,0 +1,364 @@
+!=======================================================================
+! module pt_mcmc_batched -- throughput form of the reference sampler loop.
+!
+!   call pt_control_batched(verb)     ! instead of  call pt_control(verb)
+!
+! One iteration = propose every chain -> ONE batched forward+likelihood call
+! on the GPU (rf_eval_batch) -> accept/reject every chain -> rf_commit ->
+! temperature swap.  It shares all state with the reference's modules
+! (model: k, z, dvp, dvs; likelihood: sig, log_likelihood; params: temps;
+! pt_mcmc: every counter and histogram), so init_pt_mcmc before it and
+! output_results after it work unchanged.
+!
+! The random stream is consumed in exactly the order of the reference's
+! sequential loop (src/pt_mcmc.f90:488-571): per chain the proposal draws and,
+! iff the proposal is not null, the acceptance uniform of judge_mcmc -- which
+! does not depend on the likelihood and can therefore be drawn before the
+! batched evaluation.  The trajectory is identical to pt_control's.
+!
+! Written from scratch for rf_inv_amd (it restates what one step of the
+! reference's private `mcmc` does; the reference subroutine itself evaluates
+! one chain per call and cannot be batched).  The traces stay on the device;
+! the host copy likelihood::rft is NOT kept up to date by this loop.
+!=======================================================================
+module pt_mcmc_batched
+  use iso_c_binding
+  use rfgpu_c
+  implicit none
+  public pt_control_batched
+  private
+
+contains
+
+  subroutine pt_control_batched(verb)
+    use params
+    use mt19937, only: grnd
+    use math, only: gauss
+    use prior, only: laplace, log_prior_ratio
+    use model
+    use likelihood, only: sig, log_likelihood
+    use forward, only: rf_ctx
+    use pt_mcmc
+    include "mpif.h"
+    logical, intent(in) :: verb
+    integer :: nproc, rank, ierr, it, n_tot_iter, n_all, ichain, nb, ib, i
+    integer :: itype, itarget, ilay, nlay, nlay_pad, prop_k
+    logical :: null_flag, is_valid, yn
+    real(8) :: alpha(nlay_max), beta(nlay_max), rho(nlay_max), h(nlay_max)
+    real(8) :: prop_z(k_max), prop_dvp(k_max), prop_dvs(k_max), prop_sig(ntrc)
+    real(8) :: log_prior12, r, del_s, t_cold
+    ! per-chain proposals of the current iteration
+    integer, allocatable :: p_k(:), p_type(:)
+    logical, allocatable :: p_live(:), p_acc(:)
+    real(8), allocatable :: p_z(:,:), p_dvp(:,:), p_dvs(:,:), p_sig(:,:), p_lp(:), p_logr(:)
+    ! the batch handed to the engine
+    integer(c_int32_t), allocatable :: b_id(:), b_fwd(:), b_nlay(:), b_acc(:)
+    real(c_double), allocatable :: b_layers(:,:,:), b_sig(:,:), b_logl(:)
+    ! temperature swap
+    integer :: ipack(4), rank1, rank2, ichain1, ichain2, itarget1, itarget2
+    integer :: status(MPI_STATUS_SIZE)
+    real(8) :: temp1, temp2, e1, e2, rpack(2)
+
+    call mpi_comm_size(MPI_COMM_WORLD, nproc, ierr)
+    call mpi_comm_rank(MPI_COMM_WORLD, rank, ierr)
+    n_all = nproc * nchains
+    n_tot_iter = nburn + niter
+    nlay_pad = k_max + 2
+    t_cold = 1.d0 + 1.0e-6
+
+    allocate(p_k(nchains), p_type(nchains), p_live(nchains), p_acc(nchains))
+    allocate(p_z(k_max, nchains), p_dvp(k_max, nchains), p_dvs(k_max, nchains))
+    allocate(p_sig(ntrc, nchains), p_lp(nchains), p_logr(nchains))
+    allocate(b_id(nchains), b_fwd(nchains), b_nlay(nchains), b_acc(nchains))
+    allocate(b_layers(nlay_pad, 4, nchains), b_sig(ntrc, nchains), b_logl(nchains))
+
+    ! the first evaluation of every chain (init_likelihood) becomes its current trace
+    do ichain = 1, nchains
+       b_id(ichain) = ichain - 1
+       b_acc(ichain) = 1
+    end do
+    call rfgpu_check(rf_commit(rf_ctx, int(nchains, c_int32_t), b_id, b_acc), "rf_commit")
+
+    do it = 1, n_tot_iter
+       if (verb .and. mod(it, ncorr) == 0) write(*,*) "Iteration #:", it, "/", n_tot_iter
+
+       !----------------------------------------------------------------
+       ! 1. proposals, chain by chain, in the reference's draw order
+       !----------------------------------------------------------------
+       nb = 0
+       do ichain = 1, nchains
+          log_prior12 = 0.d0
+          prop_k = k(ichain)
+          prop_dvp(1:k_max) = dvp(1:k_max, ichain)
+          prop_dvs(1:k_max) = dvs(1:k_max, ichain)
+          prop_z(1:k_max-1) = z(1:k_max-1, ichain)
+          prop_sig(1:ntrc) = sig(1:ntrc, ichain)
+          null_flag = .false.
+
+          itype = int(grnd() * ntype) + 1
+          if (itype == itype_birth) then
+             prop_k = prop_k + 1
+             if (prop_k < k_max) then
+                if (prior_mode == 1) then
+                   prop_dvp(prop_k) = laplace() * dvp_prior
+                   prop_dvs(prop_k) = laplace() * dvs_prior
+                else if (prior_mode == 2) then
+                   prop_dvp(prop_k) = gauss() * dvp_prior
+                   prop_dvs(prop_k) = gauss() * dvs_prior
+                end if
+                prop_z(prop_k) = z_min + grnd() * (z_max - z_min)
+             else
+                null_flag = .true.
+             end if
+          else if (itype == itype_death) then
+             prop_k = prop_k - 1
+             if (prop_k >= k_min) then
+                itarget = int(grnd() * (prop_k + 1)) + 1
+                do ilay = itarget, prop_k
+                   prop_dvp(ilay) = dvp(ilay + 1, ichain)
+                   prop_dvs(ilay) = dvs(ilay + 1, ichain)
+                   prop_z(ilay) = z(ilay + 1, ichain)
+                end do
+                prop_dvp(prop_k + 1) = 0.d0
+                prop_dvs(prop_k + 1) = 0.d0
+                prop_z(prop_k + 1) = 0.d0
+             else
+                null_flag = .true.
+             end if
+          else if (itype == itype_z) then
+             itarget = int(grnd() * prop_k) + 1
+             prop_z(itarget) = prop_z(itarget) + gauss() * dev_z
+             if (prop_z(itarget) < z_min .or. prop_z(itarget) > z_max) null_flag = .true.
+          else if (itype == itype_dvs) then
+             itarget = int(grnd() * (prop_k + 1)) + 1
+             if (itarget == prop_k + 1) itarget = k_max
+             prop_dvs(itarget) = prop_dvs(itarget) + gauss() * dev_dvs
+             log_prior12 = log_prior_ratio(prop_dvs(itarget), dvs(itarget, ichain), dvs_prior, prior_mode)
+          else if (itype == itype_dvp) then
+             itarget = int(grnd() * (prop_k + 1)) + 1
+             if (itarget == prop_k + 1) itarget = k_max
+             prop_dvp(itarget) = prop_dvp(itarget) + gauss() * dev_dvp
+             log_prior12 = log_prior_ratio(prop_dvp(itarget), dvp(itarget, ichain), dvp_prior, prior_mode)
+          else if (itype == itype_sig) then
+             itarget = isig_trc(int(grnd() * nsig_trc) + 1)
+             prop_sig(itarget) = prop_sig(itarget) + gauss() * dev_sig
+             if (prop_sig(itarget) < sig_min(itarget) .or. prop_sig(itarget) > sig_max(itarget)) &
+                  & null_flag = .true.
+          end if
+
+          if (.not. null_flag) then
+             call format_model(prop_k, prop_z(1:k_max-1), prop_dvp, prop_dvs, &
+                  & nlay, alpha, beta, rho, h, is_valid)
+             if (.not. is_valid) null_flag = .true.
+          end if
+
+          p_type(ichain) = itype
+          p_live(ichain) = .not. null_flag
+          p_acc(ichain) = .false.
+          if (.not. null_flag) then
+             ! the acceptance uniform of judge_mcmc, drawn at its place in the stream
+             do
+                r = grnd()
+                if (r >= epsilon(1.d0)) exit
+             end do
+             p_logr(ichain) = log(r)
+             p_lp(ichain) = log_prior12
+             p_k(ichain) = prop_k
+             p_z(1:k_max-1, ichain) = prop_z(1:k_max-1)
+             p_dvp(:, ichain) = prop_dvp
+             p_dvs(:, ichain) = prop_dvs
+             p_sig(:, ichain) = prop_sig
+             nb = nb + 1
+             b_id(nb) = ichain - 1
+             b_sig(:, nb) = prop_sig
+             if (itype /= itype_sig) then
+                b_fwd(nb) = 1
+                b_nlay(nb) = nlay
+                b_layers(:, :, nb) = 1.d0
+                b_layers(1:nlay, 1, nb) = alpha(1:nlay)
+                b_layers(1:nlay, 2, nb) = beta(1:nlay)
+                b_layers(1:nlay, 3, nb) = rho(1:nlay)
+                b_layers(1:nlay, 4, nb) = h(1:nlay)
+             else
+                b_fwd(nb) = 0
+                b_nlay(nb) = 2
+                b_layers(:, :, nb) = 1.d0
+             end if
+          end if
+       end do
+
+       !----------------------------------------------------------------
+       ! 2. one batched forward + likelihood evaluation on the GPU
+       !----------------------------------------------------------------
+       if (nb > 0) then
+          call rfgpu_check(rf_eval_batch(rf_ctx, int(nb, c_int32_t), b_id, b_fwd, b_nlay, &
+               & int(nlay_pad, c_int32_t), b_layers, b_sig, b_logl), "rf_eval_batch")
+       end if
+
+       !----------------------------------------------------------------
+       ! 3. Metropolis-Hastings decisions and state update
+       !----------------------------------------------------------------
+       do ib = 1, nb
+          ichain = b_id(ib) + 1
+          del_s = (b_logl(ib) - log_likelihood(ichain)) / temps(ichain) + p_lp(ichain)
+          yn = (p_logr(ichain) <= del_s)
+          b_acc(ib) = 0
+          if (yn) then
+             b_acc(ib) = 1
+             log_likelihood(ichain) = b_logl(ib)
+             k(ichain) = p_k(ichain)
+             dvp(1:k_max, ichain) = p_dvp(1:k_max, ichain)
+             dvs(1:k_max, ichain) = p_dvs(1:k_max, ichain)
+             z(1:k_max-1, ichain) = p_z(1:k_max-1, ichain)
+             sig(1:ntrc, ichain) = p_sig(1:ntrc, ichain)
+          end if
+          p_acc(ichain) = yn
+       end do
+       if (nb > 0) call rfgpu_check(rf_commit(rf_ctx, int(nb, c_int32_t), b_id, b_acc), "rf_commit")
+
+       !----------------------------------------------------------------
+       ! 4. counters and posterior records of the non-tempered chains
+       !----------------------------------------------------------------
+       do ichain = 1, nchains
+          if (temps(ichain) <= t_cold) then
+             nprop(p_type(ichain)) = nprop(p_type(ichain)) + 1
+             if (p_acc(ichain)) naccept(p_type(ichain)) = naccept(p_type(ichain)) + 1
+             likelihood_hist(it) = likelihood_hist(it) + log_likelihood(ichain)
+             if (it > nburn .and. mod(it, ncorr) == 0) call record_sample(ichain)
+          end if
+       end do
+
+       !----------------------------------------------------------------
+       ! 5. one temperature-swap proposal for the whole ensemble
+       !----------------------------------------------------------------
+       if (nchains < 2) cycle
+       if (rank == 0) then
+          itarget1 = int(grnd() * n_all)
+          do
+             itarget2 = int(grnd() * n_all)
+             if (itarget2 /= itarget1) exit
+          end do
+          ipack(1) = itarget1 / nchains
+          ipack(2) = itarget2 / nchains
+          ipack(3) = mod(itarget1, nchains) + 1
+          ipack(4) = mod(itarget2, nchains) + 1
+       end if
+       call mpi_bcast(ipack, 4, MPI_INTEGER4, 0, MPI_COMM_WORLD, ierr)
+       rank1 = ipack(1)
+       rank2 = ipack(2)
+       ichain1 = ipack(3)
+       ichain2 = ipack(4)
+       if (rank1 == rank .and. rank2 == rank) then
+          temp1 = temps(ichain1)
+          temp2 = temps(ichain2)
+          if (swap_ok(temp1, temp2, log_likelihood(ichain1), log_likelihood(ichain2))) then
+             temps(ichain2) = temp1
+             temps(ichain1) = temp2
+          end if
+       else if (rank1 == rank) then
+          call mpi_recv(rpack, 2, MPI_REAL8, rank2, 2018, MPI_COMM_WORLD, status, ierr)
+          temp1 = temps(ichain1)
+          temp2 = rpack(1)
+          e1 = log_likelihood(ichain1)
+          e2 = rpack(2)
+          if (swap_ok(temp1, temp2, e1, e2)) then
+             temps(ichain1) = temp2
+             rpack(1) = temp1
+          end if
+          call mpi_send(rpack, 1, MPI_REAL8, rank2, 1988, MPI_COMM_WORLD, ierr)
+       else if (rank2 == rank) then
+          rpack(1) = temps(ichain2)
+          rpack(2) = log_likelihood(ichain2)
+          call mpi_send(rpack, 2, MPI_REAL8, rank1, 2018, MPI_COMM_WORLD, ierr)
+          call mpi_recv(rpack, 1, MPI_REAL8, rank1, 1988, MPI_COMM_WORLD, status, ierr)
+          temps(ichain2) = rpack(1)
+       end if
+    end do
+
+  contains
+
+    ! Metropolis rule of the temperature exchange; draws one uniform
+    logical function swap_ok(t1, t2, l1, l2)
+      real(8), intent(in) :: t1, t2, l1, l2
+      swap_ok = (log(grnd()) <= (l2 - l1) * (1.d0 / t1 - 1.d0 / t2))
+    end function swap_ok
+
+    ! posterior bookkeeping of one non-tempered chain: the same bins, in the same
+    ! order, as the record block of the reference's step routine, so that
+    ! output_results (mcmc_out) produces identical files.
+    subroutine record_sample(jc)
+      integer, intent(in) :: jc
+      integer :: itrc, ibin, il, iz, iz1, iz2, ivp, ivs, ivpvs, nl, ismp
+      real(8) :: a(nlay_max), b(nlay_max), rh(nlay_max), th(nlay_max), tmpz
+      real(8) :: trace(nsmp, ntrc)
+      logical :: ok
+
+      nmod = nmod + 1
+      all_likelihood(nmod) = log_likelihood(jc)
+      nk(k(jc)) = nk(k(jc)) + 1
+      do itrc = 1, ntrc
+         if (sig_mode(itrc) == 1) then
+            ibin = int((sig(itrc, jc) - sig_min(itrc)) / dbin_sig(itrc)) + 1
+            nsig(ibin, itrc) = nsig(ibin, itrc) + 1
+         end if
+      end do
+      do il = 1, k(jc) - 1
+         ibin = int((z(il, jc) - z_min) / dbin_z) + 1
+         nz(ibin) = nz(ibin) + 1
+      end do
+
+      call format_model(k(jc), z(1:k_max-1, jc), dvp(1:k_max, jc), dvs(1:k_max, jc), &
+           & nl, a, b, rh, th, ok)
+      tmpz = 0.d0
+      do il = 1, nl
+         iz1 = int(tmpz / dbin_z) + 1
+         if (il < nl) then
+            iz2 = int((tmpz + th(il)) / dbin_z) + 1
+         else
+            iz2 = nbin_z + 1
+         end if
+         ivp = int((a(il) - vp_min) / dbin_vp) + 1
+         ivs = max(1, int((b(il) - vs_min) / dbin_vs) + 1)
+         ivpvs = int(((a(il) / b(il)) - vpvs_min) / dbin_vpvs) + 1
+         ivpvs = min(max(1, ivpvs), nbin_vpvs)
+         do iz = iz1, iz2 - 1
+            nvpz(iz, ivp) = nvpz(iz, ivp) + 1
+            vp_mean(iz) = vp_mean(iz) + a(il)
+            vp_model(iz, nmod) = a(il)
+            nvsz(iz, ivs) = nvsz(iz, ivs) + 1
+            nvpvsz(iz, ivpvs) = nvpvsz(iz, ivpvs) + 1
+            if (b(il) > 0.d0) then
+               vpvs_mean(iz) = vpvs_mean(iz) + a(il) / b(il)
+               vs_mean(iz) = vs_mean(iz) + b(il)
+               vs_model(iz, nmod) = b(il)
+            else
+               vpvs_mean(iz) = vpvs_min
+               vs_mean(iz) = vs_min
+               vs_model(iz, nmod) = vs_min
+            end if
+            vp_model(iz, nmod) = a(il)
+         end do
+         tmpz = tmpz + th(il)
+      end do
+
+      ! the chain's current trace lives on the device
+      call rfgpu_check(rf_get_rft(rf_ctx, int(jc - 1, c_int32_t), 0_c_int32_t, int(nsmp, c_int32_t), trace), &
+           & "rf_get_rft")
+      do itrc = 1, ntrc
+         do ismp = 1, nsmp
+            ibin = int((trace(ismp, itrc) - amp_min) / dbin_amp) + 1
+            if (ibin < 1) then
+               write(0,*) "Warning: RF amp. out of range"
+               ibin = 1
+            else if (ibin > nbin_amp) then
+               write(0,*) "Warning: RF amp. out of range"
+               ibin = nbin_amp
+            end if
+            namp(ibin, ismp, itrc) = namp(ibin, ismp, itrc) + 1
+         end do
+      end do
+    end subroutine record_sample
+
+  end subroutine pt_control_batched
+
+end module pt_mcmc_batched

@@ -78,6 +78,29 @@ module rfgpu_c
        real(c_double), intent(in) :: rft(*), sig(*)
        real(c_double), intent(out) :: logl
      end function rf_calc_likelihood_of_trace
+     integer(c_int) function rf_eval_batch(ctx, nb, walker_ids, fwd_flag, nlay, nlay_pad, layers, sig, logl) &
+          & bind(C, name="rf_eval_batch")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: nb, nlay_pad
+       integer(c_int32_t), intent(in) :: walker_ids(*), fwd_flag(*), nlay(*)
+       real(c_double), intent(in) :: layers(*), sig(*)
+       real(c_double), intent(out) :: logl(*)
+     end function rf_eval_batch
+
+     integer(c_int) function rf_commit(ctx, nb, walker_ids, accept) bind(C, name="rf_commit")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: nb
+       integer(c_int32_t), intent(in) :: walker_ids(*), accept(*)
+     end function rf_commit
+
+     integer(c_int) function rf_get_rft(ctx, walker, which, n, out) bind(C, name="rf_get_rft")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: walker, which, n
+       real(c_double), intent(out) :: out(*)
+     end function rf_get_rft
   end interface
 
 contains

@@ -5,7 +5,8 @@
 ! init_fftw, which the replaced modules no longer need, and dumps the
 ! per-iteration mean T=1 log-likelihood (what mcmc_out writes to
 ! rslt/likelihood, src/mcmc_out.f90:142) and the proposal counters.
-!   usage: drive_rfinv params.in n_iter
+!   usage: drive_rfinv params.in n_burn n_iter mode      (mode 0: the reference's
+!          pt_control, 1: our pt_control_batched)
 !=======================================================================
 program drive_rfinv
   use params
@@ -14,9 +15,10 @@ program drive_rfinv
   use likelihood
   use forward
   use pt_mcmc
+  use pt_mcmc_batched
   implicit none
   include "mpif.h"
-  integer :: nproc, rank, ierr, it, u, n_it
+  integer :: nproc, rank, ierr, it, u, n_it, mode
   character(clen_max) :: param_file, arg
 
   call mpi_init(ierr)
@@ -25,11 +27,16 @@ program drive_rfinv
   param_file = "params.in"
   if (command_argument_count() > 0) call get_command_argument(1, param_file)
   call get_params(.false., param_file)
-  if (command_argument_count() > 1) then
+  mode = 0
+  if (command_argument_count() > 2) then
      call get_command_argument(2, arg)
-     read(arg, *) n_it
-     nburn = 0          ! run exactly n_it iterations, all "sampling"
-     niter = n_it
+     read(arg, *) nburn
+     call get_command_argument(3, arg)
+     read(arg, *) niter
+  end if
+  if (command_argument_count() > 3) then
+     call get_command_argument(4, arg)
+     read(arg, *) mode
   end if
   call read_obs(.false.)
   iseed = iseed + rank * rank * 10000 + 23 * rank
@@ -39,7 +46,11 @@ program drive_rfinv
   call init_model(.false.)
   call init_likelihood(.false.)
   call init_pt_mcmc(.false.)
-  call pt_control(.false.)
+  if (mode == 0) then
+     call pt_control(.false.)
+  else
+     call pt_control_batched(.false.)
+  end if
 
   u = 79
   open(u, file = "rfinv_dump.txt", status = "unknown")
@@ -50,6 +61,11 @@ program drive_rfinv
   write(u, *) nprop(1:ntype)
   write(u, *) naccept(1:ntype)
   write(u, *) nmod
+  ! checksums of the posterior histograms (what mcmc_out would write)
+  write(u, *) sum(nk), sum(nz), sum(namp), sum(nvpz), sum(nvsz), sum(nvpvsz)
+  write(u, *) sum(int(nk, 8) * [(int(it, 8), it = 1, k_max)])
+  write(u, '(es25.17)') sum(vp_mean), sum(vs_mean), sum(vpvs_mean), sum(all_likelihood(1:nmod))
+  write(u, '(es25.17)') sum(temps), sum(log_likelihood)
   close(u)
   call mpi_finalize(ierr)
   write(*,*) "drive_rfinv: ok"
