@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("RFGPU_BENCH_WORKLOAD", "c2"), choices=sorted(WORKLOADS))
     ap.add_argument("--walkers", type=int, default=0, help="override walkers per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--swap", default="allgather", choices=["allgather", "p2p"],
+                    help="temperature exchange of tempered workloads: K disjoint pairs via one all_gather, or the "
+                         "reference's one pair per iteration via send/recv")
     ap.add_argument("--also", default="", help="comma list of extra workloads measured briefly into 'also'")
     args = ap.parse_args()
 
@@ -201,7 +204,7 @@ def main():
         d_sig = torch.from_numpy(sig).to(dev)
         d_logl = torch.empty(nb, dtype=torch.float64, device=dev)
         h_logl = torch.empty(nb, dtype=torch.float64).pin_memory()
-        swap = PTSwap(eng, nb, w["temps"], dev, seed=1234, t_high=15.0) if w["temps"] > 1 else None
+        swap = PTSwap(eng, nb, w["temps"], dev, seed=1234, t_high=15.0, mode=args.swap) if w["temps"] > 1 else None
 
         def step():
             with torch.cuda.stream(stream):
@@ -242,7 +245,8 @@ def main():
             "config": {"workload": w["desc"], "walkers_per_gpu": nb, "nfft": p.nfft, "ntrc": p.ntrc,
                        "nsmp": p.nsmp, "k_max": p.k_max, "mean_nlay": float(nlay.mean()),
                        "max_nlay": int(nlay.max()), "deconv_mode": p.deconv_mode, "sdep": p.sdep,
-                       "temperatures": w["temps"], "parallelism": f"walkers sharded x{world}"},
+                       "temperatures": w["temps"], "parallelism": f"walkers sharded x{world}",
+                       "pt_swap": (f"{args.swap}, {swap.k} pair(s)/step" if swap is not None else "none")},
             "roofline": {
                 "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
                 "achieved": float(f_spec.sum()) / (spectra_ms * 1e-3) / 1e12 if spectra_ms > 0 else None,

@@ -90,8 +90,7 @@ class PTSwap:
         self._cache = []
         self._cache_steps = cache_steps
         self._cursor = 0
-        self.n_accept = 0
-        if self.device.type == "cuda":
+        if self.device.type == "cuda" and mode != "p2p":
             self._fill_cache()
         # all_gather buffers: (T, logL) of every rank, concatenated along dim 0 (the layout both
         # RCCL and gloo accept for all_gather_into_tensor)
@@ -111,6 +110,8 @@ class PTSwap:
         torch, dist = self.torch, self.dist
         if self.device.type != "cuda":
             return self.step_host(logl)
+        if self.mode == "p2p":
+            return self.step_p2p(logl)
         if self._cursor >= self._cache_steps:
             self._fill_cache()
         pairs = self._pairs[self._cursor]
@@ -132,49 +133,54 @@ class PTSwap:
         g = self._gather.view(self.world, 2, self.nchains)
         return g[:, 0, :].reshape(-1).contiguous(), g[:, 1, :].reshape(-1).contiguous()
 
-    # -- host tensors: the reference's p2p protocol and a host all_gather (gloo tests) ---
-    def step_host(self, logl):
-        """Host-resident variant (temps/logl CPU tensors or numpy): used by the Fortran-like
-        sequential host driver and by the gloo tests.  Returns the number of accepted
-        swaps that involved this rank."""
+    # -- the reference's p2p protocol, device-agnostic (RCCL send/recv on the GPU box, gloo in
+    #    the CPU tests): one pair per iteration ---------------------------------------------
+    def step_p2p(self, logl):
+        """src/pt_mcmc.f90:498-571 with torch.distributed p2p: the pair comes from the replicated
+        schedule (every rank knows its role without a broadcast); if it spans two ranks, rank2
+        sends (T2, L2) (tag 2018), rank1 judges and returns the temperature rank2 must now hold
+        (tag 1988).  All tensor work stays on logl's device and is asynchronous there."""
         torch, dist = self.torch, self.dist
         pairs, logu = self.sched.draw()
-        temps = self.temps.numpy() if hasattr(self.temps, "numpy") else self.temps
+        temps = self.temps
+        for (i1, i2), lu in zip(pairs.tolist(), logu.tolist()):
+            r1, r2 = i1 // self.nchains, i2 // self.nchains                  # :508-509
+            c1, c2 = i1 % self.nchains, i2 % self.nchains                    # :510-511 (0-based)
+            if r1 != self.rank and r2 != self.rank:
+                continue
+            if r1 == self.rank and r2 == self.rank:                          # :525-535
+                t1, t2, e1, e2 = temps[c1].clone(), temps[c2].clone(), logl[c1], logl[c2]
+                yn = lu <= (e2 - e1) * (1.0 / t1 - 1.0 / t2)                # judge_pt :586-592
+                temps[c1] = torch.where(yn, t2, t1)
+                temps[c2] = torch.where(yn, t1, t2)
+            elif r1 == self.rank:                                            # :542-556
+                rp = torch.empty(2, dtype=torch.float64, device=temps.device)
+                dist.recv(rp, src=r2, tag=2018)
+                t1, t2, e1, e2 = temps[c1].clone(), rp[0], logl[c1], rp[1]
+                yn = lu <= (e2 - e1) * (1.0 / t1 - 1.0 / t2)
+                temps[c1] = torch.where(yn, t2, t1)
+                dist.send(torch.where(yn, t1, t2).reshape(1), dst=r2, tag=1988)
+            else:                                                            # :564-570
+                dist.send(torch.stack([temps[c2], logl[c2]]), dst=r1, tag=2018)
+                back = torch.empty(1, dtype=torch.float64, device=temps.device)
+                dist.recv(back, src=r1, tag=1988)
+                temps[c2] = back[0]
+
+    # -- host tensors (gloo tests, sequential host drivers) --------------------------------
+    def step_host(self, logl):
+        """Host-resident variant (temps/logl CPU tensors or numpy)."""
+        torch = self.torch
+        if self.mode == "p2p":
+            return self.step_p2p(torch.as_tensor(logl))
+        pairs, logu = self.sched.draw()
+        temps = self.temps.numpy()
         ll = logl.numpy() if hasattr(logl, "numpy") else np.asarray(logl)
-        nacc = 0
-        if self.mode == "allgather" and self.world > 1:
+        if self.world > 1:
             gt, gl = self._gather_global(torch.as_tensor(ll))
             g_t, g_l = gt.numpy(), gl.numpy()
-            for (i1, i2), lu in zip(pairs, logu):
-                if judge_pt(g_t[i1], g_t[i2], g_l[i1], g_l[i2], lu):
-                    g_t[i1], g_t[i2] = g_t[i2], g_t[i1]
-                    nacc += 1
-            temps[:] = g_t[self.rank * self.nchains:(self.rank + 1) * self.nchains]
-            self.n_accept += nacc
-            return nacc
+        else:
+            g_t, g_l = temps.copy(), ll
         for (i1, i2), lu in zip(pairs, logu):
-            r1, r2 = int(i1) // self.nchains, int(i2) // self.nchains       # :508-509
-            c1, c2 = int(i1) % self.nchains, int(i2) % self.nchains         # :510-511 (0-based)
-            if r1 == self.rank and r2 == self.rank:                         # :525-535
-                if judge_pt(temps[c1], temps[c2], ll[c1], ll[c2], lu):
-                    temps[c1], temps[c2] = temps[c2], temps[c1]
-                    nacc += 1
-            elif r1 == self.rank:                                           # :542-556
-                rp = torch.empty(2, dtype=torch.float64)
-                dist.recv(rp, src=r2, tag=2018)
-                t1, t2, e1, e2 = temps[c1], float(rp[0]), ll[c1], float(rp[1])
-                back = torch.tensor([t2], dtype=torch.float64)
-                if judge_pt(t1, t2, e1, e2, lu):
-                    temps[c1] = t2
-                    back[0] = t1
-                    nacc += 1
-                dist.send(back, dst=r2, tag=1988)
-            elif r2 == self.rank:                                           # :564-570
-                dist.send(torch.tensor([temps[c2], ll[c2]], dtype=torch.float64), dst=r1, tag=2018)
-                back = torch.empty(1, dtype=torch.float64)
-                dist.recv(back, src=r1, tag=1988)
-                if back[0] != temps[c2]:
-                    nacc += 1
-                temps[c2] = float(back[0])
-        self.n_accept += nacc
-        return nacc
+            if judge_pt(g_t[i1], g_t[i2], g_l[i1], g_l[i2], lu):
+                g_t[i1], g_t[i2] = g_t[i2], g_t[i1]
+        temps[:] = g_t[self.rank * self.nchains:(self.rank + 1) * self.nchains]
