@@ -11,5 +11,6 @@ from .model import RefModel, read_ref_model, format_model, vp_to_rho  # noqa: F4
 from .engine import RFEngine, RFGPUError  # noqa: F401
 from .forward import Forward  # noqa: F401
 from .likelihood import Likelihood  # noqa: F401
+from .make_syn import make_syn, write_sac  # noqa: F401
 
 __version__ = "0.1.0"

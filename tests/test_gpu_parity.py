@@ -356,3 +356,23 @@ def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, monkeypatch, chain):
         for i in range(5):
             got = eng.get_rft(i, which=1).T
             assert np.abs(got - ref_rft[i]).max() <= 1e-11 * np.abs(ref_rft[i]).max(), i
+
+
+def test_make_syn_reproduces_the_shipped_sample(oracle, golden_dir, tmp_path):
+    """rf_inv_amd.make_syn on true.velmod (land) regenerates the reference's shipped
+    sample_{1,2}.trc payloads byte for byte (float32 samples)."""
+    from rf_inv_amd import get_params, make_syn, read_obs
+
+    p = get_params(os.path.join(golden_dir, "sample_syn", "params.in"))
+    read_obs(p)
+    p.sdep = 0.0   # the shipped traces are land synthetics (SURVEY.md section 4)
+    stack = load_true_model(golden_dir)
+    cfg = make_cfg(rayps=p.rayps)
+    with _engine(cfg, p.obs[:, :p.nsmp], p.nsmp, None, max_walkers=1) as eng:
+        make_syn(p, eng, stack, str(tmp_path), seed=1)
+    for i in (1, 2):
+        ref = np.fromfile(os.path.join(golden_dir, "sample_syn", "data", f"sample_{i}.trc"), dtype="<f4")
+        got = np.fromfile(tmp_path / f"test_trace.{i:02d}", dtype="<f4")
+        assert np.array_equal(ref[158:], got[158:]) and ref[0] == got[0]
+        noisy = np.fromfile(tmp_path / f"test_trace.{i:02d}wn", dtype="<f4")
+        assert 0.002 < np.std(noisy[158:] - got[158:]) < 0.02      # filtered noise of sigma 0.01
