@@ -114,6 +114,26 @@ def alg_work(p, nlay, common):
     return f_spec, f_spec + f_rest, b
 
 
+def measured_traffic(kernel, workload, nb):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/<round>_<workload>_hbm_traffic.json, produced by tools/profile_gpu.sh: FETCH_SIZE and
+    WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction).  None when no profile of
+    this workload / walker count is committed -- bench.py itself cannot collect PMC counters."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_hbm_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("_walkers_per_gpu") not in (None, nb):
+            continue
+        for k, v in d.items():
+            if isinstance(v, dict) and k.split("<")[0] == kernel:
+                return v.get("hbm_bytes_per_launch")
+    return None
+
+
 def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
     """Oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded
     sample of the same workload: the rank's walker set, repeated until about budget_s of
@@ -237,8 +257,13 @@ def main():
         assert np.all(np.isfinite(ll_gpu)), "non-finite logL in the benchmark batch"
 
         f_spec, f_tot, b_alg = alg_work(p, nlay.astype(np.float64), eng.is_ray_common)
+        plan = eng.launch_plan
         n_l = max(prof["launches"], 1)          # batches timed
-        spectra_ms = prof["spectra_ms"] / n_l   # spectra kernel time per batch (one launch per batch)
+        # dominant kernel: fused_kernel (propagator + trace + logL in one launch) where every trace has
+        # its own forward computation, else spectra_kernel (then trace_kernel follows it)
+        spectra_ms = prof["spectra_ms"] / n_l   # one launch per batch
+        f_dom = f_tot if plan["fused"] else f_spec
+        kname = "rfgpu::fused_kernel" if plan["fused"] else "rfgpu::spectra_kernel"
         res = {
             "value": world * nb * steps / dt,
             "ms_per_step": 1e3 * dt / steps,
@@ -249,13 +274,15 @@ def main():
                        "pt_swap": (f"{args.swap}, {swap.k} pair(s)/step" if swap is not None else "none")},
             "roofline": {
                 "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
-                "achieved": float(f_spec.sum()) / (spectra_ms * 1e-3) / 1e12 if spectra_ms > 0 else None,
-                "frac": float(f_spec.sum()) / (spectra_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if spectra_ms > 0 else None,
-                "traffic": None,
-                "kernel": "rfgpu::spectra_kernel", "kernel_ms": spectra_ms,
+                "achieved": float(f_dom.sum()) / (spectra_ms * 1e-3) / 1e12 if spectra_ms > 0 else None,
+                "frac": float(f_dom.sum()) / (spectra_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if spectra_ms > 0 else None,
+                "traffic": measured_traffic(kname, workload, nb),
+                "kernel": kname, "kernel_ms": spectra_ms, "launch_plan": plan,
                 "note": "fp64: MI355X matrix (MFMA) peak == vector peak = 78.6 TF; the kernel issues fp64 VALU FMA, "
                         "MFMA not used (no rate advantage). achieved = reference-arithmetic flops (SURVEY 8d: "
-                        "570/(bin*layer)+580/bin) per launch / live HIP-event kernel time.",
+                        "570/(bin*layer)+580/bin, + FFT/shift/quadratic form when fused) per launch / live "
+                        "HIP-event kernel time; the real-form propagator executes ~1/5 of those flops, so the "
+                        "algorithmic fraction can exceed 1 (DESIGN.md section 3).",
             },
             "roofline_hbm": {
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
@@ -263,7 +290,8 @@ def main():
                 "frac": float(b_alg.sum()) * steps / dt / 1e9 / HBM_PEAK_GBS,
                 "note": "algorithmic bytes/eval (layers+sigma in, prop_rft(nfft,ntrc)+logL out) x evals/s of this rank",
             },
-            "kernel_ms": {"spectra": spectra_ms, "trace": prof["trace_ms"] / n_l, "logl": prof["logl_ms"] / n_l},
+            "kernel_ms": ({"fused": spectra_ms} if plan["fused"] else
+                          {"spectra": spectra_ms, "trace": prof["trace_ms"] / n_l}),
             "alg_gflop_per_step": float(f_tot.sum()) / 1e9,
         }
         if with_cpu and rank == 0:

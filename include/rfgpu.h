@@ -148,6 +148,13 @@ int rf_pt_swap_device(rf_ctx *ctx, int32_t npairs, const int32_t *d_pairs, const
                       double *d_temps, const double *d_logl, int32_t *d_accepted, void *stream);
 
 /* ---- instrumentation ----------------------------------------------------- */
+/* how rf_eval_batch* will launch: plan[0] = 1 when spectra + trace run as ONE fused kernel
+ * (contexts with one forward computation per trace; then ms[0] of rf_profile_read is the
+ * fused kernel and ms[1] stays 0), plan[1] = bins per phase chain (0: direct sincos),
+ * plan[2] = waves per block of the split spectra kernel, plan[3] = bin-splits per walker
+ * at a full batch. */
+int rf_get_launch_plan(const rf_ctx *ctx, int32_t *plan);
+
 /* HIP-event timing (on the streams the kernels are launched on) of the three kernels
  * of rf_eval_batch*, accumulated while enabled.  ms[3] = spectra, trace, logl totals;
  * launches[4] = batches timed, then spectra / trace / logl kernel launches (a batch is

@@ -47,6 +47,7 @@ struct rf_ctx {
     // host copies of tables
     std::vector<double> flt, r_inv;
     // launch policy
+    bool fused = false;       // one launch for spectra + trace (needs one forward computation per trace)
     int chain = 0;            // bins per phase chain in the spectra kernel (0: direct sincos)
     int waves_per_block = 4;  // waves of one walker sharing a staged layer stack
     int num_cu = 256;
@@ -329,6 +330,11 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     c->chain = (c->nh + 63) / 64 >= 16 ? 4 : 0;
     const char *env = getenv("RFGPU_CHAIN");
     if (env) c->chain = atoi(env);
+    c->fused = (c->nfwd == ntrc) && fused_lds_bytes(n, nsmp, cfg->nlay_max) <= 160 * 1024;
+    env = getenv("RFGPU_FUSED");
+    if (env) c->fused = c->fused && atoi(env) != 0;
+    if (c->fused && c->chain == 8) c->chain = 4;
+    if (c->fused && c->chain == 4 && cfg->sdep > 0.0) c->chain = 3;   // ocean: 3 columns, keep 2 waves/SIMD
     env = getenv("RFGPU_WPB");
     if (env) c->waves_per_block = atoi(env);
     *ctx_out = c;
@@ -427,13 +433,19 @@ static int run_batch(rf_ctx *c, const BatchArgs &b, hipStream_t s)
     if (b.nb > c->nslots) return fail("batch larger than max_walkers + 1");
     if (b.nlay_pad > c->cfg.nlay_max) return fail("nlay_pad exceeds nlay_max of the context");
     HIP_TRY(hipSetDevice(c->device));
-    hipEvent_t e = prof_begin(c, 0, s);
-    launch_spectra(c->tab, b, c->spec, pick_nsplit(c, b.nb), c->chain, c->waves_per_block, c->slow_list,
-                   c->slow_count, c->ws, s);
-    if (e) (void)hipEventRecord(e, s);
-    e = prof_begin(c, 1, s);
-    launch_trace(c->tab, b, c->spec, c->ws, c->slow_count, s);   // also forms logL
-    if (e) (void)hipEventRecord(e, s);
+    if (c->fused) {
+        hipEvent_t e = prof_begin(c, 0, s);
+        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, s);   // spectra + trace + logL
+        if (e) (void)hipEventRecord(e, s);
+    } else {
+        hipEvent_t e = prof_begin(c, 0, s);
+        launch_spectra(c->tab, b, c->spec, pick_nsplit(c, b.nb), c->chain, c->waves_per_block, c->slow_list,
+                       c->slow_count, c->ws, s);
+        if (e) (void)hipEventRecord(e, s);
+        e = prof_begin(c, 1, s);
+        launch_trace(c->tab, b, c->spec, c->ws, c->slow_count, s);   // also forms logL
+        if (e) (void)hipEventRecord(e, s);
+    }
     if (c->prof) c->prof_n[0] += 1;
     HIP_TRY(hipGetLastError());
     return 0;
@@ -600,6 +612,16 @@ extern "C" int rf_pt_swap_device(rf_ctx *c, int32_t npairs, const int32_t *d_pai
     HIP_TRY(hipSetDevice(c->device));
     launch_pt_swap(npairs, d_pairs, d_log_u, d_temps, d_logl, d_accepted, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
+{
+    if (!c || !plan) return fail("rf_get_launch_plan: null argument");
+    plan[0] = c->fused ? 1 : 0;
+    plan[1] = c->chain;
+    plan[2] = c->waves_per_block;
+    plan[3] = pick_nsplit(c, c->cfg.max_walkers);
     return 0;
 }
 

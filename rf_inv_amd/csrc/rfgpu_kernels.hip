@@ -348,11 +348,21 @@ __device__ __forceinline__ void store_bin(double2 *__restrict__ out_r, double2 *
     }
 }
 
+// where a finished bin goes: to the spectra buffer in HBM (split kernels) ...
+struct GlobalSink {
+    double2 *__restrict__ out_r;
+    double2 *__restrict__ out_v;
+    int nh;
+    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz) const
+    {
+        store_bin(out_r, out_v, k, nh, ur, uz);
+    }
+};
+
 // one 64-bin iteration, every phase by a full sincos evaluation
-template <int NCOL, bool FAST>
+template <int NCOL, bool FAST, class Sink>
 __device__ __forceinline__ void spectra_iter_direct(const SpectraParams &P, const double *coef, const double *tail,
-                                                    int nl, int ilay0, int ipha, double2 *__restrict__ out_r,
-                                                    double2 *__restrict__ out_v, int it, int lane)
+                                                    int nl, int ilay0, int ipha, const Sink &sink, int it, int lane)
 {
     const int k = it * 64 + lane;
     // forward.f90:245-248: omega = (iomg-1) * domg, DC bin uses the single literal 1.0e-5
@@ -362,7 +372,7 @@ __device__ __forceinline__ void spectra_iter_direct(const SpectraParams &P, cons
     for (int l = ilay0; l < nl - 1; ++l) apply_layer<NCOL, FAST>(st, coef + l * NCOEF, omg);
     double2 ur, uz;
     finish_bin<NCOL, FAST>(st, tail, omg, ipha, ur, uz);
-    store_bin(out_r, out_v, k, P.t.nh, ur, uz);
+    sink(k, ur, uz);
 }
 
 // eps = arg - k * phi, phi = (hi, lo): the rounding perturbation of the reference's
@@ -383,10 +393,9 @@ __device__ __forceinline__ double phase_eps(double arg, double kd, double phi_hi
 // rounding is part of the reference result -- is recovered to first order from
 // eps = arg - k phi (|eps| < 1e-9, second order < 1e-18).  ~13 instructions per extra
 // sincos instead of ~45.  Chain length <= BK-1 rotations (error growth ~1 ulp per step).
-template <int BK, int NCOL>
+template <int BK, int NCOL, class Sink>
 __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, const double *coef, const double *tail,
-                                                    int nl, int ilay0, int ipha, double2 *__restrict__ out_r,
-                                                    double2 *__restrict__ out_v, int it0, int lane)
+                                                    int nl, int ilay0, int ipha, const Sink &sink, int it0, int lane)
 {
     ColState<NCOL> st[BK];
     double omg[BK], kd[BK];
@@ -434,30 +443,29 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
     for (int m = 0; m < BK; ++m) {
         double2 ur, uz;
         finish_bin<NCOL, true>(st[m], tail, omg[m], ipha, ur, uz);
-        store_bin(out_r, out_v, kbin[m], P.t.nh, ur, uz);
+        sink(kbin[m], ur, uz);
     }
 }
 
 // the bins of one (walker, forward-trace) assigned to `split` of P.nsplit:
 // full chunks of BK iterations go through the chained-phase path, the remaining
 // iterations (and everything when BK == 0) through the direct path.
-template <int BK, int NCOL, bool FAST>
+template <int BK, int NCOL, bool FAST, class Sink>
 __device__ __forceinline__ void spectra_body(const SpectraParams &P, const double *coef, const double *tail,
-                                             int nl, int ilay0, int ipha, double2 *__restrict__ out_r,
-                                             double2 *__restrict__ out_v, int split, int lane)
+                                             int nl, int ilay0, int ipha, const Sink &sink, int split, int lane)
 {
     const int niter = (P.t.nh + 63) / 64;
     int it_direct0 = 0;
     if (BK > 1 && FAST) {
         const int nchunk = niter / BK;
         for (int ch = split; ch < nchunk; ch += P.nsplit)
-            spectra_chunk_chain<(BK > 1 ? BK : 2), NCOL>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, ch * BK, lane);
+            spectra_chunk_chain<(BK > 1 ? BK : 2), NCOL>(P, coef, tail, nl, ilay0, ipha, sink, ch * BK, lane);
         it_direct0 = nchunk * BK;
     }
     // leftover iterations: spread from the last split downwards (the chunk loop loads
     // the low splits first)
     for (int it = it_direct0 + (P.nsplit - 1 - split); it < niter; it += P.nsplit)
-        spectra_iter_direct<NCOL, FAST>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, it, lane);
+        spectra_iter_direct<NCOL, FAST>(P, coef, tail, nl, ilay0, ipha, sink, it, lane);
 }
 
 // Stages the layer stack of (walker ib, forward-trace f) into LDS (all threads of the
@@ -534,16 +542,16 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
     }
     const int ipha = P.t.ipha[f];
     double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
-    double2 *out_v = out_r + P.t.nh;
+    const GlobalSink sink{out_r, out_r + P.t.nh, P.t.nh};
     if (big || sea != (NCOL == 3)) {
         // rare: out-of-range phases or a layer stack of the other kind (land / ocean)
         if (BK > 1) {
             // the chained-phase kernels have the registers to spare: generic path in place
             if (split >= P.nsplit) return;
             if (sea)
-                spectra_body<0, 3, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split, lane);
+                spectra_body<0, 3, false>(P, coef, tail, nl, ilay0, ipha, sink, split, lane);
             else
-                spectra_body<0, 2, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split, lane);
+                spectra_body<0, 2, false>(P, coef, tail, nl, ilay0, ipha, sink, split, lane);
         } else if (blockIdx.x % nblk == 0 && threadIdx.x == 0) {
             // the lean direct kernel (4 waves/SIMD) defers to spectra_slow_kernel via the list
             P.slow_list[atomicAdd(P.slow_count, 1)] = bf;
@@ -551,7 +559,7 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
         return;
     }
     if (split >= P.nsplit) return;
-    spectra_body<BK, NCOL, true>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split, lane);
+    spectra_body<BK, NCOL, true>(P, coef, tail, nl, ilay0, ipha, sink, split, lane);
 }
 
 // walkers whose phases exceed the Cody-Waite range (|x| >= 1e6 rad): same body with ocml's
@@ -574,11 +582,11 @@ __global__ __launch_bounds__(64) void spectra_slow_kernel(SpectraParams P)
         stage_walker(P, ib, f, coef, tail, nl, ilay0, sea);
         const int ipha = P.t.ipha[f];
         double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
-        double2 *out_v = out_r + P.t.nh;
+        const GlobalSink sink{out_r, out_r + P.t.nh, P.t.nh};
         if (sea)
-            spectra_body<0, 3, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split, threadIdx.x);
+            spectra_body<0, 3, false>(P, coef, tail, nl, ilay0, ipha, sink, split, threadIdx.x);
         else
-            spectra_body<0, 2, false>(P, coef, tail, nl, ilay0, ipha, out_r, out_v, split, threadIdx.x);
+            spectra_body<0, 2, false>(P, coef, tail, nl, ilay0, ipha, sink, split, threadIdx.x);
     }
 }
 
@@ -878,6 +886,75 @@ struct TraceParams {
     int *slow_count;   // re-armed here for the next batch (the slow kernel ran earlier on the stream)
 };
 
+// Everything after Z is in LDS: inverse FFT, vertical max, shift / normalise / store,
+// misfit, quadratic form, log-likelihood.  Shared by trace_kernel (Z filled from the
+// spectra in HBM) and fused_kernel (Z filled straight from the propagator registers).
+__device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, double *mis, double *red, int ib,
+                                           int itrc, int walker, int ipha, bool decon, double tp, int slot, int tid)
+{
+    const DeviceTables &t = P.t;
+    const int n = t.nfft, nsmp = t.nsmp;
+    // ---- in-place mixed-radix inverse FFT, sign +, unnormalised (FFTW c2r definition) ---
+    fft_inverse_lds<TRACE_THREADS>(a, P.plan, P.log2n, t.twiddle, tid);
+    // a[fft_pad(j)].x = rx (RF trace), .y = vertical trace
+
+    double fac = 1.0;
+    if (!decon) {
+        double m = -HUGE_VAL;
+        for (int j = tid; j < n; j += TRACE_THREADS) m = fmax(m, a[fft_pad(j)].y);
+        fac = block_max(m, red);                                     // maxval(rx) forward.f90:201
+    }
+
+    // ---- time shift (+ reverse/negate for S), normalise, store, misfit ----------
+    const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
+    double *__restrict__ dst =
+        P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
+    const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
+    for (int i = tid + 1; i <= n; i += TRACE_THREADS) {
+        int j;
+        double val;
+        if (ipha == 1) {
+            j = (n - npre + i) % n;                                  // forward.f90:179
+            if (j < 0) j += n;
+            if (j == 0) j = n;
+            val = a[fft_pad(j - 1)].x;
+        } else {
+            j = (n + npre - i + 1) % n;                              // forward.f90:188
+            if (j < 0) j += n;
+            if (j == 0) j = n;
+            val = -a[fft_pad(j - 1)].x;
+        }
+        if (!decon) val = val / fac;                                 // forward.f90:202
+        dst[i - 1] = val;
+        if (i <= nsmp) mis[i - 1] = val - obs[i - 1];                // likelihood.f90:88
+    }
+    __syncthreads();
+
+    // ---- phi = (misfit . R^-1) . misfit   (likelihood.f90:92-93) -----------------
+    const double phi = quad_form(t, itrc, mis, reinterpret_cast<double *>(a), red, tid);
+    if (tid == 0) {
+        double *phis = P.w.phi + ((size_t)slot * P.w.nslots + walker) * t.ntrc;
+        // ---- log-likelihood (likelihood.f90:94-96) by the block that finishes the walker's
+        // last trace.  Hand-off of the 8-byte phi values between blocks with agent-scope
+        // atomics on both sides (write-through store, drained, then the counter; the last
+        // arriver reads with agent-scope loads) -- no release fence, which would write back
+        // the whole L2 slice of freshly written traces (measured: 2.6x on this kernel).
+        bool last = true;
+        if (t.ntrc > 1) {
+            __hip_atomic_store(phis + itrc, phi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            last = atomicAdd(P.w.done + ib, 1) == t.ntrc - 1;
+            if (last) P.w.done[ib] = 0;
+        } else {
+            phis[itrc] = phi;
+        }
+        if (last) {
+            P.b.logl[ib] = logl_from_phi(phis, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, t.ntrc > 1);
+            P.w.prop_fwd[walker] = 1;
+        }
+    }
+}
+
 __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
 {
     extern __shared__ double2 lds2[];
@@ -973,65 +1050,205 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
     }
     __syncthreads();
 
-    // ---- in-place mixed-radix inverse FFT, sign +, unnormalised (FFTW c2r definition) ---
-    fft_inverse_lds<TRACE_THREADS>(a, P.plan, P.log2n, t.twiddle, tid);
-    // a[fft_pad(j)].x = rx (RF trace), .y = vertical trace
+    trace_tail(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
+}
 
-    double fac = 1.0;
-    if (!decon) {
-        double m = -HUGE_VAL;
-        for (int j = tid; j < n; j += TRACE_THREADS) m = fmax(m, a[fft_pad(j)].y);
-        fac = block_max(m, red);                                     // maxval(rx) forward.f90:201
-    }
-
-    // ---- time shift (+ reverse/negate for S), normalise, store, misfit ----------
-    const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
-    double *__restrict__ dst =
-        P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
-    const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
-    for (int i = tid + 1; i <= n; i += TRACE_THREADS) {
-        int j;
-        double val;
-        if (ipha == 1) {
-            j = (n - npre + i) % n;                                  // forward.f90:179
-            if (j < 0) j += n;
-            if (j == 0) j = n;
-            val = a[fft_pad(j - 1)].x;
+// ---------------------------------------------------------------------------
+// fused_kernel: K1 + K2 in one launch for contexts where every trace has its own
+// forward computation (rays not common, or a single trace).  One 256-thread block per
+// (walker, trace): its 4 waves propagate a quarter of the bins each and deposit
+// Z = RF*flt + i V*flt (or, for water-level deconvolution, the raw numerator /
+// denominator pair) straight into the digit-reversed FFT array in LDS -- the spectra never
+// travel through HBM -- then the block runs the trace tail.  While one block of a CU is in
+// its latency-bound tail the other one is in its FP64-bound propagator phase.
+// ---------------------------------------------------------------------------
+struct LdsSink {
+    double2 *a;                 // padded, digit-reversed FFT array
+    double2 *side;              // [2] denominators of the DC and Nyquist bins (decon only)
+    const double *__restrict__ flt;
+    FftPlan plan;
+    int log2n, n, nh, ipha;
+    bool decon;
+    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz) const
+    {
+        if (k >= nh) return;
+        const double2 fr = make_double2(ur.x, -ur.y);    // freq_r = conjg(ur)   forward.f90:145
+        const double2 fv = make_double2(-uz.x, uz.y);    // freq_v = -conjg(uz)  forward.f90:146
+        const double2 num = ipha == 1 ? fr : fv;         // forward.f90:148-163
+        const int pk = fft_pad(fft_input_pos(plan, log2n, k));
+        const bool self = (k == 0 || 2 * k == n);
+        if (decon) {
+            // keep numerator and denominator; the water level needs the max over all bins first
+            const double2 den = ipha == 1 ? fv : fr;
+            a[pk] = num;
+            if (self)
+                side[k == 0 ? 0 : 1] = den;
+            else
+                a[fft_pad(fft_input_pos(plan, log2n, n - k))] = den;
         } else {
-            j = (n + npre - i + 1) % n;                              // forward.f90:188
-            if (j < 0) j += n;
-            if (j == 0) j = n;
-            val = -a[fft_pad(j - 1)].x;
+            const double fk = flt[k];
+            const double2 R = make_double2(num.x * fk, num.y * fk);   // forward.f90:168
+            const double2 V = make_double2(fv.x * fk, fv.y * fk);     // forward.f90:198
+            if (self) {
+                a[pk] = make_double2(R.x, V.x);          // c2r ignores Im of the DC and Nyquist bins
+            } else {
+                a[pk] = make_double2(R.x - V.y, R.y + V.x);
+                a[fft_pad(fft_input_pos(plan, log2n, n - k))] = make_double2(R.x + V.y, V.x - R.y);
+            }
         }
-        if (!decon) val = val / fac;                                 // forward.f90:202
-        dst[i - 1] = val;
-        if (i <= nsmp) mis[i - 1] = val - obs[i - 1];                // likelihood.f90:88
+    }
+};
+
+size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad);
+static FftPlan make_fft_plan(int log2n);
+
+struct FusedParams {
+    SpectraParams sp;   // t, b, nsplit (= waves per block), meta pointers unused
+    TraceParams tp;     // t, b, w, log2n, plan, slow_count
+};
+
+size_t fused_lds_bytes(int nfft, int nsmp, int nlay_pad)
+{
+    return trace_lds_bytes(nfft, nsmp, nlay_pad) + sizeof(double2) * 2 + spectra_lds_bytes(nlay_pad);
+}
+
+template <int BK, int NCOL>
+__global__ __launch_bounds__(TRACE_THREADS) void fused_kernel(FusedParams F)
+{
+    extern __shared__ double2 lds2[];
+    const TraceParams &P = F.tp;
+    const DeviceTables &t = P.t;
+    const int n = t.nfft, nh = t.nh, nsmp = t.nsmp;
+    double2 *a = lds2;
+    double *mis = reinterpret_cast<double *>(a) + trace_work_doubles(n, nsmp, P.b.nlay_pad);
+    double *red = mis + ((nsmp + 1) & ~1);
+    double2 *side = reinterpret_cast<double2 *>(red + 8);
+    double *coef = reinterpret_cast<double *>(side + 2);
+    double *tail = coef + (size_t)P.b.nlay_pad * NCOEF;
+
+    const int tid = threadIdx.x;
+    const int itrc = blockIdx.x % t.ntrc;     // == forward-trace index here (nfwd == ntrc)
+    const int ib = blockIdx.x / t.ntrc;
+    if (blockIdx.x == 0 && tid == 0) *P.slow_count = 0;
+    if (P.b.fwd_flag && !P.b.fwd_flag[ib]) {
+        // sigma-only proposal: cached quadratic form of the stored trace (likelihood.f90:81)
+        if (itrc == 0 && tid == 0) {
+            const int wk = P.b.walker_ids[ib];
+            const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * t.ntrc;
+            P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
+            P.w.prop_fwd[wk] = 0;
+        }
+        return;
+    }
+    const int walker = P.b.walker_ids[ib];
+    const int ipha = t.ipha[itrc];
+    const bool decon = t.deconv_mode == 1;
+
+    // ---- stage the layer stack, direct-arrival time --------------------------------------
+    int nl, ilay0;
+    bool sea;
+    const bool big = stage_walker(F.sp, ib, itrc, coef, tail, nl, ilay0, sea);
+    if (!decon) {
+        const int pad = P.b.nlay_pad;
+        const double *L = P.b.layers + (size_t)ib * 4 * pad;
+        const double *vel = (ipha == 1) ? L : L + pad;            // alpha for P, beta for S (:157,161)
+        const int i0 = t.sdep > 0.0 ? 1 : 0;                      // keyed on sdep (:484)
+        double *terms = tail + 16;
+        for (int i = i0 + tid; i < nl - 1; i += TRACE_THREADS)
+            terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], t.rayps[itrc]);
+        __syncthreads();
+        if (tid == 0) red[4] = arrival_sum(nl - 1 - i0, terms);
+    }
+    const int slot = 1 - P.w.cur_slot[walker];
+
+    // ---- propagator phase: 4 waves x interleaved chunks of bins -> Z in LDS ----------------
+    const LdsSink sink{a, side, t.flt + (size_t)itrc * nh, P.plan, P.log2n, n, nh, ipha, decon};
+    const int wave = tid >> 6, lane = tid & 63;
+    if (big || sea != (NCOL == 3)) {
+        if (sea)
+            spectra_body<0, 3, false>(F.sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
+        else
+            spectra_body<0, 2, false>(F.sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
+    } else {
+        spectra_body<BK, NCOL, true>(F.sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
     }
     __syncthreads();
+    const double tp = decon ? 0.0 : red[4];
 
-    // ---- phi = (misfit . R^-1) . misfit   (likelihood.f90:92-93) -----------------
-    const double phi = quad_form(t, itrc, mis, reinterpret_cast<double *>(a), red, tid);
-    if (tid == 0) {
-        double *phis = P.w.phi + ((size_t)slot * P.w.nslots + walker) * t.ntrc;
-        // ---- log-likelihood (likelihood.f90:94-96) by the block that finishes the walker's
-        // last trace.  Hand-off of the 8-byte phi values between blocks with agent-scope
-        // atomics on both sides (write-through store, drained, then the counter; the last
-        // arriver reads with agent-scope loads) -- no release fence, which would write back
-        // the whole L2 slice of freshly written traces (measured: 2.6x on this kernel).
-        bool last = true;
-        if (t.ntrc > 1) {
-            __hip_atomic_store(phis + itrc, phi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            last = atomicAdd(P.w.done + ib, 1) == t.ntrc - 1;
-            if (last) P.w.done[ib] = 0;
-        } else {
-            phis[itrc] = phi;
+    if (decon) {
+        // water_level_decon (forward.f90:447-470) in place: slot(k) holds the numerator,
+        // slot(n-k) the denominator of bin k
+        double m = -HUGE_VAL;
+        for (int k = tid; k < nh; k += TRACE_THREADS) {
+            const bool self = (k == 0 || 2 * k == n);
+            const double2 x = self ? side[k == 0 ? 0 : 1] : a[fft_pad(fft_input_pos(P.plan, P.log2n, n - k))];
+            m = fmax(m, x.x * x.x + x.y * x.y);                   // forward.f90:458
         }
-        if (last) {
-            P.b.logl[ib] = logl_from_phi(phis, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, t.ntrc > 1);
-            P.w.prop_fwd[walker] = 1;
+        const double wlvl = 0.001 * block_max(m, red);            // forward.f90:460, pcnt = 0.001 (:149)
+        const double *__restrict__ flt = t.flt + (size_t)itrc * nh;
+        for (int k = tid; k < nh; k += TRACE_THREADS) {
+            const bool self = (k == 0 || 2 * k == n);
+            const int pk = fft_pad(fft_input_pos(P.plan, P.log2n, k));
+            const int pnk = self ? pk : fft_pad(fft_input_pos(P.plan, P.log2n, n - k));
+            const double2 y = a[pk];
+            const double2 x = self ? side[k == 0 ? 0 : 1] : a[pnk];
+            const double amp = x.x * x.x + x.y * x.y;
+            const double dd = fmax(amp, wlvl);                    // forward.f90:464
+            const double2 yx = cmul(y, make_double2(x.x, -x.y));
+            const double fk = flt[k];
+            const double2 R = make_double2(yx.x / dd * fk, yx.y / dd * fk);
+            if (self) {
+                a[pk] = make_double2(R.x, 0.0);
+            } else {
+                a[pk] = R;
+                a[pnk] = make_double2(R.x, -R.y);
+            }
         }
+        __syncthreads();
     }
+    trace_tail(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
+}
+
+template <int NCOL>
+static void launch_fused_ncol(int chain, dim3 grid, size_t lds, hipStream_t s, const FusedParams &F)
+{
+    const dim3 block(TRACE_THREADS);
+    switch (chain) {
+    case 2: hipLaunchKernelGGL((fused_kernel<2, NCOL>), grid, block, lds, s, F); break;
+    case 3: hipLaunchKernelGGL((fused_kernel<3, NCOL>), grid, block, lds, s, F); break;
+    case 4: hipLaunchKernelGGL((fused_kernel<4, NCOL>), grid, block, lds, s, F); break;
+    default: hipLaunchKernelGGL((fused_kernel<0, NCOL>), grid, block, lds, s, F); break;
+    }
+}
+
+void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
+                  hipStream_t s)
+{
+    FusedParams F{};
+    F.sp = SpectraParams{t, b, nullptr, TRACE_THREADS / 64, nullptr, slow_count, w.meta_tp, w.meta_slot, w.cur_slot};
+    F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count};
+    while ((1 << F.tp.log2n) < t.nfft) ++F.tp.log2n;
+    F.tp.plan = make_fft_plan(F.tp.log2n);
+    const size_t lds = fused_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
+    static size_t lds_set[2][5] = {};
+    const int ci = chain == 2 ? 1 : chain == 3 ? 2 : chain == 4 ? 3 : 0;
+    const int ni = t.sdep > 0.0 ? 1 : 0;
+    if (lds > lds_set[ni][ci]) {   // dynamic LDS beyond 64 KiB must be opted into, per kernel
+        const void *fn = nullptr;
+        if (ni == 0)
+            fn = ci == 1 ? (const void *)fused_kernel<2, 2> : ci == 2 ? (const void *)fused_kernel<3, 2>
+                 : ci == 3 ? (const void *)fused_kernel<4, 2> : (const void *)fused_kernel<0, 2>;
+        else
+            fn = ci == 1 ? (const void *)fused_kernel<2, 3> : ci == 2 ? (const void *)fused_kernel<3, 3>
+                 : ci == 3 ? (const void *)fused_kernel<4, 3> : (const void *)fused_kernel<0, 3>;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        lds_set[ni][ci] = lds;
+    }
+    const dim3 grid((unsigned)(b.nb * t.ntrc));
+    if (ni)
+        launch_fused_ncol<3>(chain, grid, lds, s, F);
+    else
+        launch_fused_ncol<2>(chain, grid, lds, s, F);
 }
 
 // likelihood.f90:81-93 for a trace supplied by the host (the fwd_flag = .false. branch

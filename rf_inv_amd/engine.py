@@ -198,6 +198,12 @@ class RFEngine:
                                               st.cuda_stream))
 
     # ---- instrumentation -----------------------------------------------------
+    @property
+    def launch_plan(self):
+        plan = (C.c_int32 * 4)()
+        self._chk(self._lib.rf_get_launch_plan(self._ctx, plan))
+        return {"fused": bool(plan[0]), "chain": plan[1], "waves_per_block": plan[2], "nsplit": plan[3]}
+
     def profile_enable(self, on=True):
         self._chk(self._lib.rf_profile_enable(self._ctx, int(on)))
 

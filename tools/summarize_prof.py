@@ -53,3 +53,26 @@ for name, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRIT
             per = v / max(n, 1)
             note = " (x2 gfx950 correction for reads => %.1f KiB)" % (2 * per) if name == "FETCH_SIZE" else ""
             print(f"{k[:70]:70s} launches={n} avg={per:.1f}{note}")
+
+
+# machine-readable HBM traffic of the full-size launches (max over launches drops the tiny
+# set-up launch): bytes = FETCH_SIZE * 1024 * 2 (gfx950 read correction, MI355X_MICROARCH.md) +
+# WRITE_SIZE * 1024
+import json
+traffic = {}
+for name, pat in (("FETCH_SIZE", "pmc_fetch/**/*counter_collection.csv"), ("WRITE_SIZE", "pmc_write/**/*counter_collection.csv")):
+    for f in find(pat):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                if r.get("Counter_Name") != name or "rfgpu" not in r.get("Kernel_Name", ""):
+                    continue
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+                d = traffic.setdefault(k, {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})
+                d[name] = max(d[name], float(r["Counter_Value"]))
+for k, d in traffic.items():
+    d["hbm_bytes_per_launch"] = d["FETCH_SIZE"] * 1024 * 2 + d["WRITE_SIZE"] * 1024
+with open(os.path.join(out, "hbm_traffic.json"), "w") as fh:
+    json.dump(traffic, fh, indent=1)
+print("\n== HBM bytes per full-size launch (FETCH x2 + WRITE, KiB -> bytes) ==")
+for k, d in traffic.items():
+    print(f"{k[:60]:60s} {d['hbm_bytes_per_launch'] / 1e6:10.2f} MB")
