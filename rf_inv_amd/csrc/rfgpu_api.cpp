@@ -569,7 +569,7 @@ extern "C" int rf_calc_likelihood_of_trace(rf_ctx *c, const double *rft, const d
     HIP_TRY(hipMemcpyAsync(c->d_sig, sig, sizeof(double) * ntrc, hipMemcpyHostToDevice, s));
     launch_phi(c->tab, c->ws, wk, s);
     BatchArgs b{1, 2, c->d_ids, c->d_fwd, c->d_nlay, c->d_layers, c->d_sig, c->d_logl};
-    launch_logl(c->tab, b, c->ws, c->slow_count, 1, s);
+    launch_logl(c->tab, b, c->ws, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(logl, c->d_logl, sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));

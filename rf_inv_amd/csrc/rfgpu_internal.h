@@ -50,8 +50,7 @@ void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec
                   const WalkerState &w, int *slow_count, hipStream_t s);
 // log-likelihood from cached quadratic forms (used for host-owned traces; the batched path
 // forms logL inside trace_kernel)
-void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count,
-                 int nslow, hipStream_t s);
+void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 // fused K1+K2 (contexts with one forward computation per trace)
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
                   hipStream_t s);

@@ -1299,21 +1299,20 @@ void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec
 }
 
 // ---------------------------------------------------------------------------
-// K3  log-likelihood (likelihood.f90:86,94-96), one thread per batch item
+// log-likelihood from cached quadratic forms (likelihood.f90:86,94-96), one thread per item;
+// used for host-owned traces (rf_calc_likelihood_of_trace) -- the batched path forms logL in
+// trace_tail
 // ---------------------------------------------------------------------------
 struct LoglParams {
     DeviceTables t;
     BatchArgs b;
     WalkerState w;
-    int *slow_count;
-    int nslow;
 };
 
 __global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
 {
 #pragma clang fp contract(off)
     const int ib = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ib < P.nslow) P.slow_count[ib] = 0;   // re-arm the deferred-walker lists for the next batch
     if (ib >= P.b.nb) return;
     const int walker = P.b.walker_ids[ib];
     const int fwd = P.b.fwd_flag ? P.b.fwd_flag[ib] : 1;
@@ -1332,10 +1331,9 @@ __global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
     P.w.prop_fwd[walker] = fwd;
 }
 
-void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count,
-                 int nslow, hipStream_t s)
+void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
 {
-    LoglParams P{t, b, w, slow_count, nslow};
+    LoglParams P{t, b, w};
     hipLaunchKernelGGL(logl_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P);
 }
 
