@@ -137,6 +137,12 @@ int rf_commit_device(rf_ctx *ctx, int32_t nb, const int32_t *d_walker_ids,
  * (src/pt_mcmc.f90:272-285). */
 int rf_get_rft(rf_ctx *ctx, int32_t walker, int32_t which, int32_t n, double *out);
 
+/* the same for n walkers in one device gather + one copy: out is out(nout, ntrc, n)
+ * column-major (walker i at out[i * ntrc * nout]).  The batched sampler uses it once per
+ * recording iteration instead of one copy per chain. */
+int rf_get_rft_batch(rf_ctx *ctx, int32_t n, const int32_t *walker_ids, int32_t which, int32_t nout,
+                     double *out);
+
 /* ---- parallel tempering ------------------------------------------------ */
 /* judge_pt (src/pt_mcmc.f90:580-595) for npairs DISJOINT chain pairs: swap
  * temps[i1] <-> temps[i2] iff log(u) <= (L2-L1)(1/T1-1/T2).  temps/logl are device

@@ -44,6 +44,7 @@ SYMBOLS = {
     "rf_commit": (C.c_int, [_vp, C.c_int32, ip, ip]),
     "rf_commit_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "rf_get_rft": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, dp]),
+    "rf_get_rft_batch": (C.c_int, [_vp, C.c_int32, ip, C.c_int32, C.c_int32, dp]),
     "rf_pt_swap_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_get_launch_plan": (C.c_int, [_vp, ip]),
     "rf_profile_enable": (C.c_int, [_vp, C.c_int32]),

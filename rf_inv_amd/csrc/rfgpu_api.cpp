@@ -44,6 +44,8 @@ struct rf_ctx {
     int *d_ids = nullptr, *d_fwd = nullptr, *d_nlay = nullptr, *d_acc = nullptr;
     double *d_layers = nullptr, *d_sig = nullptr, *d_logl = nullptr;
     int stage_nb = 0, stage_pad = 0;
+    double *d_gather = nullptr;
+    size_t gather_bytes = 0;
     // host copies of tables
     std::vector<double> flt, r_inv;
     // launch policy
@@ -501,6 +503,32 @@ extern "C" int rf_get_rft(rf_ctx *c, int32_t walker, int32_t which, int32_t nout
     const double *src = c->ws.rft + (((size_t)slot * c->nslots + walker) * ntrc) * (size_t)n;
     HIP_TRY(hipMemcpy2D(out, sizeof(double) * nout, src, sizeof(double) * n, sizeof(double) * nout, ntrc,
                         hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int rf_get_rft_batch(rf_ctx *c, int32_t n, const int32_t *walker_ids, int32_t which, int32_t nout,
+                                double *out)
+{
+    if (!c || !walker_ids || !out) return fail("rf_get_rft_batch: null argument");
+    if (n <= 0) return 0;
+    if (nout < 1 || nout > c->cfg.nfft) return fail("rf_get_rft_batch: n out of range");
+    for (int i = 0; i < n; ++i)
+        if (walker_ids[i] < 0 || walker_ids[i] >= c->nslots) return fail("rf_get_rft_batch: walker out of range");
+    HIP_TRY(hipSetDevice(c->device));
+    if (ensure_stage(c, n, 2)) return 1;
+    const size_t bytes = sizeof(double) * (size_t)n * c->cfg.ntrc * nout;
+    if (bytes > c->gather_bytes) {
+        void *p = nullptr;
+        if (dev_alloc(c, &p, bytes)) return 1;
+        c->d_gather = (double *)p;
+        c->gather_bytes = bytes;
+    }
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_ids, walker_ids, sizeof(int) * n, hipMemcpyHostToDevice, s));
+    launch_gather_rft(c->ws, c->cfg.ntrc, c->cfg.nfft, n, c->d_ids, which, nout, c->d_gather, s);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out, c->d_gather, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
     return 0;
 }
 

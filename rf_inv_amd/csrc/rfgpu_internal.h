@@ -56,6 +56,8 @@ void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &
                   hipStream_t s);
 size_t fused_lds_bytes(int nfft, int nsmp, int nlay_pad);
 void launch_phi(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s);
+void launch_gather_rft(const WalkerState &w, int ntrc, int nfft, int n, const int *walker_ids, int which, int nout,
+                       double *out, hipStream_t s);
 void launch_commit(const WalkerState &w, int nb, const int *walker_ids, const int *accept,
                    int ntrc, hipStream_t s);
 void launch_pt_swap(int npairs, const int *pairs, const double *log_u, double *temps,

@@ -1338,6 +1338,30 @@ void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w
 }
 
 // ---------------------------------------------------------------------------
+// gather the first nout samples of many walkers' traces into one packed buffer
+// out[n][ntrc][nout] (for the posterior amplitude histogram, pt_mcmc.f90:272-285)
+// ---------------------------------------------------------------------------
+__global__ void gather_rft_kernel(WalkerState w, int ntrc, int nfft, int n, const int *walker_ids, int which,
+                                  int nout, double *out)
+{
+    const int i = blockIdx.x / ntrc, itrc = blockIdx.x % ntrc;
+    if (i >= n) return;
+    const int wk = walker_ids[i];
+    const int cur = w.cur_slot[wk];
+    const int slot = (which == 1 && w.prop_fwd[wk]) ? 1 - cur : cur;
+    const double *src = w.rft + (((size_t)slot * w.nslots + wk) * ntrc + itrc) * (size_t)nfft;
+    double *dst = out + ((size_t)i * ntrc + itrc) * (size_t)nout;
+    for (int j = threadIdx.x; j < nout; j += blockDim.x) dst[j] = src[j];
+}
+
+void launch_gather_rft(const WalkerState &w, int ntrc, int nfft, int n, const int *walker_ids, int which, int nout,
+                       double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(gather_rft_kernel, dim3((unsigned)(n * ntrc)), dim3(128), 0, s, w, ntrc, nfft, n, walker_ids,
+                       which, nout, out);
+}
+
+// ---------------------------------------------------------------------------
 // accept step (pt_mcmc.f90:190): flip the walker's current-trace slot
 // ---------------------------------------------------------------------------
 __global__ void commit_kernel(WalkerState w, int nb, const int *walker_ids, const int *accept)

@@ -187,6 +187,14 @@ class RFEngine:
         self._chk(self._lib.rf_get_rft(self._ctx, int(walker), int(which), n, _dptr(out)))
         return out.T
 
+    def get_rft_batch(self, walker_ids, which=0, n=None):
+        """rft(1:n, 1:ntrc) of many walkers in one gather: returns [len(ids), ntrc, n]."""
+        ids = np.ascontiguousarray(walker_ids, dtype=np.int32)
+        n = self.nfft if n is None else int(n)
+        out = np.empty((ids.size, self.ntrc, n))
+        self._chk(self._lib.rf_get_rft_batch(self._ctx, ids.size, _iptr(ids), int(which), n, _dptr(out)))
+        return out
+
     def pt_swap_device(self, pairs, log_u, temps, logl, accepted=None, stream=None):
         """judge_pt over pairs[npairs, 2] (torch int32), applied in order."""
         import torch

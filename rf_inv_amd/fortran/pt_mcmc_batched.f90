@@ -54,6 +54,10 @@ contains
     ! the batch handed to the engine
     integer(c_int32_t), allocatable :: b_id(:), b_fwd(:), b_nlay(:), b_acc(:)
     real(c_double), allocatable :: b_layers(:,:,:), b_sig(:,:), b_logl(:)
+    ! traces of the chains recorded in this iteration (one gather per recording iteration)
+    integer(c_int32_t), allocatable :: r_id(:)
+    real(c_double), allocatable :: r_trace(:,:,:)
+    integer :: nrec, irec
     ! temperature swap
     integer :: ipack(4), rank1, rank2, ichain1, ichain2, itarget1, itarget2
     integer :: status(MPI_STATUS_SIZE)
@@ -71,6 +75,7 @@ contains
     allocate(p_sig(ntrc, nchains), p_lp(nchains), p_logr(nchains))
     allocate(b_id(nchains), b_fwd(nchains), b_nlay(nchains), b_acc(nchains))
     allocate(b_layers(nlay_pad, 4, nchains), b_sig(ntrc, nchains), b_logl(nchains))
+    allocate(r_id(nchains), r_trace(nsmp, ntrc, nchains))
 
     ! the first evaluation of every chain (init_likelihood) becomes its current trace
     do ichain = 1, nchains
@@ -219,14 +224,26 @@ contains
        !----------------------------------------------------------------
        ! 4. counters and posterior records of the non-tempered chains
        !----------------------------------------------------------------
+       nrec = 0
        do ichain = 1, nchains
           if (temps(ichain) <= t_cold) then
              nprop(p_type(ichain)) = nprop(p_type(ichain)) + 1
              if (p_acc(ichain)) naccept(p_type(ichain)) = naccept(p_type(ichain)) + 1
              likelihood_hist(it) = likelihood_hist(it) + log_likelihood(ichain)
-             if (it > nburn .and. mod(it, ncorr) == 0) call record_sample(ichain)
+             if (it > nburn .and. mod(it, ncorr) == 0) then
+                nrec = nrec + 1
+                r_id(nrec) = ichain - 1
+             end if
           end if
        end do
+       if (nrec > 0) then
+          ! the recorded chains' current traces live on the device: one gather for all
+          call rfgpu_check(rf_get_rft_batch(rf_ctx, int(nrec, c_int32_t), r_id, 0_c_int32_t, &
+               & int(nsmp, c_int32_t), r_trace), "rf_get_rft_batch")
+          do irec = 1, nrec
+             call record_sample(r_id(irec) + 1, r_trace(:, :, irec))
+          end do
+       end if
 
        !----------------------------------------------------------------
        ! 5. one temperature-swap proposal for the whole ensemble
@@ -286,11 +303,11 @@ contains
     ! posterior bookkeeping of one non-tempered chain: the same bins, in the same
     ! order, as the record block of the reference's step routine, so that
     ! output_results (mcmc_out) produces identical files.
-    subroutine record_sample(jc)
+    subroutine record_sample(jc, trace)
       integer, intent(in) :: jc
+      real(8), intent(in) :: trace(nsmp, ntrc)
       integer :: itrc, ibin, il, iz, iz1, iz2, ivp, ivs, ivpvs, nl, ismp
       real(8) :: a(nlay_max), b(nlay_max), rh(nlay_max), th(nlay_max), tmpz
-      real(8) :: trace(nsmp, ntrc)
       logical :: ok
 
       nmod = nmod + 1
@@ -341,9 +358,6 @@ contains
          tmpz = tmpz + th(il)
       end do
 
-      ! the chain's current trace lives on the device
-      call rfgpu_check(rf_get_rft(rf_ctx, int(jc - 1, c_int32_t), 0_c_int32_t, int(nsmp, c_int32_t), trace), &
-           & "rf_get_rft")
       do itrc = 1, ntrc
          do ismp = 1, nsmp
             ibin = int((trace(ismp, itrc) - amp_min) / dbin_amp) + 1

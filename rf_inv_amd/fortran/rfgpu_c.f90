@@ -101,6 +101,14 @@ module rfgpu_c
        integer(c_int32_t), value :: walker, which, n
        real(c_double), intent(out) :: out(*)
      end function rf_get_rft
+     integer(c_int) function rf_get_rft_batch(ctx, n, walker_ids, which, nout, out) &
+          & bind(C, name="rf_get_rft_batch")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: n, which, nout
+       integer(c_int32_t), intent(in) :: walker_ids(*)
+       real(c_double), intent(out) :: out(*)
+     end function rf_get_rft_batch
   end interface
 
 contains

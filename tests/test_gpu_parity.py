@@ -376,3 +376,22 @@ def test_make_syn_reproduces_the_shipped_sample(oracle, golden_dir, tmp_path):
         assert np.array_equal(ref[158:], got[158:]) and ref[0] == got[0]
         noisy = np.fromfile(tmp_path / f"test_trace.{i:02d}wn", dtype="<f4")
         assert 0.002 < np.std(noisy[158:] - got[158:]) < 0.02      # filtered noise of sigma 0.01
+
+
+def test_get_rft_batch_equals_single_gets(oracle):
+    rng = np.random.default_rng(3)
+    cfg = make_cfg(rayps=[0.06, 0.08])
+    nsmp = 101
+    obs = np.zeros((2, nsmp))
+    stacks = [random_stack(rng, 4) for _ in range(6)]
+    nlay, layers = pack_layers(stacks, 6)
+    with _engine(cfg, obs, nsmp, None, max_walkers=6) as eng:
+        eng.eval_batch(np.arange(6), nlay, layers, np.full((6, 2), 0.1))
+        eng.commit(np.arange(6), [1, 0, 1, 1, 0, 1])
+        ids = [5, 0, 3, 1]
+        got = eng.get_rft_batch(ids, which=0, n=nsmp)
+        for i, w in enumerate(ids):
+            assert np.array_equal(got[i], eng.get_rft(w, 0, n=nsmp).T)
+        got1 = eng.get_rft_batch(ids, which=1)
+        for i, w in enumerate(ids):
+            assert np.array_equal(got1[i], eng.get_rft(w, 1).T)
