@@ -6,7 +6,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librfgpu.so")
+# RFGPU_LIB selects another build of the same ABI (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("RFGPU_LIB") or os.path.join(_HERE, "lib", "librfgpu.so")
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
