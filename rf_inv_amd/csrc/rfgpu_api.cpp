@@ -44,6 +44,8 @@ struct rf_ctx {
     int *d_ids = nullptr, *d_fwd = nullptr, *d_nlay = nullptr, *d_acc = nullptr;
     double *d_layers = nullptr, *d_sig = nullptr, *d_logl = nullptr;
     int stage_nb = 0, stage_pad = 0;
+    int *d_order = nullptr;   // [nslots] LPT dispatch order of the current batch
+    bool lpt = true;
     double *d_gather = nullptr;
     size_t gather_bytes = 0;
     // host copies of tables
@@ -316,6 +318,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->ws.done = (int *)p;
     (void)hipMemset(p, 0, sizeof(int) * c->nslots);
+    if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
+    c->d_order = (int *)p;
     c->ws.nslots = c->nslots;
     if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * c->nfwd * 2 * nh)) return cleanup(1);
     c->spec = (double2 *)p;
@@ -337,6 +341,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (env) c->fused = c->fused && atoi(env) != 0;
     if (c->fused && c->chain == 8) c->chain = 4;
     if (c->fused && c->chain == 4 && cfg->sdep > 0.0) c->chain = 3;   // ocean: 3 columns, keep 2 waves/SIMD
+    env = getenv("RFGPU_LPT");
+    if (env) c->lpt = atoi(env) != 0;
     env = getenv("RFGPU_WPB");
     if (env) c->waves_per_block = atoi(env);
     *ctx_out = c;
@@ -429,12 +435,18 @@ static int pick_nsplit(const rf_ctx *c, int nb)
     return ns;
 }
 
-static int run_batch(rf_ctx *c, const BatchArgs &b, hipStream_t s)
+static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
 {
-    if (b.nb <= 0) return 0;
-    if (b.nb > c->nslots) return fail("batch larger than max_walkers + 1");
-    if (b.nlay_pad > c->cfg.nlay_max) return fail("nlay_pad exceeds nlay_max of the context");
+    if (b_in.nb <= 0) return 0;
+    if (b_in.nb > c->nslots) return fail("batch larger than max_walkers + 1");
+    if (b_in.nlay_pad > c->cfg.nlay_max) return fail("nlay_pad exceeds nlay_max of the context");
     HIP_TRY(hipSetDevice(c->device));
+    BatchArgs b = b_in;
+    if (c->lpt && b.nb >= 2 * c->num_cu) {
+        // deepest walkers first (the sort is worth its ~5 us launch once blocks outnumber the CUs)
+        launch_order(b.nb, b.nlay, b.fwd_flag, c->d_order, s);
+        b.order = c->d_order;
+    }
     if (c->fused) {
         hipEvent_t e = prof_begin(c, 0, s);
         launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, s);   // spectra + trace + logL
@@ -459,7 +471,7 @@ extern "C" int rf_eval_batch_device(rf_ctx *c, int32_t nb, const int32_t *d_walk
 {
     if (!c || !d_walker_ids || !d_nlay || !d_layers || !d_sig || !d_logl)
         return fail("rf_eval_batch_device: null argument");
-    BatchArgs b{nb, nlay_pad, d_walker_ids, d_fwd_flag, d_nlay, d_layers, d_sig, d_logl};
+    BatchArgs b{nb, nlay_pad, d_walker_ids, d_fwd_flag, d_nlay, d_layers, d_sig, d_logl, nullptr};
     return run_batch(c, b, (hipStream_t)stream);
 }
 
@@ -481,7 +493,7 @@ extern "C" int rf_eval_batch(rf_ctx *c, int32_t nb, const int32_t *walker_ids, c
     HIP_TRY(hipMemcpyAsync(c->d_nlay, nlay, sizeof(int) * nb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_layers, layers, sizeof(double) * (size_t)nb * 4 * nlay_pad, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_sig, sig, sizeof(double) * (size_t)nb * c->cfg.ntrc, hipMemcpyHostToDevice, s));
-    BatchArgs b{nb, nlay_pad, c->d_ids, fwd_flag ? c->d_fwd : nullptr, c->d_nlay, c->d_layers, c->d_sig, c->d_logl};
+    BatchArgs b{nb, nlay_pad, c->d_ids, fwd_flag ? c->d_fwd : nullptr, c->d_nlay, c->d_layers, c->d_sig, c->d_logl, nullptr};
     if (run_batch(c, b, s)) return 1;
     HIP_TRY(hipMemcpyAsync(logl, c->d_logl, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -596,7 +608,7 @@ extern "C" int rf_calc_likelihood_of_trace(rf_ctx *c, const double *rft, const d
     HIP_TRY(hipMemcpyAsync(c->d_fwd, &one, sizeof(int), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_sig, sig, sizeof(double) * ntrc, hipMemcpyHostToDevice, s));
     launch_phi(c->tab, c->ws, wk, s);
-    BatchArgs b{1, 2, c->d_ids, c->d_fwd, c->d_nlay, c->d_layers, c->d_sig, c->d_logl};
+    BatchArgs b{1, 2, c->d_ids, c->d_fwd, c->d_nlay, c->d_layers, c->d_sig, c->d_logl, nullptr};
     launch_logl(c->tab, b, c->ws, s);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(logl, c->d_logl, sizeof(double), hipMemcpyDeviceToHost, s));

@@ -28,6 +28,7 @@ struct BatchArgs {
     const double *layers;  // [nb][4][nlay_pad]
     const double *sig;     // [nb][ntrc]
     double *logl;          // [nb]
+    const int *order;      // [nb] dispatch order (deepest walkers first) or nullptr
 };
 
 struct WalkerState {
@@ -56,6 +57,7 @@ void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &
                   hipStream_t s);
 size_t fused_lds_bytes(int nfft, int nsmp, int nlay_pad);
 void launch_phi(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s);
+void launch_order(int nb, const int *nlay, const int *fwd_flag, int *order, hipStream_t s);
 void launch_gather_rft(const WalkerState &w, int ntrc, int nfft, int n, const int *walker_ids, int which, int nout,
                        double *out, hipStream_t s);
 void launch_commit(const WalkerState &w, int nb, const int *walker_ids, const int *accept,

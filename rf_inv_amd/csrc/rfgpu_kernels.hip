@@ -516,7 +516,7 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
     const int split = (blockIdx.x % nblk) * wpb + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int f = bf % P.t.nfwd;
-    const int ib = bf / P.t.nfwd;
+    const int ib = P.b.order ? P.b.order[bf / P.t.nfwd] : bf / P.t.nfwd;
     if (P.b.fwd_flag && !P.b.fwd_flag[ib]) return;
 
     double *coef = lds;
@@ -536,13 +536,14 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
             terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], P.t.rayps[f]);
         __syncthreads();
         if (threadIdx.x == 0) {
-            P.meta_tp[bf] = arrival_sum(nl - 1 - i0, terms);
+            P.meta_tp[ib * P.t.nfwd + f] = arrival_sum(nl - 1 - i0, terms);
             if (f == 0) P.meta_slot[ib] = 1 - P.cur_slot[P.b.walker_ids[ib]];
         }
     }
     const int ipha = P.t.ipha[f];
     double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
     const GlobalSink sink{out_r, out_r + P.t.nh, P.t.nh};
+    const int bfi = ib * P.t.nfwd + f;   // (walker, forward-trace) index in batch order
     if (big || sea != (NCOL == 3)) {
         // rare: out-of-range phases or a layer stack of the other kind (land / ocean)
         if (BK > 1) {
@@ -554,7 +555,7 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
                 spectra_body<0, 2, false>(P, coef, tail, nl, ilay0, ipha, sink, split, lane);
         } else if (blockIdx.x % nblk == 0 && threadIdx.x == 0) {
             // the lean direct kernel (4 waves/SIMD) defers to spectra_slow_kernel via the list
-            P.slow_list[atomicAdd(P.slow_count, 1)] = bf;
+            P.slow_list[atomicAdd(P.slow_count, 1)] = bfi;
         }
         return;
     }
@@ -966,7 +967,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
 
     const int tid = threadIdx.x;
     const int itrc = blockIdx.x % t.ntrc;
-    const int ib = blockIdx.x / t.ntrc;
+    const int ib = P.b.order ? P.b.order[blockIdx.x / t.ntrc] : blockIdx.x / t.ntrc;
     if (blockIdx.x == 0 && tid == 0) *P.slow_count = 0;
     if (P.b.fwd_flag && !P.b.fwd_flag[ib]) {
         // sigma-only proposal: the stored trace is re-used (likelihood.f90:81), so is its
@@ -1128,7 +1129,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void fused_kernel(FusedParams F)
 
     const int tid = threadIdx.x;
     const int itrc = blockIdx.x % t.ntrc;     // == forward-trace index here (nfwd == ntrc)
-    const int ib = blockIdx.x / t.ntrc;
+    const int ib = P.b.order ? P.b.order[blockIdx.x / t.ntrc] : blockIdx.x / t.ntrc;
     if (blockIdx.x == 0 && tid == 0) *P.slow_count = 0;
     if (P.b.fwd_flag && !P.b.fwd_flag[ib]) {
         // sigma-only proposal: cached quadratic form of the stored trace (likelihood.f90:81)
@@ -1335,6 +1336,44 @@ void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w
 {
     LoglParams P{t, b, w};
     hipLaunchKernelGGL(logl_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P);
+}
+
+// ---------------------------------------------------------------------------
+// Longest-processing-time-first dispatch order.  A block's cost is proportional to the
+// walker's layer count (2 .. k_max); blocks are handed to CUs in index order, so with few
+// rounds of blocks per CU (C2: 1024 blocks on 512 slots) a deep walker dispatched late sets
+// the kernel time.  A counting sort by descending layer count (one block, LDS histogram)
+// gives order[], and block b works on batch item order[b / ntrc].  Values do not depend on it.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void order_kernel(int nb, const int *nlay, const int *fwd_flag, int *order)
+{
+    __shared__ int hist[256];   // key = min(nlay, 255); items without a forward model: key 0
+    __shared__ int start[256];
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < nb; i += blockDim.x) {
+        const int key = (fwd_flag && !fwd_flag[i]) ? 0 : min(nlay[i], 255);
+        atomicAdd(&hist[key], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = 255; k >= 0; --k) {   // descending keys first
+            start[k] = acc;
+            acc += hist[k];
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nb; i += blockDim.x) {
+        const int key = (fwd_flag && !fwd_flag[i]) ? 0 : min(nlay[i], 255);
+        order[atomicAdd(&start[key], 1)] = i;
+    }
+}
+
+void launch_order(int nb, const int *nlay, const int *fwd_flag, int *order, hipStream_t s)
+{
+    hipLaunchKernelGGL(order_kernel, dim3(1), dim3(1024), 0, s, nb, nlay, fwd_flag, order);
 }
 
 // ---------------------------------------------------------------------------
