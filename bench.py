@@ -254,7 +254,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         ll_gpu = h_logl.numpy().copy()
-        assert np.all(np.isfinite(ll_gpu)), "non-finite logL in the benchmark batch"
+        assert np.all(np.isfinite(ll_gpu)) or os.environ.get("RFGPU_ABLATE"), "non-finite logL in the benchmark batch"
 
         f_spec, f_tot, b_alg = alg_work(p, nlay.astype(np.float64), eng.is_ray_common)
         plan = eng.launch_plan

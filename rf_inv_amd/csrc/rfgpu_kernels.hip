@@ -19,6 +19,7 @@
 // consumes (1, 2 and, under an ocean, 4) are propagated.
 #include "rfgpu_internal.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace rfgpu {
 
@@ -885,6 +886,7 @@ struct TraceParams {
     int log2n;
     FftPlan plan;
     int *slow_count;   // re-armed here for the next batch (the slow kernel ran earlier on the stream)
+    int ablate;        // timing diagnostics only (RFGPU_ABLATE): stop the tail after phase N, results invalid
 };
 
 // Everything after Z is in LDS: inverse FFT, vertical max, shift / normalise / store,
@@ -895,9 +897,11 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
 {
     const DeviceTables &t = P.t;
     const int n = t.nfft, nsmp = t.nsmp;
+    if (P.ablate == 1) return;
     // ---- in-place mixed-radix inverse FFT, sign +, unnormalised (FFTW c2r definition) ---
     fft_inverse_lds<TRACE_THREADS>(a, P.plan, P.log2n, t.twiddle, tid);
     // a[fft_pad(j)].x = rx (RF trace), .y = vertical trace
+    if (P.ablate == 2) return;
 
     double fac = 1.0;
     if (!decon) {
@@ -931,8 +935,10 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
     }
     __syncthreads();
 
+    if (P.ablate == 3) return;
     // ---- phi = (misfit . R^-1) . misfit   (likelihood.f90:92-93) -----------------
     const double phi = quad_form(t, itrc, mis, reinterpret_cast<double *>(a), red, tid);
+    if (P.ablate == 4) return;
     if (tid == 0) {
         double *phis = P.w.phi + ((size_t)slot * P.w.nslots + walker) * t.ntrc;
         // ---- log-likelihood (likelihood.f90:94-96) by the block that finishes the walker's
@@ -1227,7 +1233,7 @@ void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &
 {
     FusedParams F{};
     F.sp = SpectraParams{t, b, nullptr, TRACE_THREADS / 64, nullptr, slow_count, w.meta_tp, w.meta_slot, w.cur_slot};
-    F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count};
+    F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count, getenv("RFGPU_ABLATE") ? atoi(getenv("RFGPU_ABLATE")) : 0};
     while ((1 << F.tp.log2n) < t.nfft) ++F.tp.log2n;
     F.tp.plan = make_fft_plan(F.tp.log2n);
     const size_t lds = fused_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
@@ -1286,7 +1292,7 @@ size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad)
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec, const WalkerState &w,
                   int *slow_count, hipStream_t s)
 {
-    TraceParams P{t, b, spec, w, 0, {}, slow_count};
+    TraceParams P{t, b, spec, w, 0, {}, slow_count, 0};
     while ((1 << P.log2n) < t.nfft) ++P.log2n;
     P.plan = make_fft_plan(P.log2n);
     const size_t lds = trace_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
