@@ -312,7 +312,7 @@ def main():
     main_res = run(args.workload, args.steps, args.warmup, not args.no_cpu_baseline and world == 1)
     also = {}
     for wl in [x for x in args.also.split(",") if x]:
-        r = run(wl, max(5, args.steps // 10), max(2, args.warmup // 4), False)
+        r = run(wl, max(30, args.steps // 2), max(5, args.warmup // 2), False)
         also[wl] = {k: r[k] for k in ("value", "ms_per_step", "config", "roofline", "kernel_ms")}
     if rank == 0:
         out = {"metric": "forward+likelihood evals/sec (whole node)", "value": main_res["value"], "unit": "evals/s",
