@@ -395,3 +395,53 @@ def test_get_rft_batch_equals_single_gets(oracle):
         got1 = eng.get_rft_batch(ids, which=1)
         for i, w in enumerate(ids):
             assert np.array_equal(got1[i], eng.get_rft(w, 1).T)
+
+
+def test_python_module_mirrors_forward_and_likelihood(oracle, golden_dir):
+    """rf_inv_amd.Forward / rf_inv_amd.Likelihood mirror the reference's module interfaces
+    (same names, argument meaning, 1-based chain ids) on the shipped sample_syn setup."""
+    from rf_inv_amd import Forward, Likelihood, format_model, get_params, read_obs, read_ref_model
+    from rf_inv_amd.mcmc import RJMCMC
+    from rf_inv_amd.mt19937 import MT19937
+
+    p = get_params(os.path.join(golden_dir, "sample_syn", "params.in"))
+    read_obs(p)
+    ref = read_ref_model(os.path.join(p.base_dir, p.vel_file))
+    g = MT19937(p.iseed)
+    m = RJMCMC(p, ref, None, g)          # only for the reference's init_model state
+    m.init_model()
+    k, z, dvp, dvs = m.k, m.z.T.copy(), m.dvp.T.copy(), m.dvs.T.copy()   # (k_max-1, nchains) etc.
+
+    lik = Likelihood(p, ref)
+    lik.init_likelihood(False, k=k, z=z, dvp=dvp, dvs=dvs, rng=g.grnd)
+    fwd = Forward(p, engine=lik.engine)
+    fwd.init_forward(False)
+    assert fwd.is_ray_common is False and fwd.flt.shape == (129, 2)
+    assert np.allclose(fwd.flt.T, oracle.init_filter(256, p.delta, p.a_gus), rtol=1e-15, atol=0)
+    assert lik.sig.shape == (2, 5) and np.all(lik.sig == 0.01)
+
+    cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep,
+               rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha)
+    r_inv = oracle.build_r_inv(p.nsmp, p.a_gus, p.delta)     # Likelihood.init_r_inv is LAPACK dgesvd too
+    obs = np.ascontiguousarray(p.obs[:, :p.nsmp])
+    rft_all = lik.rft                                         # rft(nfft, ntrc, nchains)
+    assert rft_all.shape == (256, 2, 5)
+    for c in range(p.nchains):
+        nl, a, b, r, h, ok = format_model(p, ref, k[c], z[:, c], dvp[:, c], dvs[:, c])
+        want = oracle.calc_rf(cfg, a, b, r, h)
+        assert np.abs(rft_all[:, :, c].T - want).max() <= 1e-12 * np.abs(want).max()
+        ll = oracle.log_likelihood(want, obs, r_inv, lik.sig[:, c], p.nsmp)
+        assert abs(lik.log_likelihood[c] - ll) <= logl_tol(ll)
+        # calc_rf through the forward mirror, with the reference's argument list
+        got = fwd.calc_rf(c + 1, nl, p.nfft, p.ntrc, p.rayps, a, b, r, h)
+        assert np.abs(got.T - want).max() <= 1e-12 * np.abs(want).max()
+    # calc_likelihood, both branches, chain ids 1-based
+    ll1, rft1 = lik.calc_likelihood(2, True, k[1], z[:, 1], dvp[:, 1], dvs[:, 1], lik.sig[:, 1])
+    assert ll1 == lik.log_likelihood[1]
+    sig2 = 3.0 * lik.sig[:, 1]
+    ll2, rft2 = lik.calc_likelihood(2, False, k[1], z[:, 1], dvp[:, 1], dvs[:, 1], sig2)
+    want2 = oracle.log_likelihood(np.ascontiguousarray(rft_all[:, :, 1].T), obs, r_inv, sig2, p.nsmp)
+    assert abs(ll2 - want2) <= logl_tol(want2) and np.array_equal(rft2, rft_all[:, :, 1])
+    with pytest.raises(ValueError):
+        fwd.calc_rf(1, 3, 128, p.ntrc, p.rayps, a, b, r, h)   # n must be params' nfft
+    lik.engine.close()
