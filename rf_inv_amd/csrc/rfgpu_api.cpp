@@ -46,6 +46,8 @@ struct rf_ctx {
     int stage_nb = 0, stage_pad = 0;
     int *d_order = nullptr;   // [nslots] LPT dispatch order of the current batch
     bool lpt = true;
+    int nsplit_override = 0;  // RFGPU_NSPLIT
+    int ablate = 0;           // RFGPU_ABLATE: timing diagnostics, stops the trace tail early (results invalid)
     double *d_gather = nullptr;
     size_t gather_bytes = 0;
     // host copies of tables
@@ -343,6 +345,10 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (c->fused && c->chain == 4 && cfg->sdep > 0.0) c->chain = 3;   // ocean: 3 columns, keep 2 waves/SIMD
     env = getenv("RFGPU_LPT");
     if (env) c->lpt = atoi(env) != 0;
+    env = getenv("RFGPU_NSPLIT");
+    if (env && atoi(env) > 0) c->nsplit_override = atoi(env);
+    env = getenv("RFGPU_ABLATE");
+    if (env) c->ablate = atoi(env);
     env = getenv("RFGPU_WPB");
     if (env) c->waves_per_block = atoi(env);
     *ctx_out = c;
@@ -430,8 +436,7 @@ static int pick_nsplit(const rf_ctx *c, int nb)
     const long waves = (long)nb * c->nfwd;
     const long want = 32L * c->num_cu;
     int ns = (int)std::min<long>(niter, std::max<long>(1, (want + waves - 1) / waves));
-    const char *env = getenv("RFGPU_NSPLIT");
-    if (env && atoi(env) > 0) ns = std::min(niter, atoi(env));
+    if (c->nsplit_override > 0) ns = std::min(niter, c->nsplit_override);
     return ns;
 }
 
@@ -449,7 +454,7 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
     }
     if (c->fused) {
         hipEvent_t e = prof_begin(c, 0, s);
-        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, s);   // spectra + trace + logL
+        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, s);   // spectra + trace + logL
         if (e) (void)hipEventRecord(e, s);
     } else {
         hipEvent_t e = prof_begin(c, 0, s);

@@ -19,7 +19,6 @@
 // consumes (1, 2 and, under an ocean, 4) are propagated.
 #include "rfgpu_internal.h"
 #include <math.h>
-#include <stdlib.h>
 
 namespace rfgpu {
 
@@ -1229,11 +1228,11 @@ static void launch_fused_ncol(int chain, dim3 grid, size_t lds, hipStream_t s, c
 }
 
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
-                  hipStream_t s)
+                  int ablate, hipStream_t s)
 {
     FusedParams F{};
     F.sp = SpectraParams{t, b, nullptr, TRACE_THREADS / 64, nullptr, slow_count, w.meta_tp, w.meta_slot, w.cur_slot};
-    F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count, getenv("RFGPU_ABLATE") ? atoi(getenv("RFGPU_ABLATE")) : 0};
+    F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count, ablate};
     while ((1 << F.tp.log2n) < t.nfft) ++F.tp.log2n;
     F.tp.plan = make_fft_plan(F.tp.log2n);
     const size_t lds = fused_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);

@@ -55,10 +55,12 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_batch_parity(oracle, case):
+def test_batch_parity(oracle, case, fused, monkeypatch):
     """rf_eval_batch: traces within 1e-12 of max|trace|, integer shifts identical by
     construction of the trace equality, logL within the north-star tolerance."""
+    monkeypatch.setenv("RFGPU_FUSED", fused)
     name, nfft, deconv, sdep, rayps, ipha, t_start, nlays = case
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     cfg = make_cfg(nfft=nfft, deconv_mode=deconv, t_start=t_start, sdep=sdep, rayps=rayps,
@@ -143,15 +145,23 @@ def test_nsplit_and_block_shape_variants_agree(oracle, monkeypatch):
     nlay, layers = pack_layers(stacks, 14)
     sig = np.full((4, 1), 0.01)
     outs = []
-    for ns, wpb in [("1", "1"), ("3", "1"), ("3", "4"), ("4", "2")]:
+    for ns, wpb, fused, lpt in [("1", "1", "0", "0"), ("3", "1", "0", "1"), ("3", "4", "0", "0"), ("4", "2", "0", "1"),
+                                ("1", "1", "1", "0"), ("1", "1", "1", "1")]:
         monkeypatch.setenv("RFGPU_NSPLIT", ns)
         monkeypatch.setenv("RFGPU_WPB", wpb)
+        monkeypatch.setenv("RFGPU_FUSED", fused)   # split kernels (spectra -> trace) vs the fused kernel
+        monkeypatch.setenv("RFGPU_LPT", lpt)       # longest-first dispatch order
         monkeypatch.setenv("RFGPU_CHAIN", "0")
         with _engine(cfg, obs, nsmp, None, max_walkers=4) as eng:
             outs.append((eng.eval_batch(np.arange(4), nlay, layers, sig), eng.get_rft(2, 1)))
-    for ll, rft in outs[1:]:
-        assert np.array_equal(ll, outs[0][0])
-        assert np.array_equal(rft, outs[0][1])
+    # the split variants (outs[0..3]) only re-partition bins and blocks: bit-identical; so are the two
+    # fused runs among themselves.  Fused vs split may differ in the last bits (the compiler contracts
+    # the filter multiply / Hermitian fill differently in the two kernels)
+    for ll, rft in outs[1:4]:
+        assert np.array_equal(ll, outs[0][0]) and np.array_equal(rft, outs[0][1])
+    assert np.array_equal(outs[5][0], outs[4][0]) and np.array_equal(outs[5][1], outs[4][1])
+    assert np.allclose(outs[4][0], outs[0][0], rtol=1e-12, atol=1e-9)
+    assert np.abs(outs[4][1] - outs[0][1]).max() <= 1e-13 * np.abs(outs[0][1]).max()
 
 
 def test_full_size_properties(oracle):
@@ -249,12 +259,14 @@ def test_pt_swap_device_matches_serial_replay(oracle, mode, k):
             assert np.array_equal(sw.temps.cpu().numpy(), temps), step
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("chain", ["0", "2", "3", "4", "8"])
-def test_chained_phase_variants_parity(oracle, monkeypatch, chain):
+def test_chained_phase_variants_parity(oracle, monkeypatch, chain, fused):
     """Every phase-chain length of the spectra kernel (0 = a full sincos per phase) meets the
     same tolerances, on land and under an ocean, including the DC bin whose omega is the
     literal 1e-5 (forward.f90:247) and a bin count that leaves leftover iterations."""
     monkeypatch.setenv("RFGPU_CHAIN", chain)
+    monkeypatch.setenv("RFGPU_FUSED", fused)
     for sdep, nfft in [(0.0, 2048), (2.0, 1024)]:
         rng = np.random.default_rng(77)
         cfg = make_cfg(nfft=nfft, sdep=sdep, rayps=[0.06, 0.10], ipha=[1, -1], t_start=-1.0)
@@ -330,13 +342,15 @@ def test_edge_shapes(oracle):
         assert np.all(eng.get_rft(2, 0) == 0.0)
 
 
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("chain", ["0", "4"])
-def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, monkeypatch, chain):
+def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, monkeypatch, chain, fused):
     """In ONE batch: ordinary walkers, one with out-of-range phases (|x| > 1e6 rad) and one whose
     stack is of the other kind than the context (a water layer, beta(1) < 0, with sdep = 0:
     calc_seis keys on beta(1), forward.f90:229, direct_arrival on sdep, :484).  Both the
     in-place generic path of the chained-phase kernels and the deferred-list kernel."""
     monkeypatch.setenv("RFGPU_CHAIN", chain)
+    monkeypatch.setenv("RFGPU_FUSED", fused)
     rng = np.random.default_rng(31)
     cfg = make_cfg(nfft=2048, rayps=[0.06, 0.07], t_start=-1.0)
     nsmp = 101
