@@ -10,6 +10,7 @@ parallel-tempering swap exchange (one all_gather of (T, logL) per step over RCCL
 Workloads (BASELINE.json configs):
   c2  (default) 1024 walkers/GPU, 1 P trace (p 0.06), nfft 4096, k_max 15 (<= 15 layers)
   c4            8192 walkers/GPU, 3 traces (P .06, P .08, S .10), k_max 30, PT swap
+  c5            8192 walkers/GPU, 4 traces (2 P + 2 S), ocean layer, k_max 30, PT swap
   c1            sample_syn shape: nfft 256, 2 traces, ocean, k_max 10 (plumbing size)
 
 Prints ONE JSON line on rank 0.
@@ -36,6 +37,11 @@ WORKLOADS = {
                temps=8,
                desc="c4: 8192 walkers/GPU (1024 chains x 8 temperatures) x 3 traces (P .06, P .08, S .10) x nfft 4096 "
                     "x <=30 layers, PT swap"),
+    "c5": dict(walkers=8192, nfft=4096, rayps=[0.06, 0.08, 0.10, 0.12], ipha=[1, 1, -1, -1], k_max=30, sdep=2.0,
+               deconv=0, temps=16,
+               desc="c5-shape: 8192 walkers/GPU x 4 traces (P .06, P .08, S .10, S .12) x nfft 4096 x ocean layer "
+                    "(sdep 2 km) x <=31 layers, PT swap (BASELINE's 'buried station' has no reference behaviour: "
+                    "the borehole branch of forward.f90:289-338 is commented out)"),
     "c1": dict(walkers=1024, nfft=256, rayps=[0.06, 0.08], ipha=[1, 1], k_max=10, sdep=2.0, deconv=0, temps=1,
                desc="c1-shape: 1024 walkers/GPU x 2 P traces x nfft 256 x ocean x <=11 layers"),
 }

@@ -16,8 +16,11 @@
  *     returns the message); evaluations never trap on out-of-domain physics,
  *     they propagate NaN like the reference;
  *   - "walker" = one chain slot owned by the context, 0-based;
- *   - host-buffer calls are synchronous at return; *_device calls take device
- *     pointers + a hipStream_t (as void*) and are asynchronous on that stream.
+ *   - host-buffer calls are synchronous at return and run on the context's own
+ *     stream; *_device calls take device pointers + a hipStream_t (as void*)
+ *     and are asynchronous on that stream: synchronise it before a host-buffer
+ *     call that depends on their result (rf_get_rft, rf_commit, ...).
+ *   - a context is not thread-safe; use one per host thread / process / GPU.
  *   - there is NO CPU fallback: if no gfx950 device is usable rf_ctx_create
  *     fails.
  */

@@ -1,0 +1,55 @@
+// FP64 vector-FMA peak of the device (datasheet MI355X: 78.6 TFLOP/s).  Not part of the
+// product: a calibration point for the roofline in DESIGN.md / bench.py.
+//   hipcc --offload-arch=gfx950 -O3 -o fp64_peak tools/fp64_peak.hip && ./fp64_peak
+#include <hip/hip_runtime.h>
+#include <cstdio>
+
+template <int CHAINS>
+__global__ __launch_bounds__(256) void fma_kernel(double *out, double a, double b, int iters)
+{
+    double x[CHAINS];
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) x[c] = threadIdx.x * 1e-3 + c;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int c = 0; c < CHAINS; ++c) x[c] = fma(x[c], a, b);
+    }
+    double s = 0;
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) s += x[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int CHAINS>
+static void run(int blocks_per_cu)
+{
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int blocks = p.multiProcessorCount * blocks_per_cu, iters = 20000;
+    double *out;
+    hipMalloc(&out, sizeof(double) * blocks * 256);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL(fma_kernel<CHAINS>, dim3(blocks), dim3(256), 0, 0, out, 0.999999, 1e-9, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        const double flops = 2.0 * CHAINS * (double)iters * blocks * 256;
+        if (rep == 2)
+            printf("chains/thread %2d, %d waves/SIMD: %.3f ms  %.1f TFLOP/s fp64\n", CHAINS, blocks_per_cu, ms,
+                   flops / ms / 1e9);
+    }
+    hipFree(out);
+}
+
+int main()
+{
+    run<1>(1); run<2>(1); run<4>(1); run<8>(1);
+    run<1>(2); run<4>(2); run<8>(2);
+    run<4>(4); run<8>(4); run<8>(8);
+    return 0;
+}
