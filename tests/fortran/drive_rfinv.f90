@@ -19,7 +19,7 @@ program drive_rfinv
   implicit none
   include "mpif.h"
   integer :: nproc, rank, ierr, it, u, n_it, mode
-  character(clen_max) :: param_file, arg
+  character(clen_max) :: param_file, arg, dump_file
 
   call mpi_init(ierr)
   call mpi_comm_size(MPI_COMM_WORLD, nproc, ierr)
@@ -53,7 +53,12 @@ program drive_rfinv
   end if
 
   u = 79
-  open(u, file = "rfinv_dump.txt", status = "unknown")
+  if (nproc == 1) then
+     dump_file = "rfinv_dump.txt"
+  else
+     write(dump_file, '(a,i0,a)') "rfinv_dump_", rank, ".txt"
+  end if
+  open(u, file = trim(dump_file), status = "unknown")
   write(u, *) nburn + niter, ntype, ncool
   do it = 1, nburn + niter
      write(u, '(es25.17)') likelihood_hist(it) / dble(ncool * nproc)
@@ -66,6 +71,7 @@ program drive_rfinv
   write(u, *) sum(int(nk, 8) * [(int(it, 8), it = 1, k_max)])
   write(u, '(es25.17)') sum(vp_mean), sum(vs_mean), sum(vpvs_mean), sum(all_likelihood(1:nmod))
   write(u, '(es25.17)') sum(temps), sum(log_likelihood)
+  write(u, '(es25.17)') temps(1:nchains)
   close(u)
   call mpi_finalize(ierr)
   write(*,*) "drive_rfinv: ok"
