@@ -114,7 +114,8 @@ int rf_calc_likelihood_of_trace(rf_ctx *ctx, const double *rft, const double *si
 /* nb independent calc_likelihood calls (the sequential chain loop of
  * src/pt_mcmc.f90:493-496 turned into one launch).
  *   walker_ids[nb]  distinct walker slots
- *   fwd_flag[nb]    or NULL (= all 1)
+ *   fwd_flag[nb]    or NULL (= all 1); 1 = forward model, 0 = sigma-only (stored trace re-used),
+ *                   < 0 = skip the item (logl = NaN, nothing changes)
  *   nlay[nb]        layers of each proposed model
  *   layers          [nb][4][nlay_pad]: alpha, beta, rho, h rows (C order)
  *   sig             [nb][ntrc]
@@ -145,6 +146,37 @@ int rf_get_rft(rf_ctx *ctx, int32_t walker, int32_t which, int32_t n, double *ou
  * recording iteration instead of one copy per chain. */
 int rf_get_rft_batch(rf_ctx *ctx, int32_t n, const int32_t *walker_ids, int32_t which, int32_t nout,
                      double *out);
+
+/* ---- format_model on the device (the step right before the path) ------------ */
+/* What format_model (src/model.f90:175-290) reads from `module params` / `module model`
+ * besides the proposal itself; sdep comes from the context. */
+typedef struct rf_model_config {
+    int32_t k_max;        /* params k_max                                                  */
+    int32_t vp_mode;      /* params vp_mode: 1 = dVp solved, 0 = Vp from the reference model */
+    int32_t nref;         /* entries of the reference velocity table                       */
+    double z_max, h_min;  /* params z_max, h_min                                            */
+    double z_ref_min, dz_ref;                         /* model z_ref_min, dz_ref (src/model.f90:36) */
+    double vp_min, vp_max, vs_min, vs_max, vpvs_min, vpvs_max; /* params validity limits   */
+    const double *vp_ref, *vs_ref;                    /* [nref] model vp_ref, vs_ref       */
+} rf_model_config;
+int rf_set_model(rf_ctx *ctx, const rf_model_config *m);
+
+/* subroutine format_model(prop_k, prop_z, prop_dvp, prop_dvs, nlay, alpha, beta, rho, h, is_valid)
+ * for nb proposals at once, all pointers device pointers: k[nb], z[nb][k_max-1],
+ * dvp[nb][k_max], dvs[nb][k_max] -> nlay[nb], layers[nb][4][nlay_pad] (nlay_pad >= k_max + 2),
+ * valid[nb] (may be NULL).  Bit-exact with the reference: same quick_sort permutation
+ * (src/sort.f90:34-68), nint look-ups, vp_to_rho with its single-precision literals. */
+int rf_format_models_device(rf_ctx *ctx, int32_t nb, const int32_t *d_k, const double *d_z,
+                            const double *d_dvp, const double *d_dvs, int32_t *d_nlay, double *d_layers,
+                            int32_t nlay_pad, int32_t *d_valid, void *stream);
+
+/* format_model + calc_likelihood for nb proposals given as (k, z, dVp, dVs): what
+ * src/pt_mcmc.f90:163-180 does per chain.  Items whose model is invalid are not evaluated
+ * (the reference turns them into null proposals): valid[i] = 0, logl[i] = NaN.
+ * fwd_flag[i] = 0 items (sigma-only) skip format_model like the reference does. */
+int rf_eval_models_device(rf_ctx *ctx, int32_t nb, const int32_t *d_walker_ids, const int32_t *d_fwd_flag,
+                          const int32_t *d_k, const double *d_z, const double *d_dvp, const double *d_dvs,
+                          const double *d_sig, double *d_logl, int32_t *d_valid, void *stream);
 
 /* ---- parallel tempering ------------------------------------------------ */
 /* judge_pt (src/pt_mcmc.f90:580-595) for npairs DISJOINT chain pairs: swap

@@ -25,6 +25,17 @@ class RFConfig(C.Structure):
     ]
 
 
+class RFModelConfig(C.Structure):
+    """struct rf_model_config of include/rfgpu.h"""
+    _fields_ = [
+        ("k_max", C.c_int32), ("vp_mode", C.c_int32), ("nref", C.c_int32),
+        ("z_max", C.c_double), ("h_min", C.c_double), ("z_ref_min", C.c_double), ("dz_ref", C.c_double),
+        ("vp_min", C.c_double), ("vp_max", C.c_double), ("vs_min", C.c_double), ("vs_max", C.c_double),
+        ("vpvs_min", C.c_double), ("vpvs_max", C.c_double),
+        ("vp_ref", dp), ("vs_ref", dp),
+    ]
+
+
 # every symbol include/rfgpu.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
 SYMBOLS = {
@@ -46,6 +57,9 @@ SYMBOLS = {
     "rf_commit_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp]),
     "rf_get_rft": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, dp]),
     "rf_get_rft_batch": (C.c_int, [_vp, C.c_int32, ip, C.c_int32, C.c_int32, dp]),
+    "rf_set_model": (C.c_int, [_vp, C.POINTER(RFModelConfig)]),
+    "rf_format_models_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
+    "rf_eval_models_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_pt_swap_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_get_launch_plan": (C.c_int, [_vp, ip]),
     "rf_profile_enable": (C.c_int, [_vp, C.c_int32]),

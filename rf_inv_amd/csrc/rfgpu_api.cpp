@@ -44,6 +44,12 @@ struct rf_ctx {
     int *d_ids = nullptr, *d_fwd = nullptr, *d_nlay = nullptr, *d_acc = nullptr;
     double *d_layers = nullptr, *d_sig = nullptr, *d_logl = nullptr;
     int stage_nb = 0, stage_pad = 0;
+    // device format_model (row f-2): model tables + per-batch outputs
+    bool have_model = false;
+    ModelConfig model{};
+    int fm_pad = 0;
+    int *d_fm_nlay = nullptr, *d_fm_flag = nullptr;
+    double *d_fm_layers = nullptr, *d_fm_scratch = nullptr;
     int *d_order = nullptr;   // [nslots] LPT dispatch order of the current batch
     bool lpt = true;
     int nsplit_override = 0;  // RFGPU_NSPLIT
@@ -619,6 +625,66 @@ extern "C" int rf_calc_likelihood_of_trace(rf_ctx *c, const double *rft, const d
     HIP_TRY(hipMemcpyAsync(logl, c->d_logl, sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     return 0;
+}
+
+extern "C" int rf_set_model(rf_ctx *c, const rf_model_config *m)
+{
+    if (!c || !m || !m->vp_ref || !m->vs_ref) return fail("rf_set_model: null argument");
+    if (m->k_max < 2 || m->nref < 1) return fail("rf_set_model: bad k_max / nref");
+    if (m->k_max + 2 > c->cfg.nlay_max) return fail("rf_set_model: k_max + 2 exceeds nlay_max of the context");
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<double> vp(m->vp_ref, m->vp_ref + m->nref), vs(m->vs_ref, m->vs_ref + m->nref);
+    const double *dvp = nullptr, *dvs = nullptr;
+    if (upload(c, vp, &dvp) || upload(c, vs, &dvs)) return 1;
+    c->model = ModelConfig{m->k_max, m->vp_mode, m->nref, c->cfg.sdep, m->z_max, m->h_min, m->z_ref_min, m->dz_ref,
+                           m->vp_min, m->vp_max, m->vs_min, m->vs_max, m->vpvs_min, m->vpvs_max, dvp, dvs};
+    c->fm_pad = m->k_max + 2;
+    void *p;
+    if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return 1;
+    c->d_fm_nlay = (int *)p;
+    if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return 1;
+    c->d_fm_flag = (int *)p;
+    if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * 4 * c->fm_pad)) return 1;
+    c->d_fm_layers = (double *)p;
+    if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * 3 * m->k_max)) return 1;
+    c->d_fm_scratch = (double *)p;
+    c->have_model = true;
+    return 0;
+}
+
+extern "C" int rf_format_models_device(rf_ctx *c, int32_t nb, const int32_t *d_k, const double *d_z,
+                                       const double *d_dvp, const double *d_dvs, int32_t *d_nlay, double *d_layers,
+                                       int32_t nlay_pad, int32_t *d_valid, void *stream)
+{
+    if (!c || !d_k || !d_z || !d_dvp || !d_dvs || !d_nlay || !d_layers) return fail("rf_format_models_device: null argument");
+    if (!c->have_model) return fail("rf_format_models_device: rf_set_model has not been called");
+    if (nb <= 0) return 0;
+    if (nb > c->nslots) return fail("rf_format_models_device: batch larger than max_walkers + 1");
+    if (nlay_pad < c->model.k_max + 2) return fail("rf_format_models_device: nlay_pad < k_max + 2");
+    HIP_TRY(hipSetDevice(c->device));
+    FormatParams P{c->model, nb, nlay_pad, d_k, d_z, d_dvp, d_dvs, nullptr, d_nlay, d_layers, c->d_fm_flag, d_valid,
+                   c->d_fm_scratch};
+    launch_format_model(P, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rf_eval_models_device(rf_ctx *c, int32_t nb, const int32_t *d_walker_ids, const int32_t *d_fwd_flag,
+                                     const int32_t *d_k, const double *d_z, const double *d_dvp, const double *d_dvs,
+                                     const double *d_sig, double *d_logl, int32_t *d_valid, void *stream)
+{
+    if (!c || !d_walker_ids || !d_k || !d_z || !d_dvp || !d_dvs || !d_sig || !d_logl)
+        return fail("rf_eval_models_device: null argument");
+    if (!c->have_model) return fail("rf_eval_models_device: rf_set_model has not been called");
+    if (nb <= 0) return 0;
+    if (nb > c->nslots) return fail("rf_eval_models_device: batch larger than max_walkers + 1");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    FormatParams P{c->model, nb, c->fm_pad, d_k, d_z, d_dvp, d_dvs, d_fwd_flag, c->d_fm_nlay, c->d_fm_layers,
+                   c->d_fm_flag, d_valid, c->d_fm_scratch};
+    launch_format_model(P, s);
+    BatchArgs b{nb, c->fm_pad, d_walker_ids, c->d_fm_flag, c->d_fm_nlay, c->d_fm_layers, d_sig, d_logl, nullptr};
+    return run_batch(c, b, s);
 }
 
 extern "C" int rf_commit_device(rf_ctx *c, int32_t nb, const int32_t *d_walker_ids, const int32_t *d_accept,

@@ -57,6 +57,25 @@ void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &
                   int ablate, hipStream_t s);
 size_t fused_lds_bytes(int nfft, int nsmp, int nlay_pad);
 void launch_phi(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s);
+struct ModelConfig {
+    int k_max, vp_mode, nref;
+    double sdep, z_max, h_min, z_ref_min, dz_ref;
+    double vp_min, vp_max, vs_min, vs_max, vpvs_min, vpvs_max;
+    const double *vp_ref, *vs_ref;   // device
+};
+struct FormatParams {
+    ModelConfig m;
+    int nb, nlay_pad;
+    const int *k;
+    const double *z, *dvp, *dvs;
+    const int *fwd_in;
+    int *nlay;
+    double *layers;
+    int *flag;
+    int *valid;
+    double *scratch;
+};
+void launch_format_model(const FormatParams &P, hipStream_t s);
 void launch_order(int nb, const int *nlay, const int *fwd_flag, int *order, hipStream_t s);
 void launch_gather_rft(const WalkerState &w, int ntrc, int nfft, int n, const int *walker_ids, int which, int nout,
                        double *out, hipStream_t s);

@@ -517,7 +517,7 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
     const int lane = threadIdx.x & 63;
     const int f = bf % P.t.nfwd;
     const int ib = P.b.order ? P.b.order[bf / P.t.nfwd] : bf / P.t.nfwd;
-    if (P.b.fwd_flag && !P.b.fwd_flag[ib]) return;
+    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) return;
 
     double *coef = lds;
     double *tail = lds + (size_t)P.b.nlay_pad * NCOEF;
@@ -974,10 +974,13 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
     const int itrc = blockIdx.x % t.ntrc;
     const int ib = P.b.order ? P.b.order[blockIdx.x / t.ntrc] : blockIdx.x / t.ntrc;
     if (blockIdx.x == 0 && tid == 0) *P.slow_count = 0;
-    if (P.b.fwd_flag && !P.b.fwd_flag[ib]) {
-        // sigma-only proposal: the stored trace is re-used (likelihood.f90:81), so is its
-        // cached quadratic form; only the log-likelihood has to be formed
-        if (itrc == 0 && tid == 0) {
+    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
+        // 0: sigma-only proposal -- the stored trace is re-used (likelihood.f90:81), so is its cached
+        // quadratic form; < 0: no evaluation at all (an invalid model from rf_eval_models_device)
+        if (itrc == 0 && tid == 0 && P.b.fwd_flag[ib] < 0) {
+            P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
+            P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
+        } else if (itrc == 0 && tid == 0) {
             const int wk = P.b.walker_ids[ib];
             const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * t.ntrc;
             P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
@@ -1136,9 +1139,13 @@ __global__ __launch_bounds__(TRACE_THREADS) void fused_kernel(FusedParams F)
     const int itrc = blockIdx.x % t.ntrc;     // == forward-trace index here (nfwd == ntrc)
     const int ib = P.b.order ? P.b.order[blockIdx.x / t.ntrc] : blockIdx.x / t.ntrc;
     if (blockIdx.x == 0 && tid == 0) *P.slow_count = 0;
-    if (P.b.fwd_flag && !P.b.fwd_flag[ib]) {
-        // sigma-only proposal: cached quadratic form of the stored trace (likelihood.f90:81)
-        if (itrc == 0 && tid == 0) {
+    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
+        // 0: sigma-only proposal -- the stored trace is re-used (likelihood.f90:81), so is its cached
+        // quadratic form; < 0: no evaluation at all (an invalid model from rf_eval_models_device)
+        if (itrc == 0 && tid == 0 && P.b.fwd_flag[ib] < 0) {
+            P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
+            P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
+        } else if (itrc == 0 && tid == 0) {
             const int wk = P.b.walker_ids[ib];
             const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * t.ntrc;
             P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
@@ -1344,6 +1351,132 @@ void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w
 }
 
 // ---------------------------------------------------------------------------
+// format_model on the device (reference src/model.f90:175-290 with vp_to_rho :298-314 and
+// the 3-array quick_sort of src/sort.f90:34-68): one thread per walker turns
+// (k, z, dVp, dVs) into the layer stack (alpha, beta, rho, h).  All of it is bookkeeping
+// that must be bit-exact -- the same unstable quicksort (ties keep the reference's
+// permutation), nint() table look-ups, no FMA contraction, single-precision literals.
+// ---------------------------------------------------------------------------
+__device__ __noinline__ double vp_to_rho_dev(double a1)
+{
+#pragma clang fp contract(off)
+    const double a2 = a1 * a1, a3 = a2 * a1, a4 = a3 * a1, a5 = a4 * a1;
+    return (double)1.6612f * a1 - (double)0.4721f * a2 + (double)0.0671f * a3 - (double)0.0043f * a4 +
+           (double)0.000106f * a5;
+}
+
+__device__ __forceinline__ void swap3(double *a, double *b, double *c, int i, int j)
+{
+    double t = a[i]; a[i] = a[j]; a[j] = t;
+    t = b[i]; b[i] = b[j]; b[j] = t;
+    t = c[i]; c[i] = c[j]; c[j] = t;
+}
+
+// the reference's recursive quick_sort (1-based il..ir inclusive) with an explicit stack
+__device__ void quick_sort3_dev(double *a, double *b, double *c, int n)
+{
+    int stack_l[32], stack_r[32], sp = 0;
+    stack_l[0] = 1;
+    stack_r[0] = n;
+    sp = 1;
+    while (sp > 0) {
+        --sp;
+        const int il = stack_l[sp], ir = stack_r[sp];
+        if (ir - il <= 0) continue;
+        const int ipiv = (il + ir) / 2;
+        const double piv = a[ipiv - 1];
+        swap3(a, b, c, ipiv - 1, ir - 1);
+        int i = il;
+        for (int j = il; j <= ir; ++j)
+            if (a[j - 1] < piv) {
+                swap3(a, b, c, i - 1, j - 1);
+                ++i;
+            }
+        swap3(a, b, c, i - 1, ir - 1);
+        // the reference recurses into (il, i) and then (i + 1, ir); the two sub-ranges are disjoint,
+        // so the order in which they are processed does not change the result.  Pushing the larger
+        // one first (the smaller is popped next) bounds the stack by log2(n) + 1 entries.
+        const int ll = il, lr = i, rl = i + 1, rr = ir;
+        if (lr - ll >= rr - rl) {
+            stack_l[sp] = ll; stack_r[sp] = lr; ++sp;
+            stack_l[sp] = rl; stack_r[sp] = rr; ++sp;
+        } else {
+            stack_l[sp] = rl; stack_r[sp] = rr; ++sp;
+            stack_l[sp] = ll; stack_r[sp] = lr; ++sp;
+        }
+    }
+}
+
+__device__ __forceinline__ int f_nint_dev(double x) { return (int)(x >= 0.0 ? floor(x + 0.5) : -floor(0.5 - x)); }
+
+__global__ __launch_bounds__(128) void format_model_kernel(FormatParams P)
+{
+#pragma clang fp contract(off)
+    const int ib = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ib >= P.nb) return;
+    const ModelConfig &m = P.m;
+    const int kmax = m.k_max, k = P.k[ib];
+    const int fwd = P.fwd_in ? P.fwd_in[ib] : 1;
+    if (fwd != 1) {          // sigma-only (or skipped) item: no model to format
+        P.nlay[ib] = 2;
+        P.flag[ib] = fwd;
+        if (P.valid) P.valid[ib] = 1;
+        return;
+    }
+    double *tz = P.scratch + (size_t)ib * 3 * kmax, *tvp = tz + kmax, *tvs = tvp + kmax;
+    for (int i = 0; i < kmax - 1; ++i) tz[i] = P.z[(size_t)ib * (kmax - 1) + i];
+    for (int i = 0; i < kmax; ++i) {
+        tvp[i] = P.dvp[(size_t)ib * kmax + i];
+        tvs[i] = P.dvs[(size_t)ib * kmax + i];
+    }
+    quick_sort3_dev(tz, tvp, tvs, k);                                        // :197-198
+    const int pad = P.nlay_pad;
+    double *A = P.layers + (size_t)ib * 4 * pad, *B = A + pad, *R = B + pad, *H = R + pad;
+    bool ok = true;
+    int i = 0;
+    if (m.sdep > 0.0) {                                                      // :201-207
+        A[i] = 1.5; B[i] = -999.0; R[i] = 1.0; H[i] = m.sdep;
+        ++i;
+    }
+    for (int j = 1; j <= k + 1; ++j) {
+        // j = 1: top layer (:210-231), 2..k: middle layers (:235-262), k+1: half-space (:265-282)
+        double zc, thick;
+        int idx;
+        if (j == 1) {
+            zc = 0.5 * (m.sdep + tz[0]);
+            thick = tz[0] - m.sdep;
+            idx = 0;
+        } else if (j <= k) {
+            zc = 0.5 * (tz[j - 1] + tz[j - 2]);
+            thick = tz[j - 1] - tz[j - 2];
+            idx = j - 1;
+        } else {
+            zc = 0.5 * (m.z_max + tz[k - 1]);
+            thick = 999.0;
+            idx = kmax - 1;
+        }
+        const int iz = f_nint_dev((zc - m.z_ref_min) / m.dz_ref) + 1;
+        const double b = m.vs_ref[iz - 1] + tvs[idx];
+        const double a = m.vp_mode == 1 ? m.vp_ref[iz - 1] + tvp[idx] : m.vp_ref[iz - 1];
+        if (a < m.vp_min || a > m.vp_max || b < m.vs_min || b > m.vs_max || a / b < m.vpvs_min ||
+            a / b > m.vpvs_max)
+            ok = false;
+        A[i] = a; B[i] = b; R[i] = vp_to_rho_dev(a); H[i] = thick;
+        if (j == 1 && thick < (double)0.125f * a) ok = false;                // :229 (not h_min)
+        if (j > 1 && j <= k && thick < m.h_min) ok = false;                  // :256
+        ++i;
+    }
+    P.nlay[ib] = i;
+    P.flag[ib] = ok ? 1 : -1;
+    if (P.valid) P.valid[ib] = ok ? 1 : 0;
+}
+
+void launch_format_model(const FormatParams &P, hipStream_t s)
+{
+    hipLaunchKernelGGL(format_model_kernel, dim3((unsigned)((P.nb + 127) / 128)), dim3(128), 0, s, P);
+}
+
+// ---------------------------------------------------------------------------
 // Longest-processing-time-first dispatch order.  A block's cost is proportional to the
 // walker's layer count (2 .. k_max); blocks are handed to CUs in index order, so with few
 // rounds of blocks per CU (C2: 1024 blocks on 512 slots) a deep walker dispatched late sets
@@ -1358,7 +1491,7 @@ __global__ __launch_bounds__(1024) void order_kernel(int nb, const int *nlay, co
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     for (int i = tid; i < nb; i += blockDim.x) {
-        const int key = (fwd_flag && !fwd_flag[i]) ? 0 : min(nlay[i], 255);
+        const int key = (fwd_flag && fwd_flag[i] != 1) ? 0 : min(nlay[i], 255);
         atomicAdd(&hist[key], 1);
     }
     __syncthreads();
@@ -1371,7 +1504,7 @@ __global__ __launch_bounds__(1024) void order_kernel(int nb, const int *nlay, co
     }
     __syncthreads();
     for (int i = tid; i < nb; i += blockDim.x) {
-        const int key = (fwd_flag && !fwd_flag[i]) ? 0 : min(nlay[i], 255);
+        const int key = (fwd_flag && fwd_flag[i] != 1) ? 0 : min(nlay[i], 255);
         order[atomicAdd(&start[key], 1)] = i;
     }
 }

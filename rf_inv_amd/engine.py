@@ -195,6 +195,41 @@ class RFEngine:
         self._chk(self._lib.rf_get_rft_batch(self._ctx, ids.size, _iptr(ids), int(which), n, _dptr(out)))
         return out
 
+    # ---- format_model on the device -----------------------------------------------
+    def set_model(self, p: Params, ref):
+        """Hands format_model's inputs (params limits + reference velocity table) to the engine."""
+        vp = np.ascontiguousarray(ref.vp_ref, dtype=np.float64)
+        vs = np.ascontiguousarray(ref.vs_ref, dtype=np.float64)
+        m = _lib.RFModelConfig(int(p.k_max), int(p.vp_mode), int(vp.size), float(p.z_max), float(p.h_min),
+                               float(ref.z_ref_min), float(ref.dz_ref), float(p.vp_min), float(p.vp_max),
+                               float(p.vs_min), float(p.vs_max), float(p.vpvs_min), float(p.vpvs_max),
+                               _dptr(vp), _dptr(vs))
+        self._chk(self._lib.rf_set_model(self._ctx, C.byref(m)))
+        self.k_max = int(p.k_max)
+
+    def format_models_device(self, k, z, dvp, dvs, nlay, layers, valid=None, stream=None):
+        """format_model for a batch, torch CUDA tensors: k[nb] int32, z[nb, k_max-1], dvp/dvs[nb, k_max]
+        -> nlay[nb] int32, layers[nb, 4, nlay_pad], valid[nb] int32."""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(layers.device)
+        self._chk(self._lib.rf_format_models_device(
+            self._ctx, k.numel(), k.data_ptr(), z.data_ptr(), dvp.data_ptr(), dvs.data_ptr(), nlay.data_ptr(),
+            layers.data_ptr(), int(layers.shape[2]), valid.data_ptr() if valid is not None else None,
+            st.cuda_stream))
+
+    def eval_models_device(self, walker_ids, k, z, dvp, dvs, sig, logl, valid=None, fwd_flag=None, stream=None):
+        """format_model + forward + likelihood for proposals given as (k, z, dVp, dVs); invalid models
+        are not evaluated (valid = 0, logL = NaN)."""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(sig.device)
+        self._chk(self._lib.rf_eval_models_device(
+            self._ctx, walker_ids.numel(), walker_ids.data_ptr(),
+            fwd_flag.data_ptr() if fwd_flag is not None else None, k.data_ptr(), z.data_ptr(), dvp.data_ptr(),
+            dvs.data_ptr(), sig.data_ptr(), logl.data_ptr(), valid.data_ptr() if valid is not None else None,
+            st.cuda_stream))
+
     def pt_swap_device(self, pairs, log_u, temps, logl, accepted=None, stream=None):
         """judge_pt over pairs[npairs, 2] (torch int32), applied in order."""
         import torch
