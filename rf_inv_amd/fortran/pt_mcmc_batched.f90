@@ -42,11 +42,11 @@ contains
     include "mpif.h"
     logical, intent(in) :: verb
     integer :: nproc, rank, ierr, it, n_tot_iter, n_all, ichain, nb, ib, i
-    integer :: itype, itarget, ilay, nlay, nlay_pad, prop_k
-    logical :: null_flag, is_valid, yn
+    integer :: itype, nlay, nlay_pad, cand_k
+    logical :: live, yn
     real(8) :: alpha(nlay_max), beta(nlay_max), rho(nlay_max), h(nlay_max)
-    real(8) :: prop_z(k_max), prop_dvp(k_max), prop_dvs(k_max), prop_sig(ntrc)
-    real(8) :: log_prior12, r, del_s, t_cold
+    real(8) :: cand_z(k_max), cand_dvp(k_max), cand_dvs(k_max), cand_sig(ntrc)
+    real(8) :: lpr, r, del_s, t_cold
     ! per-chain proposals of the current iteration
     integer, allocatable :: p_k(:), p_type(:)
     logical, allocatable :: p_live(:), p_acc(:)
@@ -92,103 +92,38 @@ contains
        !----------------------------------------------------------------
        nb = 0
        do ichain = 1, nchains
-          log_prior12 = 0.d0
-          prop_k = k(ichain)
-          prop_dvp(1:k_max) = dvp(1:k_max, ichain)
-          prop_dvs(1:k_max) = dvs(1:k_max, ichain)
-          prop_z(1:k_max-1) = z(1:k_max-1, ichain)
-          prop_sig(1:ntrc) = sig(1:ntrc, ichain)
-          null_flag = .false.
-
-          itype = int(grnd() * ntype) + 1
-          if (itype == itype_birth) then
-             prop_k = prop_k + 1
-             if (prop_k < k_max) then
-                if (prior_mode == 1) then
-                   prop_dvp(prop_k) = laplace() * dvp_prior
-                   prop_dvs(prop_k) = laplace() * dvs_prior
-                else if (prior_mode == 2) then
-                   prop_dvp(prop_k) = gauss() * dvp_prior
-                   prop_dvs(prop_k) = gauss() * dvs_prior
-                end if
-                prop_z(prop_k) = z_min + grnd() * (z_max - z_min)
-             else
-                null_flag = .true.
-             end if
-          else if (itype == itype_death) then
-             prop_k = prop_k - 1
-             if (prop_k >= k_min) then
-                itarget = int(grnd() * (prop_k + 1)) + 1
-                do ilay = itarget, prop_k
-                   prop_dvp(ilay) = dvp(ilay + 1, ichain)
-                   prop_dvs(ilay) = dvs(ilay + 1, ichain)
-                   prop_z(ilay) = z(ilay + 1, ichain)
-                end do
-                prop_dvp(prop_k + 1) = 0.d0
-                prop_dvs(prop_k + 1) = 0.d0
-                prop_z(prop_k + 1) = 0.d0
-             else
-                null_flag = .true.
-             end if
-          else if (itype == itype_z) then
-             itarget = int(grnd() * prop_k) + 1
-             prop_z(itarget) = prop_z(itarget) + gauss() * dev_z
-             if (prop_z(itarget) < z_min .or. prop_z(itarget) > z_max) null_flag = .true.
-          else if (itype == itype_dvs) then
-             itarget = int(grnd() * (prop_k + 1)) + 1
-             if (itarget == prop_k + 1) itarget = k_max
-             prop_dvs(itarget) = prop_dvs(itarget) + gauss() * dev_dvs
-             log_prior12 = log_prior_ratio(prop_dvs(itarget), dvs(itarget, ichain), dvs_prior, prior_mode)
-          else if (itype == itype_dvp) then
-             itarget = int(grnd() * (prop_k + 1)) + 1
-             if (itarget == prop_k + 1) itarget = k_max
-             prop_dvp(itarget) = prop_dvp(itarget) + gauss() * dev_dvp
-             log_prior12 = log_prior_ratio(prop_dvp(itarget), dvp(itarget, ichain), dvp_prior, prior_mode)
-          else if (itype == itype_sig) then
-             itarget = isig_trc(int(grnd() * nsig_trc) + 1)
-             prop_sig(itarget) = prop_sig(itarget) + gauss() * dev_sig
-             if (prop_sig(itarget) < sig_min(itarget) .or. prop_sig(itarget) > sig_max(itarget)) &
-                  & null_flag = .true.
-          end if
-
-          if (.not. null_flag) then
-             call format_model(prop_k, prop_z(1:k_max-1), prop_dvp, prop_dvs, &
-                  & nlay, alpha, beta, rho, h, is_valid)
-             if (.not. is_valid) null_flag = .true.
-          end if
-
+          call draw_candidate(ichain)
           p_type(ichain) = itype
-          p_live(ichain) = .not. null_flag
+          p_live(ichain) = live
           p_acc(ichain) = .false.
-          if (.not. null_flag) then
-             ! the acceptance uniform of judge_mcmc, drawn at its place in the stream
-             do
-                r = grnd()
-                if (r >= epsilon(1.d0)) exit
-             end do
-             p_logr(ichain) = log(r)
-             p_lp(ichain) = log_prior12
-             p_k(ichain) = prop_k
-             p_z(1:k_max-1, ichain) = prop_z(1:k_max-1)
-             p_dvp(:, ichain) = prop_dvp
-             p_dvs(:, ichain) = prop_dvs
-             p_sig(:, ichain) = prop_sig
-             nb = nb + 1
-             b_id(nb) = ichain - 1
-             b_sig(:, nb) = prop_sig
-             if (itype /= itype_sig) then
-                b_fwd(nb) = 1
-                b_nlay(nb) = nlay
-                b_layers(:, :, nb) = 1.d0
-                b_layers(1:nlay, 1, nb) = alpha(1:nlay)
-                b_layers(1:nlay, 2, nb) = beta(1:nlay)
-                b_layers(1:nlay, 3, nb) = rho(1:nlay)
-                b_layers(1:nlay, 4, nb) = h(1:nlay)
-             else
-                b_fwd(nb) = 0
-                b_nlay(nb) = 2
-                b_layers(:, :, nb) = 1.d0
-             end if
+          if (.not. live) cycle
+          ! the acceptance uniform of the Metropolis-Hastings test, drawn at its place in the
+          ! reference's stream (it does not depend on the likelihood)
+          do
+             r = grnd()
+             if (r >= epsilon(1.d0)) exit
+          end do
+          p_logr(ichain) = log(r)
+          p_lp(ichain) = lpr
+          p_k(ichain) = cand_k
+          p_z(1:k_max-1, ichain) = cand_z(1:k_max-1)
+          p_dvp(:, ichain) = cand_dvp
+          p_dvs(:, ichain) = cand_dvs
+          p_sig(:, ichain) = cand_sig
+          nb = nb + 1
+          b_id(nb) = ichain - 1
+          b_sig(:, nb) = cand_sig
+          b_layers(:, :, nb) = 1.d0
+          if (itype == itype_sig) then
+             b_fwd(nb) = 0          ! noise-level move: the chain's stored trace is re-used
+             b_nlay(nb) = 2
+          else
+             b_fwd(nb) = 1
+             b_nlay(nb) = nlay
+             b_layers(1:nlay, 1, nb) = alpha(1:nlay)
+             b_layers(1:nlay, 2, nb) = beta(1:nlay)
+             b_layers(1:nlay, 3, nb) = rho(1:nlay)
+             b_layers(1:nlay, 4, nb) = h(1:nlay)
           end if
        end do
 
@@ -293,6 +228,81 @@ contains
     end do
 
   contains
+
+    ! One chain's trans-dimensional proposal.  Sets (host-associated) itype, cand_*, lpr,
+    ! live and -- for live candidates -- the formatted layer stack nlay/alpha/beta/rho/h.
+    ! Every grnd()/gauss()/laplace() call sits where the reference's step routine makes it,
+    ! so the stream position after this call is the reference's.
+    subroutine draw_candidate(jc)
+      integer, intent(in) :: jc
+      integer :: pick
+      logical :: ok
+
+      cand_k = k(jc)
+      cand_dvp(:) = dvp(1:k_max, jc)
+      cand_dvs(:) = dvs(1:k_max, jc)
+      cand_z(1:k_max-1) = z(1:k_max-1, jc)
+      cand_sig(:) = sig(1:ntrc, jc)
+      lpr = 0.d0
+      live = .true.
+
+      itype = int(grnd() * ntype) + 1
+      if (itype == itype_birth) then
+         ! add an interface: perturbations first (dVp, dVs), depth last
+         cand_k = cand_k + 1
+         live = cand_k < k_max
+         if (live) then
+            select case (prior_mode)
+            case (1)
+               cand_dvp(cand_k) = laplace() * dvp_prior
+               cand_dvs(cand_k) = laplace() * dvs_prior
+            case (2)
+               cand_dvp(cand_k) = gauss() * dvp_prior
+               cand_dvs(cand_k) = gauss() * dvs_prior
+            end select
+            cand_z(cand_k) = z_min + grnd() * (z_max - z_min)
+         end if
+      else if (itype == itype_death) then
+         ! remove interface `pick`: close the gap, clear the vacated slot
+         cand_k = cand_k - 1
+         live = cand_k >= k_min
+         if (live) then
+            pick = int(grnd() * (cand_k + 1)) + 1
+            if (pick <= cand_k) then
+               cand_dvp(pick:cand_k) = dvp(pick+1:cand_k+1, jc)
+               cand_dvs(pick:cand_k) = dvs(pick+1:cand_k+1, jc)
+               cand_z(pick:cand_k) = z(pick+1:cand_k+1, jc)
+            end if
+            cand_dvp(cand_k + 1) = 0.d0
+            cand_dvs(cand_k + 1) = 0.d0
+            cand_z(cand_k + 1) = 0.d0
+         end if
+      else if (itype == itype_z) then
+         pick = int(grnd() * cand_k) + 1
+         cand_z(pick) = cand_z(pick) + gauss() * dev_z
+         live = .not. (cand_z(pick) < z_min .or. cand_z(pick) > z_max)
+      else if (itype == itype_dvs .or. itype == itype_dvp) then
+         ! velocity perturbation of one layer (the last index addresses the half-space slot)
+         pick = int(grnd() * (cand_k + 1)) + 1
+         if (pick == cand_k + 1) pick = k_max
+         if (itype == itype_dvs) then
+            cand_dvs(pick) = cand_dvs(pick) + gauss() * dev_dvs
+            lpr = log_prior_ratio(cand_dvs(pick), dvs(pick, jc), dvs_prior, prior_mode)
+         else
+            cand_dvp(pick) = cand_dvp(pick) + gauss() * dev_dvp
+            lpr = log_prior_ratio(cand_dvp(pick), dvp(pick, jc), dvp_prior, prior_mode)
+         end if
+      else if (itype == itype_sig) then
+         pick = isig_trc(int(grnd() * nsig_trc) + 1)
+         cand_sig(pick) = cand_sig(pick) + gauss() * dev_sig
+         live = .not. (cand_sig(pick) < sig_min(pick) .or. cand_sig(pick) > sig_max(pick))
+      end if
+
+      if (live) then
+         call format_model(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs, nlay, alpha, beta, rho, h, ok)
+         live = ok
+      end if
+    end subroutine draw_candidate
 
     ! Metropolis rule of the temperature exchange; draws one uniform
     logical function swap_ok(t1, t2, l1, l2)
