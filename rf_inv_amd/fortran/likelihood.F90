@@ -1,154 +1,126 @@
 !=======================================================================
-! module likelihood -- drop-in replacement of RF_INV's src/likelihood.f90.
+! module likelihood -- GPU-backed stand-in for RF_INV's likelihood module.
 !
-! Same public interface as the reference module (src/likelihood.f90:28-37):
-!     real(8), allocatable, public :: sig(:,:), rft(:,:,:), log_likelihood(:)
-!     subroutine init_likelihood(verb)
-!     subroutine calc_likelihood(chain_id, fwd_flag, prop_k, prop_z, prop_dvp,
-!                                prop_dvs, sig, prop_log_likelihood, prop_rft)
-! The forward model + misfit run on the GPU through librfgpu (include/rfgpu.h).
-! format_model stays the host's (module model), exactly where the reference
-! calls it (src/likelihood.f90:75-76).  Written from scratch.
+! Public names and argument lists are those the RF_INV host expects
+! (sig, rft, log_likelihood, init_likelihood, calc_likelihood); the work is
+! done by librfgpu (include/rfgpu.h) through module rfgpu_c.  The layer stack
+! is still produced by the host's own format_model, at the point where the
+! original module called it.  Written from scratch for rf_inv_amd.
 !
-! Build with -DRFGPU_USE_LAPACK to build the noise-covariance pseudo-inverse
-! with the host's own LAPACK dgesvd (as the reference does, bit-for-bit with
-! that LAPACK); without it librfgpu's own SVD is used.
+! -DRFGPU_USE_LAPACK : build the noise-covariance pseudo-inverse with the
+!                      host's LAPACK (dgesvd) and hand it to the engine;
+!                      default is the engine's own SVD.
 !=======================================================================
 module likelihood
-  use iso_c_binding
+  use iso_c_binding, only: c_int, c_int32_t, c_double
   use rfgpu_c
   implicit none
-  real(8), allocatable, public :: sig(:,:)
-  real(8), allocatable, public :: rft(:,:,:)
-  real(8), allocatable, public :: log_likelihood(:)
+  private
 
-  public init_likelihood, calc_likelihood
-  private init_sig, init_rft
-#ifdef RFGPU_USE_LAPACK
-  private init_r_inv_lapack
-#endif
+  real(8), allocatable, public :: sig(:,:)            ! (ntrc, nchains) noise level of each chain
+  real(8), allocatable, public :: rft(:,:,:)          ! (nfft, ntrc, nchains) current trace of each chain
+  real(8), allocatable, public :: log_likelihood(:)   ! (nchains)
+  public :: init_likelihood, calc_likelihood
 
 contains
 
   !---------------------------------------------------------------------
+  ! State of every chain: noise levels, then one forward evaluation each.
   subroutine init_likelihood(verb)
-    logical, intent(in) :: verb
-    call init_sig(verb)
-#ifdef RFGPU_USE_LAPACK
-    call init_r_inv_lapack(verb)
-#endif
-    call init_rft()
-  end subroutine init_likelihood
-
-  !---------------------------------------------------------------------
-  subroutine calc_likelihood(chain_id, fwd_flag, prop_k, prop_z, &
-       & prop_dvp, prop_dvs, sig, prop_log_likelihood, prop_rft)
-    use params, only: k_max, ntrc, nfft, nlay_max
-    use forward, only: rf_ctx
-    use model, only: format_model
-    integer, intent(in) :: prop_k, chain_id
-    logical, intent(in) :: fwd_flag
-    real(8), intent(in) :: prop_z(k_max-1), prop_dvp(k_max)
-    real(8), intent(in) :: prop_dvs(k_max), sig(ntrc)
-    real(8), intent(out) :: prop_log_likelihood
-    real(8), intent(out) :: prop_rft(nfft, ntrc)
-    integer :: nlay
-    real(8) :: alpha(nlay_max), beta(nlay_max), rho(nlay_max), h(nlay_max)
-    logical :: is_valid
-
-    if (fwd_flag) then
-       call format_model(prop_k, prop_z, prop_dvp, prop_dvs, &
-            & nlay, alpha, beta, rho, h, is_valid)
-       call rfgpu_check(rf_calc_likelihood(rf_ctx, int(chain_id - 1, c_int32_t), 1_c_int32_t, &
-            & int(nlay, c_int32_t), alpha, beta, rho, h, sig, prop_log_likelihood, prop_rft), &
-            & "rf_calc_likelihood")
-    else
-       ! sigma-only proposal: the host owns the stored trace of the chain
-       prop_rft(1:nfft, 1:ntrc) = rft(1:nfft, 1:ntrc, chain_id)
-       call rfgpu_check(rf_calc_likelihood_of_trace(rf_ctx, prop_rft, sig, prop_log_likelihood), &
-            & "rf_calc_likelihood_of_trace")
-    end if
-  end subroutine calc_likelihood
-
-  !---------------------------------------------------------------------
-  ! noise sigma of every chain: fixed, or uniform in [sig_min, sig_max]
-  subroutine init_sig(verb)
-    use params, only: sig_min, sig_max, nchains, ntrc, sig_mode
+    use params, only: nchains, ntrc, nfft, sig_mode, sig_min, sig_max
     use mt19937, only: grnd
+    use model, only: k, z, dvp, dvs
     logical, intent(in) :: verb
-    integer :: ichain, itrc
+    integer :: jc, jt
 
-    allocate(sig(ntrc, nchains))
-    do ichain = 1, nchains
-       do itrc = 1, ntrc
-          sig(itrc, ichain) = sig_min(itrc)
-          if (sig_mode(itrc) == 1) then
-             sig(itrc, ichain) = sig_min(itrc) + grnd() * (sig_max(itrc) - sig_min(itrc))
+    allocate(sig(ntrc, nchains), rft(nfft, ntrc, nchains), log_likelihood(nchains))
+
+    ! noise level: fixed at sig_min, or uniform in [sig_min, sig_max] when it is solved for
+    ! (one uniform draw per solved trace, chain-major order)
+    do jc = 1, nchains
+       do jt = 1, ntrc
+          if (sig_mode(jt) == 1) then
+             sig(jt, jc) = sig_min(jt) + grnd() * (sig_max(jt) - sig_min(jt))
+          else
+             sig(jt, jc) = sig_min(jt)
           end if
        end do
     end do
     if (verb) then
        write(*,*)
        write(*,*) "--- Initialize noise sigma ---"
-       do ichain = 1, nchains
-          write(*,*) ichain, sig(1, ichain)
-       end do
+       write(*,'(i8,es16.6)') (jc, sig(1, jc), jc = 1, nchains)
     end if
-  end subroutine init_sig
+
+#ifdef RFGPU_USE_LAPACK
+    call pseudo_inverse_from_lapack(verb)
+#endif
+
+    do jc = 1, nchains
+       call calc_likelihood(jc, .true., k(jc), z(:, jc), dvp(:, jc), dvs(:, jc), &
+            sig(:, jc), log_likelihood(jc), rft(:, :, jc))
+    end do
+  end subroutine init_likelihood
 
   !---------------------------------------------------------------------
-  ! first evaluation of every chain
-  subroutine init_rft()
-    use params, only: nfft, ntrc, nchains
-    use model, only: k, z, dvp, dvs
-    integer :: ichain
+  ! log-likelihood (and trace) of a proposed model of chain `chain_id`;
+  ! fwd_flag = .false. means "same model, new noise level": the chain's stored
+  ! trace is returned and only the misfit term is re-evaluated.
+  subroutine calc_likelihood(chain_id, fwd_flag, prop_k, prop_z, prop_dvp, prop_dvs, sig, &
+       prop_log_likelihood, prop_rft)
+    use params, only: k_max, ntrc, nfft, nlay_max
+    use forward, only: rf_ctx
+    use model, only: format_model
+    integer, intent(in)  :: chain_id, prop_k
+    logical, intent(in)  :: fwd_flag
+    real(8), intent(in)  :: prop_z(k_max-1), prop_dvp(k_max), prop_dvs(k_max), sig(ntrc)
+    real(8), intent(out) :: prop_log_likelihood, prop_rft(nfft, ntrc)
+    real(8) :: vp(nlay_max), vs(nlay_max), dens(nlay_max), thick(nlay_max)
+    integer :: nl
+    logical :: usable
 
-    allocate(rft(nfft, ntrc, nchains), log_likelihood(nchains))
-    do ichain = 1, nchains
-       call calc_likelihood(ichain, .true., k(ichain), z(:, ichain), dvp(:, ichain), &
-            & dvs(:, ichain), sig(:, ichain), log_likelihood(ichain), rft(:, :, ichain))
-    end do
-  end subroutine init_rft
+    if (.not. fwd_flag) then
+       prop_rft = rft(:, :, chain_id)
+       call rfgpu_check(rf_calc_likelihood_of_trace(rf_ctx, prop_rft, sig, prop_log_likelihood), &
+            "rf_calc_likelihood_of_trace")
+       return
+    end if
+    call format_model(prop_k, prop_z, prop_dvp, prop_dvs, nl, vp, vs, dens, thick, usable)
+    call rfgpu_check(rf_calc_likelihood(rf_ctx, int(chain_id - 1, c_int32_t), 1_c_int32_t, &
+         int(nl, c_int32_t), vp, vs, dens, thick, sig, prop_log_likelihood, prop_rft), "rf_calc_likelihood")
+  end subroutine calc_likelihood
 
 #ifdef RFGPU_USE_LAPACK
   !---------------------------------------------------------------------
-  ! Gaussian-correlated noise matrix -> SVD -> pseudo-inverse (s > 1e-3),
-  ! through the host's LAPACK, then handed to the engine.
-  subroutine init_r_inv_lapack(verb)
+  ! Truncated pseudo-inverse of the Gaussian noise-correlation matrix
+  ! R(i,j) = r**((i-j)**2), r = exp(-(a*delta)**2), singular values <= 1e-3 dropped,
+  ! computed with the host's dgesvd and uploaded to the engine.
+  subroutine pseudo_inverse_from_lapack(verb)
     use params, only: nsmp, ntrc, a_gus, delta
     use forward, only: rf_ctx
     logical, intent(in) :: verb
-    real(8), allocatable :: rm(:,:), s(:), u(:,:), vt(:,:), work(:), pinv(:,:,:), vd(:,:)
-    real(8) :: r, wq(1)
-    integer :: itrc, i, j, info, lwork
+    real(8), allocatable :: cov(:,:), sv(:), u(:,:), vt(:,:), work(:), pinv(:,:,:), scaled_v(:,:)
+    real(8) :: r, wsize(1)
+    integer :: jt, i, j, info
 
-    allocate(rm(nsmp, nsmp), s(nsmp), u(nsmp, nsmp), vt(nsmp, nsmp), vd(nsmp, nsmp))
+    allocate(cov(nsmp, nsmp), sv(nsmp), u(nsmp, nsmp), vt(nsmp, nsmp), scaled_v(nsmp, nsmp))
     allocate(pinv(nsmp, nsmp, ntrc))
-    do itrc = 1, ntrc
-       r = exp(-a_gus(itrc)**2 * delta**2)
-       do i = 1, nsmp
-          do j = 1, nsmp
-             rm(j, i) = r ** ((i - j) ** 2)
-          end do
-       end do
-       call dgesvd('A', 'A', nsmp, nsmp, rm, nsmp, s, u, nsmp, vt, nsmp, wq, -1, info)
-       lwork = nint(wq(1))
-       allocate(work(lwork))
-       call dgesvd('A', 'A', nsmp, nsmp, rm, nsmp, s, u, nsmp, vt, nsmp, work, lwork, info)
+    do jt = 1, ntrc
+       r = exp(-a_gus(jt)**2 * delta**2)
+       forall (i = 1:nsmp, j = 1:nsmp) cov(j, i) = r ** ((i - j) ** 2)
+       call dgesvd('A', 'A', nsmp, nsmp, cov, nsmp, sv, u, nsmp, vt, nsmp, wsize, -1, info)
+       allocate(work(nint(wsize(1))))
+       call dgesvd('A', 'A', nsmp, nsmp, cov, nsmp, sv, u, nsmp, vt, nsmp, work, size(work), info)
        deallocate(work)
        if (info /= 0) call rfgpu_check(int(info, c_int), "dgesvd")
        do i = 1, nsmp
-          if (s(i) > 1.0d-3) then
-             vd(:, i) = vt(i, :) / s(i)
-          else
-             vd(:, i) = 0.d0
-          end if
+          scaled_v(:, i) = merge(vt(i, :) / sv(i), 0.d0, sv(i) > 1.0d-3)
        end do
-       pinv(:, :, itrc) = matmul(vd, transpose(u))
+       pinv(:, :, jt) = matmul(scaled_v, transpose(u))
     end do
     call rfgpu_check(rf_set_r_inv(rf_ctx, pinv), "rf_set_r_inv")
     if (verb) write(*,*) "R inverse built with host LAPACK"
-  end subroutine init_r_inv_lapack
+  end subroutine pseudo_inverse_from_lapack
 #endif
 
 end module likelihood
