@@ -408,6 +408,7 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
         init_cols<NCOL>(st[m]);
     }
     const bool dc = kbin[0] == 0;
+#pragma unroll 2
     for (int l = ilay0; l < nl - 1; ++l) {
         const double *c = coef + l * NCOEF;
         const double xi = c[0], eta = c[1], h = c[2];
