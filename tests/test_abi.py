@@ -84,3 +84,21 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".f90", ".F90")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "rf_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_header_is_plain_c_and_a_c_host_links(tmp_path):
+    """include/rfgpu.h compiles as C99 and a C program links against librfgpu.so (tests/c/abi_smoke.c)."""
+    import subprocess
+
+    from rf_inv_amd import _lib
+
+    _lib.load()
+    exe = tmp_path / "abi_smoke"
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "abi_smoke.c"), "-o", str(exe), "-L", libdir, "-lrfgpu",
+                           "-lm", f"-Wl,-rpath,{libdir}"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "abi 1 rank" in r.stdout
+    assert "no context: rf_ctx_create: no HIP device" in r.stdout or "calc_rf rc 0" in r.stdout
