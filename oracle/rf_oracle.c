@@ -57,9 +57,14 @@
  *       reference ships.
  * Branches with NO reference-derived known answers: S-phase traces and
  * water-level deconvolution.  They are restated from the cited lines and
- * cross-checked by an independent numpy restatement (oracle/rf_oracle.py:
- * calc_seis_numpy) and by identities in tests/, but are "parity unpinned" by
- * reference outputs -- see DESIGN.md.
+ * checked by (a) an independent numpy restatement (oracle/rf_oracle.py:
+ * calc_seis_numpy; tests/test_oracle_kat.py water-level test), (b) a
+ * physics known answer that does not come from the reference: for a
+ * homogeneous half-space u_r/u_z must equal the classic free-surface
+ * apparent-angle relations for P and for SV incidence
+ * (test_homogeneous_halfspace_apparent_angle), which exercises the S
+ * boundary-condition lines.  They remain "parity unpinned" by reference
+ * outputs -- see DESIGN.md.
  */
 #include <math.h>
 #include <stdlib.h>

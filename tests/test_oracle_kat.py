@@ -182,3 +182,43 @@ def test_format_model_sample_reference(oracle, golden_dir):
     # thin middle layer (h < h_min)
     z[:3] = [12.0, 4.0, 4.04]
     assert oracle.format_model(mcfg, 3, z, dvp, dvs)[5] is False
+
+
+@pytest.mark.parametrize("ipha", [1, -1])
+def test_homogeneous_halfspace_apparent_angle(oracle, ipha):
+    """Physics known answer, independent of the reference: when the layer equals the half-space the
+    surface ratio u_r/u_z is the classic free-surface apparent-incidence relation, real and
+    frequency independent --  P: -2 b^2 p eta / (1 - 2 b^2 p^2),  SV: (1 - 2 b^2 p^2) / (2 b^2 p xi)
+    (eta, xi = vertical S, P slowness).  Pins the S-incidence boundary-condition lines
+    (forward.f90:273-274) and the E^-1 entries they use, which no reference fixture covers."""
+    a, b, rho, p = 6.1, 3.4, 2.7, 0.07
+    alpha, beta, dens, h = [a, a], [b, b], [rho, rho], [7.3, 999.0]
+    ur, uz = oracle.calc_seis(256, 0.05, p, ipha, alpha, beta, dens, h)
+    eta = np.sqrt(1 / b**2 - p**2)
+    xi = np.sqrt(1 / a**2 - p**2)
+    bp = 1 - 2 * b**2 * p**2
+    want = -2 * b**2 * p * eta / bp if ipha == 1 else bp / (2 * b**2 * p * xi)
+    ratio = ur / uz
+    assert np.abs(ratio.imag).max() < 1e-10
+    assert np.abs(ratio.real - want).max() < 1e-10 * abs(want)
+    # and with no thickness dependence at all
+    ur2, uz2 = oracle.calc_seis(256, 0.05, p, ipha, alpha, beta, dens, [0.4, 999.0])
+    assert np.abs(ur2 / uz2 - ratio).max() < 1e-10
+
+
+@pytest.mark.parametrize("ipha", [1, -1])
+def test_water_level_decon_against_numpy_restatement(oracle, golden_dir, ipha):
+    """water_level_decon (forward.f90:447-470) and its call sites (:148-153): the C restatement
+    against a separate numpy one built from calc_seis' raw output."""
+    alpha, beta, rho, h = _true_model(golden_dir)
+    delta = float(np.float32(0.05))
+    p = 0.07
+    cfg = dict(nfft=256, deconv_mode=1, delta=delta, t_start=-1.0, sdep=0.0, rayps=[p], a_gus=[4.0], ipha=[ipha])
+    _, npre, rff, fv = oracle.calc_rf(cfg, alpha, beta, rho, h, want_stages=True)
+    ur, uz = oracle.calc_seis(256, delta, p, ipha, alpha, beta, rho, h)
+    freq_r, freq_v = np.conj(ur), -np.conj(uz)            # :145-146
+    y, x = (freq_r, freq_v) if ipha == 1 else (freq_v, freq_r)
+    amp = (x * np.conj(x)).real
+    want = y * np.conj(x) / np.maximum(amp, 0.001 * amp.max())
+    assert np.abs(rff[0] - want).max() <= 1e-13 * np.abs(want).max()
+    assert np.array_equal(fv[0], freq_v) and npre[0] == 20  # tp = 0 in deconvolution mode
