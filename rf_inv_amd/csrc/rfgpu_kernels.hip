@@ -1174,6 +1174,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void fused_kernel(FusedParams F)
         if (tid == 0) red[4] = arrival_sum(nl - 1 - i0, terms);
     }
     const int slot = 1 - P.w.cur_slot[walker];
+    if (P.ablate == 5) return;   // timing diagnostics: launch + staging only
 
     // ---- propagator phase: 4 waves x interleaved chunks of bins -> Z in LDS ----------------
     const LdsSink sink{a, side, t.flt + (size_t)itrc * nh, P.plan, P.log2n, n, nh, ipha, decon};
