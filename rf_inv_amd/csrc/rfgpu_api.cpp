@@ -58,6 +58,7 @@ struct rf_ctx {
     size_t gather_bytes = 0;
     // host copies of tables
     std::vector<double> flt, r_inv;
+    std::vector<int> h_order;
     // launch policy
     bool fused = false;       // one launch for spectra + trace (needs one forward computation per trace)
     int chain = 0;            // bins per phase chain in the spectra kernel (0: direct sincos)
@@ -453,7 +454,7 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
     if (b_in.nlay_pad > c->cfg.nlay_max) return fail("nlay_pad exceeds nlay_max of the context");
     HIP_TRY(hipSetDevice(c->device));
     BatchArgs b = b_in;
-    if (c->lpt && b.nb >= 2 * c->num_cu) {
+    if (c->lpt && !b.order && b.nb >= 2 * c->num_cu) {
         // deepest walkers first (the sort is worth its ~5 us launch once blocks outnumber the CUs)
         launch_order(b.nb, b.nlay, b.fwd_flag, c->d_order, s);
         b.order = c->d_order;
@@ -505,6 +506,17 @@ extern "C" int rf_eval_batch(rf_ctx *c, int32_t nb, const int32_t *walker_ids, c
     HIP_TRY(hipMemcpyAsync(c->d_layers, layers, sizeof(double) * (size_t)nb * 4 * nlay_pad, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_sig, sig, sizeof(double) * (size_t)nb * c->cfg.ntrc, hipMemcpyHostToDevice, s));
     BatchArgs b{nb, nlay_pad, c->d_ids, fwd_flag ? c->d_fwd : nullptr, c->d_nlay, c->d_layers, c->d_sig, c->d_logl, nullptr};
+    if (c->lpt && nb >= 2 * c->num_cu) {
+        // host buffers: the longest-first order is a counting sort here, no extra launch
+        c->h_order.resize(nb);
+        int hist[257] = {0};
+        auto key = [&](int i) { return (fwd_flag && fwd_flag[i] != 1) ? 0 : std::min(nlay[i], 255); };
+        for (int i = 0; i < nb; ++i) ++hist[256 - key(i)];          // descending keys first
+        for (int k = 1; k <= 256; ++k) hist[k] += hist[k - 1];
+        for (int i = nb - 1; i >= 0; --i) c->h_order[--hist[256 - key(i)]] = i;
+        HIP_TRY(hipMemcpyAsync(c->d_order, c->h_order.data(), sizeof(int) * nb, hipMemcpyHostToDevice, s));
+        b.order = c->d_order;
+    }
     if (run_batch(c, b, s)) return 1;
     HIP_TRY(hipMemcpyAsync(logl, c->d_logl, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
