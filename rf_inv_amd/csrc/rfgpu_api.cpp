@@ -54,6 +54,8 @@ struct rf_ctx {
     bool lpt = true;
     int nsplit_override = 0;  // RFGPU_NSPLIT
     int ablate = 0;           // RFGPU_ABLATE: timing diagnostics, stops the trace tail early (results invalid)
+    double *h_single_in = nullptr, *h_single_out = nullptr;   // pinned staging of the per-call drop-in
+    double *d_single_in = nullptr, *d_single_out = nullptr;
     double *d_gather = nullptr;
     size_t gather_bytes = 0;
     // host copies of tables
@@ -368,6 +370,8 @@ extern "C" int rf_ctx_destroy(rf_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->owned) (void)hipFree(p);
+    if (c->h_single_in) (void)hipHostFree(c->h_single_in);
+    if (c->h_single_out) (void)hipHostFree(c->h_single_out);
     for (auto &q : c->ev_pool) {
         (void)hipEventDestroy(q.e0);
         (void)hipEventDestroy(q.e1);
@@ -567,29 +571,64 @@ extern "C" int rf_get_rft_batch(rf_ctx *c, int32_t n, const int32_t *walker_ids,
     return 0;
 }
 
+// Per-call drop-in (one chain per call, src/pt_mcmc.f90:178-180).  Latency matters here, not
+// throughput: one pinned host->device copy of the packed inputs, the evaluation, a gather of the
+// proposed trace next to logL, one device->host copy, one synchronisation.
 extern "C" int rf_calc_likelihood(rf_ctx *c, int32_t walker, int32_t fwd_flag, int32_t nlay,
                                   const double *alpha, const double *beta, const double *rho, const double *h,
                                   const double *sig, double *prop_log_likelihood, double *prop_rft)
 {
     if (!c || !sig || !prop_log_likelihood) return fail("rf_calc_likelihood: null argument");
     if (walker < 0 || walker >= c->nslots) return fail("rf_calc_likelihood: walker out of range");
-    int nl = nlay;
-    std::vector<double> layers;
     if (fwd_flag) {
         if (!alpha || !beta || !rho || !h) return fail("rf_calc_likelihood: null layer arrays");
         if (nlay < 2 || nlay > c->cfg.nlay_max) return fail("rf_calc_likelihood: nlay out of range");
-        layers.resize((size_t)4 * nlay);
-        std::memcpy(&layers[0], alpha, sizeof(double) * nlay);
-        std::memcpy(&layers[nlay], beta, sizeof(double) * nlay);
-        std::memcpy(&layers[2 * (size_t)nlay], rho, sizeof(double) * nlay);
-        std::memcpy(&layers[3 * (size_t)nlay], h, sizeof(double) * nlay);
-    } else {
-        nl = 2;
-        layers.assign(8, 1.0);
     }
-    const int32_t ids[1] = {walker}, ff[1] = {fwd_flag ? 1 : 0}, nls[1] = {nl};
-    if (rf_eval_batch(c, 1, ids, ff, nls, nl, layers.data(), sig, prop_log_likelihood)) return 1;
-    if (prop_rft) return rf_get_rft(c, walker, 1, c->cfg.nfft, prop_rft);
+    HIP_TRY(hipSetDevice(c->device));
+    const int ntrc = c->cfg.ntrc, n = c->cfg.nfft, pad = c->cfg.nlay_max;
+    // packed layout (doubles): [0] ids: walker, fwd, nlay as 3 ints (+1 pad int) | layers[4][pad] | sig[ntrc]
+    const size_t in_doubles = 2 + (size_t)4 * pad + ntrc;
+    const size_t out_doubles = 1 + (size_t)n * ntrc;
+    if (!c->h_single_in) {
+        HIP_TRY(hipHostMalloc((void **)&c->h_single_in, sizeof(double) * in_doubles, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc((void **)&c->h_single_out, sizeof(double) * out_doubles, hipHostMallocDefault));
+        void *p = nullptr;
+        if (dev_alloc(c, &p, sizeof(double) * in_doubles)) return 1;
+        c->d_single_in = (double *)p;
+        if (dev_alloc(c, &p, sizeof(double) * out_doubles)) return 1;
+        c->d_single_out = (double *)p;
+    }
+    int *hi = reinterpret_cast<int *>(c->h_single_in);
+    const int nl = fwd_flag ? nlay : 2;
+    hi[0] = walker;
+    hi[1] = fwd_flag ? 1 : 0;
+    hi[2] = nl;
+    hi[3] = 0;
+    double *hl = c->h_single_in + 2;
+    for (size_t i = 0; i < (size_t)4 * pad; ++i) hl[i] = 1.0;
+    if (fwd_flag) {
+        std::memcpy(hl, alpha, sizeof(double) * nlay);
+        std::memcpy(hl + pad, beta, sizeof(double) * nlay);
+        std::memcpy(hl + 2 * (size_t)pad, rho, sizeof(double) * nlay);
+        std::memcpy(hl + 3 * (size_t)pad, h, sizeof(double) * nlay);
+    }
+    std::memcpy(hl + 4 * (size_t)pad, sig, sizeof(double) * ntrc);
+    hipStream_t s = c->stream;
+    HIP_TRY(hipMemcpyAsync(c->d_single_in, c->h_single_in, sizeof(double) * in_doubles, hipMemcpyHostToDevice, s));
+    const int *di = reinterpret_cast<const int *>(c->d_single_in);
+    const double *dl = c->d_single_in + 2;
+    BatchArgs b{1, pad, di, di + 1, di + 2, dl, dl + 4 * (size_t)pad, c->d_single_out, nullptr};
+    if (run_batch(c, b, s)) return 1;
+    size_t back = 1;
+    if (prop_rft) {
+        launch_gather_rft(c->ws, ntrc, n, 1, di, 1, n, c->d_single_out + 1, s);
+        HIP_TRY(hipGetLastError());
+        back = out_doubles;
+    }
+    HIP_TRY(hipMemcpyAsync(c->h_single_out, c->d_single_out, sizeof(double) * back, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    *prop_log_likelihood = c->h_single_out[0];
+    if (prop_rft) std::memcpy(prop_rft, c->h_single_out + 1, sizeof(double) * (size_t)n * ntrc);
     return 0;
 }
 
