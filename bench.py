@@ -290,6 +290,12 @@ def main():
                 "frac": float(f_dom.sum()) / (spectra_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if spectra_ms > 0 else None,
                 "traffic": measured_traffic(kname, workload, nb),
                 "kernel": kname, "kernel_ms": spectra_ms, "launch_plan": plan,
+                # executed (not algorithmic) fp64 rate, an ESTIMATE from the ISA of the chained-phase loop:
+                # ~86 fp64 VALU ops per (bin, layer), ~60 % of them FMAs -> ~140 flop; + ~300 flop per bin
+                # for the boundary condition
+                "executed_tflops_est": (float((nlay - 1 - (1 if p.sdep > 0 else 0)).sum() * 140.0 + 300.0 * nb)
+                                        * (1 if eng.is_ray_common else p.ntrc) * (p.nfft // 2 + 1)
+                                        / (spectra_ms * 1e-3) / 1e12) if spectra_ms > 0 else None,
                 "note": "fp64: MI355X matrix (MFMA) peak == vector peak = 78.6 TF; the kernel issues fp64 VALU FMA, "
                         "MFMA not used (no rate advantage). achieved = reference-arithmetic flops (SURVEY 8d: "
                         "570/(bin*layer)+580/bin, + FFT/shift/quadratic form when fused) per launch / live "
