@@ -303,6 +303,23 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     T.domg = 2.0 * pi / (n * cfg->delta);   // forward.f90:241
     T.omg_dc = (double)1.0e-5f;             // forward.f90:247 single-precision literal
     std::vector<double> r_inv_t = transpose_r_inv(c->r_inv, ntrc, nsmp);
+    T.nh_active = nullptr;
+    if (const char *cut = getenv("RFGPU_BIN_CUTOFF")) {
+        // opt-in: skip bins whose filter weight is below cutoff * flt(0) (e.g. 1e-20: their
+        // contribution to any sample is ~1e4 below the FFT's own rounding noise); off by default,
+        // the default path evaluates every bin like the reference
+        const double tol = atof(cut);
+        if (tol > 0.0 && tol < 1.0) {
+            std::vector<int> act(ntrc);
+            for (int t = 0; t < ntrc; ++t) {
+                int last = 0;
+                for (int k = 0; k < nh; ++k)
+                    if (c->flt[(size_t)k + (size_t)nh * t] >= tol * c->flt[(size_t)nh * t]) last = k;
+                act[t] = last + 1;
+            }
+            if (upload(c, act, &T.nh_active)) return cleanup(1);
+        }
+    }
     if (upload(c, c->flt, &T.flt) || upload(c, obs, &T.obs) || upload(c, r_inv_t, &T.r_inv_t) ||
         upload(c, rayps, &T.rayps) || upload(c, ipha, &T.ipha) || upload(c, tw, &T.twiddle))
         return cleanup(1);

@@ -18,6 +18,7 @@ struct DeviceTables {
     const double *rayps;    // [ntrc]
     const int *ipha;        // [ntrc]
     const double2 *twiddle; // [nfft/2]  exp(+2 pi i k / nfft)
+    const int *nh_active;   // [ntrc] bins with a non-negligible filter weight, or nullptr (all bins)
 };
 
 struct BatchArgs {

@@ -1177,15 +1177,25 @@ __global__ __launch_bounds__(TRACE_THREADS) void fused_kernel(FusedParams F)
     if (P.ablate == 5) return;   // timing diagnostics: launch + staging only
 
     // ---- propagator phase: 4 waves x interleaved chunks of bins -> Z in LDS ----------------
-    const LdsSink sink{a, side, t.flt + (size_t)itrc * nh, P.plan, P.log2n, n, nh, ipha, decon};
+    // Optional (off by default, RFGPU_BIN_CUTOFF): bins whose Gaussian filter weight is below
+    // cutoff * flt(0) are not propagated; their Z entries are zero.  Only without deconvolution
+    // (the water level needs the maximum over every bin).
+    const int nh_eff = (t.nh_active && !decon) ? t.nh_active[itrc] : nh;
+    SpectraParams sp = F.sp;
+    sp.t.nh = nh_eff;
+    for (int k = nh_eff + tid; k < nh; k += TRACE_THREADS) {
+        a[fft_pad(fft_input_pos(P.plan, P.log2n, k))] = make_double2(0.0, 0.0);
+        if (k != 0 && 2 * k != n) a[fft_pad(fft_input_pos(P.plan, P.log2n, n - k))] = make_double2(0.0, 0.0);
+    }
+    const LdsSink sink{a, side, t.flt + (size_t)itrc * nh, P.plan, P.log2n, n, nh_eff, ipha, decon};
     const int wave = tid >> 6, lane = tid & 63;
     if (big || sea != (NCOL == 3)) {
         if (sea)
-            spectra_body<0, 3, false>(F.sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
+            spectra_body<0, 3, false>(sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
         else
-            spectra_body<0, 2, false>(F.sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
+            spectra_body<0, 2, false>(sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
     } else {
-        spectra_body<BK, NCOL, true>(F.sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
+        spectra_body<BK, NCOL, true>(sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
     }
     __syncthreads();
     const double tp = decon ? 0.0 : red[4];

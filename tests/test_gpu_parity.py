@@ -459,3 +459,33 @@ def test_python_module_mirrors_forward_and_likelihood(oracle, golden_dir):
     with pytest.raises(ValueError):
         fwd.calc_rf(1, 3, 128, p.ntrc, p.rayps, a, b, r, h)   # n must be params' nfft
     lik.engine.close()
+
+
+def test_optional_filter_support_cutoff(oracle, monkeypatch):
+    """RFGPU_BIN_CUTOFF (opt-in, off by default): bins whose Gaussian filter weight is below
+    1e-20 of the DC weight are not propagated.  Their contribution is far below the FFT's rounding
+    noise: traces agree with the full evaluation (and the oracle) within the usual tolerances."""
+    rng = np.random.default_rng(12)
+    cfg = make_cfg(nfft=4096, rayps=[0.06, 0.10], a_gus=[4.0, 2.5], ipha=[1, -1], t_start=-1.0)
+    nsmp = 101
+    true = random_stack(rng, 5)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, int(n)) for n in (3, 12, 25)] + [true]
+    nlay, layers = pack_layers(stacks, 27)
+    sig = np.full((4, 2), 0.01)
+    ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
+    out = {}
+    for cut in ("", "1e-20"):
+        if cut:
+            monkeypatch.setenv("RFGPU_BIN_CUTOFF", cut)
+        with _engine(cfg, obs, nsmp, r_inv, max_walkers=4) as eng:
+            ll = eng.eval_batch(np.arange(4), nlay, layers, sig)
+            out[cut] = (ll, np.stack([eng.get_rft(i, 1).T for i in range(4)]))
+    for cut in out:
+        ll, rft = out[cut]
+        assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (cut, np.abs(ll - ref_ll).max())
+        for i in range(4):
+            assert np.abs(rft[i] - ref_rft[i]).max() <= 1e-12 * np.abs(ref_rft[i]).max()
+    # the cut-off run differs from the full one by less than 1e-15 of the trace scale
+    assert np.abs(out["1e-20"][1] - out[""][1]).max() <= 1e-15 * np.abs(out[""][1]).max()
