@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RFGPU_ABI_VERSION 1
+#define RFGPU_ABI_VERSION 2
 
 typedef struct rf_ctx rf_ctx;
 
@@ -187,6 +187,62 @@ int rf_eval_models_device(rf_ctx *ctx, int32_t nb, const int32_t *d_walker_ids, 
  * (the RNG stays on the host; temperatures move, states stay: src/pt_mcmc.f90:532-535). */
 int rf_pt_swap_device(rf_ctx *ctx, int32_t npairs, const int32_t *d_pairs, const double *d_log_u,
                       double *d_temps, const double *d_logl, int32_t *d_accepted, void *stream);
+
+/* ---- posterior accumulation ---------------------------- */
+/* The "record sampled model" block of subroutine mcmc (src/pt_mcmc.f90:204-286) with the
+ * accumulators of module pt_mcmc (allocated/zeroed src/pt_mcmc.f90:394-421) kept on the
+ * device, so that the traces of the recorded chains never leave HBM.  Bin widths are
+ * formed as src/pt_mcmc.f90:423-430.  Needs rf_set_model (the V-z profile runs
+ * format_model, :240-242).  Layouts are the reference's (column-major):
+ * nk[k_max], nz[nbin_z], nsig[ntrc][nbin_sig], namp[ntrc][nsmp][nbin_amp],
+ * nvpz[nbin_vp][nbin_z], nvsz[nbin_vs][nbin_z], nvpvsz[nbin_vpvs][nbin_z],
+ * vp_mean/vs_mean/vpvs_mean[nbin_z], vp_model/vs_model[max_models][nbin_z],
+ * all_likelihood[max_models] -- i.e. exactly the memory of the Fortran arrays
+ * nsig(nbin_sig,ntrc), namp(nbin_amp,nsmp,ntrc), nvpz(nbin_z,nbin_vp), vp_model(nbin_z,:) ... */
+typedef struct rf_post_config {
+    int32_t nbin_z, nbin_vs, nbin_vp, nbin_vpvs, nbin_sig, nbin_amp;  /* params, src/params.f90:293-314 */
+    double amp_min, amp_max;                                          /* src/params.f90:317           */
+    double z_min;                                                     /* params z_min (nz bins, :229) */
+    const double *sig_min, *sig_max;                                  /* [ntrc]                        */
+    const int32_t *sig_mode;                                          /* [ntrc] 1 = sigma solved       */
+    int64_t max_models;   /* capacity of vp_model / vs_model / all_likelihood (the reference sizes it
+                             int(nchains*niter/ncorr), :407-409); 0 = do not keep per-model profiles */
+} rf_post_config;
+int rf_post_create(rf_ctx *ctx, const rf_post_config *cfg);
+int rf_post_reset(rf_ctx *ctx);
+
+/* Record n chains, in order, exactly as n consecutive passes through src/pt_mcmc.f90:204-286
+ * would (the fp64 sums vp_mean / vs_mean / vpvs_mean -- and the ocean-layer ASSIGNMENTS
+ * :263-264 -- are applied in that order, so they are bit-identical to the reference's).
+ * walker_ids[n] name the chains whose CURRENT trace feeds the amplitude histogram;
+ * k[n], z[n][k_max-1], dvp[n][k_max], dvs[n][k_max], sig[n][ntrc], logl[n] are the chains'
+ * current state.  temps (may be NULL) applies the reference's filter temp <= 1 + 1e-6 (:204)
+ * on the device: chains above it are skipped.  The caller applies the iteration filter
+ * (iter > nburn, mod(iter, ncorr) == 0).  _device: all pointers are device pointers and the
+ * call is asynchronous on `stream`; the host variant stages and synchronises.
+ * Departures (the reference has undefined behaviour there): histogram indices outside an
+ * array are clamped to its edge bins; models beyond max_models are counted but their
+ * profile rows are dropped.  Amplitudes outside [amp_min, amp_max) go to the edge bins as in
+ * :274-281, counted in amp_out_of_range instead of the reference's warning line. */
+int rf_post_record(rf_ctx *ctx, int32_t n, const int32_t *walker_ids, const int32_t *k, const double *z,
+                   const double *dvp, const double *dvs, const double *sig, const double *logl,
+                   const double *temps);
+int rf_post_record_device(rf_ctx *ctx, int32_t n, const int32_t *d_walker_ids, const int32_t *d_k,
+                          const double *d_z, const double *d_dvp, const double *d_dvs, const double *d_sig,
+                          const double *d_logl, const double *d_temps, void *stream);
+
+/* Copy the accumulators to host arrays (any pointer may be NULL = not wanted).  Synchronises
+ * the context stream; after rf_post_record_device on another stream the caller synchronises
+ * that stream first. */
+typedef struct rf_post_result {
+    int32_t *nmod;                 /* [1]                                     */
+    int32_t *nk, *nz, *nsig, *namp, *nvpz, *nvsz, *nvpvsz;
+    double *vp_mean, *vs_mean, *vpvs_mean;
+    double *vp_model, *vs_model;   /* [max_models][nbin_z]; unused rows keep vs_model(1,:) = -999.9 (:419) */
+    double *all_likelihood;        /* [max_models]                            */
+    int64_t *amp_out_of_range;     /* [1]                                     */
+} rf_post_result;
+int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
 
 /* ---- instrumentation ----------------------------------------------------- */
 /* how rf_eval_batch* will launch: plan[0] = 1 when spectra + trace run as ONE fused kernel

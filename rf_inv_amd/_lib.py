@@ -36,6 +36,28 @@ class RFModelConfig(C.Structure):
     ]
 
 
+class RFPostConfig(C.Structure):
+    """struct rf_post_config of include/rfgpu.h"""
+    _fields_ = [
+        ("nbin_z", C.c_int32), ("nbin_vs", C.c_int32), ("nbin_vp", C.c_int32), ("nbin_vpvs", C.c_int32),
+        ("nbin_sig", C.c_int32), ("nbin_amp", C.c_int32),
+        ("amp_min", C.c_double), ("amp_max", C.c_double), ("z_min", C.c_double),
+        ("sig_min", dp), ("sig_max", dp), ("sig_mode", ip),
+        ("max_models", C.c_int64),
+    ]
+
+
+class RFPostResult(C.Structure):
+    """struct rf_post_result of include/rfgpu.h"""
+    _fields_ = [
+        ("nmod", ip),
+        ("nk", ip), ("nz", ip), ("nsig", ip), ("namp", ip), ("nvpz", ip), ("nvsz", ip), ("nvpvsz", ip),
+        ("vp_mean", dp), ("vs_mean", dp), ("vpvs_mean", dp),
+        ("vp_model", dp), ("vs_model", dp), ("all_likelihood", dp),
+        ("amp_out_of_range", C.POINTER(C.c_int64)),
+    ]
+
+
 # every symbol include/rfgpu.h declares: name -> (restype, argtypes)
 _vp = C.c_void_p
 SYMBOLS = {
@@ -61,6 +83,11 @@ SYMBOLS = {
     "rf_format_models_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "rf_eval_models_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_pt_swap_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rf_post_create": (C.c_int, [_vp, C.POINTER(RFPostConfig)]),
+    "rf_post_reset": (C.c_int, [_vp]),
+    "rf_post_record": (C.c_int, [_vp, C.c_int32, ip, ip, dp, dp, dp, dp, dp, dp]),
+    "rf_post_record_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rf_post_read": (C.c_int, [_vp, C.POINTER(RFPostResult)]),
     "rf_get_launch_plan": (C.c_int, [_vp, ip]),
     "rf_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "rf_profile_read": (C.c_int, [_vp, dp, C.POINTER(C.c_int64), C.c_int32]),

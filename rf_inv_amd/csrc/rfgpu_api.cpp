@@ -51,6 +51,14 @@ struct rf_ctx {
     int *d_fm_nlay = nullptr, *d_fm_flag = nullptr;
     double *d_fm_layers = nullptr, *d_fm_scratch = nullptr;
     int *d_order = nullptr;   // [nslots] LPT dispatch order of the current batch
+    // posterior accumulators (row f-3)
+    bool have_post = false;
+    PostConfig post{};
+    PostState pst{};
+    std::vector<std::pair<void *, size_t>> post_zero;   // accumulators cleared by rf_post_reset
+    int *d_post_nlay = nullptr, *d_post_flag = nullptr, *d_post_k = nullptr;
+    double *d_post_layers = nullptr, *d_post_scratch = nullptr;
+    double *d_post_in = nullptr;   // staging of rf_post_record's host arrays
     bool lpt = true;
     int nsplit_override = 0;  // RFGPU_NSPLIT
     int ablate = 0;           // RFGPU_ABLATE: timing diagnostics, stops the trace tail early (results invalid)
@@ -791,6 +799,173 @@ extern "C" int rf_pt_swap_device(rf_ctx *c, int32_t npairs, const int32_t *d_pai
     HIP_TRY(hipSetDevice(c->device));
     launch_pt_swap(npairs, d_pairs, d_log_u, d_temps, d_logl, d_accepted, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
+// posterior accumulation (src/pt_mcmc.f90:204-286 on the device; kernels in rfgpu_posterior.hip)
+// ---------------------------------------------------------------------------
+template <class T>
+static int post_alloc(rf_ctx *c, T **p, size_t count, bool zeroed)
+{
+    void *q = nullptr;
+    if (dev_alloc(c, &q, sizeof(T) * count)) return 1;
+    *p = static_cast<T *>(q);
+    if (zeroed) c->post_zero.emplace_back(q, sizeof(T) * count);
+    return 0;
+}
+
+extern "C" int rf_post_reset(rf_ctx *c)
+{
+    if (!c || !c->have_post) return fail("rf_post_reset: rf_post_create has not been called");
+    HIP_TRY(hipSetDevice(c->device));
+    for (auto &z : c->post_zero) HIP_TRY(hipMemsetAsync(z.first, 0, z.second, c->stream));
+    if (c->post.max_models > 0) {
+        // vs_model(1,:) = -999.9d0 marks unused slots (src/pt_mcmc.f90:419, read by src/mcmc_out.f90:115)
+        std::vector<double> col((size_t)c->post.max_models, -999.9);
+        HIP_TRY(hipMemcpy2DAsync(c->pst.vs_model, sizeof(double) * c->post.nbin_z, col.data(), sizeof(double),
+                                 sizeof(double), (size_t)c->post.max_models, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));   // col goes out of scope
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int rf_post_create(rf_ctx *c, const rf_post_config *p)
+{
+    if (!c || !p || !p->sig_min || !p->sig_max || !p->sig_mode) return fail("rf_post_create: null argument");
+    if (!c->have_model) return fail("rf_post_create: rf_set_model has not been called");
+    if (c->have_post) return fail("rf_post_create: already created for this context");
+    if (p->nbin_z < 1 || p->nbin_vs < 1 || p->nbin_vp < 1 || p->nbin_vpvs < 1 || p->nbin_sig < 1 || p->nbin_amp < 1)
+        return fail("rf_post_create: every nbin_* must be >= 1");
+    if (p->max_models < 0) return fail("rf_post_create: max_models < 0");
+    HIP_TRY(hipSetDevice(c->device));
+    const int ntrc = c->cfg.ntrc, nsmp = c->cfg.nsmp, kmax = c->model.k_max;
+    PostConfig &q = c->post;
+    q = PostConfig{};
+    q.nbin_z = p->nbin_z; q.nbin_vs = p->nbin_vs; q.nbin_vp = p->nbin_vp;
+    q.nbin_vpvs = p->nbin_vpvs; q.nbin_sig = p->nbin_sig; q.nbin_amp = p->nbin_amp;
+    q.k_max = kmax; q.ntrc = ntrc; q.nsmp = nsmp; q.nfft = c->cfg.nfft;
+    // bin widths as src/pt_mcmc.f90:423-430 (double / integer)
+    q.amp_min = p->amp_min;
+    q.dbin_amp = (p->amp_max - p->amp_min) / p->nbin_amp;
+    q.dbin_vp = (c->model.vp_max - c->model.vp_min) / p->nbin_vp;
+    q.dbin_vs = (c->model.vs_max - c->model.vs_min) / p->nbin_vs;
+    q.dbin_z = (c->model.z_max - 0.0) / p->nbin_z;
+    q.dbin_vpvs = (c->model.vpvs_max - c->model.vpvs_min) / p->nbin_vpvs;
+    q.z_min = p->z_min;
+    q.vp_min = c->model.vp_min; q.vs_min = c->model.vs_min; q.vpvs_min = c->model.vpvs_min;
+    q.max_models = p->max_models;
+    std::vector<double> smin(p->sig_min, p->sig_min + ntrc), dsig(ntrc);
+    std::vector<int> smode(p->sig_mode, p->sig_mode + ntrc);
+    for (int t = 0; t < ntrc; ++t) dsig[t] = (p->sig_max[t] - p->sig_min[t]) / p->nbin_sig;
+    if (upload(c, smin, &q.sig_min) || upload(c, dsig, &q.dbin_sig) || upload(c, smode, &q.sig_mode)) return 1;
+
+    PostState &st = c->pst;
+    const size_t nm = (size_t)std::max<int64_t>(p->max_models, 1);
+    if (post_alloc(c, &st.nmod, 2, true) || post_alloc(c, &st.nk, kmax, true) ||
+        post_alloc(c, &st.nz, q.nbin_z, true) || post_alloc(c, &st.nsig, (size_t)ntrc * q.nbin_sig, true) ||
+        post_alloc(c, &st.namp, (size_t)ntrc * nsmp * q.nbin_amp, true) ||
+        post_alloc(c, &st.nvpz, (size_t)q.nbin_vp * q.nbin_z, true) ||
+        post_alloc(c, &st.nvsz, (size_t)q.nbin_vs * q.nbin_z, true) ||
+        post_alloc(c, &st.nvpvsz, (size_t)q.nbin_vpvs * q.nbin_z, true) ||
+        post_alloc(c, &st.vp_mean, q.nbin_z, true) || post_alloc(c, &st.vs_mean, q.nbin_z, true) ||
+        post_alloc(c, &st.vpvs_mean, q.nbin_z, true) || post_alloc(c, &st.vp_model, nm * q.nbin_z, true) ||
+        post_alloc(c, &st.vs_model, nm * q.nbin_z, true) || post_alloc(c, &st.all_likelihood, nm, true) ||
+        post_alloc(c, &st.amp_oor, 1, true) || post_alloc(c, &st.sel, c->nslots, false) ||
+        post_alloc(c, &st.nsel, 1, true) || post_alloc(c, &st.row_a, (size_t)c->nslots * q.nbin_z, false) ||
+        post_alloc(c, &st.row_b, (size_t)c->nslots * q.nbin_z, false) ||
+        post_alloc(c, &c->d_post_nlay, c->nslots, false) || post_alloc(c, &c->d_post_flag, c->nslots, false) ||
+        post_alloc(c, &c->d_post_k, 2 * (size_t)c->nslots, false) ||
+        post_alloc(c, &c->d_post_layers, (size_t)c->nslots * 4 * c->fm_pad, false) ||
+        post_alloc(c, &c->d_post_scratch, (size_t)c->nslots * 3 * kmax, false) ||
+        post_alloc(c, &c->d_post_in, (size_t)c->nslots * (3 * (size_t)kmax + ntrc + 2), false))
+        return 1;
+    c->have_post = true;
+    return rf_post_reset(c);
+}
+
+extern "C" int rf_post_record_device(rf_ctx *c, int32_t n, const int32_t *d_walker_ids, const int32_t *d_k,
+                                     const double *d_z, const double *d_dvp, const double *d_dvs,
+                                     const double *d_sig, const double *d_logl, const double *d_temps, void *stream)
+{
+    if (!c || !d_walker_ids || !d_k || !d_z || !d_dvp || !d_dvs || !d_sig || !d_logl)
+        return fail("rf_post_record_device: null argument");
+    if (!c->have_post) return fail("rf_post_record_device: rf_post_create has not been called");
+    if (n <= 0) return 0;
+    if (n > c->nslots) return fail("rf_post_record_device: batch larger than max_walkers + 1");
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = (hipStream_t)stream;
+    // format_model of every chain in the batch (:240-242); rows of filtered-out chains are unused
+    FormatParams P{c->model, n, c->fm_pad, d_k, d_z, d_dvp, d_dvs, nullptr, c->d_post_nlay, c->d_post_layers,
+                   c->d_post_flag, nullptr, c->d_post_scratch};
+    launch_format_model(P, s);
+    PostBatch b{n, d_walker_ids, d_k, d_z, d_sig, d_logl, d_temps, c->d_post_nlay, c->d_post_layers, c->fm_pad};
+    launch_post_record(c->post, c->pst, b, c->ws, s);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int rf_post_record(rf_ctx *c, int32_t n, const int32_t *walker_ids, const int32_t *k, const double *z,
+                              const double *dvp, const double *dvs, const double *sig, const double *logl,
+                              const double *temps)
+{
+    if (!c || !walker_ids || !k || !z || !dvp || !dvs || !sig || !logl) return fail("rf_post_record: null argument");
+    if (!c->have_post) return fail("rf_post_record: rf_post_create has not been called");
+    if (n <= 0) return 0;
+    if (n > c->nslots) return fail("rf_post_record: batch larger than max_walkers + 1");
+    const int kmax = c->model.k_max, ntrc = c->cfg.ntrc;
+    for (int i = 0; i < n; ++i) {
+        if (walker_ids[i] < 0 || walker_ids[i] >= c->nslots) return fail("rf_post_record: walker out of range");
+        if (k[i] < 1 || k[i] >= kmax) return fail("rf_post_record: k out of range");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const size_t N = (size_t)n;
+    double *dz = c->d_post_in, *ddvp = dz + N * (kmax - 1), *ddvs = ddvp + N * kmax, *dsig = ddvs + N * kmax,
+           *dlogl = dsig + N * ntrc, *dtemps = dlogl + N;
+    int *dids = c->d_post_k, *dk = dids + n;
+    HIP_TRY(hipMemcpyAsync(dids, walker_ids, sizeof(int) * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dk, k, sizeof(int) * N, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dz, z, sizeof(double) * N * (kmax - 1), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ddvp, dvp, sizeof(double) * N * kmax, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(ddvs, dvs, sizeof(double) * N * kmax, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dsig, sig, sizeof(double) * N * ntrc, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(dlogl, logl, sizeof(double) * N, hipMemcpyHostToDevice, s));
+    if (temps) HIP_TRY(hipMemcpyAsync(dtemps, temps, sizeof(double) * N, hipMemcpyHostToDevice, s));
+    if (rf_post_record_device(c, n, dids, dk, dz, ddvp, ddvs, dsig, dlogl, temps ? dtemps : nullptr, s)) return 1;
+    HIP_TRY(hipStreamSynchronize(s));   // the host arrays may be reused on return
+    return 0;
+}
+
+extern "C" int rf_post_read(rf_ctx *c, const rf_post_result *o)
+{
+    if (!c || !o) return fail("rf_post_read: null argument");
+    if (!c->have_post) return fail("rf_post_read: rf_post_create has not been called");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const PostConfig &q = c->post;
+    const PostState &st = c->pst;
+    const size_t nz = q.nbin_z, nm = (size_t)q.max_models;
+    auto get = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        if (!dst || !bytes) return hipSuccess;
+        return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    };
+    HIP_TRY(get(o->nmod, st.nmod, sizeof(int)));
+    HIP_TRY(get(o->nk, st.nk, sizeof(int) * q.k_max));
+    HIP_TRY(get(o->nz, st.nz, sizeof(int) * nz));
+    HIP_TRY(get(o->nsig, st.nsig, sizeof(int) * (size_t)q.ntrc * q.nbin_sig));
+    HIP_TRY(get(o->namp, st.namp, sizeof(int) * (size_t)q.ntrc * q.nsmp * q.nbin_amp));
+    HIP_TRY(get(o->nvpz, st.nvpz, sizeof(int) * (size_t)q.nbin_vp * nz));
+    HIP_TRY(get(o->nvsz, st.nvsz, sizeof(int) * (size_t)q.nbin_vs * nz));
+    HIP_TRY(get(o->nvpvsz, st.nvpvsz, sizeof(int) * (size_t)q.nbin_vpvs * nz));
+    HIP_TRY(get(o->vp_mean, st.vp_mean, sizeof(double) * nz));
+    HIP_TRY(get(o->vs_mean, st.vs_mean, sizeof(double) * nz));
+    HIP_TRY(get(o->vpvs_mean, st.vpvs_mean, sizeof(double) * nz));
+    HIP_TRY(get(o->vp_model, st.vp_model, sizeof(double) * nm * nz));
+    HIP_TRY(get(o->vs_model, st.vs_model, sizeof(double) * nm * nz));
+    HIP_TRY(get(o->all_likelihood, st.all_likelihood, sizeof(double) * nm));
+    HIP_TRY(get(o->amp_out_of_range, st.amp_oor, sizeof(long long)));
     return 0;
 }
 

@@ -85,6 +85,35 @@ void launch_commit(const WalkerState &w, int nb, const int *walker_ids, const in
 void launch_pt_swap(int npairs, const int *pairs, const double *log_u, double *temps,
                     const double *logl, int *accepted, hipStream_t s);
 
+// ---- posterior accumulation (rfgpu_posterior.hip) --------------------------------
+struct PostConfig {
+    int nbin_z, nbin_vs, nbin_vp, nbin_vpvs, nbin_sig, nbin_amp;
+    int k_max, ntrc, nsmp, nfft;
+    double amp_min, dbin_amp, z_min, dbin_z, dbin_vp, dbin_vs, dbin_vpvs;
+    double vp_min, vs_min, vpvs_min;
+    const double *sig_min, *dbin_sig;   // [ntrc] device
+    const int *sig_mode;                // [ntrc] device
+    long long max_models;
+};
+struct PostState {
+    int *nmod;                          // [2]: models recorded, base index of the batch in flight
+    int *nk, *nz, *nsig, *namp, *nvpz, *nvsz, *nvpvsz;
+    double *vp_mean, *vs_mean, *vpvs_mean, *vp_model, *vs_model, *all_likelihood;
+    long long *amp_oor;
+    int *sel, *nsel;                    // [nslots], [1]: batch items that pass the temperature filter
+    double *row_a, *row_b;              // [nslots][nbin_z] per-model profile rows of the batch
+};
+struct PostBatch {
+    int n;
+    const int *walker_ids, *k;
+    const double *z, *sig, *logl, *temps;
+    const int *nlay;                    // from format_model
+    const double *layers;
+    int nlay_pad;
+};
+void launch_post_record(const PostConfig &c, const PostState &st, const PostBatch &b, const WalkerState &w,
+                        hipStream_t s);
+
 size_t spectra_lds_bytes(int nlay_pad);
 size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad);
 

@@ -19,7 +19,10 @@
 ! Written from scratch for rf_inv_amd (it restates what one step of the
 ! reference's private `mcmc` does; the reference subroutine itself evaluates
 ! one chain per call and cannot be batched).  The traces stay on the device;
-! the host copy likelihood::rft is NOT kept up to date by this loop.
+! the host copy likelihood::rft is NOT kept up to date by this loop.  The
+! posterior accumulators (src/pt_mcmc.f90:204-286) are kept on the device too
+! (rf_post_record) and copied into module pt_mcmc's arrays after the last
+! iteration, so the recorded chains' traces never cross PCIe.
 !=======================================================================
 module pt_mcmc_batched
   use iso_c_binding
@@ -54,10 +57,10 @@ contains
     ! the batch handed to the engine
     integer(c_int32_t), allocatable :: b_id(:), b_fwd(:), b_nlay(:), b_acc(:)
     real(c_double), allocatable :: b_layers(:,:,:), b_sig(:,:), b_logl(:)
-    ! traces of the chains recorded in this iteration (one gather per recording iteration)
+    ! device-side posterior accumulation
     integer(c_int32_t), allocatable :: r_id(:)
-    real(c_double), allocatable :: r_trace(:,:,:)
-    integer :: nrec, irec
+    real(c_double), allocatable, target :: r_temps(:)
+    logical :: record_now
     ! temperature swap
     integer :: ipack(4), rank1, rank2, ichain1, ichain2, itarget1, itarget2
     integer :: status(MPI_STATUS_SIZE)
@@ -75,7 +78,8 @@ contains
     allocate(p_sig(ntrc, nchains), p_lp(nchains), p_logr(nchains))
     allocate(b_id(nchains), b_fwd(nchains), b_nlay(nchains), b_acc(nchains))
     allocate(b_layers(nlay_pad, 4, nchains), b_sig(ntrc, nchains), b_logl(nchains))
-    allocate(r_id(nchains), r_trace(nsmp, ntrc, nchains))
+    allocate(r_id(nchains), r_temps(nchains))
+    call setup_device_posterior()
 
     ! the first evaluation of every chain (init_likelihood) becomes its current trace
     do ichain = 1, nchains
@@ -159,25 +163,20 @@ contains
        !----------------------------------------------------------------
        ! 4. counters and posterior records of the non-tempered chains
        !----------------------------------------------------------------
-       nrec = 0
+       record_now = (it > nburn .and. mod(it, ncorr) == 0)
        do ichain = 1, nchains
           if (temps(ichain) <= t_cold) then
              nprop(p_type(ichain)) = nprop(p_type(ichain)) + 1
              if (p_acc(ichain)) naccept(p_type(ichain)) = naccept(p_type(ichain)) + 1
              likelihood_hist(it) = likelihood_hist(it) + log_likelihood(ichain)
-             if (it > nburn .and. mod(it, ncorr) == 0) then
-                nrec = nrec + 1
-                r_id(nrec) = ichain - 1
-             end if
           end if
        end do
-       if (nrec > 0) then
-          ! the recorded chains' current traces live on the device: one gather for all
-          call rfgpu_check(rf_get_rft_batch(rf_ctx, int(nrec, c_int32_t), r_id, 0_c_int32_t, &
-               & int(nsmp, c_int32_t), r_trace), "rf_get_rft_batch")
-          do irec = 1, nrec
-             call record_sample(r_id(irec) + 1, r_trace(:, :, irec))
-          end do
+       if (record_now) then
+          ! every chain's state goes down; the device keeps the non-tempered ones (temps filter)
+          ! and reads their current traces where the evaluation left them
+          r_temps(1:nchains) = temps(1:nchains)
+          call rfgpu_check(rf_post_record(rf_ctx, int(nchains, c_int32_t), r_id, k, z, dvp, dvs, sig, &
+               & log_likelihood, c_loc(r_temps)), "rf_post_record")
        end if
 
        !----------------------------------------------------------------
@@ -226,6 +225,8 @@ contains
           temps(ichain2) = rpack(1)
        end if
     end do
+
+    call fetch_device_posterior()
 
   contains
 
@@ -310,78 +311,66 @@ contains
       swap_ok = (log(grnd()) <= (l2 - l1) * (1.d0 / t1 - 1.d0 / t2))
     end function swap_ok
 
-    ! posterior bookkeeping of one non-tempered chain: the same bins, in the same
-    ! order, as the record block of the reference's step routine, so that
-    ! output_results (mcmc_out) produces identical files.
-    subroutine record_sample(jc, trace)
-      integer, intent(in) :: jc
-      real(8), intent(in) :: trace(nsmp, ntrc)
-      integer :: itrc, ibin, il, iz, iz1, iz2, ivp, ivs, ivpvs, nl, ismp
-      real(8) :: a(nlay_max), b(nlay_max), rh(nlay_max), th(nlay_max), tmpz
-      logical :: ok
+    ! Hands format_model's tables and the histogram layout of init_pt_mcmc
+    ! (src/pt_mcmc.f90:394-430) to the engine.
+    subroutine setup_device_posterior()
+      type(rf_model_config) :: mc
+      type(rf_post_config) :: pc
+      real(c_double), allocatable, target, save :: t_vp(:), t_vs(:), t_smin(:), t_smax(:)
+      integer(c_int32_t), allocatable, target, save :: t_smode(:)
+      integer :: ic
 
-      nmod = nmod + 1
-      all_likelihood(nmod) = log_likelihood(jc)
-      nk(k(jc)) = nk(k(jc)) + 1
-      do itrc = 1, ntrc
-         if (sig_mode(itrc) == 1) then
-            ibin = int((sig(itrc, jc) - sig_min(itrc)) / dbin_sig(itrc)) + 1
-            nsig(ibin, itrc) = nsig(ibin, itrc) + 1
-         end if
+      if (allocated(t_vp)) deallocate(t_vp, t_vs, t_smin, t_smax, t_smode)
+      allocate(t_vp(size(vp_ref)), t_vs(size(vs_ref)), t_smin(ntrc), t_smax(ntrc), t_smode(ntrc))
+      t_vp = vp_ref
+      t_vs = vs_ref
+      t_smin = sig_min(1:ntrc)
+      t_smax = sig_max(1:ntrc)
+      t_smode = sig_mode(1:ntrc)
+      mc%k_max = k_max;  mc%vp_mode = vp_mode;  mc%nref = size(vp_ref)
+      mc%z_max = z_max;  mc%h_min = h_min;  mc%z_ref_min = z_ref_min;  mc%dz_ref = dz_ref
+      mc%vp_min = vp_min;  mc%vp_max = vp_max;  mc%vs_min = vs_min;  mc%vs_max = vs_max
+      mc%vpvs_min = vpvs_min;  mc%vpvs_max = vpvs_max
+      mc%vp_ref = c_loc(t_vp);  mc%vs_ref = c_loc(t_vs)
+      call rfgpu_check(rf_set_model(rf_ctx, mc), "rf_set_model")
+      pc%nbin_z = nbin_z;  pc%nbin_vs = nbin_vs;  pc%nbin_vp = nbin_vp;  pc%nbin_vpvs = nbin_vpvs
+      pc%nbin_sig = nbin_sig;  pc%nbin_amp = nbin_amp
+      pc%amp_min = amp_min;  pc%amp_max = amp_max;  pc%z_min = z_min
+      pc%sig_min = c_loc(t_smin);  pc%sig_max = c_loc(t_smax);  pc%sig_mode = c_loc(t_smode)
+      pc%max_models = size(all_likelihood)
+      call rfgpu_check(rf_post_create(rf_ctx, pc), "rf_post_create")
+      do ic = 1, nchains
+         r_id(ic) = ic - 1
       end do
-      do il = 1, k(jc) - 1
-         ibin = int((z(il, jc) - z_min) / dbin_z) + 1
-         nz(ibin) = nz(ibin) + 1
-      end do
+    end subroutine setup_device_posterior
 
-      call format_model(k(jc), z(1:k_max-1, jc), dvp(1:k_max, jc), dvs(1:k_max, jc), &
-           & nl, a, b, rh, th, ok)
-      tmpz = 0.d0
-      do il = 1, nl
-         iz1 = int(tmpz / dbin_z) + 1
-         if (il < nl) then
-            iz2 = int((tmpz + th(il)) / dbin_z) + 1
-         else
-            iz2 = nbin_z + 1
-         end if
-         ivp = int((a(il) - vp_min) / dbin_vp) + 1
-         ivs = max(1, int((b(il) - vs_min) / dbin_vs) + 1)
-         ivpvs = int(((a(il) / b(il)) - vpvs_min) / dbin_vpvs) + 1
-         ivpvs = min(max(1, ivpvs), nbin_vpvs)
-         do iz = iz1, iz2 - 1
-            nvpz(iz, ivp) = nvpz(iz, ivp) + 1
-            vp_mean(iz) = vp_mean(iz) + a(il)
-            vp_model(iz, nmod) = a(il)
-            nvsz(iz, ivs) = nvsz(iz, ivs) + 1
-            nvpvsz(iz, ivpvs) = nvpvsz(iz, ivpvs) + 1
-            if (b(il) > 0.d0) then
-               vpvs_mean(iz) = vpvs_mean(iz) + a(il) / b(il)
-               vs_mean(iz) = vs_mean(iz) + b(il)
-               vs_model(iz, nmod) = b(il)
-            else
-               vpvs_mean(iz) = vpvs_min
-               vs_mean(iz) = vs_min
-               vs_model(iz, nmod) = vs_min
-            end if
-            vp_model(iz, nmod) = a(il)
-         end do
-         tmpz = tmpz + th(il)
-      end do
+    ! Device accumulators -> the arrays of module pt_mcmc that output_results reads.
+    subroutine fetch_device_posterior()
+      type(rf_post_result) :: pr
+      integer(c_int32_t), target :: t_nmod
+      integer(c_int64_t), target :: t_oor
+      integer(c_int32_t), allocatable, target :: t_nk(:), t_nz(:), t_nsig(:,:), t_namp(:,:,:)
+      integer(c_int32_t), allocatable, target :: t_nvpz(:,:), t_nvsz(:,:), t_nvpvsz(:,:)
+      real(c_double), allocatable, target :: t_vpm(:), t_vsm(:), t_vpvsm(:), t_vpmod(:,:), t_vsmod(:,:), t_all(:)
+      integer :: nm
 
-      do itrc = 1, ntrc
-         do ismp = 1, nsmp
-            ibin = int((trace(ismp, itrc) - amp_min) / dbin_amp) + 1
-            if (ibin < 1) then
-               write(0,*) "Warning: RF amp. out of range"
-               ibin = 1
-            else if (ibin > nbin_amp) then
-               write(0,*) "Warning: RF amp. out of range"
-               ibin = nbin_amp
-            end if
-            namp(ibin, ismp, itrc) = namp(ibin, ismp, itrc) + 1
-         end do
-      end do
-    end subroutine record_sample
+      nm = size(all_likelihood)
+      allocate(t_nk(k_max), t_nz(nbin_z), t_nsig(nbin_sig, ntrc), t_namp(nbin_amp, nsmp, ntrc))
+      allocate(t_nvpz(nbin_z, nbin_vp), t_nvsz(nbin_z, nbin_vs), t_nvpvsz(nbin_z, nbin_vpvs))
+      allocate(t_vpm(nbin_z), t_vsm(nbin_z), t_vpvsm(nbin_z), t_vpmod(nbin_z, nm), t_vsmod(nbin_z, nm), t_all(nm))
+      pr%nmod = c_loc(t_nmod);  pr%nk = c_loc(t_nk);  pr%nz = c_loc(t_nz);  pr%nsig = c_loc(t_nsig)
+      pr%namp = c_loc(t_namp);  pr%nvpz = c_loc(t_nvpz);  pr%nvsz = c_loc(t_nvsz);  pr%nvpvsz = c_loc(t_nvpvsz)
+      pr%vp_mean = c_loc(t_vpm);  pr%vs_mean = c_loc(t_vsm);  pr%vpvs_mean = c_loc(t_vpvsm)
+      pr%vp_model = c_loc(t_vpmod);  pr%vs_model = c_loc(t_vsmod);  pr%all_likelihood = c_loc(t_all)
+      pr%amp_out_of_range = c_loc(t_oor)
+      call rfgpu_check(rf_post_read(rf_ctx, pr), "rf_post_read")
+      nmod = t_nmod
+      nk = t_nk;  nz = t_nz;  nsig = t_nsig;  namp = t_namp
+      nvpz = t_nvpz;  nvsz = t_nvsz;  nvpvsz = t_nvpvsz
+      vp_mean = t_vpm;  vs_mean = t_vsm;  vpvs_mean = t_vpvsm
+      vp_model = t_vpmod;  vs_model = t_vsmod;  all_likelihood = t_all
+      if (t_oor > 0) write(0,*) "Warning: RF amp. out of range (", t_oor, " samples)"
+    end subroutine fetch_device_posterior
 
   end subroutine pt_control_batched
 

@@ -19,6 +19,31 @@ module rfgpu_c
      integer(c_int32_t) :: max_walkers, nlay_max, device
   end type rf_config
 
+  ! struct rf_model_config
+  type, bind(C) :: rf_model_config
+     integer(c_int32_t) :: k_max, vp_mode, nref
+     real(c_double)     :: z_max, h_min, z_ref_min, dz_ref
+     real(c_double)     :: vp_min, vp_max, vs_min, vs_max, vpvs_min, vpvs_max
+     type(c_ptr)        :: vp_ref, vs_ref
+  end type rf_model_config
+
+  ! struct rf_post_config
+  type, bind(C) :: rf_post_config
+     integer(c_int32_t) :: nbin_z, nbin_vs, nbin_vp, nbin_vpvs, nbin_sig, nbin_amp
+     real(c_double)     :: amp_min, amp_max, z_min
+     type(c_ptr)        :: sig_min, sig_max, sig_mode
+     integer(c_int64_t) :: max_models
+  end type rf_post_config
+
+  ! struct rf_post_result (c_null_ptr = not wanted)
+  type, bind(C) :: rf_post_result
+     type(c_ptr) :: nmod
+     type(c_ptr) :: nk, nz, nsig, namp, nvpz, nvsz, nvpvsz
+     type(c_ptr) :: vp_mean, vs_mean, vpvs_mean
+     type(c_ptr) :: vp_model, vs_model, all_likelihood
+     type(c_ptr) :: amp_out_of_range
+  end type rf_post_result
+
   interface
      integer(c_int) function rf_ctx_create(cfg, ctx_out) bind(C, name="rf_ctx_create")
        import :: c_int, c_ptr, rf_config
@@ -109,6 +134,40 @@ module rfgpu_c
        integer(c_int32_t), intent(in) :: walker_ids(*)
        real(c_double), intent(out) :: out(*)
      end function rf_get_rft_batch
+
+     integer(c_int) function rf_set_model(ctx, m) bind(C, name="rf_set_model")
+       import :: c_int, c_ptr, rf_model_config
+       type(c_ptr), value :: ctx
+       type(rf_model_config), intent(in) :: m
+     end function rf_set_model
+
+     integer(c_int) function rf_post_create(ctx, cfg) bind(C, name="rf_post_create")
+       import :: c_int, c_ptr, rf_post_config
+       type(c_ptr), value :: ctx
+       type(rf_post_config), intent(in) :: cfg
+     end function rf_post_create
+
+     integer(c_int) function rf_post_reset(ctx) bind(C, name="rf_post_reset")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function rf_post_reset
+
+     ! temps = c_null_ptr: no temperature filter
+     integer(c_int) function rf_post_record(ctx, n, walker_ids, k, z, dvp, dvs, sig, logl, temps) &
+          & bind(C, name="rf_post_record")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: n
+       integer(c_int32_t), intent(in) :: walker_ids(*), k(*)
+       real(c_double), intent(in) :: z(*), dvp(*), dvs(*), sig(*), logl(*)
+       type(c_ptr), value :: temps
+     end function rf_post_record
+
+     integer(c_int) function rf_post_read(ctx, res) bind(C, name="rf_post_read")
+       import :: c_int, c_ptr, rf_post_result
+       type(c_ptr), value :: ctx
+       type(rf_post_result), intent(in) :: res
+     end function rf_post_read
   end interface
 
 contains

@@ -138,6 +138,7 @@ class RJMCMC:
         self.log_likelihood = np.zeros(n)
         self.temps = np.ones(n)
         self.counters: Counters | None = None
+        self.posterior = None   # rf_inv_amd.posterior.Posterior: device-side record step when set
 
     # ---- initialisation, in the order of src/rf_inv.f90:83-91 --------------------------
     def _draw_prior(self):
@@ -199,9 +200,14 @@ class RJMCMC:
         self.temps[:p.ncool] = 1.0
         for c in range(p.ncool, p.nchains):
             self.temps[c] = math.exp(self.rng.grnd() * math.log(p.t_high))   # :450-452
+        labels = {self.itype_birth: "Birth proposal", self.itype_death: "Death proposal",
+                  self.itype_z: "Moving interface depth proposal", self.itype_dvs: "Perturbing dVs proposal",
+                  self.itype_dvp: "Perturbing dVs proposal",          # sic, src/pt_mcmc.f90:380
+                  self.itype_sig: "Perturbing sigma proposal"}
         self.counters = Counters(nprop=np.zeros(self.ntype + 1, dtype=np.int64),
                                  naccept=np.zeros(self.ntype + 1, dtype=np.int64),
-                                 likelihood_hist=np.zeros(p.nburn + p.niter + 1))
+                                 likelihood_hist=np.zeros(p.nburn + p.niter + 1),
+                                 labels=[labels[i] for i in range(1, self.ntype + 1)])
 
     # ---- one chain's proposal (src/pt_mcmc.f90:74-169) -------------------------------------
     def _propose(self, c) -> _Proposal:
@@ -306,6 +312,10 @@ class RJMCMC:
                 if accepted[c]:
                     cnt.naccept[props[c].itype] += 1
                 cnt.likelihood_hist[it] += self.log_likelihood[c]
+        if self.posterior is not None and it > p.nburn and it % p.ncorr == 0:              # :204-286
+            # every chain goes down; the device keeps the non-tempered ones (temps filter) in chain order
+            self.posterior.record(np.arange(p.nchains), self.k, self.z[:, :max(p.k_max - 1, 1)], self.dvp,
+                                  self.dvs, self.sig, self.log_likelihood, temps=self.temps)
         if p.nchains >= 2:                                                                # :498-535
             g = self.rng
             n_all = p.nchains

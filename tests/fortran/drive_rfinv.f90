@@ -5,8 +5,10 @@
 ! init_fftw, which the replaced modules no longer need, and dumps the
 ! per-iteration mean T=1 log-likelihood (what mcmc_out writes to
 ! rslt/likelihood, src/mcmc_out.f90:142) and the proposal counters.
-!   usage: drive_rfinv params.in n_burn n_iter mode      (mode 0: the reference's
-!          pt_control, 1: our pt_control_batched)
+!   usage: drive_rfinv params.in n_burn n_iter mode [out]  (mode 0: the reference's
+!          pt_control, 1: our pt_control_batched; a fifth argument makes the reference's own
+!          output_results (src/mcmc_out.f90, compiled unmodified) write its result files
+!          into params.in's output directory)
 !=======================================================================
 program drive_rfinv
   use params
@@ -16,6 +18,7 @@ program drive_rfinv
   use forward
   use pt_mcmc
   use pt_mcmc_batched
+  use mcmc_out
   implicit none
   include "mpif.h"
   integer :: nproc, rank, ierr, it, u, n_it, mode
@@ -73,6 +76,7 @@ program drive_rfinv
   write(u, '(es25.17)') sum(temps), sum(log_likelihood)
   write(u, '(es25.17)') temps(1:nchains)
   close(u)
+  if (command_argument_count() > 4) call output_results(nproc, rank, .false.)
   call mpi_finalize(ierr)
   write(*,*) "drive_rfinv: ok"
 end program drive_rfinv

@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in rfgpu.h but not exported by librfgpu.so"
         assert n in _lib.SYMBOLS, f"{n} not bound in rf_inv_amd/_lib.py"
     assert sorted(_lib.SYMBOLS) == names
-    assert lib.rf_abi_version() == 1
+    assert lib.rf_abi_version() == 2
 
 
 def test_config_struct_layout_matches_header():
@@ -37,6 +37,17 @@ def test_config_struct_layout_matches_header():
     assert _lib.RFConfig.delta.offset == 16 and _lib.RFConfig.rayps.offset == 40
     assert _lib.RFConfig.ldobs.offset == 72 and _lib.RFConfig.r_inv.offset == 80
     assert _lib.RFConfig.max_walkers.offset == 88
+
+
+def test_posterior_struct_layouts_match_header():
+    from rf_inv_amd import _lib
+
+    # struct rf_post_config: 6 int32, 3 double, 3 ptr, int64
+    assert C.sizeof(_lib.RFPostConfig) == 24 + 24 + 24 + 8
+    assert _lib.RFPostConfig.amp_min.offset == 24 and _lib.RFPostConfig.sig_min.offset == 48
+    assert _lib.RFPostConfig.max_models.offset == 72
+    # struct rf_post_result: 15 pointers
+    assert C.sizeof(_lib.RFPostResult) == 15 * 8 and _lib.RFPostResult.amp_out_of_range.offset == 14 * 8
 
 
 def test_no_cpu_fallback_ctx_create_fails_loudly_without_gpu():
@@ -100,5 +111,5 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
                            "-lm", f"-Wl,-rpath,{libdir}"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi 1 rank" in r.stdout
+    assert "abi 2 rank" in r.stdout
     assert "no context: rf_ctx_create: no HIP device" in r.stdout or "calc_rf rc 0" in r.stdout

@@ -84,6 +84,8 @@ def test_fortran_dropin_modules_on_sample_syn(oracle, golden_dir, tmp_path):
 
 
 RFINV = os.path.join(ROOT, "oracle", "_ref", "drive_rfinv")
+RESULT_FILES = ["all_models", "likelihood", "num_interface.ppd", "syn_trace.ppd", "interface_depth.ppd", "sigma.ppd",
+                "vs_z.ppd", "vp_z.ppd", "vpvs_z.ppd", "vs_z.mean", "vp_z.mean", "vpvs_z.mean"]
 
 
 @pytest.mark.gpu
@@ -134,9 +136,11 @@ def test_reference_sampler_on_top_of_the_dropin_modules(oracle, golden_dir, tmp_
 def test_fortran_batched_sampler_equals_reference_sampler(golden_dir, tmp_path):
     """rf_inv_amd/fortran/pt_mcmc_batched.f90 (propose-all -> rf_eval_batch -> accept-all) against
     the reference's own sequential pt_control on the same GPU engine: the complete dumps --
-    likelihood history, proposal/accept counters, posterior-histogram checksums (what mcmc_out
-    writes), final temperatures and log-likelihoods -- are identical, burn-in and recording
-    phases included."""
+    likelihood history, proposal/accept counters, posterior checksums, final temperatures and
+    log-likelihoods -- are identical, burn-in and recording phases included; and so is every result
+    file the reference's own output_results (src/mcmc_out.f90, compiled unmodified) writes: mode 0
+    fills the histograms on the host as the reference does (src/pt_mcmc.f90:204-286), mode 1 on the
+    device (rf_post_record), traces never leaving HBM."""
     if not os.path.exists(RFINV):
         pytest.skip("oracle/_ref/drive_rfinv not built (no Fortran compiler / reference tree at build time)")
     dumps = []
@@ -144,12 +148,16 @@ def test_fortran_batched_sampler_equals_reference_sampler(golden_dir, tmp_path):
         work = tmp_path / f"run{mode}"
         shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
         os.makedirs(work / "rslt")
-        r = subprocess.run([RFINV, "params.in", "60", "240", mode], cwd=work, env=dict(os.environ),
+        r = subprocess.run([RFINV, "params.in", "60", "240", mode, "out"], cwd=work, env=dict(os.environ),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0 and "drive_rfinv: ok" in r.stdout, r.stdout + r.stderr
         dumps.append(open(work / "rfinv_dump.txt").read())
     assert len(dumps[0].split()) > 300
     assert dumps[0] == dumps[1]
+    for name in RESULT_FILES:
+        a, b = open(tmp_path / "run0" / "rslt" / name).read(), open(tmp_path / "run1" / "rslt" / name).read()
+        assert a == b, name
+        assert len(a) > 0 or name == "sigma.ppd", name
 
 
 @pytest.mark.gpu
@@ -165,13 +173,15 @@ def test_fortran_batched_sampler_two_mpi_ranks(golden_dir, tmp_path):
         work = tmp_path / f"mpi{mode}"
         shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
         os.makedirs(work / "rslt")
-        r = subprocess.run([mpiexec, "-np", "2", RFINV, "params.in", "40", "160", mode], cwd=work,
+        r = subprocess.run([mpiexec, "-np", "2", RFINV, "params.in", "40", "160", mode, "out"], cwd=work,
                            env=dict(os.environ), capture_output=True, text=True, timeout=900)
         if r.returncode != 0 and ("hydra" in r.stderr.lower() or "unable" in r.stderr.lower()):
             pytest.skip("mpiexec cannot start processes here: " + r.stderr[-200:])
         assert r.returncode == 0 and r.stdout.count("drive_rfinv: ok") == 2, r.stdout + r.stderr
         dumps.append([open(work / f"rfinv_dump_{k}.txt").read() for k in (0, 1)])
     assert dumps[0][0] == dumps[1][0] and dumps[0][1] == dumps[1][1]
+    for name in RESULT_FILES:       # output_results' mpi_reduce / mpi_gather over the two ranks' accumulators
+        assert open(tmp_path / "mpi0" / "rslt" / name).read() == open(tmp_path / "mpi1" / "rslt" / name).read(), name
     assert dumps[0][0] != dumps[0][1]          # the two ranks run different chains (seed depends on rank)
     # temperatures moved between ranks at least once: rank 0 started with [1, tempered...]
     t0 = [float(x) for x in dumps[0][0].split()[-5:]]

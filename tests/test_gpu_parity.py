@@ -22,7 +22,7 @@ def test_library_is_the_hip_one():
     from rf_inv_amd import _lib
 
     lib = _lib.load()
-    assert lib.rf_abi_version() == 1
+    assert lib.rf_abi_version() == 2
     assert os.path.basename(_lib.LIB_PATH) == "librfgpu.so"
 
 
