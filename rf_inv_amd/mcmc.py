@@ -124,11 +124,47 @@ class Counters:
     labels: list = field(default_factory=list)
 
 
-class RJMCMC:
-    """Chain state of one rank + the iteration loop (single rank: nproc = 1)."""
+class TorchComm:
+    """The three MPI calls of pt_control (src/pt_mcmc.f90:518,544-556,564-570) over
+    torch.distributed: one rank per GPU, backend "nccl" (= RCCL, tensors on `device`) or "gloo"
+    (device=None, host tensors)."""
 
-    def __init__(self, p: Params, ref: RefModel, evaluator, rng: MT19937):
+    def __init__(self, device=None, group=None):
+        import torch
+        import torch.distributed as dist
+
+        self._t, self._d, self.device, self.group = torch, dist, device, group
+        self.rank, self.nproc = dist.get_rank(group), dist.get_world_size(group)
+
+    def bcast_ints(self, vals, n):
+        t = self._t.tensor(list(vals) if self.rank == 0 else [0] * n, dtype=self._t.int32, device=self.device)
+        self._d.broadcast(t, src=0, group=self.group)
+        return [int(v) for v in t.cpu()]
+
+    def send(self, vals, dst):
+        self._d.send(self._t.tensor(list(vals), dtype=self._t.float64, device=self.device), dst=dst,
+                     group=self.group)
+
+    def recv(self, n, src):
+        t = self._t.zeros(n, dtype=self._t.float64, device=self.device)
+        self._d.recv(t, src=src, group=self.group)
+        return [float(v) for v in t.cpu()]
+
+
+def rank_seed(iseed: int, rank: int) -> int:
+    """src/rf_inv.f90:73-74: every rank seeds its own MT19937 stream."""
+    return iseed + rank * rank * 10000 + 23 * rank
+
+
+class RJMCMC:
+    """Chain state of one rank + the iteration loop.  Single rank by default; with `comm`
+    (TorchComm) the temperature exchange runs over all ranks' chains as in pt_control."""
+
+    def __init__(self, p: Params, ref: RefModel, evaluator, rng: MT19937, comm=None):
         self.p, self.ref, self.ev, self.rng = p, ref, evaluator, rng
+        self.comm = comm
+        self.rank = comm.rank if comm is not None else 0
+        self.nproc = comm.nproc if comm is not None else 1
         n, kmax = p.nchains, p.k_max
         self.k = np.zeros(n, dtype=np.int64)
         self.z = np.zeros((n, max(kmax - 1, 1)))
@@ -316,19 +352,42 @@ class RJMCMC:
             # every chain goes down; the device keeps the non-tempered ones (temps filter) in chain order
             self.posterior.record(np.arange(p.nchains), self.k, self.z[:, :max(p.k_max - 1, 1)], self.dvp,
                                   self.dvs, self.sig, self.log_likelihood, temps=self.temps)
-        if p.nchains >= 2:                                                                # :498-535
-            g = self.rng
-            n_all = p.nchains
+        if p.nchains >= 2:
+            self._swap_temperatures()
+        return accepted
+
+    def _swap_temperatures(self):
+        """One temperature-exchange proposal for the whole ensemble (src/pt_mcmc.f90:498-571):
+        rank 0 picks two distinct global chains; temperatures move, states stay."""
+        p, g, nc = self.p, self.rng, self.p.nchains
+        n_all = nc * self.nproc
+        pack = None
+        if self.rank == 0:                                                                # :501-515
             i1 = int(g.grnd() * n_all)
             while True:
                 i2 = int(g.grnd() * n_all)
                 if i2 != i1:
                     break
-            t1, t2 = self.temps[i1], self.temps[i2]
-            del_s = (self.log_likelihood[i2] - self.log_likelihood[i1]) * (1.0 / t1 - 1.0 / t2)   # :586
+            pack = [i1 // nc, i2 // nc, i1 % nc, i2 % nc]
+        if self.nproc > 1:
+            pack = self.comm.bcast_ints(pack, 4)                                          # :518
+        rank1, rank2, c1, c2 = pack
+        if rank1 == self.rank and rank2 == self.rank:                                     # :525-535
+            t1, t2 = self.temps[c1], self.temps[c2]
+            del_s = (self.log_likelihood[c2] - self.log_likelihood[c1]) * (1.0 / t1 - 1.0 / t2)   # :586
             if math.log(g.grnd()) <= del_s:
-                self.temps[i2], self.temps[i1] = t1, t2
-        return accepted
+                self.temps[c2], self.temps[c1] = t1, t2
+        elif rank1 == self.rank:                                                          # :538-557
+            t2, e2 = self.comm.recv(2, rank2)
+            t1, e1 = self.temps[c1], self.log_likelihood[c1]
+            back = t2
+            if math.log(g.grnd()) <= (e2 - e1) * (1.0 / t1 - 1.0 / t2):
+                self.temps[c1] = t2
+                back = t1
+            self.comm.send([back], rank2)
+        elif rank2 == self.rank:                                                          # :560-570
+            self.comm.send([self.temps[c2], self.log_likelihood[c2]], rank1)
+            self.temps[c2] = self.comm.recv(1, rank1)[0]
 
     def mean_t1_likelihood(self, it: int) -> float:
         """The value written to rslt/likelihood (src/mcmc_out.f90:142), single rank."""

@@ -214,3 +214,57 @@ def test_python_driver_result_files_equal_reference_writer(golden_dir, tmp_path,
     a, b = np.array(_read_cols(out / "likelihood")), np.array(_read_cols(work / "rslt" / "likelihood"))
     assert a.shape == b.shape == (nburn + niter, 2)
     assert np.allclose(a, b, rtol=1e-12, atol=1e-9)      # logL: the two hosts add the terms identically
+
+
+def _compare_result_dirs(ours, theirs, n_it, sigma_solved):
+    for name in ("syn_trace.ppd", "vs_z.ppd", "vp_z.ppd", "vpvs_z.ppd", "vs_z.mean", "vp_z.mean", "vpvs_z.mean"):
+        assert open(os.path.join(ours, name)).read() == open(os.path.join(theirs, name)).read(), name
+    for name in ("all_models", "num_interface.ppd", "interface_depth.ppd", "sigma.ppd"):
+        a, b = _read_cols(os.path.join(ours, name)), _read_cols(os.path.join(theirs, name))
+        assert len(a) == len(b) and a == b, name
+        assert len(a) > 0 or (name == "sigma.ppd" and not sigma_solved), name
+    a, b = np.array(_read_cols(os.path.join(ours, "likelihood"))), np.array(_read_cols(os.path.join(theirs, "likelihood")))
+    assert a.shape == b.shape == (n_it, 2)
+    assert np.allclose(a, b, rtol=1e-12, atol=1e-9)
+
+
+def test_two_rank_python_main_equals_two_rank_reference_run(golden_dir, tmp_path):
+    """`python -m rf_inv_amd.run` as two ranks (gloo control messages, both on the one GPU of the test
+    box) against the reference's own pt_control + output_results under `mpiexec -np 2`: per-rank random
+    streams, the cross-rank temperature exchange and the merge of the two ranks' device accumulators give
+    the same twelve files."""
+    import sys
+
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(RFINV) or not os.path.exists(mpiexec):
+        pytest.skip("drive_rfinv or mpiexec not available")
+    nburn, niter = 30, 120
+
+    def prepare(name):
+        work = tmp_path / name
+        shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
+        os.makedirs(work / "rslt")
+        txt = open(work / "params.in").read().splitlines()
+        vals = [i for i, line in enumerate(txt) if line.strip() and not line.startswith("#")]
+        txt[vals[1]], txt[vals[2]] = str(nburn), str(niter)       # N_BURN, N_ITER follow the output directory
+        open(work / "params.in", "w").write("\n".join(txt) + "\n")
+        return work
+
+    ref_dir = prepare("ref")
+    r = subprocess.run([mpiexec, "-np", "2", RFINV, "params.in", str(nburn), str(niter), "0", "out"], cwd=ref_dir,
+                       env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    if r.returncode != 0 and ("hydra" in r.stderr.lower() or "unable" in r.stderr.lower()):
+        pytest.skip("mpiexec cannot start processes here: " + r.stderr[-200:])
+    assert r.returncode == 0 and r.stdout.count("drive_rfinv: ok") == 2, r.stdout + r.stderr
+
+    our_dir = prepare("ours")
+    port = 29500 + os.getpid() % 1000
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), RF_INV_BACKEND="gloo", PYTHONPATH=ROOT)
+        procs.append(subprocess.Popen([sys.executable, "-m", "rf_inv_amd.run", "params.in"], cwd=our_dir, env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [pr.communicate(timeout=900)[0] for pr in procs]
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)
+    _compare_result_dirs(our_dir / "rslt", ref_dir / "rslt", nburn + niter, sigma_solved=False)

@@ -121,3 +121,93 @@ def test_trajectory_pin_on_gpu(oracle, golden_dir):
     assert np.array_equal(m.k, m2.k) and np.array_equal(m.counters.naccept, m2.counters.naccept)
     assert np.allclose(vals, vals2, rtol=1e-11, atol=1e-8)
     eng.close()
+
+
+# ---- two ranks: the cross-rank temperature exchange (src/pt_mcmc.f90:498-571) ----------------------
+class _QueueComm:
+    """In-process transport with TorchComm's three methods (threads + queues): the replay the gloo
+    run is compared with."""
+
+    def __init__(self, rank, nproc, boxes, bcast_boxes):
+        self.rank, self.nproc, self.boxes, self.bcast_boxes = rank, nproc, boxes, bcast_boxes
+
+    def bcast_ints(self, vals, n):
+        if self.rank == 0:
+            for r in range(1, self.nproc):
+                self.bcast_boxes[r].put(list(vals))
+            return list(vals)
+        return self.bcast_boxes[self.rank].get(timeout=120)
+
+    def send(self, vals, dst):
+        self.boxes[(self.rank, dst)].put(list(vals))
+
+    def recv(self, n, src):
+        return self.boxes[(src, self.rank)].get(timeout=120)
+
+
+def _run_rank(p, ref, ev, comm, rank, n_it):
+    from rf_inv_amd.mcmc import rank_seed
+
+    m = RJMCMC(p, ref, ev, MT19937(rank_seed(p.iseed, rank)), comm=comm)
+    m.init_model(); m.init_likelihood(); m.init_pt_mcmc()
+    for it in range(1, n_it + 1):
+        m.iterate(it)
+    return dict(temps=m.temps.copy(), logl=m.log_likelihood.copy(), nprop=m.counters.nprop.copy(),
+                nacc=m.counters.naccept.copy(), hist=m.counters.likelihood_hist.copy(), k=m.k.copy())
+
+
+def _gloo_rank(rank, world, port, golden_dir, n_it, q):
+    import torch.distributed as dist
+
+    from oracle import rf_oracle
+    from rf_inv_amd.mcmc import TorchComm
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    p, ref = _setup(golden_dir)
+    p.nburn, p.niter = 0, n_it
+    out = _run_rank(p, ref, OracleEvaluator(rf_oracle, p), TorchComm(device=None), rank, n_it)
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_driver_gloo_equals_in_process_replay(oracle, golden_dir):
+    import queue
+    import threading
+
+    import torch.multiprocessing as mp
+
+    n_it, world = 40, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = 29100 + os.getpid() % 800
+    procs = [ctx.Process(target=_gloo_rank, args=(r, world, port, golden_dir, n_it, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get() for _ in range(world))
+    for pr in procs:
+        pr.join(120)
+        assert pr.exitcode == 0
+
+    boxes = {(a, b): queue.Queue() for a in range(world) for b in range(world)}
+    bb = {r: queue.Queue() for r in range(world)}
+    res = {}
+
+    def work(rank):
+        p, ref = _setup(golden_dir)
+        p.nburn, p.niter = 0, n_it
+        res[rank] = _run_rank(p, ref, OracleEvaluator(oracle, p), _QueueComm(rank, world, boxes, bb), rank, n_it)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join(600) for t in th]
+    assert set(res) == {0, 1}
+    for r in range(world):
+        for key in res[r]:
+            assert np.array_equal(res[r][key], got[r][key]), (r, key)
+    # the ranks run different streams; the ensemble's temperatures are conserved as a multiset
+    assert not np.array_equal(got[0]["logl"], got[1]["logl"])
+    p, _ = _setup(golden_dir)
+    all_t = np.sort(np.concatenate([got[0]["temps"], got[1]["temps"]]))
+    assert np.sum(all_t == 1.0) == 2 * p.ncool and all_t.size == 2 * p.nchains
