@@ -293,13 +293,13 @@ def main():
                 # executed (not algorithmic) fp64 rate, an ESTIMATE from the ISA of the chained-phase loop:
                 # ~86 fp64 VALU ops per (bin, layer), ~60 % of them FMAs -> ~140 flop; + ~300 flop per bin
                 # for the boundary condition
-                "executed_tflops_est": (float((nlay - 1 - (1 if p.sdep > 0 else 0)).sum() * 140.0 + 300.0 * nb)
+                "executed_tflops_est": (float((nlay - 1 - (1 if p.sdep > 0 else 0)).sum() * 100.0 + 300.0 * nb)
                                         * (1 if eng.is_ray_common else p.ntrc) * (p.nfft // 2 + 1)
                                         / (spectra_ms * 1e-3) / 1e12) if spectra_ms > 0 else None,
                 "note": "fp64: MI355X matrix (MFMA) peak == vector peak = 78.6 TF; the kernel issues fp64 VALU FMA, "
                         "MFMA not used (no rate advantage). achieved = reference-arithmetic flops (SURVEY 8d: "
                         "570/(bin*layer)+580/bin, + FFT/shift/quadratic form when fused) per launch / live "
-                        "HIP-event kernel time; the real-form propagator executes ~1/5 of those flops, so the "
+                        "HIP-event kernel time; the eigen-coordinate real-form propagator executes ~1/6 of those flops, so the "
                         "algorithmic fraction can exceed 1 (DESIGN.md section 3).",
             },
             "roofline_hbm": {

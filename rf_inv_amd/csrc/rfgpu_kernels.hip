@@ -71,23 +71,30 @@ __device__ __noinline__ double arrival_sum(int n, const double *terms)
 // ---------------------------------------------------------------------------
 // K1  spectra
 // ---------------------------------------------------------------------------
-// LDS image per (walker, forward-trace), staged once per wave:
-//   coef[l][0..19]  per solid layer l (0-based, l < nlay-1):
+// Formulation.  Every solid-layer propagator of the reference (forward.f90:403-418) is
+// P = T A T^-1 with T = diag(1, i, w, i w) and A(h) real and free of explicit w, and
+// A = U R U^-1: R rotates a P pair (a_p, b_p) by the layer's P phase w xi h and an S pair
+// (a_s, b_s) by its S phase w eta h; U (layer_basis below) is constant per layer.  The chain
+// E^-1 P_n ... P_1 is therefore
+//     (E^-1 T U_n) R_n (U_n^-1 U_{n-1}) R_{n-1} ... R_1 (U_1^-1 e_j):
+// per (bin, layer) and propagated column 2 rotations (8 flop-instructions) and one change of
+// eigen-coordinates G = U_next^-1 U_this, which couples only (a_p, b_s) and (b_p, a_s) -- two 2x2
+// blocks, 8 instructions, wave-uniform coefficients.  The phases are the reference's own doubles
+// (w xi) h.  Only the columns the boundary condition consumes are propagated (1, 2; ocean: + 4).
+//
+// LDS image per (walker, forward-trace), staged once per block:
+//   coef[l][0..NCOEF-1]  per solid layer l (0-based, l < nlay-1):
 //      0 xi   1 eta   2 h
-//      3 k1 = 2 b2 p2          4 k2 = bp
-//      5 k5 = 2 b2 rho p bp    6 k6 = -p / rho
-//      7 k7 = p 2 b2 xi        8 k8n = -p bp / eta
-//      9 k9 = p bp / xi       10 k10n = -p 2 b2 eta
-//     11 k11n = -rho 4 b2^2 p2 xi   12 k12n = -rho bp^2 / eta
-//     13 k13n = -rho bp^2 / xi      14 k14n = -rho 4 b2^2 p2 eta
-//     15 k15 = p2 / (xi rho)        16 k16 = eta / rho
-//     17 k17 = xi / rho             18 k18 = p2 / (eta rho)
-//     19,20 phi_xi  = domg*xi*h  as a double-double (hi, lo)   } phase per bin of the layer and
-//     21,22 phi_eta = domg*eta*h as a double-double            } cos/sin of 64 bins of phase:
-//     23,24 cos, sin(64 phi_xi)   25,26 cos, sin(64 phi_eta)   } the chained-phase path (below)
-//     27 pad
-//   tail[0..7]  g1..g8 : rows 3,4 of E^-1 T of the half-space
-//   tail[8..10] water layer: xi_w, h_w, rho_w / xi_w
+//      3..10  G: a_p'<-(a_p, b_s), b_s'<-(a_p, b_s), b_p'<-(b_p, a_s), a_s'<-(b_p, a_s)
+//             (identity below the last solid layer)
+//     11,12 phi_xi  = domg*xi*h  as a double-double (hi, lo)   } phase per bin of the layer and
+//     13,14 phi_eta = domg*eta*h as a double-double            } cos/sin of 64 bins of phase:
+//     15,16 cos, sin(64 phi_xi)   17,18 cos, sin(64 phi_eta)   } the chained-phase path (below)
+//     19 pad
+//   tail[0..7]   rows 3,4 of E^-1 T of the half-space in the last solid layer's eigen-coordinates
+//   tail[8..10]  water layer: xi_w, h_w, rho_w / xi_w
+//   tail[11..16] unit columns 1, 2, 4 in the top solid layer's eigen-coordinates (stage_start)
+//   tail[24..]   per-layer direct-arrival terms
 __device__ __forceinline__ void sincos_cw(double x, double &sn, double &cs);
 
 __device__ __forceinline__ void stage_phase(double *c4, double *cs2, double domg, double slow, double h)
@@ -107,53 +114,105 @@ __device__ __forceinline__ void stage_phase(double *c4, double *cs2, double domg
     cs2[1] = fma(c, d, s);
 }
 
-__device__ __forceinline__ void stage_layer_coef(double *c, double alpha, double beta, double rho,
-                                                 double h, double p, double domg)
+// Eigen-coordinates of a solid layer (see the header comment): x = U q with q = (a_p, b_p, a_s, b_s),
+//   x1 = p a_p + eta b_s          x4 = rho bp a_p - 2 b^2 rho p eta b_s        (support {1,4})
+//   x2 = xi b_p + p a_s           x3 = -2 b^2 rho p xi b_p + rho bp a_s        (support {2,3})
+// and q = W^T x,
+//   a_p = 2 b^2 p x1 + x4 / rho   b_s = (bp x1 - (p / rho) x4) / eta
+//   a_s = 2 b^2 p x2 + x3 / rho   b_p = (bp x2 - (p / rho) x3) / xi
+struct LayerBasis {
+    double p, xi, eta, rho, bp, tb2p;   // tb2p = 2 beta^2 p
+};
+
+__device__ __forceinline__ LayerBasis layer_basis(double alpha, double beta, double rho, double p)
 {
-    const double b2 = beta * beta;
-    const double p2 = p * p;
-    const double bp = 1.0 - 2.0 * b2 * p2;
-    const double eta = sqrt(1.0 / b2 - p2);
-    const double xi = sqrt(1.0 / (alpha * alpha) - p2);
-    const double b4p2 = 4.0 * b2 * b2 * p2;
-    c[0] = xi;
-    c[1] = eta;
-    c[2] = h;
-    c[3] = 2.0 * b2 * p2;
-    c[4] = bp;
-    c[5] = 2.0 * b2 * rho * p * bp;
-    c[6] = -p / rho;
-    c[7] = p * (2.0 * b2 * xi);
-    c[8] = -p * (bp / eta);
-    c[9] = p * (bp / xi);
-    c[10] = -p * (2.0 * b2 * eta);
-    c[11] = -rho * (b4p2 * xi);
-    c[12] = -rho * (bp * bp / eta);
-    c[13] = -rho * (bp * bp / xi);
-    c[14] = -rho * (b4p2 * eta);
-    c[15] = p2 / xi / rho;
-    c[16] = eta / rho;
-    c[17] = xi / rho;
-    c[18] = p2 / eta / rho;
-    stage_phase(c + 19, c + 23, domg, xi, h);
-    stage_phase(c + 21, c + 25, domg, eta, h);
-    c[27] = 0.0;
+    LayerBasis b;
+    const double b2 = beta * beta, p2 = p * p;
+    b.p = p;
+    b.rho = rho;
+    b.bp = 1.0 - 2.0 * b2 * p2;
+    b.eta = sqrt(1.0 / b2 - p2);
+    b.xi = sqrt(1.0 / (alpha * alpha) - p2);
+    b.tb2p = 2.0 * b2 * p;
+    return b;
 }
 
-__device__ __forceinline__ void stage_halfspace(double *g, double alpha, double beta, double rho, double p)
+// c[3..10] = G = W_next^T U_this: the change of eigen-coordinates across the interface below the
+// layer (two 2x2 blocks: (a_p, b_s) and (b_p, a_s)); identity after the last solid layer
+__device__ __forceinline__ void stage_layer_coef(double *c, const LayerBasis &u, double h, double domg,
+                                                 const LayerBasis *w)
 {
-    // rows 3 and 4 of E^-1 (forward.f90:370-377) times T = diag(1, i, w, i w)
+    c[0] = u.xi;
+    c[1] = u.eta;
+    c[2] = h;
+    if (w) {
+        const double pr = w->p / w->rho;            // p / rho'
+        const double m = u.tb2p * u.rho;            // 2 b^2 rho p
+        c[3] = fma(w->tb2p, u.p, (u.rho / w->rho) * u.bp);                  // a_p' <- a_p
+        c[4] = u.eta * (w->tb2p - m / w->rho);                              // a_p' <- b_s
+        c[5] = (w->bp * u.p - pr * (u.rho * u.bp)) / w->eta;                // b_s' <- a_p
+        c[6] = u.eta * (w->bp + pr * m) / w->eta;                           // b_s' <- b_s
+        c[7] = u.xi * (w->bp + pr * m) / w->xi;                             // b_p' <- b_p
+        c[8] = (w->bp * u.p - pr * (u.rho * u.bp)) / w->xi;                 // b_p' <- a_s
+        c[9] = u.xi * (w->tb2p - m / w->rho);                               // a_s' <- b_p
+        c[10] = fma(w->tb2p, u.p, (u.rho / w->rho) * u.bp);                 // a_s' <- a_s
+    } else {
+        c[3] = 1.0; c[4] = 0.0; c[5] = 0.0; c[6] = 1.0;
+        c[7] = 1.0; c[8] = 0.0; c[9] = 0.0; c[10] = 1.0;
+    }
+    stage_phase(c + 11, c + 15, domg, u.xi, h);
+    stage_phase(c + 13, c + 17, domg, u.eta, h);
+    c[19] = 0.0;
+}
+
+// tail[0..7]: rows 3 and 4 of E^-1 (forward.f90:370-377) times T = diag(1, i, w, i w), expressed in
+// the eigen-coordinates of the last solid layer (`last`; nullptr: no solid layer, physical
+// coordinates).  Row r: re = g[0] v[0] + g[1] v[3], im = g[2] v[1] + g[3] v[2] (halfspace_row).
+__device__ __forceinline__ void stage_halfspace(double *g, double alpha, double beta, double rho, double p,
+                                                const LayerBasis *last)
+{
     const double eta = sqrt(1.0 / (beta * beta) - p * p);
     const double xi = sqrt(1.0 / (alpha * alpha) - p * p);
     const double bp = 1.0 - 2.0 * beta * beta * p * p;
-    g[0] = beta * beta * p / alpha;        // re: B1
-    g[1] = 1.0 / (2.0 * rho * alpha);      // re: B4
-    g[2] = -bp / (2.0 * alpha * xi);       // im: B2
-    g[3] = p / (2.0 * rho * alpha * xi);   // im: B3
-    g[4] = bp / (2.0 * beta * eta);        // re: B1
-    g[5] = -p / (2.0 * rho * beta * eta);  // re: B4
-    g[6] = beta * p;                       // im: B2
-    g[7] = 1.0 / (2.0 * rho * beta);       // im: B3
+    double e[8];
+    e[0] = beta * beta * p / alpha;        // re: x1
+    e[1] = 1.0 / (2.0 * rho * alpha);      // re: x4
+    e[2] = -bp / (2.0 * alpha * xi);       // im: x2
+    e[3] = p / (2.0 * rho * alpha * xi);   // im: x3
+    e[4] = bp / (2.0 * beta * eta);        // re: x1
+    e[5] = -p / (2.0 * rho * beta * eta);  // re: x4
+    e[6] = beta * p;                       // im: x2
+    e[7] = 1.0 / (2.0 * rho * beta);       // im: x3
+    for (int r = 0; r < 2; ++r) {
+        const double *q = e + 4 * r;
+        double *o = g + 4 * r;
+        if (last) {
+            const double m = last->tb2p * last->rho, rb = last->rho * last->bp;
+            o[0] = fma(q[0], last->p, q[1] * rb);               // a_p
+            o[1] = last->eta * (q[0] - q[1] * m);               // b_s
+            o[2] = last->xi * (q[2] - q[3] * m);                // b_p
+            o[3] = fma(q[2], last->p, q[3] * rb);               // a_s
+        } else {
+            o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
+        }
+    }
+}
+
+// tail[11..16]: the unit columns 1, 2 (and 4, ocean) of the product in the eigen-coordinates of the
+// top solid layer: e1 -> (a_p, b_s) = (t[0], t[1]); e2 -> (b_p, a_s) = (t[2], t[3]);
+// e4 -> (a_p, b_s) = (t[4], t[5])
+__device__ __forceinline__ void stage_start(double *t, const LayerBasis *top)
+{
+    if (top) {
+        t[0] = top->tb2p;
+        t[1] = top->bp / top->eta;
+        t[2] = top->bp / top->xi;
+        t[3] = top->tb2p;
+        t[4] = 1.0 / top->rho;
+        t[5] = -(top->p / top->rho) / top->eta;
+    } else {
+        t[0] = 1.0; t[1] = 0.0; t[2] = 1.0; t[3] = 0.0; t[4] = 0.0; t[5] = 1.0;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -219,30 +278,25 @@ __device__ __forceinline__ void phase_sincos(double x, double &sn, double &cs)
         sincos(x, &sn, &cs);
 }
 
-// one layer applied to NCOL real column vectors, v <- A v, given the layer's phases
+// one layer applied to NCOL columns held in the layer's eigen-coordinates (a_p, b_p, a_s, b_s):
+// rotate the P pair by the layer's P phase and the S pair by its S phase, then change to the
+// next layer's coordinates (c[3..10])
 template <int NCOL>
 __device__ __forceinline__ void apply_layer_trig(ColState<NCOL> &s, const double *__restrict__ c, double sx,
                                                  double cx, double se, double ce)
 {
-    const double a = fma(c[3], cx, c[4] * ce);    // A11 = A33
-    const double e = fma(c[4], cx, c[3] * ce);    // A22 = A44
-    const double d = cx - ce;
-    const double x41 = c[5] * d;                  // A41 = -A32
-    const double x23 = c[6] * d;                  // A23 = -A14
-    const double x21 = fma(c[7], sx, c[8] * se);  // A21 = -A34
-    const double x12 = fma(c[9], sx, c[10] * se); // A43 = -A12
-    const double p31 = fma(c[11], sx, c[12] * se);
-    const double p42 = fma(c[13], sx, c[14] * se);
-    const double p13 = fma(c[15], sx, c[16] * se);
-    const double p24 = fma(c[17], sx, c[18] * se);
+    const double g0 = c[3], g1 = c[4], g2 = c[5], g3 = c[6], g4 = c[7], g5 = c[8], g6 = c[9], g7 = c[10];
 #pragma unroll
     for (int j = 0; j < NCOL; ++j) {
-        const double v1 = s.v[j][0], v2 = s.v[j][1], v3 = s.v[j][2], v4 = s.v[j][3];
-        // sum over k = 1..4 in order, like matmul (forward.f90:262)
-        s.v[j][0] = fma(-x23, v4, fma(p13, v3, fma(-x12, v2, a * v1)));
-        s.v[j][1] = fma(p24, v4, fma(x23, v3, fma(e, v2, x21 * v1)));
-        s.v[j][2] = fma(-x21, v4, fma(a, v3, fma(-x41, v2, p31 * v1)));
-        s.v[j][3] = fma(e, v4, fma(x12, v3, fma(p42, v2, x41 * v1)));
+        const double ap = s.v[j][0], bp = s.v[j][1], as = s.v[j][2], bs = s.v[j][3];
+        const double rap = fma(cx, ap, -(sx * bp));
+        const double rbp = fma(sx, ap, cx * bp);
+        const double ras = fma(ce, as, -(se * bs));
+        const double rbs = fma(se, as, ce * bs);
+        s.v[j][0] = fma(g1, rbs, g0 * rap);
+        s.v[j][3] = fma(g3, rbs, g2 * rap);
+        s.v[j][1] = fma(g5, ras, g4 * rbp);
+        s.v[j][2] = fma(g7, ras, g6 * rbp);
     }
 }
 
@@ -328,15 +382,21 @@ struct SpectraParams {
 // registers.
 
 template <int NCOL>
-__device__ __forceinline__ void init_cols(ColState<NCOL> &st)
+__device__ __forceinline__ void init_cols(ColState<NCOL> &st, const double *tail)
 {
+    const double *t = tail + 11;   // stage_start
 #pragma unroll
     for (int j = 0; j < NCOL; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) st.v[j][r] = 0.0;
-    st.v[0][0] = 1.0;
-    st.v[1][1] = 1.0;
-    if (NCOL == 3) st.v[2][3] = 1.0;
+    st.v[0][0] = t[0];
+    st.v[0][3] = t[1];
+    st.v[1][1] = t[2];
+    st.v[1][2] = t[3];
+    if (NCOL == 3) {
+        st.v[2][0] = t[4];
+        st.v[2][3] = t[5];
+    }
 }
 
 __device__ __forceinline__ void store_bin(double2 *__restrict__ out_r, double2 *__restrict__ out_v, int k, int nh,
@@ -368,7 +428,7 @@ __device__ __forceinline__ void spectra_iter_direct(const SpectraParams &P, cons
     // forward.f90:245-248: omega = (iomg-1) * domg, DC bin uses the single literal 1.0e-5
     const double omg = k == 0 ? P.t.omg_dc : (double)k * P.t.domg;
     ColState<NCOL> st;
-    init_cols<NCOL>(st);
+    init_cols<NCOL>(st, tail);
     for (int l = ilay0; l < nl - 1; ++l) apply_layer<NCOL, FAST>(st, coef + l * NCOEF, omg);
     double2 ur, uz;
     finish_bin<NCOL, FAST>(st, tail, omg, ipha, ur, uz);
@@ -405,14 +465,14 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
         kbin[m] = (it0 + m) * 64 + lane;
         kd[m] = (double)kbin[m];
         omg[m] = kbin[m] == 0 ? P.t.omg_dc : kd[m] * P.t.domg;
-        init_cols<NCOL>(st[m]);
+        init_cols<NCOL>(st[m], tail);
     }
     const bool dc = kbin[0] == 0;
 #pragma unroll 2
     for (int l = ilay0; l < nl - 1; ++l) {
         const double *c = coef + l * NCOEF;
         const double xi = c[0], eta = c[1], h = c[2];
-        const double Cx = c[23], Sx = c[24], Ce = c[25], Se = c[26];
+        const double Cx = c[15], Sx = c[16], Ce = c[17], Se = c[18];
         double sx, cx, se, ce;
         // first bin: direct evaluation of the reference's argument
         const double ax0 = (omg[0] * xi) * h, ae0 = (omg[0] * eta) * h;
@@ -421,8 +481,8 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
         apply_layer_trig<NCOL>(st[0], c, sx, cx, se, ce);
         // exact-angle start of the chain: remove the first bin's own perturbation.  The DC
         // bin's omega is the literal 1e-5 (not 0 * domg): its chain starts from angle 0.
-        const double ex0 = phase_eps(ax0, kd[0], c[19], c[20]);
-        const double ee0 = phase_eps(ae0, kd[0], c[21], c[22]);
+        const double ex0 = phase_eps(ax0, kd[0], c[11], c[12]);
+        const double ee0 = phase_eps(ae0, kd[0], c[13], c[14]);
         double cEx = dc ? 1.0 : fma(sx, ex0, cx);
         double sEx = dc ? 0.0 : fma(-cx, ex0, sx);
         double cEe = dc ? 1.0 : fma(se, ee0, ce);
@@ -434,8 +494,8 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
             sEx = fma(sEx, Cx, tx * Sx);
             cEe = fma(te, Ce, -(sEe * Se));
             sEe = fma(sEe, Ce, te * Se);
-            const double ex = phase_eps((omg[m] * xi) * h, kd[m], c[19], c[20]);
-            const double ee = phase_eps((omg[m] * eta) * h, kd[m], c[21], c[22]);
+            const double ex = phase_eps((omg[m] * xi) * h, kd[m], c[11], c[12]);
+            const double ee = phase_eps((omg[m] * eta) * h, kd[m], c[13], c[14]);
             apply_layer_trig<NCOL>(st[m], c, fma(cEx, ex, sEx), fma(-sEx, ex, cEx), fma(cEe, ee, sEe),
                                    fma(-sEe, ee, cEe));
         }
@@ -486,11 +546,24 @@ __device__ __forceinline__ bool stage_walker(const SpectraParams &P, int ib, int
     for (int l = threadIdx.x; l < nl - 1; l += blockDim.x)
         if (l >= ilay0) {
             double *c = coef + l * NCOEF;
-            stage_layer_coef(c, L[l], L[pad + l], L[2 * pad + l], L[3 * pad + l], p, P.t.domg);
+            const LayerBasis u = layer_basis(L[l], L[pad + l], L[2 * pad + l], p);
+            if (l + 1 < nl - 1) {
+                const LayerBasis w = layer_basis(L[l + 1], L[pad + l + 1], L[2 * pad + l + 1], p);
+                stage_layer_coef(c, u, L[3 * pad + l], P.t.domg, &w);
+            } else {
+                stage_layer_coef(c, u, L[3 * pad + l], P.t.domg, nullptr);
+            }
             big |= fabs(omg_max * fmax(c[0], c[1]) * c[2]) >= SINCOS_CW_LIMIT;
         }
     if (threadIdx.x == 0) {
-        stage_halfspace(tail, L[nl - 1], L[pad + nl - 1], L[2 * pad + nl - 1], p);
+        const bool solid = nl - 1 > ilay0;      // at least one solid layer above the half-space
+        LayerBasis top, last;
+        if (solid) {
+            top = layer_basis(L[ilay0], L[pad + ilay0], L[2 * pad + ilay0], p);
+            last = layer_basis(L[nl - 2], L[pad + nl - 2], L[2 * pad + nl - 2], p);
+        }
+        stage_halfspace(tail, L[nl - 1], L[pad + nl - 1], L[2 * pad + nl - 1], p, solid ? &last : nullptr);
+        stage_start(tail + 11, solid ? &top : nullptr);
         if (sea) {
             const double xiw = sqrt(1.0 / (L[0] * L[0]) - p * p);   // forward.f90:431
             tail[8] = xiw;
@@ -532,7 +605,7 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
         const double *L = P.b.layers + (size_t)ib * 4 * pad;
         const double *vel = (P.t.ipha[f] == 1) ? L : L + pad;   // alpha for P, beta for S (:157,161)
         const int i0 = P.t.sdep > 0.0 ? 1 : 0;                  // keyed on sdep (:484)
-        double *terms = tail + 16;
+        double *terms = tail + 24;
         for (int i = i0 + (int)threadIdx.x; i < nl - 1; i += blockDim.x)
             terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], P.t.rayps[f]);
         __syncthreads();
@@ -592,7 +665,7 @@ __global__ __launch_bounds__(64) void spectra_slow_kernel(SpectraParams P)
     }
 }
 
-size_t spectra_lds_bytes(int nlay_pad) { return sizeof(double) * ((size_t)nlay_pad * (NCOEF + 1) + 16); }
+size_t spectra_lds_bytes(int nlay_pad) { return sizeof(double) * ((size_t)nlay_pad * (NCOEF + 1) + 24); }
 
 template <int NCOL>
 static void launch_spectra_ncol(int chain, dim3 grid, dim3 block, size_t lds, hipStream_t s, const SpectraParams &P)
@@ -1167,7 +1240,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void fused_kernel(FusedParams F)
         const double *L = P.b.layers + (size_t)ib * 4 * pad;
         const double *vel = (ipha == 1) ? L : L + pad;            // alpha for P, beta for S (:157,161)
         const int i0 = t.sdep > 0.0 ? 1 : 0;                      // keyed on sdep (:484)
-        double *terms = tail + 16;
+        double *terms = tail + 24;
         for (int i = i0 + tid; i < nl - 1; i += TRACE_THREADS)
             terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], t.rayps[itrc]);
         __syncthreads();
