@@ -291,7 +291,7 @@ def main():
                 "traffic": measured_traffic(kname, workload, nb),
                 "kernel": kname, "kernel_ms": spectra_ms, "launch_plan": plan,
                 # executed (not algorithmic) fp64 rate, an ESTIMATE from the ISA of the chained-phase loop:
-                # ~86 fp64 VALU ops per (bin, layer), ~60 % of them FMAs -> ~140 flop; + ~300 flop per bin
+                # ~65 fp64 VALU ops per (bin, layer), ~55 % of them FMAs -> ~100 flop; + ~300 flop per bin
                 # for the boundary condition
                 "executed_tflops_est": (float((nlay - 1 - (1 if p.sdep > 0 else 0)).sum() * 100.0 + 300.0 * nb)
                                         * (1 if eng.is_ray_common else p.ntrc) * (p.nfft // 2 + 1)
