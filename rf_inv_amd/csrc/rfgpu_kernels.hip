@@ -97,6 +97,17 @@ __device__ __noinline__ double arrival_sum(int n, const double *terms)
 //   tail[24..]   per-layer direct-arrival terms
 __device__ __forceinline__ void sincos_cw(double x, double &sn, double &cs);
 
+// vertical slowness sqrt(1/v^2 - p^2) exactly as the reference's double arithmetic forms it
+// (forward.f90:394-395: no FMA on the reference's x86-64 build); it enters the phase argument
+// (omega * slowness) * h, whose rounding is part of the reference result
+__device__ __forceinline__ double vertical_slowness(double v, double p)
+{
+#pragma clang fp contract(off)
+    const double inv = 1.0 / (v * v);
+    const double p2 = p * p;
+    return sqrt(inv - p2);
+}
+
 __device__ __forceinline__ void stage_phase(double *c4, double *cs2, double domg, double slow, double h)
 {
     // phi = domg * slow * h as hi + lo (error-free products), then cos/sin(64 phi)
@@ -131,38 +142,54 @@ __device__ __forceinline__ LayerBasis layer_basis(double alpha, double beta, dou
     b.p = p;
     b.rho = rho;
     b.bp = 1.0 - 2.0 * b2 * p2;
-    b.eta = sqrt(1.0 / b2 - p2);
-    b.xi = sqrt(1.0 / (alpha * alpha) - p2);
+    b.eta = vertical_slowness(beta, p);
+    b.xi = vertical_slowness(alpha, p);
     b.tb2p = 2.0 * b2 * p;
     return b;
 }
 
 // c[3..10] = G = W_next^T U_this: the change of eigen-coordinates across the interface below the
-// layer (two 2x2 blocks: (a_p, b_s) and (b_p, a_s)); identity after the last solid layer
-__device__ __forceinline__ void stage_layer_coef(double *c, const LayerBasis &u, double h, double domg,
-                                                 const LayerBasis *w)
+// layer (two 2x2 blocks: (a_p, b_s) and (b_p, a_s)); identity after the last solid layer.  Staged in
+// four independent parts so that the four waves of a block share the latency (stage_walker):
+//   part 0: the (a_p, b_s) block, c[3..6]   (needs the S slownesses only)
+//   part 1: the (b_p, a_s) block, c[7..10]  (needs the P slownesses only)
+//   part 2: xi, h and the P phase constants;  part 3: eta and the S phase constants
+struct LayerHalf {
+    double p, rho, bp, tb2p, slow;   // slow = eta (part 0) or xi (part 1)
+};
+
+__device__ __forceinline__ LayerHalf layer_half(double vslow, double beta, double rho, double p)
 {
-    c[0] = u.xi;
-    c[1] = u.eta;
-    c[2] = h;
-    if (w) {
-        const double pr = w->p / w->rho;            // p / rho'
-        const double m = u.tb2p * u.rho;            // 2 b^2 rho p
-        c[3] = fma(w->tb2p, u.p, (u.rho / w->rho) * u.bp);                  // a_p' <- a_p
-        c[4] = u.eta * (w->tb2p - m / w->rho);                              // a_p' <- b_s
-        c[5] = (w->bp * u.p - pr * (u.rho * u.bp)) / w->eta;                // b_s' <- a_p
-        c[6] = u.eta * (w->bp + pr * m) / w->eta;                           // b_s' <- b_s
-        c[7] = u.xi * (w->bp + pr * m) / w->xi;                             // b_p' <- b_p
-        c[8] = (w->bp * u.p - pr * (u.rho * u.bp)) / w->xi;                 // b_p' <- a_s
-        c[9] = u.xi * (w->tb2p - m / w->rho);                               // a_s' <- b_p
-        c[10] = fma(w->tb2p, u.p, (u.rho / w->rho) * u.bp);                 // a_s' <- a_s
-    } else {
-        c[3] = 1.0; c[4] = 0.0; c[5] = 0.0; c[6] = 1.0;
-        c[7] = 1.0; c[8] = 0.0; c[9] = 0.0; c[10] = 1.0;
+    LayerHalf b;
+    const double b2 = beta * beta, p2 = p * p;
+    b.p = p;
+    b.rho = rho;
+    b.bp = 1.0 - 2.0 * b2 * p2;
+    b.tb2p = 2.0 * b2 * p;
+    b.slow = vertical_slowness(vslow, p);
+    return b;
+}
+
+// part 0 (slow = eta) writes c[3..6]; part 1 (slow = xi) writes c[7..10]; the two blocks have the
+// same entries up to their order: block 0 = (a_p'<-a_p, a_p'<-b_s, b_s'<-a_p, b_s'<-b_s),
+// block 1 = (b_p'<-b_p, b_p'<-a_s, a_s'<-b_p, a_s'<-a_s)
+__device__ __forceinline__ void stage_interface(double *g, int part, const LayerHalf &u, const LayerHalf *w)
+{
+    if (!w) {
+        g[0] = 1.0; g[1] = 0.0; g[2] = 0.0; g[3] = 1.0;
+        return;
     }
-    stage_phase(c + 11, c + 15, domg, u.xi, h);
-    stage_phase(c + 13, c + 17, domg, u.eta, h);
-    c[19] = 0.0;
+    const double pr = w->p / w->rho;            // p / rho'
+    const double m = u.tb2p * u.rho;            // 2 b^2 rho p
+    const double diag_a = fma(w->tb2p, u.p, (u.rho / w->rho) * u.bp);
+    const double off_a = u.slow * (w->tb2p - m / w->rho);
+    const double off_b = (w->bp * u.p - pr * (u.rho * u.bp)) / w->slow;
+    const double diag_b = u.slow * (w->bp + pr * m) / w->slow;
+    if (part == 0) {
+        g[0] = diag_a; g[1] = off_a; g[2] = off_b; g[3] = diag_b;
+    } else {
+        g[0] = diag_b; g[1] = off_b; g[2] = off_a; g[3] = diag_a;
+    }
 }
 
 // tail[0..7]: rows 3 and 4 of E^-1 (forward.f90:370-377) times T = diag(1, i, w, i w), expressed in
@@ -171,8 +198,8 @@ __device__ __forceinline__ void stage_layer_coef(double *c, const LayerBasis &u,
 __device__ __forceinline__ void stage_halfspace(double *g, double alpha, double beta, double rho, double p,
                                                 const LayerBasis *last)
 {
-    const double eta = sqrt(1.0 / (beta * beta) - p * p);
-    const double xi = sqrt(1.0 / (alpha * alpha) - p * p);
+    const double eta = vertical_slowness(beta, p);
+    const double xi = vertical_slowness(alpha, p);
     const double bp = 1.0 - 2.0 * beta * beta * p * p;
     double e[8];
     e[0] = beta * beta * p / alpha;        // re: x1
@@ -543,33 +570,55 @@ __device__ __forceinline__ bool stage_walker(const SpectraParams &P, int ib, int
     ilay0 = sea ? 1 : 0;
     const double omg_max = (double)(P.t.nh - 1) * P.t.domg;
     bool big = false;
-    for (int l = threadIdx.x; l < nl - 1; l += blockDim.x)
-        if (l >= ilay0) {
+    // four independent parts per layer (stage_interface) + the walker constants: one part per wave
+    // when the block has four, so the block waits for the longest part, not for their sum
+    const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool solid = nl - 1 > ilay0;          // at least one solid layer above the half-space
+    for (int part = wave; part < 4; part += nw) {
+        const double *V = (part == 1 || part == 2) ? L : L + pad;   // parts 1, 2: alpha (xi); 0, 3: beta (eta)
+        for (int l = lane; l < nl - 1; l += 64) {
+            if (l < ilay0) continue;
             double *c = coef + l * NCOEF;
-            const LayerBasis u = layer_basis(L[l], L[pad + l], L[2 * pad + l], p);
-            if (l + 1 < nl - 1) {
-                const LayerBasis w = layer_basis(L[l + 1], L[pad + l + 1], L[2 * pad + l + 1], p);
-                stage_layer_coef(c, u, L[3 * pad + l], P.t.domg, &w);
+            if (part < 2) {
+                const LayerHalf u = layer_half(V[l], L[pad + l], L[2 * pad + l], p);
+                if (l + 1 < nl - 1) {
+                    const LayerHalf w = layer_half(V[l + 1], L[pad + l + 1], L[2 * pad + l + 1], p);
+                    stage_interface(c + 3 + 4 * part, part, u, &w);
+                } else {
+                    stage_interface(c + 3 + 4 * part, part, u, nullptr);
+                }
             } else {
-                stage_layer_coef(c, u, L[3 * pad + l], P.t.domg, nullptr);
+                const double hl = L[3 * pad + l];
+                const double slow = vertical_slowness(V[l], p);
+                if (part == 2) {
+                    c[0] = slow;
+                    c[2] = hl;
+                    stage_phase(c + 11, c + 15, P.t.domg, slow, hl);
+                } else {
+                    c[1] = slow;
+                    c[19] = 0.0;
+                    stage_phase(c + 13, c + 17, P.t.domg, slow, hl);
+                }
+                big |= fabs(omg_max * slow * hl) >= SINCOS_CW_LIMIT;
             }
-            big |= fabs(omg_max * fmax(c[0], c[1]) * c[2]) >= SINCOS_CW_LIMIT;
         }
-    if (threadIdx.x == 0) {
-        const bool solid = nl - 1 > ilay0;      // at least one solid layer above the half-space
-        LayerBasis top, last;
-        if (solid) {
-            top = layer_basis(L[ilay0], L[pad + ilay0], L[2 * pad + ilay0], p);
-            last = layer_basis(L[nl - 2], L[pad + nl - 2], L[2 * pad + nl - 2], p);
+        // walker constants, by the last lane of the waves with the lighter parts
+        if (part == 2 && lane == 63) {
+            LayerBasis last;
+            if (solid) last = layer_basis(L[nl - 2], L[pad + nl - 2], L[2 * pad + nl - 2], p);
+            stage_halfspace(tail, L[nl - 1], L[pad + nl - 1], L[2 * pad + nl - 1], p, solid ? &last : nullptr);
         }
-        stage_halfspace(tail, L[nl - 1], L[pad + nl - 1], L[2 * pad + nl - 1], p, solid ? &last : nullptr);
-        stage_start(tail + 11, solid ? &top : nullptr);
-        if (sea) {
-            const double xiw = sqrt(1.0 / (L[0] * L[0]) - p * p);   // forward.f90:431
-            tail[8] = xiw;
-            tail[9] = L[3 * pad];
-            tail[10] = L[2 * pad] / xiw;
-            big |= fabs(omg_max * xiw * L[3 * pad]) >= SINCOS_CW_LIMIT;
+        if (part == 3 && lane == 63) {
+            LayerBasis top;
+            if (solid) top = layer_basis(L[ilay0], L[pad + ilay0], L[2 * pad + ilay0], p);
+            stage_start(tail + 11, solid ? &top : nullptr);
+            if (sea) {
+                const double xiw = vertical_slowness(L[0], p);   // forward.f90:431
+                tail[8] = xiw;
+                tail[9] = L[3 * pad];
+                tail[10] = L[2 * pad] / xiw;
+                big |= fabs(omg_max * xiw * L[3 * pad]) >= SINCOS_CW_LIMIT;
+            }
         }
     }
     return __syncthreads_or(big);
