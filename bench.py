@@ -238,12 +238,20 @@ def main():
         h_logl = torch.empty(nb, dtype=torch.float64).pin_memory()
         swap = PTSwap(eng, nb, w["temps"], dev, seed=1234, t_high=15.0, mode=args.swap) if w["temps"] > 1 else None
 
+        # logL read-back: without a swap step the kernel writes logL straight into the pinned
+        # (device-mapped) host buffer -- no copy kernel after the evaluation; with a swap step logL
+        # is consumed on the device first and copied afterwards
+        zero_copy = swap is None and not os.environ.get("RFGPU_BENCH_COPY")
+
         def step():
             with torch.cuda.stream(stream):
-                eng.eval_batch_device(d_ids, d_nlay, d_layers, d_sig, d_logl, stream=stream)
-                if swap is not None:
-                    swap.step(d_logl, stream)
-                h_logl.copy_(d_logl, non_blocking=True)
+                if zero_copy:
+                    eng.eval_batch_device(d_ids, d_nlay, d_layers, d_sig, h_logl, stream=stream)
+                else:
+                    eng.eval_batch_device(d_ids, d_nlay, d_layers, d_sig, d_logl, stream=stream)
+                    if swap is not None:
+                        swap.step(d_logl, stream)
+                    h_logl.copy_(d_logl, non_blocking=True)
 
         def barrier():
             if world > 1:
@@ -282,6 +290,7 @@ def main():
             "config": {"workload": w["desc"], "walkers_per_gpu": nb, "nfft": p.nfft, "ntrc": p.ntrc,
                        "nsmp": p.nsmp, "k_max": p.k_max, "mean_nlay": float(nlay.mean()),
                        "max_nlay": int(nlay.max()), "deconv_mode": p.deconv_mode, "sdep": p.sdep,
+                       "logl_readback": "kernel writes pinned host memory" if zero_copy else "device buffer + async copy",
                        "temperatures": w["temps"], "parallelism": f"walkers sharded x{world}",
                        "pt_swap": (f"{args.swap}, {swap.k} pair(s)/step" if swap is not None else "none")},
             "roofline": {
