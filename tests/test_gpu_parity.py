@@ -48,9 +48,10 @@ CASES = [
     ("land_S_decon", 256, 1, 0.0, (0.10,), (-1,), -1.0, (4,)),
     ("land_PPS", 512, 0, 0.0, (0.06, 0.08, 0.10), (1, 1, -1), -1.0, (3, 15, 30)),
     ("land_common", 256, 0, 0.0, (0.06, 0.06), (1, 1), 0.0, (3, 7)),
-    ("ocean_P", 256, 0, 2.0, (0.06, 0.08), (1, 1), 0.0, (3, 5, 11)),
+    # nlay 2 under an ocean = water directly on the half-space: no solid layer, the product is the identity
+    ("ocean_P", 256, 0, 2.0, (0.06, 0.08), (1, 1), 0.0, (2, 3, 5, 11)),
     ("ocean_PS_decon", 256, 1, 2.0, (0.06, 0.10), (1, -1), -1.0, (4, 8)),
-    ("ocean_S", 256, 0, 2.0, (0.10,), (-1,), -2.0, (5,)),
+    ("ocean_S", 256, 0, 2.0, (0.10,), (-1,), -2.0, (2, 5)),
     ("big_fft", 4096, 0, 0.0, (0.06,), (1,), 0.0, (15,)),
 ]
 
