@@ -1208,13 +1208,30 @@ struct LdsSink {
     FftPlan plan;
     int log2n, n, nh, ipha;
     bool decon;
+    // n = 4096 with three radix-16 passes (every BASELINE shape): a lane's bins are k = lane + 64 it,
+    // so the base-16 digit reversal splits into a per-lane constant and a term of the iteration:
+    // pos(k) = (lane & 15) 256 + (lane >> 4) 16  +  64 (it & 3) + (it >> 2)
+    bool r16x3;
+    int lane_pos, lane_pos_m;   // of the lane and of its mirror lane (64 - lane) & 63
+    __device__ __forceinline__ int pos_of(int k) const
+    {
+        if (!r16x3) return fft_pad(fft_input_pos(plan, log2n, k));
+        const int it = k >> 6;
+        return fft_pad(lane_pos + ((it & 3) << 6) + (it >> 2));
+    }
+    __device__ __forceinline__ int pos_of_mirror(int k) const   // position of bin n - k, 0 < k < n / 2
+    {
+        if (!r16x3) return fft_pad(fft_input_pos(plan, log2n, n - k));
+        const int it = (k & 63) ? 63 - (k >> 6) : 64 - (k >> 6);
+        return fft_pad(lane_pos_m + ((it & 3) << 6) + (it >> 2));
+    }
     __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz) const
     {
         if (k >= nh) return;
         const double2 fr = make_double2(ur.x, -ur.y);    // freq_r = conjg(ur)   forward.f90:145
         const double2 fv = make_double2(-uz.x, uz.y);    // freq_v = -conjg(uz)  forward.f90:146
         const double2 num = ipha == 1 ? fr : fv;         // forward.f90:148-163
-        const int pk = fft_pad(fft_input_pos(plan, log2n, k));
+        const int pk = pos_of(k);
         const bool self = (k == 0 || 2 * k == n);
         if (decon) {
             // keep numerator and denominator; the water level needs the max over all bins first
@@ -1223,7 +1240,7 @@ struct LdsSink {
             if (self)
                 side[k == 0 ? 0 : 1] = den;
             else
-                a[fft_pad(fft_input_pos(plan, log2n, n - k))] = den;
+                a[pos_of_mirror(k)] = den;
         } else {
             const double fk = flt[k];
             const double2 R = make_double2(num.x * fk, num.y * fk);   // forward.f90:168
@@ -1232,7 +1249,7 @@ struct LdsSink {
                 a[pk] = make_double2(R.x, V.x);          // c2r ignores Im of the DC and Nyquist bins
             } else {
                 a[pk] = make_double2(R.x - V.y, R.y + V.x);
-                a[fft_pad(fft_input_pos(plan, log2n, n - k))] = make_double2(R.x + V.y, V.x - R.y);
+                a[pos_of_mirror(k)] = make_double2(R.x + V.y, V.x - R.y);
             }
         }
     }
@@ -1316,8 +1333,12 @@ __global__ __launch_bounds__(TRACE_THREADS) void fused_kernel(FusedParams F)
         a[fft_pad(fft_input_pos(P.plan, P.log2n, k))] = make_double2(0.0, 0.0);
         if (k != 0 && 2 * k != n) a[fft_pad(fft_input_pos(P.plan, P.log2n, n - k))] = make_double2(0.0, 0.0);
     }
-    const LdsSink sink{a, side, t.flt + (size_t)itrc * nh, P.plan, P.log2n, n, nh_eff, ipha, decon};
     const int wave = tid >> 6, lane = tid & 63;
+    const bool r16x3 = P.log2n == 12 && P.plan.npass == 3 && P.plan.radix_log2[0] == 4 && P.plan.radix_log2[1] == 4 &&
+                       P.plan.radix_log2[2] == 4;
+    const int lane_m = (64 - lane) & 63;
+    const LdsSink sink{a, side, t.flt + (size_t)itrc * nh, P.plan, P.log2n, n, nh_eff, ipha, decon, r16x3,
+                       ((lane & 15) << 8) + ((lane >> 4) << 4), ((lane_m & 15) << 8) + ((lane_m >> 4) << 4)};
     if (big || sea != (NCOL == 3)) {
         if (sea)
             spectra_body<0, 3, false>(sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
