@@ -7,7 +7,7 @@
 namespace rfgpu {
 
 // doubles of per-layer coefficients staged in LDS (see stage_layer_coef)
-constexpr int NCOEF = 20;
+constexpr int NCOEF = 24;
 
 struct DeviceTables {
     int nfft, nh, ntrc, nfwd, nsmp, deconv_mode, ray_common;

@@ -103,7 +103,9 @@ __device__ __noinline__ double arrival_sum(int n, const double *terms)
 //     11,12 phi_xi  = domg*xi*h  as a double-double (hi, lo)   } phase per bin of the layer and
 //     13,14 phi_eta = domg*eta*h as a double-double            } cos/sin of 64 bins of phase:
 //     15,16 cos, sin(64 phi_xi)   17,18 cos, sin(64 phi_eta)   } the chained-phase path (below)
-//     19 pad
+//     19,20 sin, cos of the layer's P phase at the Nyquist bin   } that bin has an iteration of its own
+//     21,22 sin, cos of the layer's S phase at the Nyquist bin   } (one active lane): spectra_iter_nyquist
+//     23 pad
 //   tail[0..7]   rows 3,4 of E^-1 T of the half-space in the last solid layer's eigen-coordinates
 //   tail[8..10]  water layer: xi_w, h_w, rho_w / xi_w
 //   tail[11..16] unit columns 1, 2, 4 in the top solid layer's eigen-coordinates (stage_start)
@@ -469,6 +471,26 @@ __device__ __forceinline__ void spectra_iter_direct(const SpectraParams &P, cons
     sink(k, ur, uz);
 }
 
+// The iteration that holds the Nyquist bin has one active lane (nfft / 2 is a multiple of 64): a whole
+// wave walks the layer stack for it, so its sines and cosines come from the staged constants
+// (same function, same argument as spectra_iter_direct would use: identical values).
+template <int NCOL, class Sink>
+__device__ __forceinline__ void spectra_iter_nyquist(const SpectraParams &P, const double *coef, const double *tail,
+                                                     int nl, int ilay0, int ipha, const Sink &sink, int it, int lane)
+{
+    const int k = it * 64 + lane;
+    const double omg = (double)k * P.t.domg;
+    ColState<NCOL> st;
+    init_cols<NCOL>(st, tail);
+    for (int l = ilay0; l < nl - 1; ++l) {
+        const double *c = coef + l * NCOEF;
+        apply_layer_trig<NCOL>(st, c, c[19], c[20], c[21], c[22]);
+    }
+    double2 ur, uz;
+    finish_bin<NCOL, true>(st, tail, omg, ipha, ur, uz);
+    sink(k, ur, uz);
+}
+
 // eps = arg - k * phi, phi = (hi, lo): the rounding perturbation of the reference's
 // argument (omega*xi)*z relative to the exact multiple k*phi.  (arg - k*phi_hi) is exact
 // (Sterbenz), the product k*phi is error-free through fma.
@@ -559,8 +581,12 @@ __device__ __forceinline__ void spectra_body(const SpectraParams &P, const doubl
     }
     // leftover iterations: spread from the last split downwards (the chunk loop loads
     // the low splits first)
-    for (int it = it_direct0 + (P.nsplit - 1 - split); it < niter; it += P.nsplit)
-        spectra_iter_direct<NCOL, FAST>(P, coef, tail, nl, ilay0, ipha, sink, it, lane);
+    for (int it = it_direct0 + (P.nsplit - 1 - split); it < niter; it += P.nsplit) {
+        if (FAST && it > 0 && it * 128 == P.t.nfft)
+            spectra_iter_nyquist<NCOL>(P, coef, tail, nl, ilay0, ipha, sink, it, lane);
+        else
+            spectra_iter_direct<NCOL, FAST>(P, coef, tail, nl, ilay0, ipha, sink, it, lane);
+    }
 }
 
 // Stages the layer stack of (walker ib, forward-trace f) into LDS (all threads of the
@@ -576,6 +602,7 @@ __device__ __forceinline__ bool stage_walker(const SpectraParams &P, int ib, int
     sea = L[pad] < 0.0;          // beta(1) < 0  (forward.f90:229)
     ilay0 = sea ? 1 : 0;
     const double omg_max = (double)(P.t.nh - 1) * P.t.domg;
+    const double omg_nyq = (double)(P.t.nfft / 2) * P.t.domg;
     bool big = false;
     // four independent parts per layer (stage_interface) + the walker constants: one part per wave
     // when the block has four, so the block waits for the longest part, not for their sum
@@ -597,14 +624,21 @@ __device__ __forceinline__ bool stage_walker(const SpectraParams &P, int ib, int
             } else {
                 const double hl = L[3 * pad + l];
                 const double slow = vertical_slowness(V[l], p);
+                // phases of the Nyquist bin, argument formed like the reference (forward.f90:397-400)
+                double sn, cn;
+                sincos_cw((omg_nyq * slow) * hl, sn, cn);
                 if (part == 2) {
                     c[0] = slow;
                     c[2] = hl;
                     stage_phase(c + 11, c + 15, P.t.domg, slow, hl);
+                    c[19] = sn;
+                    c[20] = cn;
                 } else {
                     c[1] = slow;
-                    c[19] = 0.0;
                     stage_phase(c + 13, c + 17, P.t.domg, slow, hl);
+                    c[21] = sn;
+                    c[22] = cn;
+                    c[23] = 0.0;
                 }
                 big |= fabs(omg_max * slow * hl) >= SINCOS_CW_LIMIT;
             }
