@@ -513,32 +513,39 @@ template <int BK, int NCOL, class Sink>
 __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, const double *coef, const double *tail,
                                                     int nl, int ilay0, int ipha, const Sink &sink, int it0, int lane)
 {
+    // long chains keep only the first bin's index and rebuild k, omega of the others where they are
+    // used (2 instructions per bin and layer; the values are the same doubles) to stay within the
+    // register budget of two waves per SIMD
+    constexpr bool LEAN = BK >= 8;
     ColState<NCOL> st[BK];
-    double omg[BK], kd[BK];
-    int kbin[BK];
+    double omg[LEAN ? 1 : BK], kd[LEAN ? 1 : BK];
+    const int k0 = it0 * 64 + lane;
+    const double kd0 = (double)k0;
+    const double omg0 = k0 == 0 ? P.t.omg_dc : kd0 * P.t.domg;
 #pragma unroll
     for (int m = 0; m < BK; ++m) {
-        kbin[m] = (it0 + m) * 64 + lane;
-        kd[m] = (double)kbin[m];
-        omg[m] = kbin[m] == 0 ? P.t.omg_dc : kd[m] * P.t.domg;
+        if (!LEAN) {
+            kd[m] = (double)(k0 + 64 * m);
+            omg[m] = (k0 + 64 * m) == 0 ? P.t.omg_dc : kd[m] * P.t.domg;
+        }
         init_cols<NCOL>(st[m], tail);
     }
-    const bool dc = kbin[0] == 0;
-#pragma unroll 2
+    const bool dc = k0 == 0;
+#pragma unroll BK >= 8 ? 1 : 2
     for (int l = ilay0; l < nl - 1; ++l) {
         const double *c = coef + l * NCOEF;
         const double xi = c[0], eta = c[1], h = c[2];
         const double Cx = c[15], Sx = c[16], Ce = c[17], Se = c[18];
         double sx, cx, se, ce;
         // first bin: direct evaluation of the reference's argument
-        const double ax0 = (omg[0] * xi) * h, ae0 = (omg[0] * eta) * h;
+        const double ax0 = (omg0 * xi) * h, ae0 = (omg0 * eta) * h;
         sincos_cw(ax0, sx, cx);
         sincos_cw(ae0, se, ce);
         apply_layer_trig<NCOL>(st[0], c, sx, cx, se, ce);
         // exact-angle start of the chain: remove the first bin's own perturbation.  The DC
         // bin's omega is the literal 1e-5 (not 0 * domg): its chain starts from angle 0.
-        const double ex0 = phase_eps(ax0, kd[0], c[11], c[12]);
-        const double ee0 = phase_eps(ae0, kd[0], c[13], c[14]);
+        const double ex0 = phase_eps(ax0, kd0, c[11], c[12]);
+        const double ee0 = phase_eps(ae0, kd0, c[13], c[14]);
         double cEx = dc ? 1.0 : fma(sx, ex0, cx);
         double sEx = dc ? 0.0 : fma(-cx, ex0, sx);
         double cEe = dc ? 1.0 : fma(se, ee0, ce);
@@ -550,17 +557,21 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
             sEx = fma(sEx, Cx, tx * Sx);
             cEe = fma(te, Ce, -(sEe * Se));
             sEe = fma(sEe, Ce, te * Se);
-            const double ex = phase_eps((omg[m] * xi) * h, kd[m], c[11], c[12]);
-            const double ee = phase_eps((omg[m] * eta) * h, kd[m], c[13], c[14]);
+            const double kdm = LEAN ? kd0 + (double)(64 * m) : kd[m];     // exact: small integers
+            const double omgm = LEAN ? kdm * P.t.domg : omg[m];
+            const double ex = phase_eps((omgm * xi) * h, kdm, c[11], c[12]);
+            const double ee = phase_eps((omgm * eta) * h, kdm, c[13], c[14]);
             apply_layer_trig<NCOL>(st[m], c, fma(cEx, ex, sEx), fma(-sEx, ex, cEx), fma(cEe, ee, sEe),
                                    fma(-sEe, ee, cEe));
         }
     }
 #pragma unroll
     for (int m = 0; m < BK; ++m) {
+        const int km = k0 + 64 * m;
+        const double omgm = km == 0 ? P.t.omg_dc : (double)km * P.t.domg;
         double2 ur, uz;
-        finish_bin<NCOL, true>(st[m], tail, omg[m], ipha, ur, uz);
-        sink(kbin[m], ur, uz);
+        finish_bin<NCOL, true>(st[m], tail, omgm, ipha, ur, uz);
+        sink(km, ur, uz);
     }
 }
 
@@ -1303,7 +1314,7 @@ size_t fused_lds_bytes(int nfft, int nsmp, int nlay_pad)
 }
 
 template <int BK, int NCOL>
-__global__ __launch_bounds__(TRACE_THREADS) void fused_kernel(FusedParams F)
+__global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
 {
     extern __shared__ double2 lds2[];
     const TraceParams &P = F.tp;
@@ -1426,6 +1437,7 @@ static void launch_fused_ncol(int chain, dim3 grid, size_t lds, hipStream_t s, c
     case 2: hipLaunchKernelGGL((fused_kernel<2, NCOL>), grid, block, lds, s, F); break;
     case 3: hipLaunchKernelGGL((fused_kernel<3, NCOL>), grid, block, lds, s, F); break;
     case 4: hipLaunchKernelGGL((fused_kernel<4, NCOL>), grid, block, lds, s, F); break;
+    case 8: hipLaunchKernelGGL((fused_kernel<8, NCOL>), grid, block, lds, s, F); break;
     default: hipLaunchKernelGGL((fused_kernel<0, NCOL>), grid, block, lds, s, F); break;
     }
 }
@@ -1440,17 +1452,15 @@ void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &
     F.tp.plan = make_fft_plan(F.tp.log2n);
     const size_t lds = fused_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
     static size_t lds_set[2][5] = {};
-    const int ci = chain == 2 ? 1 : chain == 3 ? 2 : chain == 4 ? 3 : 0;
+    const int ci = chain == 2 ? 1 : chain == 3 ? 2 : chain == 4 ? 3 : chain == 8 ? 4 : 0;
     const int ni = t.sdep > 0.0 ? 1 : 0;
     if (lds > lds_set[ni][ci]) {   // dynamic LDS beyond 64 KiB must be opted into, per kernel
-        const void *fn = nullptr;
-        if (ni == 0)
-            fn = ci == 1 ? (const void *)fused_kernel<2, 2> : ci == 2 ? (const void *)fused_kernel<3, 2>
-                 : ci == 3 ? (const void *)fused_kernel<4, 2> : (const void *)fused_kernel<0, 2>;
-        else
-            fn = ci == 1 ? (const void *)fused_kernel<2, 3> : ci == 2 ? (const void *)fused_kernel<3, 3>
-                 : ci == 3 ? (const void *)fused_kernel<4, 3> : (const void *)fused_kernel<0, 3>;
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        static const void *const fns[2][5] = {
+            {(const void *)fused_kernel<0, 2>, (const void *)fused_kernel<2, 2>, (const void *)fused_kernel<3, 2>,
+             (const void *)fused_kernel<4, 2>, (const void *)fused_kernel<8, 2>},
+            {(const void *)fused_kernel<0, 3>, (const void *)fused_kernel<2, 3>, (const void *)fused_kernel<3, 3>,
+             (const void *)fused_kernel<4, 3>, (const void *)fused_kernel<8, 3>}};
+        (void)hipFuncSetAttribute(fns[ni][ci], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set[ni][ci] = lds;
     }
     const dim3 grid((unsigned)(b.nb * t.ntrc));
