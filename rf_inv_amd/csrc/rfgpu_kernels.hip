@@ -962,6 +962,27 @@ __device__ __forceinline__ void fft_pass(double2 *a, int log2n, int stride_log2,
     }
 }
 
+// The last pass of an n = 16 * THREADS transform (one radix-16 butterfly per thread, stride n / 16)
+// with its 16 outputs left in registers: v[k] is sample tid + (bitrev4(k) << (log2n - 4)).
+template <int THREADS>
+__device__ __forceinline__ void fft_last_pass16_regs(const double2 *a, int log2n, const double2 *__restrict__ tw,
+                                                     int tid, double2 (&v)[16])
+{
+    const int n = 1 << log2n, sl = log2n - 4;
+    double2 w[16];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) w[k] = tw[(tid * k) & ((n >> 1) - 1)];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = a[fft_pad(tid + (k << sl))];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const bool neg = (tid * k) >= (n >> 1);   // exp(i(t + pi)) = -exp(it)
+        const double2 wk = neg ? make_double2(-w[k].x, -w[k].y) : w[k];
+        v[k] = cmul(v[k], wk);
+    }
+    dft_regs<4>(v);
+}
+
 template <int THREADS>
 __device__ __forceinline__ void fft_inverse_lds(double2 *a, const FftPlan &pl, int log2n,
                                                 const double2 *__restrict__ tw, int tid)
@@ -1072,6 +1093,45 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
     const DeviceTables &t = P.t;
     const int n = t.nfft, nsmp = t.nsmp;
     if (P.ablate == 1) return;
+    double *__restrict__ dst =
+        P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
+    const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
+    if (n == 16 * TRACE_THREADS && P.plan.radix_log2[P.plan.npass - 1] == 4) {
+        // nfft 4096: the last radix-16 pass has exactly one butterfly per thread; its outputs stay in
+        // registers for the vertical maximum, the shift and the store -- one LDS write pass, two LDS
+        // read passes and a barrier less than the general path below.  Same values, same operations.
+        int stride_log2 = 0;
+        for (int p = 0; p + 1 < P.plan.npass; ++p) {
+            fft_pass<4, TRACE_THREADS>(a, P.log2n, stride_log2, t.twiddle, tid);   // log2n 12: all radix 16
+            stride_log2 += 4;
+            __syncthreads();
+        }
+        double2 v[16];
+        fft_last_pass16_regs<TRACE_THREADS>(a, P.log2n, t.twiddle, tid, v);
+        if (P.ablate == 2) return;
+        double fac = 1.0;
+        if (!decon) {
+            double m = -HUGE_VAL;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) m = fmax(m, v[k].y);
+            fac = block_max(m, red);                                     // maxval(rx) forward.f90:201
+        }
+        const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j = tid + (bitrev_small<4>(k) << (P.log2n - 4)) + 1;   // 1-based sample of rx
+            // invert the reference's maps rft(i) = rx(mod(n - npre + i, n)) (forward.f90:179) and
+            // rft(i) = -rx(mod(n + npre - i + 1, n)) (:188), index 0 standing for n
+            int i = ipha == 1 ? (j + npre) % n : (n + npre + 1 - j) % n;
+            if (i < 0) i += n;
+            if (i == 0) i = n;
+            double val = ipha == 1 ? v[k].x : -v[k].x;
+            if (!decon) val = val / fac;                                 // forward.f90:202
+            dst[i - 1] = val;
+            if (i <= nsmp) mis[i - 1] = val - obs[i - 1];                // likelihood.f90:88
+        }
+        __syncthreads();
+    } else {
     // ---- in-place mixed-radix inverse FFT, sign +, unnormalised (FFTW c2r definition) ---
     fft_inverse_lds<TRACE_THREADS>(a, P.plan, P.log2n, t.twiddle, tid);
     // a[fft_pad(j)].x = rx (RF trace), .y = vertical trace
@@ -1086,9 +1146,6 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
 
     // ---- time shift (+ reverse/negate for S), normalise, store, misfit ----------
     const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
-    double *__restrict__ dst =
-        P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
-    const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
     for (int i = tid + 1; i <= n; i += TRACE_THREADS) {
         int j;
         double val;
@@ -1108,6 +1165,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
         if (i <= nsmp) mis[i - 1] = val - obs[i - 1];                // likelihood.f90:88
     }
     __syncthreads();
+    }
 
     if (P.ablate == 3) return;
     // ---- phi = (misfit . R^-1) . misfit   (likelihood.f90:92-93) -----------------
