@@ -1127,7 +1127,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
             if (i == 0) i = n;
             double val = ipha == 1 ? v[k].x : -v[k].x;
             if (!decon) val = val / fac;                                 // forward.f90:202
-            dst[i - 1] = val;
+            __builtin_nontemporal_store(val, &dst[i - 1]);   // written once, read rarely: keep it out of L2
             if (i <= nsmp) mis[i - 1] = val - obs[i - 1];                // likelihood.f90:88
         }
         __syncthreads();
