@@ -606,73 +606,82 @@ __device__ __forceinline__ void spectra_body(const SpectraParams &P, const doubl
 __device__ __forceinline__ bool stage_walker(const SpectraParams &P, int ib, int f, double *coef, double *tail,
                                              int &nl, int &ilay0, bool &sea)
 {
-    nl = P.b.nlay[ib];
     const int pad = P.b.nlay_pad;
     const double *L = P.b.layers + (size_t)ib * 4 * pad;
+    // every load below is independent of nlay (padding entries of the stack are readable): the layer
+    // values travel in the same memory round trip as the layer count
+    nl = P.b.nlay[ib];
     const double p = P.t.rayps[f];
-    sea = L[pad] < 0.0;          // beta(1) < 0  (forward.f90:229)
-    ilay0 = sea ? 1 : 0;
+    const double beta1 = L[pad];
     const double omg_max = (double)(P.t.nh - 1) * P.t.domg;
     const double omg_nyq = (double)(P.t.nfft / 2) * P.t.domg;
     bool big = false;
     // four independent parts per layer (stage_interface) + the walker constants: one part per wave
     // when the block has four, so the block waits for the longest part, not for their sum
     const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool solid = nl - 1 > ilay0;          // at least one solid layer above the half-space
     for (int part = wave; part < 4; part += nw) {
         const double *V = (part == 1 || part == 2) ? L : L + pad;   // parts 1, 2: alpha (xi); 0, 3: beta (eta)
-        for (int l = lane; l < nl - 1; l += 64) {
-            if (l < ilay0) continue;
+        for (int l = lane; l < pad - 1; l += 64) {
+            // this layer and the one below it
+            const double v0 = V[l], a0 = L[l], b0 = L[pad + l], r0 = L[2 * pad + l], h0 = L[3 * pad + l];
+            const double v1 = V[l + 1], a1 = L[l + 1], b1 = L[pad + l + 1], r1 = L[2 * pad + l + 1];
+            sea = beta1 < 0.0;       // beta(1) < 0  (forward.f90:229)
+            ilay0 = sea ? 1 : 0;
+            const bool solid = nl - 1 > ilay0;          // at least one solid layer above the half-space
             double *c = coef + l * NCOEF;
-            if (part < 2) {
-                const LayerHalf u = layer_half(V[l], L[pad + l], L[2 * pad + l], p);
-                if (l + 1 < nl - 1) {
-                    const LayerHalf w = layer_half(V[l + 1], L[pad + l + 1], L[2 * pad + l + 1], p);
-                    stage_interface(c + 3 + 4 * part, part, u, &w);
+            if (l >= ilay0 && l < nl - 1) {
+                if (part < 2) {
+                    const LayerHalf u = layer_half(v0, b0, r0, p);
+                    if (l + 1 < nl - 1) {
+                        const LayerHalf w = layer_half(v1, b1, r1, p);
+                        stage_interface(c + 3 + 4 * part, part, u, &w);
+                    } else {
+                        stage_interface(c + 3 + 4 * part, part, u, nullptr);
+                    }
                 } else {
-                    stage_interface(c + 3 + 4 * part, part, u, nullptr);
+                    const double slow = vertical_slowness(v0, p);
+                    // phases of the Nyquist bin, argument formed like the reference (forward.f90:397-400)
+                    double sn, cn;
+                    sincos_cw((omg_nyq * slow) * h0, sn, cn);
+                    if (part == 2) {
+                        c[0] = slow;
+                        c[2] = h0;
+                        stage_phase(c + 11, c + 15, P.t.domg, slow, h0);
+                        c[19] = sn;
+                        c[20] = cn;
+                    } else {
+                        c[1] = slow;
+                        stage_phase(c + 13, c + 17, P.t.domg, slow, h0);
+                        c[21] = sn;
+                        c[22] = cn;
+                        c[23] = 0.0;
+                    }
+                    big |= fabs(omg_max * slow * h0) >= SINCOS_CW_LIMIT;
                 }
-            } else {
-                const double hl = L[3 * pad + l];
-                const double slow = vertical_slowness(V[l], p);
-                // phases of the Nyquist bin, argument formed like the reference (forward.f90:397-400)
-                double sn, cn;
-                sincos_cw((omg_nyq * slow) * hl, sn, cn);
-                if (part == 2) {
-                    c[0] = slow;
-                    c[2] = hl;
-                    stage_phase(c + 11, c + 15, P.t.domg, slow, hl);
-                    c[19] = sn;
-                    c[20] = cn;
-                } else {
-                    c[1] = slow;
-                    stage_phase(c + 13, c + 17, P.t.domg, slow, hl);
-                    c[21] = sn;
-                    c[22] = cn;
-                    c[23] = 0.0;
-                }
-                big |= fabs(omg_max * slow * hl) >= SINCOS_CW_LIMIT;
             }
-        }
-        // walker constants, by the last lane of the waves with the lighter parts
-        if (part == 2 && lane == 63) {
-            LayerBasis last;
-            if (solid) last = layer_basis(L[nl - 2], L[pad + nl - 2], L[2 * pad + nl - 2], p);
-            stage_halfspace(tail, L[nl - 1], L[pad + nl - 1], L[2 * pad + nl - 1], p, solid ? &last : nullptr);
-        }
-        if (part == 3 && lane == 63) {
-            LayerBasis top;
-            if (solid) top = layer_basis(L[ilay0], L[pad + ilay0], L[2 * pad + ilay0], p);
-            stage_start(tail + 11, solid ? &top : nullptr);
-            if (sea) {
-                const double xiw = vertical_slowness(L[0], p);   // forward.f90:431
+            // walker constants, by the lanes of the lighter parts that already hold the layers involved
+            if (part == 2 && l == nl - 2) {
+                // half-space = layer l + 1; the last solid layer (if any) = layer l
+                LayerBasis last;
+                if (solid) last = layer_basis(a0, b0, r0, p);
+                stage_halfspace(tail, a1, b1, r1, p, solid ? &last : nullptr);
+            }
+            if (part == 3 && l == (solid ? ilay0 : 0)) {
+                LayerBasis top;
+                if (solid) top = layer_basis(a0, b0, r0, p);
+                stage_start(tail + 11, solid ? &top : nullptr);
+            }
+            if (part == 3 && l == 0 && sea) {
+                const double xiw = vertical_slowness(a0, p);   // forward.f90:431
                 tail[8] = xiw;
-                tail[9] = L[3 * pad];
-                tail[10] = L[2 * pad] / xiw;
-                big |= fabs(omg_max * xiw * L[3 * pad]) >= SINCOS_CW_LIMIT;
+                tail[9] = h0;
+                tail[10] = r0 / xiw;
+                big |= fabs(omg_max * xiw * h0) >= SINCOS_CW_LIMIT;
             }
         }
     }
+    sea = beta1 < 0.0;
+    ilay0 = sea ? 1 : 0;
     return __syncthreads_or(big);
 }
 
