@@ -23,7 +23,7 @@
 namespace rfgpu {
 
 // ---------------------------------------------------------------------------
-// small complex helpers (same operation order as the oracle's c_mul / c_div)
+// small complex helpers (same operation order as the oracle's c_mul)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ double2 cmul(double2 a, double2 b)
 {
@@ -32,23 +32,13 @@ __device__ __forceinline__ double2 cmul(double2 a, double2 b)
 __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ double2 cneg(double2 a) { return make_double2(-a.x, -a.y); }
-// Smith's complex division, as Fortran compilers emit for complex(8) a / b
-__device__ __forceinline__ double2 cdiv(double2 a, double2 b)
-{
-    double r, d;
-    if (fabs(b.x) >= fabs(b.y)) {
-        r = b.y / b.x;
-        d = b.x + b.y * r;
-        return make_double2((a.x + a.y * r) / d, (a.y - a.x * r) / d);
-    }
-    r = b.x / b.y;
-    d = b.y + b.x * r;
-    return make_double2((a.x * r + a.y) / d, (a.y * r - a.x) / d);
-}
-
 // Two quotients over one denominator (the boundary conditions divide both displacement components
-// by the same determinant): Smith's range reduction with cdiv's branch choice and numerator forms,
-// branch-free, and one reciprocal instead of four divisions by d (<= 1.5 ulp from cdiv's quotients).
+// by the same determinant).  Fortran compilers emit Smith's range-reduced division for complex(8)
+// a / b (the oracle's c_div): |b.re| >= |b.im| ? r = b.im / b.re, d = b.re + b.im r,
+// ((a.re + a.im r) / d, (a.im - a.re r) / d) : r = b.re / b.im, d = b.im + b.re r,
+// ((a.re r + a.im) / d, (a.im r - a.re) / d).  Here: the same branch choice and numerator forms,
+// branch-free, the reduction shared by both quotients and one reciprocal instead of four divisions
+// by d (each quotient <= 1.5 ulp from Smith's).
 __device__ __forceinline__ void cdiv2(double2 a1, double2 a2, double2 b, double2 &x1, double2 &x2)
 {
     const bool sel = fabs(b.x) >= fabs(b.y);
