@@ -238,8 +238,9 @@ typedef struct rf_post_result {
     int32_t *nmod;                 /* [1]                                     */
     int32_t *nk, *nz, *nsig, *namp, *nvpz, *nvsz, *nvpvsz;
     double *vp_mean, *vs_mean, *vpvs_mean;
-    double *vp_model, *vs_model;   /* [max_models][nbin_z]; unused rows keep vs_model(1,:) = -999.9 (:419) */
-    double *all_likelihood;        /* [max_models]                            */
+    double *vp_model, *vs_model;   /* [max_models][nbin_z]: only the first min(nmod, max_models) rows    */
+    double *all_likelihood;        /* [max_models]          are written; the caller's later rows keep     */
+                                   /* what init_pt_mcmc put there (vs_model(1,:) = -999.9, :419)          */
     int64_t *amp_out_of_range;     /* [1]                                     */
 } rf_post_result;
 int rf_post_read(rf_ctx *ctx, const rf_post_result *out);

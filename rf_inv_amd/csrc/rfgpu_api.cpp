@@ -828,13 +828,8 @@ extern "C" int rf_post_reset(rf_ctx *c)
     if (!c || !c->have_post) return fail("rf_post_reset: rf_post_create has not been called");
     HIP_TRY(hipSetDevice(c->device));
     for (auto &z : c->post_zero) HIP_TRY(hipMemsetAsync(z.first, 0, z.second, c->stream));
-    if (c->post.max_models > 0) {
-        // vs_model(1,:) = -999.9d0 marks unused slots (src/pt_mcmc.f90:419, read by src/mcmc_out.f90:115)
-        std::vector<double> col((size_t)c->post.max_models, -999.9);
-        HIP_TRY(hipMemcpy2DAsync(c->pst.vs_model, sizeof(double) * c->post.nbin_z, col.data(), sizeof(double),
-                                 sizeof(double), (size_t)c->post.max_models, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));   // col goes out of scope
-    }
+    launch_post_mark_unused(c->post, c->pst, c->stream);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -959,7 +954,10 @@ extern "C" int rf_post_read(rf_ctx *c, const rf_post_result *o)
         if (!dst || !bytes) return hipSuccess;
         return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
     };
-    HIP_TRY(get(o->nmod, st.nmod, sizeof(int)));
+    int nmod = 0;
+    HIP_TRY(hipMemcpy(&nmod, st.nmod, sizeof(int), hipMemcpyDeviceToHost));
+    if (o->nmod) *o->nmod = nmod;
+    const size_t nrows = std::min((size_t)std::max(nmod, 0), nm);   // model slots in use
     HIP_TRY(get(o->nk, st.nk, sizeof(int) * q.k_max));
     HIP_TRY(get(o->nz, st.nz, sizeof(int) * nz));
     HIP_TRY(get(o->nsig, st.nsig, sizeof(int) * (size_t)q.ntrc * q.nbin_sig));
@@ -970,9 +968,9 @@ extern "C" int rf_post_read(rf_ctx *c, const rf_post_result *o)
     HIP_TRY(get(o->vp_mean, st.vp_mean, sizeof(double) * nz));
     HIP_TRY(get(o->vs_mean, st.vs_mean, sizeof(double) * nz));
     HIP_TRY(get(o->vpvs_mean, st.vpvs_mean, sizeof(double) * nz));
-    HIP_TRY(get(o->vp_model, st.vp_model, sizeof(double) * nm * nz));
-    HIP_TRY(get(o->vs_model, st.vs_model, sizeof(double) * nm * nz));
-    HIP_TRY(get(o->all_likelihood, st.all_likelihood, sizeof(double) * nm));
+    HIP_TRY(get(o->vp_model, st.vp_model, sizeof(double) * nrows * nz));
+    HIP_TRY(get(o->vs_model, st.vs_model, sizeof(double) * nrows * nz));
+    HIP_TRY(get(o->all_likelihood, st.all_likelihood, sizeof(double) * nrows));
     HIP_TRY(get(o->amp_out_of_range, st.amp_oor, sizeof(long long)));
     return 0;
 }

@@ -113,6 +113,7 @@ struct PostBatch {
 };
 void launch_post_record(const PostConfig &c, const PostState &st, const PostBatch &b, const WalkerState &w,
                         hipStream_t s);
+void launch_post_mark_unused(const PostConfig &c, const PostState &st, hipStream_t s);
 
 size_t spectra_lds_bytes(int nlay_pad);
 size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad);

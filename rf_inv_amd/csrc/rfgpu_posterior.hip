@@ -170,6 +170,20 @@ __global__ void post_finish_kernel(PostState st)
     st.nmod[0] += *st.nsel;
 }
 
+// vs_model(1, :) = -999.9 marks unused model slots (src/pt_mcmc.f90:419, read by src/mcmc_out.f90:115)
+__global__ void post_mark_unused_kernel(double *vs_model, int nbin_z, long long max_models)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < max_models) vs_model[(size_t)i * nbin_z] = -999.9;
+}
+
+void launch_post_mark_unused(const PostConfig &c, const PostState &st, hipStream_t s)
+{
+    if (c.max_models <= 0) return;
+    hipLaunchKernelGGL(post_mark_unused_kernel, dim3((unsigned)((c.max_models + 255) / 256)), dim3(256), 0, s,
+                       st.vs_model, c.nbin_z, c.max_models);
+}
+
 void launch_post_record(const PostConfig &c, const PostState &st, const PostBatch &b, const WalkerState &w,
                         hipStream_t s)
 {

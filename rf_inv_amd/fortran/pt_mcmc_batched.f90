@@ -354,7 +354,16 @@ contains
       real(c_double), allocatable, target :: t_vpm(:), t_vsm(:), t_vpvsm(:), t_vpmod(:,:), t_vsmod(:,:), t_all(:)
       integer :: nm
 
-      nm = size(all_likelihood)
+      ! how many model slots are in use (the profile arrays are sized for every chain, only the
+      ! non-tempered ones record)
+      pr%nmod = c_loc(t_nmod)
+      pr%nk = c_null_ptr;  pr%nz = c_null_ptr;  pr%nsig = c_null_ptr;  pr%namp = c_null_ptr
+      pr%nvpz = c_null_ptr;  pr%nvsz = c_null_ptr;  pr%nvpvsz = c_null_ptr
+      pr%vp_mean = c_null_ptr;  pr%vs_mean = c_null_ptr;  pr%vpvs_mean = c_null_ptr
+      pr%vp_model = c_null_ptr;  pr%vs_model = c_null_ptr;  pr%all_likelihood = c_null_ptr
+      pr%amp_out_of_range = c_null_ptr
+      call rfgpu_check(rf_post_read(rf_ctx, pr), "rf_post_read")
+      nm = max(1, min(int(t_nmod), size(all_likelihood)))
       allocate(t_nk(k_max), t_nz(nbin_z), t_nsig(nbin_sig, ntrc), t_namp(nbin_amp, nsmp, ntrc))
       allocate(t_nvpz(nbin_z, nbin_vp), t_nvsz(nbin_z, nbin_vs), t_nvpvsz(nbin_z, nbin_vpvs))
       allocate(t_vpm(nbin_z), t_vsm(nbin_z), t_vpvsm(nbin_z), t_vpmod(nbin_z, nm), t_vsmod(nbin_z, nm), t_all(nm))
@@ -368,7 +377,12 @@ contains
       nk = t_nk;  nz = t_nz;  nsig = t_nsig;  namp = t_namp
       nvpz = t_nvpz;  nvsz = t_nvsz;  nvpvsz = t_nvpvsz
       vp_mean = t_vpm;  vs_mean = t_vsm;  vpvs_mean = t_vpvsm
-      vp_model = t_vpmod;  vs_model = t_vsmod;  all_likelihood = t_all
+      if (t_nmod > 0) then
+         nm = min(int(t_nmod), size(all_likelihood))
+         vp_model(:, 1:nm) = t_vpmod(:, 1:nm)
+         vs_model(:, 1:nm) = t_vsmod(:, 1:nm)
+         all_likelihood(1:nm) = t_all(1:nm)
+      end if
       if (t_oor > 0) write(0,*) "Warning: RF amp. out of range (", t_oor, " samples)"
     end subroutine fetch_device_posterior
 

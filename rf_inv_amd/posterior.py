@@ -116,6 +116,8 @@ class Posterior:
             vs_model=np.zeros((nm if with_models else 0, p.nbin_z)),
             all_likelihood=np.zeros(nm if with_models else 0))
         keep = with_models and nm > 0
+        if keep:
+            r.vs_model[:, 0] = -999.9        # unused slots as init_pt_mcmc leaves them (src/pt_mcmc.f90:419)
         out = _lib.RFPostResult(
             C.pointer(nmod), _iptr(r.nk), _iptr(r.nz), _iptr(r.nsig), _iptr(r.namp), _iptr(r.nvpz), _iptr(r.nvsz),
             _iptr(r.nvpvsz), _dptr(r.vp_mean), _dptr(r.vs_mean), _dptr(r.vpvs_mean),
