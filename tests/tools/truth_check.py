@@ -10,7 +10,7 @@ walkers three ways --
 
 and prints the distribution of |logL - truth| / |truth| for oracle and gpu, and |gpu - oracle|.
 
-    python tools/truth_check.py --workload c4 --n 24
+    python tests/tools/truth_check.py --workload c4 --n 24
 """
 import argparse
 import os
@@ -18,7 +18,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 LD, CLD = np.longdouble, np.clongdouble
 
