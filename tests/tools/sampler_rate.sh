@@ -2,7 +2,7 @@
 # End-to-end sampler rate (MCMC steps/s) of the Fortran drop-in on the GPU box:
 #   mode 0 = reference pt_control, one GPU call per chain step (per-call drop-in)
 #   mode 1 = pt_control_batched (one rf_eval_batch per iteration)
-# usage: tools/sampler_rate.sh <nchains> <niter>
+# usage: tests/tools/sampler_rate.sh <nchains> <niter>
 NCH=${1:-4096}; NIT=${2:-100}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 for mode in 0 1; do
