@@ -374,14 +374,10 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     c->fused = (c->nfwd == ntrc) && fused_lds_bytes(n, nsmp, cfg->nlay_max) <= 160 * 1024;
     const char *env = getenv("RFGPU_FUSED");
     if (env) c->fused = c->fused && atoi(env) != 0;
-    // fused kernel, land, deep stacks: chains of 8 when that gives each of the block's four waves whole
-    // chunks (nfft 4096: 4 chunks of 8 iterations + the Nyquist iteration).  The saving grows with the
-    // layer count (measured C4, <= 30 layers: +7 %; C2, <= 15 layers: +2 %) and costs 20 spilled VGPRs of
-    // loop invariants (+27 MB of scratch traffic per 1024-walker launch), so shallow contexts keep 4.
+    // fused kernel, land: chains of 8 when that gives each of the block's four waves whole chunks
+    // (nfft 4096: 4 chunks of 8 iterations + the Nyquist iteration); measured C4 +7 %, C2 +2 % over 4.
     // Ocean (3 propagated columns): chains of 3 stay within two waves per SIMD without spills.
-    if (c->fused && c->chain == 4 && cfg->sdep <= 0.0 && cfg->nlay_max >= 24 && (niter / 8) >= 4 &&
-        (niter / 8) % 4 == 0)
-        c->chain = 8;
+    if (c->fused && c->chain == 4 && cfg->sdep <= 0.0 && (niter / 8) >= 4 && (niter / 8) % 4 == 0) c->chain = 8;
     if (c->fused && c->chain == 4 && cfg->sdep > 0.0) c->chain = 3;
     env = getenv("RFGPU_CHAIN");
     if (env) c->chain = atoi(env);

@@ -527,15 +527,25 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
         const double xi = c[0], eta = c[1], h = c[2];
         const double Cx = c[15], Sx = c[16], Ce = c[17], Se = c[18];
         double sx, cx, se, ce;
+        // long chains: k and omega of the first bin are rebuilt from the bin index in every layer
+        // (the empty asm keeps the compiler from hoisting them back into registers that it would
+        // then have to spill: 4 instructions per layer against 8 scratch reloads)
+        double kd0l = kd0, omg0l = omg0;
+        if (LEAN) {
+            int kk = k0;
+            asm volatile("" : "+v"(kk));
+            kd0l = (double)kk;
+            omg0l = kk == 0 ? P.t.omg_dc : kd0l * P.t.domg;
+        }
         // first bin: direct evaluation of the reference's argument
-        const double ax0 = (omg0 * xi) * h, ae0 = (omg0 * eta) * h;
+        const double ax0 = (omg0l * xi) * h, ae0 = (omg0l * eta) * h;
         sincos_cw(ax0, sx, cx);
         sincos_cw(ae0, se, ce);
         apply_layer_trig<NCOL>(st[0], c, sx, cx, se, ce);
         // exact-angle start of the chain: remove the first bin's own perturbation.  The DC
         // bin's omega is the literal 1e-5 (not 0 * domg): its chain starts from angle 0.
-        const double ex0 = phase_eps(ax0, kd0, c[11], c[12]);
-        const double ee0 = phase_eps(ae0, kd0, c[13], c[14]);
+        const double ex0 = phase_eps(ax0, kd0l, c[11], c[12]);
+        const double ee0 = phase_eps(ae0, kd0l, c[13], c[14]);
         double cEx = dc ? 1.0 : fma(sx, ex0, cx);
         double sEx = dc ? 0.0 : fma(-cx, ex0, sx);
         double cEe = dc ? 1.0 : fma(se, ee0, ce);
@@ -547,7 +557,7 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
             sEx = fma(sEx, Cx, tx * Sx);
             cEe = fma(te, Ce, -(sEe * Se));
             sEe = fma(sEe, Ce, te * Se);
-            const double kdm = LEAN ? kd0 + (double)(64 * m) : kd[m];     // exact: small integers
+            const double kdm = LEAN ? kd0l + (double)(64 * m) : kd[m];    // exact: small integers
             const double omgm = LEAN ? kdm * P.t.domg : omg[m];
             const double ex = phase_eps((omgm * xi) * h, kdm, c[11], c[12]);
             const double ee = phase_eps((omgm * eta) * h, kdm, c[13], c[14]);
