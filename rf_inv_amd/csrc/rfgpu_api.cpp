@@ -376,9 +376,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (env) c->fused = c->fused && atoi(env) != 0;
     // fused kernel, land: chains of 8 when that gives each of the block's four waves whole chunks
     // (nfft 4096: 4 chunks of 8 iterations + the Nyquist iteration); measured C4 +7 %, C2 +2 % over 4.
-    // Ocean (3 propagated columns): chains of 3 stay within two waves per SIMD without spills.
+    // Ocean (3 propagated columns): chains of 4 (239 VGPRs; 8 would not fit two waves per SIMD).
     if (c->fused && c->chain == 4 && cfg->sdep <= 0.0 && (niter / 8) >= 4 && (niter / 8) % 4 == 0) c->chain = 8;
-    if (c->fused && c->chain == 4 && cfg->sdep > 0.0) c->chain = 3;
     env = getenv("RFGPU_CHAIN");
     if (env) c->chain = atoi(env);
     env = getenv("RFGPU_LPT");

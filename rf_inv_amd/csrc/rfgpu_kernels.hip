@@ -503,10 +503,10 @@ template <int BK, int NCOL, class Sink>
 __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, const double *coef, const double *tail,
                                                     int nl, int ilay0, int ipha, const Sink &sink, int it0, int lane)
 {
-    // long chains keep only the first bin's index and rebuild k, omega of the others where they are
-    // used (2 instructions per bin and layer; the values are the same doubles) to stay within the
-    // register budget of two waves per SIMD
-    constexpr bool LEAN = BK >= 8;
+    // long chains (and the 3-column ocean kernel) keep only the first bin's index and rebuild k, omega
+    // of the others where they are used (2 instructions per bin and layer; the values are the same
+    // doubles) to stay within the register budget of two waves per SIMD
+    constexpr bool LEAN = BK >= 8 || (NCOL == 3 && BK >= 4);
     ColState<NCOL> st[BK];
     double omg[LEAN ? 1 : BK], kd[LEAN ? 1 : BK];
     const int k0 = it0 * 64 + lane;
@@ -521,7 +521,7 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
         init_cols<NCOL>(st[m], tail);
     }
     const bool dc = k0 == 0;
-#pragma unroll BK >= 8 ? 1 : 2
+#pragma unroll LEAN ? 1 : 2
     for (int l = ilay0; l < nl - 1; ++l) {
         const double *c = coef + l * NCOEF;
         const double xi = c[0], eta = c[1], h = c[2];
