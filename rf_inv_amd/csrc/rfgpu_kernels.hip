@@ -1768,12 +1768,25 @@ __global__ __launch_bounds__(1024) void order_kernel(int nb, const int *nlay, co
         atomicAdd(&hist[key], 1);
     }
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int k = 255; k >= 0; --k) {   // descending keys first
-            start[k] = acc;
-            acc += hist[k];
+    // exclusive prefix sum over descending keys: thread t < 256 owns key 255 - t; a shuffle scan inside
+    // each of the four waves, then the totals of the waves before it
+    __shared__ int wave_tot[4];
+    int incl = 0, mine = 0;
+    if (tid < 256) {
+        mine = hist[255 - tid];
+        incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int v = __shfl_up(incl, o, 64);
+            if ((tid & 63) >= o) incl += v;
         }
+        if ((tid & 63) == 63) wave_tot[tid >> 6] = incl;
+    }
+    __syncthreads();
+    if (tid < 256) {
+        int before = 0;
+        for (int w = 0; w < (tid >> 6); ++w) before += wave_tot[w];
+        start[255 - tid] = before + incl - mine;
     }
     __syncthreads();
     for (int i = tid; i < nb; i += blockDim.x) {
