@@ -1131,8 +1131,8 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
             const int j = tid + (bitrev_small<4>(k) << (P.log2n - 4)) + 1;   // 1-based sample of rx
             // invert the reference's maps rft(i) = rx(mod(n - npre + i, n)) (forward.f90:179) and
             // rft(i) = -rx(mod(n + npre - i + 1, n)) (:188), index 0 standing for n
-            int i = ipha == 1 ? (j + npre) % n : (n + npre + 1 - j) % n;
-            if (i < 0) i += n;
+            // n is a power of two: mod(x, n) of the reference = x & (n - 1), also for negative x
+            int i = (ipha == 1 ? j + npre : n + npre + 1 - j) & (n - 1);
             if (i == 0) i = n;
             double val = ipha == 1 ? v[k].x : -v[k].x;
             if (!decon) val = val / fac;                                 // forward.f90:202
@@ -1158,14 +1158,13 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
     for (int i = tid + 1; i <= n; i += TRACE_THREADS) {
         int j;
         double val;
+        // n is a power of two: the reference's mod(x, n) = x & (n - 1), also for negative x
         if (ipha == 1) {
-            j = (n - npre + i) % n;                                  // forward.f90:179
-            if (j < 0) j += n;
+            j = (n - npre + i) & (n - 1);                            // forward.f90:179
             if (j == 0) j = n;
             val = a[fft_pad(j - 1)].x;
         } else {
-            j = (n + npre - i + 1) % n;                              // forward.f90:188
-            if (j < 0) j += n;
+            j = (n + npre - i + 1) & (n - 1);                        // forward.f90:188
             if (j == 0) j = n;
             val = -a[fft_pad(j - 1)].x;
         }
