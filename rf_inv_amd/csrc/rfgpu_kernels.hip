@@ -971,22 +971,42 @@ __device__ __forceinline__ void fft_pass(double2 *a, int log2n, int stride_log2,
     }
 }
 
-// The last pass of an n = 16 * THREADS transform (one radix-16 butterfly per thread, stride n / 16)
-// with its 16 outputs left in registers: v[k] is sample tid + (bitrev4(k) << (log2n - 4)).
-template <int THREADS>
-__device__ __forceinline__ void fft_last_pass16_regs(const double2 *a, int log2n, const double2 *__restrict__ tw,
-                                                     int tid, double2 (&v)[16])
+// n = 4096 = 16^3 with 256 threads: every pass is one radix-16 butterfly per thread.  The twiddles of
+// passes 2 and 3 depend only on the thread index, so their 30 loads (L2-resident table) are issued
+// before pass 1 and land while it runs; the last pass leaves its 16 outputs in registers:
+// v[k] is sample tid + (bitrev4(k) << 8).  Same operations as fft_pass, pass by pass.
+__device__ __forceinline__ void fft4096_regs(double2 *a, const double2 *__restrict__ tw, int tid, double2 (&v)[16])
 {
-    const int n = 1 << log2n, sl = log2n - 4;
-    double2 w[16];
+    constexpr int HALF = 2048;
+    double2 w2[16], w3[16];
+    const int jp = tid & 15;
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w[k] = tw[(tid * k) & ((n >> 1) - 1)];
+    for (int k = 1; k < 16; ++k) w2[k] = tw[((jp * k) << 4) & (HALF - 1)];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = a[fft_pad(tid + (k << sl))];
+    for (int k = 1; k < 16; ++k) w3[k] = tw[(tid * k) & (HALF - 1)];
+    fft_pass<4, TRACE_THREADS>(a, 12, 0, tw, tid);          // pass 1: stride 1, no twiddles
+    __syncthreads();
+    {                                                       // pass 2: stride 16
+        const int base = ((tid >> 4) << 8) + jp;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = a[fft_pad(base + (k << 4))];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) {
+            const bool neg = ((jp * k) << 4) >= HALF;       // exp(i(t + pi)) = -exp(it)
+            const double2 wk = neg ? make_double2(-w2[k].x, -w2[k].y) : w2[k];
+            v[k] = cmul(v[k], wk);
+        }
+        dft_regs<4>(v);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a[fft_pad(base + (bitrev_small<4>(k) << 4))] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = a[fft_pad(tid + (k << 8))];   // pass 3: stride 256
 #pragma unroll
     for (int k = 1; k < 16; ++k) {
-        const bool neg = (tid * k) >= (n >> 1);   // exp(i(t + pi)) = -exp(it)
-        const double2 wk = neg ? make_double2(-w[k].x, -w[k].y) : w[k];
+        const bool neg = (tid * k) >= HALF;
+        const double2 wk = neg ? make_double2(-w3[k].x, -w3[k].y) : w3[k];
         v[k] = cmul(v[k], wk);
     }
     dft_regs<4>(v);
@@ -1105,18 +1125,12 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
     double *__restrict__ dst =
         P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
-    if (n == 16 * TRACE_THREADS && P.plan.radix_log2[P.plan.npass - 1] == 4) {
+    if (n == 4096 && TRACE_THREADS == 256) {
         // nfft 4096: the last radix-16 pass has exactly one butterfly per thread; its outputs stay in
         // registers for the vertical maximum, the shift and the store -- one LDS write pass, two LDS
         // read passes and a barrier less than the general path below.  Same values, same operations.
-        int stride_log2 = 0;
-        for (int p = 0; p + 1 < P.plan.npass; ++p) {
-            fft_pass<4, TRACE_THREADS>(a, P.log2n, stride_log2, t.twiddle, tid);   // log2n 12: all radix 16
-            stride_log2 += 4;
-            __syncthreads();
-        }
         double2 v[16];
-        fft_last_pass16_regs<TRACE_THREADS>(a, P.log2n, t.twiddle, tid, v);
+        fft4096_regs(a, t.twiddle, tid, v);
         if (P.ablate == 2) return;
         double fac = 1.0;
         if (!decon) {
