@@ -1111,6 +1111,7 @@ struct TraceParams {
     FftPlan plan;
     int *slow_count;   // re-armed here for the next batch (the slow kernel ran earlier on the stream)
     int ablate;        // timing diagnostics only (RFGPU_ABLATE): stop the tail after phase N, results invalid
+    int defer_logl;    // multi-trace, many rounds of blocks: logL by logl_deferred_kernel after this launch
 };
 
 // Everything after Z is in LDS: inverse FFT, vertical max, shift / normalise / store,
@@ -1201,7 +1202,11 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
         // arriver reads with agent-scope loads) -- no release fence, which would write back
         // the whole L2 slice of freshly written traces (measured: 2.6x on this kernel).
         bool last = true;
-        if (t.ntrc > 1) {
+        if (P.defer_logl) {
+            // the kernel boundary orders the per-trace phi values; no atomics, no drain inside the block
+            phis[itrc] = phi;
+            last = false;
+        } else if (t.ntrc > 1) {
             __hip_atomic_store(phis + itrc, phi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             last = atomicAdd(P.w.done + ib, 1) == t.ntrc - 1;
@@ -1523,11 +1528,11 @@ static void launch_fused_ncol(int chain, dim3 grid, size_t lds, hipStream_t s, c
 }
 
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
-                  int ablate, hipStream_t s)
+                  int ablate, int defer_logl, hipStream_t s)
 {
     FusedParams F{};
     F.sp = SpectraParams{t, b, nullptr, TRACE_THREADS / 64, nullptr, slow_count, w.meta_tp, w.meta_slot, w.cur_slot};
-    F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count, ablate};
+    F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count, ablate, defer_logl};
     while ((1 << F.tp.log2n) < t.nfft) ++F.tp.log2n;
     F.tp.plan = make_fft_plan(F.tp.log2n);
     const size_t lds = fused_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
@@ -1584,7 +1589,7 @@ size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad)
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec, const WalkerState &w,
                   int *slow_count, hipStream_t s)
 {
-    TraceParams P{t, b, spec, w, 0, {}, slow_count, 0};
+    TraceParams P{t, b, spec, w, 0, {}, slow_count, 0, 0};
     while ((1 << P.log2n) < t.nfft) ++P.log2n;
     P.plan = make_fft_plan(P.log2n);
     const size_t lds = trace_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
@@ -1628,6 +1633,26 @@ __global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
     }
     P.b.logl[ib] = ll;
     P.w.prop_fwd[walker] = fwd;
+}
+
+// logL of the forward evaluations of a batch whose fused / trace kernel ran with defer_logl: the
+// quadratic forms of all traces are in the proposal half; same arithmetic as logl_from_phi.
+__global__ __launch_bounds__(256) void logl_deferred_kernel(LoglParams P)
+{
+    const int ib = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ib >= P.b.nb) return;
+    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) return;   // sigma-only / skipped items were finished in the main kernel
+    const int walker = P.b.walker_ids[ib];
+    const int slot = 1 - P.w.cur_slot[walker];
+    const double *phi = P.w.phi + ((size_t)slot * P.w.nslots + walker) * P.t.ntrc;
+    P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * P.t.ntrc, P.t.ntrc, P.t.nsmp, false);
+    P.w.prop_fwd[walker] = 1;
+}
+
+void launch_logl_deferred(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
+{
+    LoglParams P{t, b, w};
+    hipLaunchKernelGGL(logl_deferred_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P);
 }
 
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)

@@ -490,3 +490,36 @@ def test_optional_filter_support_cutoff(oracle, monkeypatch):
             assert np.abs(rft[i] - ref_rft[i]).max() <= 1e-12 * np.abs(ref_rft[i]).max()
     # the cut-off run differs from the full one by less than 1e-15 of the trace scale
     assert np.abs(out["1e-20"][1] - out[""][1]).max() <= 1e-15 * np.abs(out[""][1]).max()
+
+
+@pytest.mark.parametrize("defer", ["0", "1"])
+def test_deferred_loglikelihood_kernel(oracle, monkeypatch, defer):
+    """Multi-trace batches can form logL in a follow-up kernel instead of the cross-block hand-off inside
+    the fused kernel (RFGPU_DEFER_LOGL; chosen by batch size by default): same values, including
+    sigma-only items (fwd_flag 0) and a second evaluation after a commit."""
+    monkeypatch.setenv("RFGPU_DEFER_LOGL", defer)
+    rng = np.random.default_rng(321)
+    cfg = make_cfg(nfft=512, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], t_start=-1.0)
+    nsmp = 101
+    true = random_stack(rng, 5)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, int(n)) for n in rng.integers(2, 20, 40)]
+    nlay, layers = pack_layers(stacks, 22)
+    nb = len(stacks)
+    sig = np.column_stack([np.full(nb, 0.01), np.full(nb, 0.02), rng.uniform(0.01, 0.05, nb)])
+    ref = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb) as eng:
+        ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+        assert np.all(np.abs(ll - ref) <= logl_tol(ref)), np.abs(ll - ref).max()
+        eng.commit(np.arange(nb), np.ones(nb, dtype=np.int32))
+        # half of the walkers: sigma-only proposals on their committed traces; the others: new models
+        ff = (np.arange(nb) % 2).astype(np.int32)
+        sig2 = sig * 1.5
+        stacks2 = [random_stack(rng, int(n)) for n in rng.integers(2, 20, nb)]
+        nlay2, layers2 = pack_layers(stacks2, 22)
+        ll2 = eng.eval_batch(np.arange(nb), nlay2, layers2, sig2, fwd_flag=ff)
+        use_l = np.where(ff[:, None, None] == 1, layers2, layers)
+        use_n = np.where(ff == 1, nlay2, nlay)
+        ref2 = oracle.eval_batch(cfg, obs, r_inv, use_n, use_l, sig2, nsmp)
+        assert np.all(np.abs(ll2 - ref2) <= logl_tol(ref2)), np.abs(ll2 - ref2).max()
