@@ -197,6 +197,38 @@ def test_full_size_properties(oracle):
     assert np.all(np.abs(ll[idx] - ref) <= logl_tol(ref))
 
 
+def test_full_size_properties_three_traces(oracle, monkeypatch):
+    """BASELINE config-4 shape (nfft 4096, 3 traces P/P/S, <= 30 layers) at 1024 walkers = 3072 blocks:
+    the default launch plan here is 8-bin phase chains + logL by the follow-up kernel.  Properties that
+    do not need the oracle at full size, bit-identity with the in-kernel logL hand-off, and a sampled
+    oracle check."""
+    rng = np.random.default_rng(4)
+    cfg = make_cfg(nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1])
+    nsmp = 101
+    true = random_stack(rng, 6)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    nb = 1024
+    stacks = [random_stack(rng, int(rng.integers(2, 31))) for _ in range(nb - 1)] + [true]
+    nlay, layers = pack_layers(stacks, 32)
+    sig = np.column_stack([np.full(nb, 0.01), np.full(nb, 0.02), np.full(nb, 0.03)])
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb) as eng:
+        plan = eng.launch_plan
+        assert plan["fused"] and plan["chain"] == 8
+        ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+        perm = rng.permutation(nb)
+        ll_p = eng.eval_batch(np.arange(nb), nlay[perm], layers[perm], sig)
+        assert np.array_equal(ll_p, ll[perm])                              # walkers are independent
+        expect = -nsmp * (np.log(0.01) + np.log(0.02) + np.log(0.03))
+        assert abs(ll[-1] - expect) < 1e-6 and np.all(ll[:-1] < ll[-1])    # the true model maximises logL
+    monkeypatch.setenv("RFGPU_DEFER_LOGL", "0")
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb) as eng:
+        assert np.array_equal(eng.eval_batch(np.arange(nb), nlay, layers, sig), ll)   # same arithmetic either way
+    idx = rng.choice(nb, 12, replace=False)
+    ref = oracle.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], nsmp)
+    assert np.all(np.abs(ll[idx] - ref) <= logl_tol(ref)), np.abs(ll[idx] - ref).max()
+
+
 def test_r_inv_builtin_matches_lapack(oracle):
     from rf_inv_amd.engine import compute_r_inv
 
