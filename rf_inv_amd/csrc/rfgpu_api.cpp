@@ -355,6 +355,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->ws.done = (int *)p;
     (void)hipMemset(p, 0, sizeof(int) * c->nslots);
+    if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * ntrc * nsmp)) return cleanup(1);
+    c->ws.misfit = (double *)p;
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->d_order = (int *)p;
     c->ws.nslots = c->nslots;
@@ -495,12 +497,16 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         b.order = c->d_order;
     }
     if (c->fused) {
-        // several traces per walker and at least two rounds of blocks: the cross-block hand-off of the
-        // per-trace quadratic forms (atomics + a drain while the block still holds its CU slot, ~3 us) is
-        // replaced by a one-thread-per-walker kernel after the launch (measured C4 +3 %, C5 +3 %, C1 shape
-        // +5 %); smaller batches keep the single launch
-        const int defer = c->defer_logl >= 0 ? c->defer_logl
-                          : (c->cfg.ntrc > 1 && (long long)b.nb * c->cfg.ntrc >= 2LL * 2 * c->num_cu);
+        // several traces per walker and at least two rounds of blocks: the block ends with the trace store;
+        // misfits go to HBM (808 B per trace) and two small follow-up kernels form the quadratic forms -- the
+        // rows of R^-1 fetched once per 8 walkers instead of once per block, same arithmetic -- and logL.  That removes from
+        // every block the R^-1 read (80 KB from L2), the cross-block hand-off of phi and ~5 us of holding
+        // its CU slot (measured C4 +5 %, C5 +6 %, C1 shape +13 %).  Smaller batches (the per-call drop-in), single-trace
+        // contexts and long windows (misfits of 8 walkers must fit the follow-up kernel's LDS) keep the
+        // single launch.
+        const int defer_ok = phi_deferred_lds_bytes(c->cfg.nsmp) <= 60 * 1024;
+        const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl
+                          : (c->cfg.ntrc > 1 && (long long)b.nb * c->cfg.ntrc >= 2LL * 2 * c->num_cu));
         hipEvent_t e = prof_begin(c, 0, s);
         launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, s);   // spectra + trace (+ logL)
         if (e) (void)hipEventRecord(e, s);

@@ -40,6 +40,7 @@ struct WalkerState {
     double *meta_tp;  // [nslots * nfwd] per batch item: direct-arrival time (spectra -> trace kernel)
     int *meta_slot;   // [nslots] per batch item: destination half of the proposal
     int *done;        // [nslots] per batch item: traces finished (last one forms logL), self-resetting
+    double *misfit;   // [nslots][ntrc][nsmp] per batch item: misfits handed to the deferred phi / logL kernel
     int nslots;
 };
 
@@ -58,6 +59,7 @@ void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &
                   int ablate, int defer_logl, hipStream_t s);
 // logL of a batch launched with defer_logl (one thread per batch item, after the fused kernel)
 void launch_logl_deferred(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
+size_t phi_deferred_lds_bytes(int nsmp);
 size_t fused_lds_bytes(int nfft, int nsmp, int nlay_pad);
 void launch_phi(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s);
 struct ModelConfig {

@@ -1111,7 +1111,7 @@ struct TraceParams {
     FftPlan plan;
     int *slow_count;   // re-armed here for the next batch (the slow kernel ran earlier on the stream)
     int ablate;        // timing diagnostics only (RFGPU_ABLATE): stop the tail after phase N, results invalid
-    int defer_logl;    // multi-trace, many rounds of blocks: logL by logl_deferred_kernel after this launch
+    int defer_logl;    // misfits to HBM; quadratic form + logL by phi_logl_deferred_kernel after this launch
 };
 
 // Everything after Z is in LDS: inverse FFT, vertical max, shift / normalise / store,
@@ -1126,6 +1126,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
     double *__restrict__ dst =
         P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
+    double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
     if (n == 4096 && TRACE_THREADS == 256) {
         // nfft 4096: the last radix-16 pass has exactly one butterfly per thread; its outputs stay in
         // registers for the vertical maximum, the shift and the store -- one LDS write pass, two LDS
@@ -1152,8 +1153,15 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
             double val = ipha == 1 ? v[k].x : -v[k].x;
             if (!decon) val = val / fac;                                 // forward.f90:202
             __builtin_nontemporal_store(val, &dst[i - 1]);   // written once, read rarely: keep it out of L2
-            if (i <= nsmp) mis[i - 1] = val - obs[i - 1];                // likelihood.f90:88
+            if (i <= nsmp) {
+                const double m = val - obs[i - 1];                       // likelihood.f90:88
+                if (P.defer_logl)
+                    mis_g[i - 1] = m;
+                else
+                    mis[i - 1] = m;
+            }
         }
+        if (P.defer_logl) return;   // quadratic form and logL: phi_logl_deferred_kernel, after this launch
         __syncthreads();
     } else {
     // ---- in-place mixed-radix inverse FFT, sign +, unnormalised (FFTW c2r definition) ---
@@ -1185,8 +1193,15 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
         }
         if (!decon) val = val / fac;                                 // forward.f90:202
         dst[i - 1] = val;
-        if (i <= nsmp) mis[i - 1] = val - obs[i - 1];                // likelihood.f90:88
+        if (i <= nsmp) {
+            const double m = val - obs[i - 1];                       // likelihood.f90:88
+            if (P.defer_logl)
+                mis_g[i - 1] = m;
+            else
+                mis[i - 1] = m;
+        }
     }
+    if (P.defer_logl) return;
     __syncthreads();
     }
 
@@ -1202,11 +1217,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
         // arriver reads with agent-scope loads) -- no release fence, which would write back
         // the whole L2 slice of freshly written traces (measured: 2.6x on this kernel).
         bool last = true;
-        if (P.defer_logl) {
-            // the kernel boundary orders the per-trace phi values; no atomics, no drain inside the block
-            phis[itrc] = phi;
-            last = false;
-        } else if (t.ntrc > 1) {
+        if (t.ntrc > 1) {
             __hip_atomic_store(phis + itrc, phi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             last = atomicAdd(P.w.done + ib, 1) == t.ntrc - 1;
@@ -1635,8 +1646,88 @@ __global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
     P.w.prop_fwd[walker] = fwd;
 }
 
-// logL of the forward evaluations of a batch whose fused / trace kernel ran with defer_logl: the
-// quadratic forms of all traces are in the proposal half; same arithmetic as logl_from_phi.
+// Follow-up kernels of a batch whose fused kernel ran with defer_logl (likelihood.f90:87-98).
+//
+// (1) phi_deferred_kernel: the quadratic forms.  One 256-thread block per (PHI_W batch items, trace);
+// the arithmetic is quad_form's, operation for operation (lanes own columns j of R^-1, the four waves
+// own contiguous row quarters, quarter sums combined in wave order, the final dot product by a wave
+// reduction) -- so the values are bit-identical to the in-kernel path -- but a row of R^-1 is fetched once
+// for PHI_W items instead of once per block.
+constexpr int PHI_W = 8;
+
+__global__ __launch_bounds__(256) void phi_deferred_kernel(LoglParams P)
+{
+    extern __shared__ double lds[];
+    const int nsmp = P.t.nsmp, ntrc = P.t.ntrc;
+    double *mis = lds;                                    // [PHI_W][nsmp]
+    double *part = mis + (size_t)PHI_W * nsmp;            // [4][PHI_W][nsmp]
+    double *red = part + (size_t)4 * PHI_W * nsmp;        // [4][PHI_W]
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int it = blockIdx.x % ntrc, ib0 = (blockIdx.x / ntrc) * PHI_W;
+    for (int e = tid; e < PHI_W * nsmp; e += 256) {
+        const int w = e / nsmp, i = e - w * nsmp, ib = ib0 + w;
+        const bool live = ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1);
+        mis[e] = live ? P.w.misfit[((size_t)ib * ntrc + it) * nsmp + i] : 0.0;
+    }
+    __syncthreads();
+    const double *__restrict__ RT = P.t.r_inv_t + (size_t)it * nsmp * nsmp;
+    const int rows = (nsmp + 3) >> 2;
+    const int r0 = wv * rows, r1 = min(nsmp, r0 + rows);
+    // two columns per lane and pass (j, j + 64): twice the loads in flight per row
+    for (int j = lane; j < nsmp; j += 128) {
+        const int j2 = j + 64;
+        const bool two = j2 < nsmp;
+        double acc0[PHI_W], acc1[PHI_W];
+#pragma unroll
+        for (int w = 0; w < PHI_W; ++w) acc0[w] = acc1[w] = 0.0;
+#pragma unroll 4
+        for (int i = r0; i < r1; ++i) {
+            const double xa = RT[(size_t)i * nsmp + j];
+            const double xb = two ? RT[(size_t)i * nsmp + j2] : 0.0;
+#pragma unroll
+            for (int w = 0; w < PHI_W; ++w) {
+                const double m = mis[w * nsmp + i];
+                acc0[w] = fma(m, xa, acc0[w]);
+                acc1[w] = fma(m, xb, acc1[w]);
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < PHI_W; ++w) {
+            part[((size_t)wv * PHI_W + w) * nsmp + j] = acc0[w];
+            if (two) part[((size_t)wv * PHI_W + w) * nsmp + j2] = acc1[w];
+        }
+    }
+    __syncthreads();
+    double acc[PHI_W];
+#pragma unroll
+    for (int w = 0; w < PHI_W; ++w) acc[w] = 0.0;
+    for (int j = tid; j < nsmp; j += 256) {
+#pragma unroll
+        for (int w = 0; w < PHI_W; ++w) {
+            const double *pw = part + (size_t)w * nsmp + j;
+            const size_t q = (size_t)PHI_W * nsmp;
+            const double phi1 = ((pw[0] + pw[q]) + pw[2 * q]) + pw[3 * q];
+            acc[w] = fma(phi1, mis[w * nsmp + j], acc[w]);
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < PHI_W; ++w) {
+        const double v = wave_sum(acc[w]);
+        if (lane == 0) red[wv * PHI_W + w] = v;
+    }
+    __syncthreads();
+    if (tid < PHI_W) {
+        const int ib = ib0 + tid;
+        if (ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1)) {
+            const int walker = P.b.walker_ids[ib];
+            const int slot = 1 - P.w.cur_slot[walker];
+            P.w.phi[((size_t)slot * P.w.nslots + walker) * ntrc + it] =
+                (red[tid] + red[PHI_W + tid]) + (red[2 * PHI_W + tid] + red[3 * PHI_W + tid]);
+        }
+    }
+}
+
+// (2) logl_deferred_kernel: logL from the quadratic forms of all traces, one thread per batch item.
 __global__ __launch_bounds__(256) void logl_deferred_kernel(LoglParams P)
 {
     const int ib = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1649,9 +1740,14 @@ __global__ __launch_bounds__(256) void logl_deferred_kernel(LoglParams P)
     P.w.prop_fwd[walker] = 1;
 }
 
+size_t phi_deferred_lds_bytes(int nsmp) { return sizeof(double) * ((size_t)5 * PHI_W * nsmp + 4 * PHI_W); }
+
 void launch_logl_deferred(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
 {
     LoglParams P{t, b, w};
+    const unsigned groups = (unsigned)((b.nb + PHI_W - 1) / PHI_W);
+    hipLaunchKernelGGL(phi_deferred_kernel, dim3(groups * (unsigned)t.ntrc), dim3(256), phi_deferred_lds_bytes(t.nsmp), s,
+                       P);
     hipLaunchKernelGGL(logl_deferred_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P);
 }
 

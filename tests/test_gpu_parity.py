@@ -199,9 +199,9 @@ def test_full_size_properties(oracle):
 
 def test_full_size_properties_three_traces(oracle, monkeypatch):
     """BASELINE config-4 shape (nfft 4096, 3 traces P/P/S, <= 30 layers) at 1024 walkers = 3072 blocks:
-    the default launch plan here is 8-bin phase chains + logL by the follow-up kernel.  Properties that
-    do not need the oracle at full size, bit-identity with the in-kernel logL hand-off, and a sampled
-    oracle check."""
+    the default launch plan here is 8-bin phase chains + quadratic forms and logL by the follow-up kernel.
+    Properties that do not need the oracle at full size, agreement with the in-kernel path, and a
+    sampled oracle check."""
     rng = np.random.default_rng(4)
     cfg = make_cfg(nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1])
     nsmp = 101
@@ -524,15 +524,16 @@ def test_optional_filter_support_cutoff(oracle, monkeypatch):
     assert np.abs(out["1e-20"][1] - out[""][1]).max() <= 1e-15 * np.abs(out[""][1]).max()
 
 
+@pytest.mark.parametrize("nsmp", [101, 161])
 @pytest.mark.parametrize("defer", ["0", "1"])
-def test_deferred_loglikelihood_kernel(oracle, monkeypatch, defer):
+def test_deferred_loglikelihood_kernel(oracle, monkeypatch, defer, nsmp):
     """Multi-trace batches can form logL in a follow-up kernel instead of the cross-block hand-off inside
     the fused kernel (RFGPU_DEFER_LOGL; chosen by batch size by default): same values, including
-    sigma-only items (fwd_flag 0) and a second evaluation after a commit."""
+    sigma-only items (fwd_flag 0) and a second evaluation after a commit.  nsmp 101: R^-1 held in
+    registers by the follow-up kernel; 161: streamed."""
     monkeypatch.setenv("RFGPU_DEFER_LOGL", defer)
     rng = np.random.default_rng(321)
     cfg = make_cfg(nfft=512, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], t_start=-1.0)
-    nsmp = 101
     true = random_stack(rng, 5)
     obs = synth_obs(oracle, cfg, true, nsmp)
     r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
