@@ -505,8 +505,11 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         // contexts and long windows (misfits of 8 walkers must fit the follow-up kernel's LDS) keep the
         // single launch.
         const int defer_ok = phi_deferred_lds_bytes(c->cfg.nsmp) <= 60 * 1024;
+        // (single trace: one follow-up kernel; it pays from four rounds of blocks on -- measured C3 +6 %,
+        // C2, two rounds, -2 %)
+        const long long blocks = (long long)b.nb * c->cfg.ntrc, round = 2LL * c->num_cu;
         const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl
-                          : (c->cfg.ntrc > 1 && (long long)b.nb * c->cfg.ntrc >= 2LL * 2 * c->num_cu));
+                          : (c->cfg.ntrc > 1 ? blocks >= 2 * round : blocks >= 4 * round));
         hipEvent_t e = prof_begin(c, 0, s);
         launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, s);   // spectra + trace (+ logL)
         if (e) (void)hipEventRecord(e, s);

@@ -1721,8 +1721,12 @@ __global__ __launch_bounds__(256) void phi_deferred_kernel(LoglParams P)
         if (ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1)) {
             const int walker = P.b.walker_ids[ib];
             const int slot = 1 - P.w.cur_slot[walker];
-            P.w.phi[((size_t)slot * P.w.nslots + walker) * ntrc + it] =
-                (red[tid] + red[PHI_W + tid]) + (red[2 * PHI_W + tid] + red[3 * PHI_W + tid]);
+            const double phi = (red[tid] + red[PHI_W + tid]) + (red[2 * PHI_W + tid] + red[3 * PHI_W + tid]);
+            P.w.phi[((size_t)slot * P.w.nslots + walker) * ntrc + it] = phi;
+            if (ntrc == 1) {   // nothing to wait for: logL right here, no second follow-up kernel
+                P.b.logl[ib] = logl_from_phi(&phi, P.b.sig + ib, 1, nsmp, false);
+                P.w.prop_fwd[walker] = 1;
+            }
         }
     }
 }
@@ -1748,7 +1752,8 @@ void launch_logl_deferred(const DeviceTables &t, const BatchArgs &b, const Walke
     const unsigned groups = (unsigned)((b.nb + PHI_W - 1) / PHI_W);
     hipLaunchKernelGGL(phi_deferred_kernel, dim3(groups * (unsigned)t.ntrc), dim3(256), phi_deferred_lds_bytes(t.nsmp), s,
                        P);
-    hipLaunchKernelGGL(logl_deferred_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P);
+    if (t.ntrc > 1)
+        hipLaunchKernelGGL(logl_deferred_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P);
 }
 
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
