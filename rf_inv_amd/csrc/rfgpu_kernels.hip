@@ -1111,12 +1111,13 @@ struct TraceParams {
     FftPlan plan;
     int *slow_count;   // re-armed here for the next batch (the slow kernel ran earlier on the stream)
     int ablate;        // timing diagnostics only (RFGPU_ABLATE): stop the tail after phase N, results invalid
-    int defer_logl;    // misfits to HBM; quadratic form + logL by phi_logl_deferred_kernel after this launch
+    int defer_logl;    // misfits to HBM; quadratic form + logL by phi_deferred_kernel (+ logl_deferred_kernel) after this launch
 };
 
 // Everything after Z is in LDS: inverse FFT, vertical max, shift / normalise / store,
-// misfit, quadratic form, log-likelihood.  Shared by trace_kernel (Z filled from the
-// spectra in HBM) and fused_kernel (Z filled straight from the propagator registers).
+// misfit, quadratic form, log-likelihood (defer_logl: up to the misfit, which then goes to HBM for
+// the follow-up kernels).  Shared by trace_kernel (Z filled from the spectra in HBM) and
+// fused_kernel (Z filled straight from the propagator registers).
 __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, double *mis, double *red, int ib,
                                            int itrc, int walker, int ipha, bool decon, double tp, int slot, int tid)
 {
@@ -1161,7 +1162,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
                     mis[i - 1] = m;
             }
         }
-        if (P.defer_logl) return;   // quadratic form and logL: phi_logl_deferred_kernel, after this launch
+        if (P.defer_logl) return;   // quadratic form and logL: phi_deferred_kernel (+ logl_deferred_kernel), after this launch
         __syncthreads();
     } else {
     // ---- in-place mixed-radix inverse FFT, sign +, unnormalised (FFTW c2r definition) ---
@@ -1616,7 +1617,7 @@ void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec
 // ---------------------------------------------------------------------------
 // log-likelihood from cached quadratic forms (likelihood.f90:86,94-96), one thread per item;
 // used for host-owned traces (rf_calc_likelihood_of_trace) -- the batched path forms logL in
-// trace_tail
+// trace_tail or, for large batches, in the follow-up kernels below (defer_logl)
 // ---------------------------------------------------------------------------
 struct LoglParams {
     DeviceTables t;
