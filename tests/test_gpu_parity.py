@@ -202,6 +202,8 @@ def test_full_size_properties_three_traces(oracle, monkeypatch):
     the default launch plan here is 8-bin phase chains + quadratic forms and logL by the follow-up kernel.
     Properties that do not need the oracle at full size, agreement with the in-kernel path, and a
     sampled oracle check."""
+    for var in ("RFGPU_FUSED", "RFGPU_CHAIN", "RFGPU_DEFER_LOGL"):   # the default launch plan is the subject here
+        monkeypatch.delenv(var, raising=False)
     rng = np.random.default_rng(4)
     cfg = make_cfg(nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1])
     nsmp = 101
