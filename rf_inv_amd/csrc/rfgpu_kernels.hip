@@ -1548,7 +1548,10 @@ void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &
     while ((1 << F.tp.log2n) < t.nfft) ++F.tp.log2n;
     F.tp.plan = make_fft_plan(F.tp.log2n);
     const size_t lds = fused_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
-    static size_t lds_set[2][5] = {};
+    static size_t lds_set_dev[16][2][5] = {};   // the attribute is per device and per kernel
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t (&lds_set)[2][5] = lds_set_dev[dev & 15];
     const int ci = chain == 2 ? 1 : chain == 3 ? 2 : chain == 4 ? 3 : chain == 8 ? 4 : 0;
     const int ni = t.sdep > 0.0 ? 1 : 0;
     if (lds > lds_set[ni][ci]) {   // dynamic LDS beyond 64 KiB must be opted into, per kernel
@@ -1605,7 +1608,10 @@ void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec
     while ((1 << P.log2n) < t.nfft) ++P.log2n;
     P.plan = make_fft_plan(P.log2n);
     const size_t lds = trace_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
-    static size_t lds_set = 0;
+    static size_t lds_set_dev[16] = {};   // the attribute is per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t &lds_set = lds_set_dev[dev & 15];
     if (lds > lds_set) {  // dynamic LDS beyond 64 KiB must be opted into
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
