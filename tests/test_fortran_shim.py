@@ -186,3 +186,28 @@ def test_fortran_batched_sampler_two_mpi_ranks(golden_dir, tmp_path):
     # temperatures moved between ranks at least once: rank 0 started with [1, tempered...]
     t0 = [float(x) for x in dumps[0][0].split()[-5:]]
     assert len(t0) == 5 and all(x >= 1.0 for x in t0)
+
+
+@pytest.mark.gpu
+def test_fortran_batched_sampler_many_chains(golden_dir, tmp_path):
+    """600 chains, 100 of them non-tempered: the batched sampler's evaluation goes through the large-batch
+    launch plan (misfits to HBM, quadratic forms and logL by follow-up kernels) while the reference's
+    pt_control evaluates chain by chain inside the fused kernel.  Both arithmetic paths are the same
+    operation for operation, so the dumps and the result files are identical."""
+    if not os.path.exists(RFINV):
+        pytest.skip("oracle/_ref/drive_rfinv not built (no Fortran compiler / reference tree at build time)")
+    outs = []
+    for mode in ("0", "1"):
+        work = tmp_path / f"big{mode}"
+        shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
+        os.makedirs(work / "rslt")
+        txt = open(work / "params.in").read().splitlines()
+        vals = [i for i, line in enumerate(txt) if line.strip() and not line.lstrip().startswith("#")]
+        txt[vals[4]], txt[vals[5]] = "600", "100"          # N_CHAINS, N_COOL
+        open(work / "params.in", "w").write("\n".join(txt) + "\n")
+        r = subprocess.run([RFINV, "params.in", "10", "30", mode, "out"], cwd=work, env=dict(os.environ),
+                           capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and "drive_rfinv: ok" in r.stdout, r.stdout + r.stderr
+        outs.append([open(work / "rfinv_dump.txt").read()] + [open(work / "rslt" / n).read() for n in RESULT_FILES])
+    assert outs[0] == outs[1]
+    assert int(outs[0][0].split()[2]) == 100               # ncool
