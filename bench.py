@@ -172,8 +172,8 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default=os.environ.get("RFGPU_BENCH_WORKLOAD", "c2"), choices=sorted(WORKLOADS))
     ap.add_argument("--walkers", type=int, default=0, help="override walkers per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -336,7 +336,7 @@ def main():
     main_res = run(args.workload, args.steps, args.warmup, not args.no_cpu_baseline and world == 1)
     also = {}
     for wl in [x for x in args.also.split(",") if x]:
-        r = run(wl, max(30, args.steps // 2), max(5, args.warmup // 2), False)
+        r = run(wl, max(30, min(200, args.steps // 2)), max(5, min(20, args.warmup // 2)), False)
         also[wl] = {k: r[k] for k in ("value", "ms_per_step", "config", "roofline", "kernel_ms")}
     if rank == 0:
         out = {"metric": "forward+likelihood evals/sec (whole node)", "value": main_res["value"], "unit": "evals/s",
