@@ -33,6 +33,9 @@ HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 WORKLOADS = {
     "c2": dict(walkers=1024, nfft=4096, rayps=[0.06], ipha=[1], k_max=15, sdep=0.0, deconv=0, temps=1,
                desc="c2: 1024 walkers/GPU x 1 P trace (p=0.06) x nfft 4096 (2049 bins) x <=15 layers, T=1"),
+    "c2d": dict(walkers=1024, nfft=4096, rayps=[0.06], ipha=[1], k_max=15, sdep=0.0, deconv=1, temps=1,
+                desc="c2 with water-level deconvolution (deconv_mode 1): 1024 walkers/GPU x 1 P trace x nfft 4096 "
+                     "x <=15 layers"),
     "c3": dict(walkers=8192, nfft=4096, rayps=[0.06], ipha=[1], k_max=15, sdep=0.0, deconv=0, temps=8,
                desc="c3: 8192 walkers/GPU (1024 chains x 8 temperatures) x 1 P trace x nfft 4096 x <=15 layers, "
                     "PT swap on the device"),
