@@ -558,3 +558,21 @@ def test_deferred_loglikelihood_kernel(oracle, monkeypatch, defer, nsmp):
         use_n = np.where(ff == 1, nlay2, nlay)
         ref2 = oracle.eval_batch(cfg, obs, r_inv, use_n, use_l, sig2, nsmp)
         assert np.all(np.abs(ll2 - ref2) <= logl_tol(ref2)), np.abs(ll2 - ref2).max()
+
+
+def test_long_time_window(oracle):
+    """nsmp 1500 (the reference allows up to npts_max = 2000, src/params.f90:413): an 18 MB R^-1 per
+    trace, the quadratic form's row quarters beyond one 64-lane pass of columns, P and S traces."""
+    rng = np.random.default_rng(5)
+    nsmp = 1500
+    cfg = make_cfg(nfft=4096, rayps=[0.06, 0.09], ipha=[1, -1], t_start=-5.0)
+    true = random_stack(rng, 5)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, int(n)) for n in (7, 15, 28)] + [true]
+    nlay, layers = pack_layers(stacks, 30)
+    sig = np.full((4, 2), 0.02)
+    ref = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=4, nlay_max=30) as eng:
+        ll = eng.eval_batch(np.arange(4), nlay, layers, sig)
+    assert np.all(np.abs(ll - ref) <= logl_tol(ref)), np.abs(ll - ref)
