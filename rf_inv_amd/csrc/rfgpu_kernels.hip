@@ -1012,6 +1012,35 @@ __device__ __forceinline__ void fft4096_regs(double2 *a, const double2 *__restri
     dft_regs<4>(v);
 }
 
+// n = 256 * R with R = 2, 4, 8 (nfft 512, 1024, 2048): the passes before the last through LDS as in
+// fft_inverse_lds, the last pass -- one radix-R butterfly per thread, stride 256 -- left in registers:
+// v[k] is sample tid + (bitrev_R(k) << 8).
+template <int LOG2R>
+__device__ __forceinline__ void fft_regs_last(double2 *a, const FftPlan &pl, int log2n, const double2 *__restrict__ tw,
+                                              int tid, double2 (&v)[1 << LOG2R])
+{
+    constexpr int R = 1 << LOG2R;
+    const int n = 1 << log2n;
+    int stride_log2 = 0;
+    for (int p = 0; p + 1 < pl.npass; ++p) {
+        fft_pass<4, TRACE_THREADS>(a, log2n, stride_log2, tw, tid);   // these sizes: radix 16 before the last
+        stride_log2 += 4;
+        __syncthreads();
+    }
+    double2 w[R];
+#pragma unroll
+    for (int k = 1; k < R; ++k) w[k] = tw[(tid * k) & ((n >> 1) - 1)];
+#pragma unroll
+    for (int k = 0; k < R; ++k) v[k] = a[fft_pad(tid + (k << 8))];
+#pragma unroll
+    for (int k = 1; k < R; ++k) {
+        const bool neg = (tid * k) >= (n >> 1);   // exp(i(t + pi)) = -exp(it)
+        const double2 wk = neg ? make_double2(-w[k].x, -w[k].y) : w[k];
+        v[k] = cmul(v[k], wk);
+    }
+    dft_regs<LOG2R>(v);
+}
+
 template <int THREADS>
 __device__ __forceinline__ void fft_inverse_lds(double2 *a, const FftPlan &pl, int log2n,
                                                 const double2 *__restrict__ tw, int tid)
@@ -1114,6 +1143,53 @@ struct TraceParams {
     int defer_logl;    // misfits to HBM; quadratic form + logL by phi_deferred_kernel (+ logl_deferred_kernel) after this launch
 };
 
+// FFT with the last pass in registers, vertical maximum, shift / normalise / store and misfit for
+// nfft = 256 * 2^LOG2R (trace_tail).  Returns true when the block is finished (ablation, or the misfits
+// went to HBM for the follow-up kernels).
+template <int LOG2R>
+__device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 *a, double *mis, double *mis_g,
+                                                  double *__restrict__ dst, const double *__restrict__ obs,
+                                                  double *red, int ipha, bool decon, double tp, int tid)
+{
+    constexpr int R = 1 << LOG2R;
+    const DeviceTables &t = P.t;
+    const int n = t.nfft, nsmp = t.nsmp;
+    double2 v[R];
+    if constexpr (LOG2R == 4)
+        fft4096_regs(a, t.twiddle, tid, v);
+    else
+        fft_regs_last<LOG2R>(a, P.plan, P.log2n, t.twiddle, tid, v);
+    if (P.ablate == 2) return true;
+    double fac = 1.0;
+    if (!decon) {
+        double m = -HUGE_VAL;
+#pragma unroll
+        for (int k = 0; k < R; ++k) m = fmax(m, v[k].y);
+        fac = block_max(m, red);                                     // maxval(rx) forward.f90:201
+    }
+    const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int j = tid + (bitrev_small<LOG2R>(k) << 8) + 1;       // 1-based sample of rx
+        // invert the reference's maps rft(i) = rx(mod(n - npre + i, n)) (forward.f90:179) and
+        // rft(i) = -rx(mod(n + npre - i + 1, n)) (:188), index 0 standing for n
+        // n is a power of two: mod(x, n) of the reference = x & (n - 1), also for negative x
+        int i = (ipha == 1 ? j + npre : n + npre + 1 - j) & (n - 1);
+        if (i == 0) i = n;
+        double val = ipha == 1 ? v[k].x : -v[k].x;
+        if (!decon) val = val / fac;                                 // forward.f90:202
+        __builtin_nontemporal_store(val, &dst[i - 1]);   // written once, read rarely: keep it out of L2
+        if (i <= nsmp) {
+            const double m = val - obs[i - 1];                       // likelihood.f90:88
+            if (P.defer_logl)
+                mis_g[i - 1] = m;
+            else
+                mis[i - 1] = m;
+        }
+    }
+    return P.defer_logl != 0;   // quadratic form and logL: phi_deferred_kernel (+ logl_deferred_kernel), after this launch
+}
+
 // Everything after Z is in LDS: inverse FFT, vertical max, shift / normalise / store,
 // misfit, quadratic form, log-likelihood (defer_logl: up to the misfit, which then goes to HBM for
 // the follow-up kernels).  Shared by trace_kernel (Z filled from the spectra in HBM) and
@@ -1128,41 +1204,19 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
         P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
     double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
-    if (n == 4096 && TRACE_THREADS == 256) {
-        // nfft 4096: the last radix-16 pass has exactly one butterfly per thread; its outputs stay in
-        // registers for the vertical maximum, the shift and the store -- one LDS write pass, two LDS
-        // read passes and a barrier less than the general path below.  Same values, same operations.
-        double2 v[16];
-        fft4096_regs(a, t.twiddle, tid, v);
-        if (P.ablate == 2) return;
-        double fac = 1.0;
-        if (!decon) {
-            double m = -HUGE_VAL;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) m = fmax(m, v[k].y);
-            fac = block_max(m, red);                                     // maxval(rx) forward.f90:201
+    if (TRACE_THREADS == 256 && n >= 512 && n <= 4096) {
+        // nfft 512 .. 4096: the last pass has exactly one butterfly (radix nfft / 256) per thread; its
+        // outputs stay in registers for the vertical maximum, the shift and the store -- one LDS write
+        // pass, two LDS read passes and a barrier less than the general path below.  Same values, same
+        // operations.
+        bool done = false;
+        switch (P.log2n) {
+        case 12: done = tail_in_registers<4>(P, a, mis, mis_g, dst, obs, red, ipha, decon, tp, tid); break;
+        case 11: done = tail_in_registers<3>(P, a, mis, mis_g, dst, obs, red, ipha, decon, tp, tid); break;
+        case 10: done = tail_in_registers<2>(P, a, mis, mis_g, dst, obs, red, ipha, decon, tp, tid); break;
+        default: done = tail_in_registers<1>(P, a, mis, mis_g, dst, obs, red, ipha, decon, tp, tid); break;
         }
-        const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int j = tid + (bitrev_small<4>(k) << (P.log2n - 4)) + 1;   // 1-based sample of rx
-            // invert the reference's maps rft(i) = rx(mod(n - npre + i, n)) (forward.f90:179) and
-            // rft(i) = -rx(mod(n + npre - i + 1, n)) (:188), index 0 standing for n
-            // n is a power of two: mod(x, n) of the reference = x & (n - 1), also for negative x
-            int i = (ipha == 1 ? j + npre : n + npre + 1 - j) & (n - 1);
-            if (i == 0) i = n;
-            double val = ipha == 1 ? v[k].x : -v[k].x;
-            if (!decon) val = val / fac;                                 // forward.f90:202
-            __builtin_nontemporal_store(val, &dst[i - 1]);   // written once, read rarely: keep it out of L2
-            if (i <= nsmp) {
-                const double m = val - obs[i - 1];                       // likelihood.f90:88
-                if (P.defer_logl)
-                    mis_g[i - 1] = m;
-                else
-                    mis[i - 1] = m;
-            }
-        }
-        if (P.defer_logl) return;   // quadratic form and logL: phi_deferred_kernel (+ logl_deferred_kernel), after this launch
+        if (done) return;   // ablation / deferred quadratic form
         __syncthreads();
     } else {
     // ---- in-place mixed-radix inverse FFT, sign +, unnormalised (FFTW c2r definition) ---
