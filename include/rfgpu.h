@@ -254,7 +254,9 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
 int rf_get_launch_plan(const rf_ctx *ctx, int32_t *plan);
 
 /* HIP-event timing (on the streams the kernels are launched on) of the three kernels
- * of rf_eval_batch*, accumulated while enabled.  ms[3] = spectra, trace, logl totals;
+ * of rf_eval_batch*, accumulated while enabled.  on = 1 times every batch, on = k > 1 every k-th
+ * batch (an event record costs ~4 us of stream time: sampling keeps a timed loop undisturbed),
+ * 0 switches it off.  ms[3] = spectra, trace, logl totals over the timed batches;
  * launches[4] = batches timed, then spectra / trace / logl kernel launches (a batch is
  * pipelined in chunks, so there can be several spectra / trace launches per batch). */
 int rf_profile_enable(rf_ctx *ctx, int32_t on);

@@ -79,6 +79,9 @@ struct rf_ctx {
     // profiling: a pool of event quads so that timing never synchronises inside a
     // timed loop (flushed lazily / when the pool is exhausted)
     bool prof = false;
+    int prof_every = 1;        // time every prof_every-th batch (event records cost ~4 us each on the stream)
+    long long prof_batch = 0;  // batches seen while profiling
+    bool prof_this = false;    // the batch being launched is a timed one
     struct Timed { int kind; hipEvent_t e0, e1; };
     std::vector<Timed> ev_pool;
     size_t ev_used = 0;
@@ -451,7 +454,7 @@ static void flush_profile(rf_ctx *c)
 // record after the launch (nullptr when profiling is off)
 static hipEvent_t prof_begin(rf_ctx *c, int kind, hipStream_t s)
 {
-    if (!c->prof) return nullptr;
+    if (!c->prof || !c->prof_this) return nullptr;
     constexpr size_t kMaxPool = 4096;
     if (c->ev_used == c->ev_pool.size()) {
         if (c->ev_pool.size() >= kMaxPool) {
@@ -491,6 +494,7 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
     if (b_in.nlay_pad > c->cfg.nlay_max) return fail("nlay_pad exceeds nlay_max of the context");
     HIP_TRY(hipSetDevice(c->device));
     BatchArgs b = b_in;
+    c->prof_this = c->prof && (c->prof_batch++ % c->prof_every) == 0;
     if (c->lpt && !b.order && b.nb >= 2 * c->num_cu) {
         // deepest walkers first (the sort is worth its ~5 us launch once blocks outnumber the CUs)
         launch_order(b.nb, b.nlay, b.fwd_flag, c->d_order, s);
@@ -523,7 +527,7 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         launch_trace(c->tab, b, c->spec, c->ws, c->slow_count, s);   // also forms logL
         if (e) (void)hipEventRecord(e, s);
     }
-    if (c->prof) c->prof_n[0] += 1;
+    if (c->prof_this) c->prof_n[0] += 1;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1004,6 +1008,8 @@ extern "C" int rf_profile_enable(rf_ctx *c, int32_t on)
     if (!c) return fail("rf_profile_enable: null context");
     if (!on) flush_profile(c);
     c->prof = on != 0;
+    c->prof_every = on > 1 ? on : 1;
+    c->prof_batch = 0;
     return 0;
 }
 

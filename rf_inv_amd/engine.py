@@ -248,6 +248,7 @@ class RFEngine:
         return {"fused": bool(plan[0]), "chain": plan[1], "waves_per_block": plan[2], "nsplit": plan[3]}
 
     def profile_enable(self, on=True):
+        """on: False / True (every batch) / k > 1 (every k-th batch is timed)."""
         self._chk(self._lib.rf_profile_enable(self._ctx, int(on)))
 
     def profile_read(self, reset=True):
