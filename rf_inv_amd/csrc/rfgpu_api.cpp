@@ -51,6 +51,9 @@ struct rf_ctx {
     int *d_fm_nlay = nullptr, *d_fm_flag = nullptr;
     double *d_fm_layers = nullptr, *d_fm_scratch = nullptr;
     int *d_order = nullptr;   // [nslots] LPT dispatch order of the current batch
+    int *d_order_alt = nullptr;   // [nslots] the order the running launch computes for the next one
+    int order_next_nb = 0;    // d_order_alt holds an order for a batch of this size (0: none)
+    bool order_reuse = true;  // RFGPU_ORDER_REUSE=0: a fresh order_kernel before every launch
     // posterior accumulators (row f-3)
     bool have_post = false;
     PostConfig post{};
@@ -362,6 +365,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     c->ws.misfit = (double *)p;
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->d_order = (int *)p;
+    if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
+    c->d_order_alt = (int *)p;
     c->ws.nslots = c->nslots;
     if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * c->nfwd * 2 * nh)) return cleanup(1);
     c->spec = (double2 *)p;
@@ -392,6 +397,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (env && atoi(env) > 0) c->nsplit_override = atoi(env);
     env = getenv("RFGPU_ABLATE");
     if (env) c->ablate = atoi(env);
+    env = getenv("RFGPU_ORDER_REUSE");
+    if (env) c->order_reuse = atoi(env) != 0;
     env = getenv("RFGPU_DEFER_LOGL");
     if (env) c->defer_logl = atoi(env) != 0;
     env = getenv("RFGPU_WPB");
@@ -495,10 +502,22 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
     HIP_TRY(hipSetDevice(c->device));
     BatchArgs b = b_in;
     c->prof_this = c->prof && (c->prof_batch++ % c->prof_every) == 0;
+    int *order_next = nullptr;
     if (c->lpt && !b.order && b.nb >= 2 * c->num_cu) {
-        // deepest walkers first (the sort is worth its ~5 us launch once blocks outnumber the CUs)
-        launch_order(b.nb, b.nlay, b.fwd_flag, c->d_order, s);
+        // deepest walkers first (worth it once blocks outnumber the CUs).  Fused path: the previous
+        // launch of a batch of this size left the order in d_order_alt (sorted by its own depths -- one
+        // proposal step stale for this launch, which costs a little balance, never correctness), and
+        // this launch does the same for the next; otherwise a ~4 us order_kernel in front.
+        if (c->fused && c->order_reuse && c->order_next_nb == b.nb) {
+            std::swap(c->d_order, c->d_order_alt);
+        } else {
+            launch_order(b.nb, b.nlay, b.fwd_flag, c->d_order, s);
+        }
         b.order = c->d_order;
+        if (c->fused && c->order_reuse) order_next = c->d_order_alt;
+        c->order_next_nb = order_next ? b.nb : 0;
+    } else {
+        c->order_next_nb = 0;
     }
     if (c->fused) {
         // several traces per walker and at least two rounds of blocks: the block ends with the trace store;
@@ -515,7 +534,7 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl
                           : (c->cfg.ntrc > 1 ? blocks >= 2 * round : blocks >= 4 * round));
         hipEvent_t e = prof_begin(c, 0, s);
-        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, s);   // spectra + trace (+ logL)
+        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, s);   // spectra + trace (+ logL)
         if (e) (void)hipEventRecord(e, s);
         if (defer) launch_logl_deferred(c->tab, b, c->ws, s);
     } else {

@@ -1457,7 +1457,11 @@ static FftPlan make_fft_plan(int log2n);
 struct FusedParams {
     SpectraParams sp;   // t, b, nsplit (= waves per block), meta pointers unused
     TraceParams tp;     // t, b, w, log2n, plan, slow_count
+    int *order_next;    // nullptr, or: block 0 sorts this batch's items by depth for the NEXT launch
 };
+
+__device__ __forceinline__ void order_block(int nb, const int *nlay, const int *fwd_flag, int *order, int *hist,
+                                            int *start, int *wave_tot);
 
 size_t fused_lds_bytes(int nfft, int nsmp, int nlay_pad)
 {
@@ -1479,9 +1483,21 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
     double *tail = coef + (size_t)P.b.nlay_pad * NCOEF;
 
     const int tid = threadIdx.x;
-    const int itrc = blockIdx.x % t.ntrc;     // == forward-trace index here (nfwd == ntrc)
-    const int ib = P.b.order ? P.b.order[blockIdx.x / t.ntrc] : blockIdx.x / t.ntrc;
-    if (blockIdx.x == 0 && tid == 0) *P.slow_count = 0;
+    const int bid = blockIdx.x;
+    if (F.order_next && bid == P.b.nb * t.ntrc) {
+        // Longest-first dispatch order for the next launch of this batch shape, computed by one extra
+        // block instead of a separate kernel in front of every launch.  It is the LAST block: it takes the
+        // first slot that becomes free near the end of the launch, where the shallowest walkers leave slack
+        // (as the first block it delayed one slot's whole sequence and with it the kernel).  The next
+        // launch's depths differ from these by a proposal step (+-1 layer for some walkers): the order is
+        // then slightly stale, which costs balance, never correctness.
+        int *w = reinterpret_cast<int *>(lds2);
+        order_block(P.b.nb, P.b.nlay, P.b.fwd_flag, F.order_next, w, w + 256, w + 512);
+        return;
+    }
+    const int itrc = bid % t.ntrc;            // == forward-trace index here (nfwd == ntrc)
+    const int ib = P.b.order ? P.b.order[bid / t.ntrc] : bid / t.ntrc;
+    if (bid == 0 && tid == 0) *P.slow_count = 0;
     if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
         // 0: sigma-only proposal -- the stored trace is re-used (likelihood.f90:81), so is its cached
         // quadratic form; < 0: no evaluation at all (an invalid model from rf_eval_models_device)
@@ -1594,9 +1610,10 @@ static void launch_fused_ncol(int chain, dim3 grid, size_t lds, hipStream_t s, c
 }
 
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
-                  int ablate, int defer_logl, hipStream_t s)
+                  int ablate, int defer_logl, int *order_next, hipStream_t s)
 {
     FusedParams F{};
+    F.order_next = order_next;
     F.sp = SpectraParams{t, b, nullptr, TRACE_THREADS / 64, nullptr, slow_count, w.meta_tp, w.meta_slot, w.cur_slot};
     F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count, ablate, defer_logl};
     while ((1 << F.tp.log2n) < t.nfft) ++F.tp.log2n;
@@ -1617,7 +1634,7 @@ void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &
         (void)hipFuncSetAttribute(fns[ni][ci], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         lds_set[ni][ci] = lds;
     }
-    const dim3 grid((unsigned)(b.nb * t.ntrc));
+    const dim3 grid((unsigned)(b.nb * t.ntrc) + (order_next ? 1u : 0u));
     if (ni)
         launch_fused_ncol<3>(chain, grid, lds, s, F);
     else
@@ -1956,11 +1973,11 @@ void launch_format_model(const FormatParams &P, hipStream_t s)
 // the kernel time.  A counting sort by descending layer count (one block, LDS histogram)
 // gives order[], and block b works on batch item order[b / ntrc].  Values do not depend on it.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void order_kernel(int nb, const int *nlay, const int *fwd_flag, int *order)
+// the counting sort, by one block of >= 256 threads; hist / start: 256 ints of LDS each, wave_tot: 4
+__device__ __forceinline__ void order_block(int nb, const int *nlay, const int *fwd_flag, int *order, int *hist,
+                                            int *start, int *wave_tot)
 {
-    __shared__ int hist[256];   // key = min(nlay, 255); items without a forward model: key 0
-    __shared__ int start[256];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x;   // key = min(nlay, 255); items without a forward model: key 0
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     for (int i = tid; i < nb; i += blockDim.x) {
@@ -1970,7 +1987,6 @@ __global__ __launch_bounds__(1024) void order_kernel(int nb, const int *nlay, co
     __syncthreads();
     // exclusive prefix sum over descending keys: thread t < 256 owns key 255 - t; a shuffle scan inside
     // each of the four waves, then the totals of the waves before it
-    __shared__ int wave_tot[4];
     int incl = 0, mine = 0;
     if (tid < 256) {
         mine = hist[255 - tid];
@@ -1993,6 +2009,12 @@ __global__ __launch_bounds__(1024) void order_kernel(int nb, const int *nlay, co
         const int key = (fwd_flag && fwd_flag[i] != 1) ? 0 : min(nlay[i], 255);
         order[atomicAdd(&start[key], 1)] = i;
     }
+}
+
+__global__ __launch_bounds__(1024) void order_kernel(int nb, const int *nlay, const int *fwd_flag, int *order)
+{
+    __shared__ int hist[256], start[256], wave_tot[4];
+    order_block(nb, nlay, fwd_flag, order, hist, start, wave_tot);
 }
 
 void launch_order(int nb, const int *nlay, const int *fwd_flag, int *order, hipStream_t s)
