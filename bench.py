@@ -270,11 +270,16 @@ def main():
         # HIP events around the dominant kernel of every 8th step of the timed region: an event record costs
         # ~4 us of stream time, so timing every step would slow the loop it measures by ~8 % at C2
         eng.profile_enable(0 if os.environ.get("RFGPU_BENCH_NOPROF") else min(8, max(1, steps // 8)))
+        import gc
+
+        gc.collect()
+        gc.disable()            # no collector pause inside the (short) timed region
         t0 = time.perf_counter()
         for _ in range(steps):
             step()
         barrier()
         dt = time.perf_counter() - t0
+        gc.enable()
         eng.profile_enable(False)
         prof = eng.profile_read()
         if world > 1:
