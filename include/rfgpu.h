@@ -124,7 +124,10 @@ int rf_calc_likelihood_of_trace(rf_ctx *ctx, const double *rft, const double *si
 int rf_eval_batch(rf_ctx *ctx, int32_t nb, const int32_t *walker_ids, const int32_t *fwd_flag,
                   const int32_t *nlay, int32_t nlay_pad, const double *layers,
                   const double *sig, double *logl);
-/* same with every pointer a device pointer; asynchronous on `stream`. */
+/* same with every pointer a device pointer; asynchronous on `stream`.  d_logl may also be pinned
+ * (device-mapped) host memory.  Calls on one context share per-context state (trace slots, the
+ * dispatch order a launch prepares for the next one): issue them on one stream, or synchronise
+ * between streams yourself. */
 int rf_eval_batch_device(rf_ctx *ctx, int32_t nb, const int32_t *d_walker_ids,
                          const int32_t *d_fwd_flag, const int32_t *d_nlay, int32_t nlay_pad,
                          const double *d_layers, const double *d_sig, double *d_logl,
