@@ -660,13 +660,12 @@ extern "C" int rf_calc_likelihood(rf_ctx *c, int32_t walker, int32_t fwd_flag, i
     const size_t in_doubles = 2 + (size_t)4 * pad + ntrc;
     const size_t out_doubles = 1 + (size_t)n * ntrc;
     if (!c->h_single_in) {
-        HIP_TRY(hipHostMalloc((void **)&c->h_single_in, sizeof(double) * in_doubles, hipHostMallocDefault));
-        HIP_TRY(hipHostMalloc((void **)&c->h_single_out, sizeof(double) * out_doubles, hipHostMallocDefault));
-        void *p = nullptr;
-        if (dev_alloc(c, &p, sizeof(double) * in_doubles)) return 1;
-        c->d_single_in = (double *)p;
-        if (dev_alloc(c, &p, sizeof(double) * out_doubles)) return 1;
-        c->d_single_out = (double *)p;
+        // pinned, device-mapped staging: the kernels read the packed inputs and write logL and the gathered
+        // trace straight through PCIe -- no copy launches on this latency-bound path
+        HIP_TRY(hipHostMalloc((void **)&c->h_single_in, sizeof(double) * in_doubles, hipHostMallocMapped));
+        HIP_TRY(hipHostMalloc((void **)&c->h_single_out, sizeof(double) * out_doubles, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&c->d_single_in, c->h_single_in, 0));
+        HIP_TRY(hipHostGetDevicePointer((void **)&c->d_single_out, c->h_single_out, 0));
     }
     int *hi = reinterpret_cast<int *>(c->h_single_in);
     const int nl = fwd_flag ? nlay : 2;
@@ -684,18 +683,14 @@ extern "C" int rf_calc_likelihood(rf_ctx *c, int32_t walker, int32_t fwd_flag, i
     }
     std::memcpy(hl + 4 * (size_t)pad, sig, sizeof(double) * ntrc);
     hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->d_single_in, c->h_single_in, sizeof(double) * in_doubles, hipMemcpyHostToDevice, s));
     const int *di = reinterpret_cast<const int *>(c->d_single_in);
     const double *dl = c->d_single_in + 2;
     BatchArgs b{1, pad, di, di + 1, di + 2, dl, dl + 4 * (size_t)pad, c->d_single_out, nullptr};
     if (run_batch(c, b, s)) return 1;
-    size_t back = 1;
     if (prop_rft) {
         launch_gather_rft(c->ws, ntrc, n, 1, di, 1, n, c->d_single_out + 1, s);
         HIP_TRY(hipGetLastError());
-        back = out_doubles;
     }
-    HIP_TRY(hipMemcpyAsync(c->h_single_out, c->d_single_out, sizeof(double) * back, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     *prop_log_likelihood = c->h_single_out[0];
     if (prop_rft) std::memcpy(prop_rft, c->h_single_out + 1, sizeof(double) * (size_t)n * ntrc);
