@@ -68,6 +68,7 @@ struct rf_ctx {
     int defer_logl = -1;      // RFGPU_DEFER_LOGL: -1 = by batch size, 0 / 1 = never / always
     double *h_single_in = nullptr, *h_single_out = nullptr;   // pinned staging of the per-call drop-in
     double *d_single_in = nullptr, *d_single_out = nullptr;
+    double *single_trace_out = nullptr;   // set by rf_calc_likelihood around its run_batch: extra trace copy
     double *d_gather = nullptr;
     size_t gather_bytes = 0;
     // host copies of tables
@@ -534,7 +535,7 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl
                           : (c->cfg.ntrc > 1 ? blocks >= 2 * round : blocks >= 4 * round));
         hipEvent_t e = prof_begin(c, 0, s);
-        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, s);   // spectra + trace (+ logL)
+        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, c->single_trace_out, s);
         if (e) (void)hipEventRecord(e, s);
         if (defer) launch_logl_deferred(c->tab, b, c->ws, s);
     } else {
@@ -686,8 +687,14 @@ extern "C" int rf_calc_likelihood(rf_ctx *c, int32_t walker, int32_t fwd_flag, i
     const int *di = reinterpret_cast<const int *>(c->d_single_in);
     const double *dl = c->d_single_in + 2;
     BatchArgs b{1, pad, di, di + 1, di + 2, dl, dl + 4 * (size_t)pad, c->d_single_out, nullptr};
-    if (run_batch(c, b, s)) return 1;
-    if (prop_rft) {
+    // fused path with a forward evaluation: the kernel itself writes the proposed trace to the mapped
+    // buffer; otherwise (split kernels, or the stored trace of a sigma-only call) a gather kernel does
+    const bool direct = prop_rft && fwd_flag && c->fused;
+    c->single_trace_out = direct ? c->d_single_out + 1 : nullptr;
+    const int rc = run_batch(c, b, s);
+    c->single_trace_out = nullptr;
+    if (rc) return 1;
+    if (prop_rft && !direct) {
         launch_gather_rft(c->ws, ntrc, n, 1, di, 1, n, c->d_single_out + 1, s);
         HIP_TRY(hipGetLastError());
     }

@@ -56,7 +56,7 @@ void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 // fused K1+K2 (contexts with one forward computation per trace)
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
-                  int ablate, int defer_logl, int *order_next, hipStream_t s);
+                  int ablate, int defer_logl, int *order_next, double *extra_out, hipStream_t s);
 // logL of a batch launched with defer_logl (one thread per batch item, after the fused kernel)
 void launch_logl_deferred(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 size_t phi_deferred_lds_bytes(int nsmp);

@@ -1141,6 +1141,8 @@ struct TraceParams {
     int *slow_count;   // re-armed here for the next batch (the slow kernel ran earlier on the stream)
     int ablate;        // timing diagnostics only (RFGPU_ABLATE): stop the tail after phase N, results invalid
     int defer_logl;    // misfits to HBM; quadratic form + logL by phi_deferred_kernel (+ logl_deferred_kernel) after this launch
+    double *extra_out; // nullptr, or [ntrc][nfft] (device-mapped host memory): second copy of the proposed trace of
+                       // batch item 0 -- the per-call drop-in gets prop_rft without a gather kernel
 };
 
 // FFT with the last pass in registers, vertical maximum, shift / normalise / store and misfit for
@@ -1148,8 +1150,9 @@ struct TraceParams {
 // went to HBM for the follow-up kernels).
 template <int LOG2R>
 __device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 *a, double *mis, double *mis_g,
-                                                  double *__restrict__ dst, const double *__restrict__ obs,
-                                                  double *red, int ipha, bool decon, double tp, int tid)
+                                                  double *__restrict__ dst, double *xout,
+                                                  const double *__restrict__ obs, double *red, int ipha, bool decon,
+                                                  double tp, int tid)
 {
     constexpr int R = 1 << LOG2R;
     const DeviceTables &t = P.t;
@@ -1179,6 +1182,7 @@ __device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 
         double val = ipha == 1 ? v[k].x : -v[k].x;
         if (!decon) val = val / fac;                                 // forward.f90:202
         __builtin_nontemporal_store(val, &dst[i - 1]);   // written once, read rarely: keep it out of L2
+        if (xout) xout[i - 1] = val;
         if (i <= nsmp) {
             const double m = val - obs[i - 1];                       // likelihood.f90:88
             if (P.defer_logl)
@@ -1204,6 +1208,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
         P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
     double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
+    double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
     if (TRACE_THREADS == 256 && n >= 512 && n <= 4096) {
         // nfft 512 .. 4096: the last pass has exactly one butterfly (radix nfft / 256) per thread; its
         // outputs stay in registers for the vertical maximum, the shift and the store -- one LDS write
@@ -1211,10 +1216,10 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
         // operations.
         bool done = false;
         switch (P.log2n) {
-        case 12: done = tail_in_registers<4>(P, a, mis, mis_g, dst, obs, red, ipha, decon, tp, tid); break;
-        case 11: done = tail_in_registers<3>(P, a, mis, mis_g, dst, obs, red, ipha, decon, tp, tid); break;
-        case 10: done = tail_in_registers<2>(P, a, mis, mis_g, dst, obs, red, ipha, decon, tp, tid); break;
-        default: done = tail_in_registers<1>(P, a, mis, mis_g, dst, obs, red, ipha, decon, tp, tid); break;
+        case 12: done = tail_in_registers<4>(P, a, mis, mis_g, dst, xout, obs, red, ipha, decon, tp, tid); break;
+        case 11: done = tail_in_registers<3>(P, a, mis, mis_g, dst, xout, obs, red, ipha, decon, tp, tid); break;
+        case 10: done = tail_in_registers<2>(P, a, mis, mis_g, dst, xout, obs, red, ipha, decon, tp, tid); break;
+        default: done = tail_in_registers<1>(P, a, mis, mis_g, dst, xout, obs, red, ipha, decon, tp, tid); break;
         }
         if (done) return;   // ablation / deferred quadratic form
         __syncthreads();
@@ -1248,6 +1253,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
         }
         if (!decon) val = val / fac;                                 // forward.f90:202
         dst[i - 1] = val;
+        if (xout) xout[i - 1] = val;
         if (i <= nsmp) {
             const double m = val - obs[i - 1];                       // likelihood.f90:88
             if (P.defer_logl)
@@ -1610,12 +1616,12 @@ static void launch_fused_ncol(int chain, dim3 grid, size_t lds, hipStream_t s, c
 }
 
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
-                  int ablate, int defer_logl, int *order_next, hipStream_t s)
+                  int ablate, int defer_logl, int *order_next, double *extra_out, hipStream_t s)
 {
     FusedParams F{};
     F.order_next = order_next;
     F.sp = SpectraParams{t, b, nullptr, TRACE_THREADS / 64, nullptr, slow_count, w.meta_tp, w.meta_slot, w.cur_slot};
-    F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count, ablate, defer_logl};
+    F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count, ablate, defer_logl, extra_out};
     while ((1 << F.tp.log2n) < t.nfft) ++F.tp.log2n;
     F.tp.plan = make_fft_plan(F.tp.log2n);
     const size_t lds = fused_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
@@ -1675,7 +1681,7 @@ size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad)
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec, const WalkerState &w,
                   int *slow_count, hipStream_t s)
 {
-    TraceParams P{t, b, spec, w, 0, {}, slow_count, 0, 0};
+    TraceParams P{t, b, spec, w, 0, {}, slow_count, 0, 0, nullptr};
     while ((1 << P.log2n) < t.nfft) ++P.log2n;
     P.plan = make_fft_plan(P.log2n);
     const size_t lds = trace_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
