@@ -1,0 +1,78 @@
+"""Randomised parity sweep (GPU box): random contexts (nfft, traces, phases, ocean, deconvolution, window,
+batch size, fwd flags) against the CPU oracle with the tolerances of tests/helpers.py.  Not part of the
+pytest suites (minutes of oracle time); run by hand:  python tests/tools/fuzz_parity.py [ncases] [seed]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import DELTA, logl_tol, make_cfg, pack_layers, random_stack, synth_obs  # noqa: E402
+from oracle import rf_oracle as oracle  # noqa: E402
+from rf_inv_amd import RFEngine  # noqa: E402
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    oracle.build()
+    rng = np.random.default_rng(seed)
+    worst = 0.0
+    for case in range(ncases):
+        nfft = int(rng.choice([256, 512, 1024, 2048, 4096]))
+        ntrc = int(rng.integers(1, 5))
+        ocean = bool(rng.integers(0, 2))
+        sdep = 2.0 if ocean else 0.0
+        deconv = int(rng.integers(0, 2))
+        ipha = [int(rng.choice([1, -1])) for _ in range(ntrc)]
+        rayps = [float(rng.uniform(0.04, 0.075)) if ph == 1 else float(rng.uniform(0.09, 0.12)) for ph in ipha]
+        if rng.integers(0, 4) == 0 and ntrc > 1:      # common rays now and then
+            rayps = [rayps[0]] * ntrc
+            ipha = [ipha[0]] * ntrc
+        a_gus = [float(rng.choice([2.5, 4.0, 6.0])) for _ in range(ntrc)]
+        t_start = float(rng.choice([0.0, -1.0, -3.0]))
+        nsmp = int(rng.choice([61, 101, 161]))
+        kmax = int(rng.choice([6, 15, 30]))
+        nb = int(rng.choice([1, 3, 17, 130, 300, 700]))
+        cfg = make_cfg(nfft=nfft, deconv_mode=deconv, t_start=t_start, sdep=sdep, rayps=rayps, a_gus=a_gus, ipha=ipha)
+        true = random_stack(rng, int(rng.integers(3, 7)), ocean, sdep)
+        obs = synth_obs(oracle, cfg, true, nsmp)
+        r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+        lo = 3 if ocean else 2
+        stacks = [random_stack(rng, int(rng.integers(lo, kmax + 2)), ocean, sdep) for _ in range(nb)]
+        nlay, layers = pack_layers(stacks, kmax + 2)
+        sig = rng.uniform(0.01, 0.05, (nb, ntrc))
+        ref = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads())
+        with RFEngine(nfft=nfft, delta=cfg["delta"], t_start=t_start, deconv_mode=deconv, sdep=sdep, rayps=cfg["rayps"],
+                      a_gus=cfg["a_gus"], ipha=cfg["ipha"], obs=obs, nsmp=nsmp, r_inv=r_inv, max_walkers=nb,
+                      nlay_max=kmax + 2) as eng:
+            ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+            eng.commit(np.arange(nb), np.ones(nb, dtype=np.int32))
+            # second evaluation: mixed forward / sigma-only items
+            ff = rng.integers(0, 2, nb).astype(np.int32)
+            sig2 = sig * rng.uniform(0.8, 1.6)
+            stacks2 = [random_stack(rng, int(rng.integers(lo, kmax + 2)), ocean, sdep) for _ in range(nb)]
+            nlay2, layers2 = pack_layers(stacks2, kmax + 2)
+            ll2 = eng.eval_batch(np.arange(nb), nlay2, layers2, sig2, fwd_flag=ff)
+        use_l = np.where(ff[:, None, None] == 1, layers2, layers)
+        use_n = np.where(ff == 1, nlay2, nlay)
+        ref2 = oracle.eval_batch(cfg, obs, r_inv, use_n, use_l, sig2, nsmp, nthreads=oracle.max_threads())
+        ok = True
+        for got, want in ((ll, ref), (ll2, ref2)):
+            fin = np.isfinite(want)
+            bad = (np.isnan(got) != np.isnan(want)) | (fin & ~(np.abs(got - want) <= logl_tol(want)))
+            if bad.any():
+                ok = False
+                i = int(np.argmax(bad))
+                print("  MISMATCH item", i, got[i], want[i], "nlay", (nlay if got is ll else use_n)[i])
+            rel = np.abs(got - want)[fin] / np.maximum(np.abs(want[fin]), 1.0)
+            worst = max(worst, float(rel.max()) if rel.size else 0.0)
+        print(f"case {case:3d} nfft {nfft} ntrc {ntrc} ipha {ipha} ocean {int(ocean)} decon {deconv} nsmp {nsmp} "
+              f"kmax {kmax} nb {nb}: {'ok' if ok else 'FAIL'}", flush=True)
+    print("worst relative difference over all cases: %.2e" % worst)
+
+
+if __name__ == "__main__":
+    main()
