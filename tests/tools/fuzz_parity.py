@@ -66,7 +66,24 @@ def main():
             if bad.any():
                 ok = False
                 i = int(np.argmax(bad))
-                print("  MISMATCH item", i, got[i], want[i], "nlay", (nlay if got is ll else use_n)[i])
+                nl_i = int((nlay if got is ll else use_n)[i])
+                print("  MISMATCH item", i, got[i], want[i], "nlay", nl_i)
+                if os.environ.get("FUZZ_TRUTH"):
+                    # who is closer to the exactly evaluated formulas?  (80-bit long double, tests/tools/truth_check.py)
+                    import types
+
+                    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+                    import truth_check as tc
+
+                    pp = types.SimpleNamespace(nfft=nfft, nsmp=nsmp, delta=cfg["delta"], t_start=t_start, sdep=sdep,
+                                               ntrc=ntrc, ipha=cfg["ipha"], rayps=cfg["rayps"])
+                    lay_i = (layers if got is ll else use_l)[i]
+                    sg_i = (sig if got is ll else sig2)[i]
+                    if deconv == 0:
+                        t = tc.logl_truth(pp, oracle.init_filter(nfft, cfg["delta"], cfg["a_gus"]), obs, r_inv, nl_i,
+                                          lay_i, sg_i, oracle)
+                        print("    truth %.17g  |gpu-truth|/|truth| %.2e  |oracle-truth|/|truth| %.2e"
+                              % (float(t), float(abs(got[i] - t) / abs(t)), float(abs(want[i] - t) / abs(t))))
             rel = np.abs(got - want)[fin] / np.maximum(np.abs(want[fin]), 1.0)
             worst = max(worst, float(rel.max()) if rel.size else 0.0)
         print(f"case {case:3d} nfft {nfft} ntrc {ntrc} ipha {ipha} ocean {int(ocean)} decon {deconv} nsmp {nsmp} "
