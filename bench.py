@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- forward+likelihood evaluations/s of the HIP hot path on N MI355X.
 
-One "step" = one batched pass of the hot path (rf_eval_batch_device: spectra ->
-trace -> logL) over every walker resident on the rank, inputs already in HBM, logL
-read back to pinned host memory.  Walkers shard across ranks with no data-path
-collective (weak scaling: per-GPU work fixed); workloads with tempered chains add the
-parallel-tempering swap exchange (one all_gather of (T, logL) per step over RCCL).
+One "step" = one batched pass of the hot path (rf_eval_batch_device: propagator spectra ->
+trace -> logL) over every walker resident on the rank, inputs already in HBM, followed by the
+parallel-tempering swap step and the logL read-back to pinned host memory.  Walkers shard
+across ranks with no data-path collective (weak scaling: per-GPU work fixed); the swap step
+is one all_gather of (T, logL) per step over RCCL when N > 1.
 
 Workloads (BASELINE.json configs):
-  c2  (default) 1024 walkers/GPU, 1 P trace (p 0.06), nfft 4096, k_max 15 (<= 15 layers)
-  c4            8192 walkers/GPU, 3 traces (P .06, P .08, S .10), k_max 30, PT swap
-  c5            8192 walkers/GPU, 4 traces (2 P + 2 S), ocean layer, k_max 30, PT swap
-  c1            sample_syn shape: nfft 256, 2 traces, ocean, k_max 10 (plumbing size)
+  c4  (default)  the north-star shape, one GPU's shard of configs[3]: 8192 walkers/GPU
+                 (1024 chains x 8 temperatures), 3 traces (P .06, P .08, S .10), nfft 4096
+                 (2049 bins), <= 30 layers, PT swap
+  c2             1024 walkers/GPU, 1 P trace (p 0.06), nfft 4096, <= 15 layers
+  c3             8192 walkers/GPU (1024 x 8 temperatures), 1 P trace, PT swap on the device
+  c5             8192 walkers/GPU, 4 traces (2 P + 2 S), ocean layer, <= 31 layers, PT swap
+  c4common       c4 with ONE ray for all three traces (common-ray / "single FWD" mode,
+                 src/forward.f90:59-91,141): spectra_kernel -> trace_kernel split path
+  c1, c2d        sample_syn shape (nfft 256) / c2 with water-level deconvolution
 
-Prints ONE JSON line on rank 0.
+At N = 1 the default run also measures c2, c3, c5 and c4common briefly into "also".
+Prints ONE JSON line on rank 0.  Refuses to run with RFGPU_* variables in the environment
+(the library reads none; a stray one must not be mistaken for a setting) -- non-default
+launch plans are explicit `--opt name=value` flags and are echoed in `config`.
 """
 import argparse
+import glob
+import hashlib
 import json
 import math
 import os
@@ -29,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector == matrix peak (datasheet)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
+ENV_ALLOWED = {"RFGPU_BENCH_BACKEND"}   # "gloo": functional test of the N > 1 path on one GPU
 
 WORKLOADS = {
     "c2": dict(walkers=1024, nfft=4096, rayps=[0.06], ipha=[1], k_max=15, sdep=0.0, deconv=0, temps=1,
@@ -41,8 +52,13 @@ WORKLOADS = {
                     "PT swap on the device"),
     "c4": dict(walkers=8192, nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], k_max=30, sdep=0.0, deconv=0,
                temps=8,
-               desc="c4: 8192 walkers/GPU (1024 chains x 8 temperatures) x 3 traces (P .06, P .08, S .10) x nfft 4096 "
-                    "x <=30 layers, PT swap"),
+               desc="c4 (north-star shape, one GPU's shard of BASELINE configs[3]): 8192 walkers/GPU (1024 chains x 8 "
+                    "temperatures) x 3 traces (P .06, P .08, S .10) x nfft 4096 (2049 bins) x <=30 layers, PT swap"),
+    "c4common": dict(walkers=8192, nfft=4096, rayps=[0.06, 0.06, 0.06], ipha=[1, 1, 1], a_gus=[4.0, 2.5, 1.5],
+                     k_max=30, sdep=0.0, deconv=0, temps=8,
+                     desc="c4common (single-FWD / common-ray mode, forward.f90:59-91,141): 8192 walkers/GPU x 3 P traces "
+                          "of ONE ray (p .06; Gaussian a 4.0, 2.5, 1.5) x nfft 4096 x <=30 layers, PT swap; one "
+                          "propagator pass feeds three traces: spectra_kernel -> trace_kernel"),
     "c5": dict(walkers=8192, nfft=4096, rayps=[0.06, 0.08, 0.10, 0.12], ipha=[1, 1, -1, -1], k_max=30, sdep=2.0,
                deconv=0, temps=16,
                desc="c5-shape: 8192 walkers/GPU x 4 traces (P .06, P .08, S .10, S .12) x nfft 4096 x ocean layer "
@@ -63,7 +79,7 @@ def make_params(w):
     p.ntrc, p.nfft = n, w["nfft"]
     p.rayps = np.array(w["rayps"], dtype=np.float64)
     p.ipha = np.array(w["ipha"], dtype=np.int32)
-    p.a_gus = np.full(n, 4.0)
+    p.a_gus = np.array(w.get("a_gus", [4.0] * n), dtype=np.float64)
     p.sig_min = np.full(n, 0.01); p.sig_max = np.full(n, 0.01); p.sig_mode = np.zeros(n, dtype=np.int32)
     p.k_min, p.k_max, p.sdep, p.deconv_mode = 1, w["k_max"], w["sdep"], w["deconv"]
     p.delta = float(np.float32(0.05))
@@ -126,89 +142,160 @@ def alg_work(p, nlay, common):
     return f_spec, f_spec + f_rest, b
 
 
-def measured_traffic(kernel, workload, nb):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/<round>_<workload>_hbm_traffic.json, produced by tools/profile_gpu.sh: FETCH_SIZE and
-    WRITE_SIZE in separate runs, FETCH doubled per the gfx950 correction).  None when no profile of
-    this workload / walker count is committed -- bench.py itself cannot collect PMC counters."""
-    import glob
-
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_{workload}_hbm_traffic.json")), reverse=True):
+def committed_counters(kernel, grid_threads):
+    """Per-launch hardware counters of `kernel` at exactly this launch shape from the newest committed
+    profile (profiles/rNN_counters.json, written by tools/collect_counters.sh from separate rocprofv3
+    --pmc passes over THIS script; FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md).  bench.py itself cannot collect PMC counters.  None when no launch of that
+    kernel and grid is in the file."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")), reverse=True):
         try:
             d = json.load(open(f))
         except Exception:
             continue
-        if d.get("_walkers_per_gpu") not in (None, nb):
-            continue
-        for k, v in d.items():
-            if isinstance(v, dict) and k.split("<")[0] == kernel:
-                return v.get("hbm_bytes_per_launch")
+        for e in d.get("kernels", []):
+            if e["kernel"].split("<")[0] == kernel and int(e["grid_threads"]) == int(grid_threads):
+                out = dict(e["counters"])
+                out["_file"] = os.path.relpath(f, ROOT)
+                out["_lib_sha256"] = d.get("lib_sha256")
+                return out
     return None
 
 
+def executed_fp64_flops(c):
+    """fp64 flops one launch EXECUTED, from the SQ_INSTS_VALU_*_F64 wave-instruction counters
+    (64 lanes; an FMA is 2 flops) -- the count the fp64 VALU roofline is priced on."""
+    try:
+        return 64.0 * (c["SQ_INSTS_VALU_ADD_F64"] + c["SQ_INSTS_VALU_MUL_F64"] + c["SQ_INSTS_VALU_TRANS_F64"]
+                       + 2.0 * c["SQ_INSTS_VALU_FMA_F64"])
+    except (KeyError, TypeError):
+        return None
+
+
+def physical_cores():
+    """Physical cores of the host (unique (package, core) pairs), not SMT threads."""
+    try:
+        seen, phys, core = set(), None, None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                phys = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                core = line.split(":")[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    seen.add((phys, core))
+                phys = core = None
+        n = len(seen)
+    except OSError:
+        n = 0
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return max(1, min(n or avail, avail))
+
+
 def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
-    """Oracle (CPU restatement, kind 'port') timed on this box's host cores on a bounded
-    sample of the same workload: the rank's walker set, repeated until about budget_s of
-    wall time.  The reference itself cannot be built in this image (needs FFTW3 + LAPACK),
-    see DESIGN.md."""
+    """The CPU side of the comparison, on a bounded sample of the same workload: oracle/rf_oracle.c
+    (a scalar fp64 restatement of the reference's arithmetic, kind "port"), one OpenMP thread per
+    PHYSICAL core.  The reference itself cannot be built in this image without stand-ins for FFTW3 /
+    LAPACK, so its own per-core rate is carried as `ref_ratio` from SURVEY.md
+    section 6's probe of the unmodified reference (same shapes) against this port, both single-core."""
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "cores")
     from oracle import rf_oracle as orc
 
     orc.build()
     cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep,
                rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha)
-    cores = max(1, min(orc.max_threads(), os.cpu_count() or 1))
+    cores = max(1, min(physical_cores(), orc.max_threads()))
     nb = len(nlay)
+    # parity sample + a first timing on a slice that one pass finishes quickly
+    n0 = min(nb, 16 * cores)
     t0 = time.perf_counter()
-    ll = orc.eval_batch(cfg, obs, r_inv, nlay, layers, sig, p.nsmp, nthreads=cores)   # also the parity sample
-    dt1 = time.perf_counter() - t0
-    reps = int(max(1, min(2000, budget_s / max(dt1, 1e-3))))
-    big = (np.tile(nlay, reps), np.tile(layers, (reps, 1, 1)), np.tile(sig, (reps, 1)))
+    ll = orc.eval_batch(cfg, obs, r_inv, nlay[:n0], layers[:n0], sig[:n0], p.nsmp, nthreads=cores)
+    dt0 = time.perf_counter() - t0
+    n = int(min(max(n0, budget_s / max(dt0, 1e-3) * n0), 200 * nb))
+    idx = np.arange(n) % nb
     t0 = time.perf_counter()
-    orc.eval_batch(cfg, obs, r_inv, big[0], big[1], big[2], p.nsmp, nthreads=cores)
+    ll_all = orc.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], p.nsmp, nthreads=cores)
     dt = time.perf_counter() - t0
-    n = nb * reps
-    return {"value": n / dt, "unit": "evals/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} passes over the rank's {nb} walkers ({n} evals), oracle/rf_oracle.c "
-                      f"(gcc -O2 -ffp-contract=off, OpenMP x{cores} threads), {dt:.1f} s wall"}, ll, nb
+    # single-core rate of the port on the same sample (for the per-core comparison with the reference probe)
+    n1 = max(8, min(nb, int(2.0 / max(dt / n * cores, 1e-4))))
+    t0 = time.perf_counter()
+    orc.eval_batch(cfg, obs, r_inv, nlay[:n1], layers[:n1], sig[:n1], p.nsmp, nthreads=1)
+    dt1 = time.perf_counter() - t0
+    base = {"value": n / dt, "unit": "evals/s", "cores": cores, "kind": "port",
+            "per_core": n / dt / cores, "single_core": n1 / dt1,
+            "sample": f"{n} evals = the rank's walker set cycled ({nb} walkers, mean {float(nlay.mean()):.1f} layers), "
+                      f"oracle/rf_oracle.c (gcc -O2 -ffp-contract=off, OpenMP x{cores} threads = physical cores, "
+                      f"{dt:.1f} s wall); single-core rate on {n1} evals"}
+    nuse = min(nb, n)
+    return base, ll_all[:nuse], nuse
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default=os.environ.get("RFGPU_BENCH_WORKLOAD", "c2"), choices=sorted(WORKLOADS))
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
     ap.add_argument("--walkers", type=int, default=0, help="override walkers per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--swap", default="allgather", choices=["allgather", "p2p"],
                     help="temperature exchange of tempered workloads: K disjoint pairs via one all_gather, or the "
                          "reference's one pair per iteration via send/recv")
-    ap.add_argument("--also", default="", help="comma list of extra workloads measured briefly into 'also'")
+    ap.add_argument("--also", default=None,
+                    help="comma list of extra workloads measured briefly into 'also' (default at N = 1: "
+                         "c2,c3,c5,c4common; '' for none)")
+    ap.add_argument("--prewarm-seconds", type=float, default=1.0,
+                    help="untimed steps run for at least this long before --warmup (clock ramp; independent of --warmup)")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="launch-plan option (rf_set_option); echoed in config.overrides")
+    ap.add_argument("--lib", default=None, help="another build of librfgpu.so (A/B timing); echoed in config.lib")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not time the dominant kernel with HIP events")
+    ap.add_argument("--copy-logl", action="store_true", help="always read logL back with an async copy")
     args = ap.parse_args()
 
+    stray = sorted(k for k in os.environ if k.startswith("RFGPU_") and k not in ENV_ALLOWED)
+    if stray:
+        raise SystemExit(f"bench.py: refusing to run with {stray} in the environment: librfgpu reads no environment "
+                         "variables; use --opt name=value / --lib (both are echoed in the JSON line)")
+    overrides = {}
+    for kv in args.opt:
+        k, _, v = kv.partition("=")
+        overrides[k.strip()] = float(v)
+
     import torch
+
+    from rf_inv_amd import _lib
+
+    _lib.load(args.lib)
+    lib_sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    backend = os.environ.get("RFGPU_BENCH_BACKEND", "nccl")
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("RFGPU_BENCH_BACKEND", "nccl")   # "gloo": functional test of the N > 1 path on one GPU
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    if os.environ.get("RFGPU_BENCH_BACKEND", "nccl") != "nccl":
+    if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    def run(workload, steps, warmup, with_cpu):
-        from rf_inv_amd import RFEngine, read_ref_model
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def run(workload, steps, warmup, with_cpu, parity_n=64):
+        from rf_inv_amd import RFEngine, format_model, read_ref_model
         from rf_inv_amd.likelihood import init_r_inv
         from rf_inv_amd.pt import PTSwap
 
@@ -221,9 +308,7 @@ def main():
         nlay, layers = draw_walkers(p, ref, rank * nb, nb)
         sig = np.full((nb, p.ntrc), 0.01)
         r_inv = init_r_inv(p.nsmp, p.a_gus, p.delta)
-        # observed traces: noise-free synthetic of a fixed 3-interface model, produced by the
-        # HIP path itself
-        from rf_inv_amd import format_model
+        # observed traces: noise-free synthetic of a fixed 3-interface model, produced by the HIP path itself
         zt = np.zeros(max(p.k_max - 1, 1)); dvt = np.zeros(p.k_max); dst = np.zeros(p.k_max)
         zt[:3] = [3.1 + p.sdep, 7.7 + p.sdep, 14.2 + p.sdep]; dst[:3] = [-0.6, 0.2, 0.5]; dst[p.k_max - 1] = 0.9
         nl_t, a_t, b_t, r_t, h_t, ok = format_model(p, ref, 3, zt, dvt, dst)
@@ -233,7 +318,7 @@ def main():
                   device=local_rank)
         with RFEngine(obs=np.zeros((p.ntrc, p.nsmp)), r_inv=r_inv, max_walkers=1, **kw) as e0:
             obs = np.ascontiguousarray(e0.calc_rf(nl_t, a_t, b_t, r_t, h_t)[:p.nsmp].T)
-        eng = RFEngine(obs=obs, r_inv=r_inv, max_walkers=nb, **kw)
+        eng = RFEngine(obs=obs, r_inv=r_inv, max_walkers=nb, options=overrides, **kw)
 
         stream = torch.cuda.Stream(device=dev)
         d_ids = torch.arange(nb, dtype=torch.int32, device=dev)
@@ -247,7 +332,7 @@ def main():
         # logL read-back: without a swap step the kernel writes logL straight into the pinned
         # (device-mapped) host buffer -- no copy kernel after the evaluation; with a swap step logL
         # is consumed on the device first and copied afterwards
-        zero_copy = swap is None and not os.environ.get("RFGPU_BENCH_COPY")
+        zero_copy = swap is None and not args.copy_logl
 
         def step():
             with torch.cuda.stream(stream):
@@ -259,96 +344,154 @@ def main():
                         swap.step(d_logl, stream)
                     h_logl.copy_(d_logl, non_blocking=True)
 
-        def barrier():
-            if world > 1:
-                dist.barrier()
+        # ---- pre-warm by TIME (clock ramp, allocator, dispatch order of the running batch), then --warmup steps
+        t_pre = time.perf_counter()
+        n_pre = 0
+        while True:
+            for _ in range(8):
+                step()
+            n_pre += 8
             torch.cuda.synchronize(dev)
-
+            if time.perf_counter() - t_pre >= args.prewarm_seconds:
+                break
         for _ in range(warmup):
             step()
         barrier()
-        # HIP events around the dominant kernel of every 8th step of the timed region: an event record costs
-        # ~4 us of stream time, so timing every step would slow the loop it measures by ~8 % at C2
-        eng.profile_enable(0 if os.environ.get("RFGPU_BENCH_NOPROF") else min(8, max(1, steps // 8)))
+        # HIP events (library side, on the launch stream) around the dominant kernel, and torch events on the same
+        # stream around whole steps, both on every `every`-th step of the timed region: an event pair costs ~4 us of
+        # stream time -- at C2 (0.09 ms steps) timing every step would slow the loop it measures by ~8 %
+        every = 1 if steps <= 16 else min(8, max(1, steps // 8))
+        eng.profile_enable(0 if args.no_kernel_events else every)
+        marks = []
         import gc
 
         gc.collect()
-        gc.disable()            # no collector pause inside the (short) timed region
+        gc.disable()            # no collector pause inside the (possibly short) timed region
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        for i in range(steps):
+            if i % every == 0:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                step()
+                e1.record(stream)
+                marks.append((e0, e1))
+            else:
+                step()
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
         eng.profile_enable(False)
         prof = eng.profile_read()
+        step_ms = np.array([a.elapsed_time(b) for a, b in marks])
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         ll_gpu = h_logl.numpy().copy()
-        assert np.all(np.isfinite(ll_gpu)) or os.environ.get("RFGPU_ABLATE"), "non-finite logL in the benchmark batch"
+        plan = eng.launch_plan
+        assert plan["build"] == "production" or overrides or args.lib, plan
+        assert np.all(np.isfinite(ll_gpu)), "non-finite logL in the benchmark batch"
 
         f_spec, f_tot, b_alg = alg_work(p, nlay.astype(np.float64), eng.is_ray_common)
-        plan = eng.launch_plan
         n_l = max(prof["launches"], 1)          # batches timed
         # dominant kernel: fused_kernel (propagator + trace + logL in one launch) where every trace has
         # its own forward computation, else spectra_kernel (then trace_kernel follows it)
-        spectra_ms = prof["spectra_ms"] / n_l   # one launch per batch
+        kernel_ms = prof["spectra_ms"] / n_l if prof["launches"] else None
         f_dom = f_tot if plan["fused"] else f_spec
         kname = "rfgpu::fused_kernel" if plan["fused"] else "rfgpu::spectra_kernel"
+        if plan["fused"]:
+            grid_threads = 256 * (nb * p.ntrc + (1 if (plan["lpt"] and plan["order_reuse"] and nb >= 512) else 0))
+        else:
+            grid_threads = None   # split path: matched by name only (nsplit decides the grid)
+        ctr = committed_counters(kname, grid_threads) if grid_threads else None
+        exe = executed_fp64_flops(ctr) if ctr else None
+        t_k = kernel_ms * 1e-3 if kernel_ms else None
+        roof = {
+            "bound": "fp64_valu", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
+            # EXECUTED fp64 flops of one launch (committed SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 counters of this
+            # kernel at this launch shape) / live HIP-event kernel time: a hardware fraction, <= 1
+            "achieved": exe / t_k / 1e12 if exe and t_k else None,
+            "frac": exe / t_k / 1e12 / FP64_PEAK_TFLOPS if exe and t_k else None,
+            "traffic": (2048.0 * ctr["FETCH_SIZE"] + 1024.0 * ctr["WRITE_SIZE"]) if ctr and "FETCH_SIZE" in ctr
+                       and "WRITE_SIZE" in ctr else None,
+            "kernel": kname, "kernel_ms": kernel_ms, "grid_threads": grid_threads,
+            "executed_gflop_per_launch": exe / 1e9 if exe else None,
+            "counters": ({"file": ctr["_file"], "lib_sha256_matches_this_build": ctr["_lib_sha256"] == lib_sha}
+                         if ctr else None),
+            # SURVEY.md 8d's ALGORITHMIC figure (reference arithmetic: 570 flop/(bin*layer) + 580/bin, + FFT /
+            # shift / quadratic form when fused) over the same kernel time.  The eigen-coordinate real-form
+            # propagator executes ~1/5 of those flops, so this ratio exceeds 1; it is not a hardware fraction.
+            "algorithmic": {"gflop_per_launch": float(f_dom.sum()) / 1e9,
+                            "tflops": float(f_dom.sum()) / t_k / 1e12 if t_k else None,
+                            "ratio_to_peak": float(f_dom.sum()) / t_k / 1e12 / FP64_PEAK_TFLOPS if t_k else None},
+            "note": "fp64 vector ALU roofline: MI355X FP64 matrix (MFMA) peak == vector peak = 78.6 TF, the kernel "
+                    "issues fp64 VALU FMA/MUL/ADD, MFMA not used.",
+        }
         res = {
             "value": world * nb * steps / dt,
             "ms_per_step": 1e3 * dt / steps,
+            "ms_per_step_median": float(np.median(step_ms)) if len(step_ms) else None,
+            "ms_per_step_p10_p90": [float(np.percentile(step_ms, 10)), float(np.percentile(step_ms, 90))]
+                                   if len(step_ms) else None,
             "config": {"workload": w["desc"], "walkers_per_gpu": nb, "nfft": p.nfft, "ntrc": p.ntrc,
                        "nsmp": p.nsmp, "k_max": p.k_max, "mean_nlay": float(nlay.mean()),
                        "max_nlay": int(nlay.max()), "deconv_mode": p.deconv_mode, "sdep": p.sdep,
+                       "ray_common": bool(eng.is_ray_common),
                        "logl_readback": "kernel writes pinned host memory" if zero_copy else "device buffer + async copy",
                        "temperatures": w["temps"], "parallelism": f"walkers sharded x{world}",
-                       "pt_swap": (f"{args.swap}, {swap.k} pair(s)/step" if swap is not None else "none")},
-            "roofline": {
-                "bound": "mfma", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
-                "achieved": float(f_dom.sum()) / (spectra_ms * 1e-3) / 1e12 if spectra_ms > 0 else None,
-                "frac": float(f_dom.sum()) / (spectra_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if spectra_ms > 0 else None,
-                "traffic": measured_traffic(kname, workload, nb),
-                "kernel": kname, "kernel_ms": spectra_ms, "launch_plan": plan,
-                # executed (not algorithmic) fp64 rate, an ESTIMATE from the ISA of the chained-phase loop:
-                # ~65 fp64 VALU ops per (bin, layer), ~55 % of them FMAs -> ~100 flop; + ~300 flop per bin
-                # for the boundary condition
-                "executed_tflops_est": (float((nlay - 1 - (1 if p.sdep > 0 else 0)).sum() * 100.0 + 300.0 * nb)
-                                        * (1 if eng.is_ray_common else p.ntrc) * (p.nfft // 2 + 1)
-                                        / (spectra_ms * 1e-3) / 1e12) if spectra_ms > 0 else None,
-                "note": "fp64: MI355X matrix (MFMA) peak == vector peak = 78.6 TF; the kernel issues fp64 VALU FMA, "
-                        "MFMA not used (no rate advantage). achieved = reference-arithmetic flops (SURVEY 8d: "
-                        "570/(bin*layer)+580/bin, + FFT/shift/quadratic form when fused) per launch / live "
-                        "HIP-event kernel time; the eigen-coordinate real-form propagator executes ~1/6 of those flops, so the "
-                        "algorithmic fraction can exceed 1 (DESIGN.md section 3).",
-            },
+                       "pt_swap": (f"{args.swap}, {swap.k} pair(s)/step" if swap is not None else "none"),
+                       "launch_plan": plan, "overrides": overrides,
+                       "lib": {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "sha256": lib_sha,
+                               "default_build": args.lib is None},
+                       "prewarm": {"seconds": args.prewarm_seconds, "steps": n_pre},
+                       "events_every": every},
+            "roofline": roof,
             "roofline_hbm": {
                 "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
                 "achieved": float(b_alg.sum()) * steps / dt / 1e9,
                 "frac": float(b_alg.sum()) * steps / dt / 1e9 / HBM_PEAK_GBS,
-                "note": "algorithmic bytes/eval (layers+sigma in, prop_rft(nfft,ntrc)+logL out) x evals/s of this rank",
+                "note": "algorithmic bytes/eval (layers+sigma in, prop_rft(nfft,ntrc)+logL out) x evals/s of this rank; "
+                        "the path is FP64-ALU bound, not HBM bound",
             },
-            "kernel_ms": ({"fused": spectra_ms} if plan["fused"] else
-                          {"spectra": spectra_ms, "trace": prof["trace_ms"] / n_l}),
+            "kernel_ms": ({"fused": kernel_ms} if plan["fused"] else
+                          {"spectra": kernel_ms, "trace": prof["trace_ms"] / n_l}),
             "alg_gflop_per_step": float(f_tot.sum()) / 1e9,
         }
-        if with_cpu and rank == 0:
-            base, ll_cpu, n = cpu_baseline(p, obs, r_inv, nlay, layers, sig)
-            res["cpu_baseline"] = base
+        if rank == 0 and (with_cpu or parity_n):
+            if with_cpu:
+                base, ll_cpu, n = cpu_baseline(p, obs, r_inv, nlay, layers, sig)
+                res["cpu_baseline"] = base
+            else:
+                from oracle import rf_oracle as orc
+
+                orc.build()
+                cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep,
+                           rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha)
+                n = min(nb, parity_n)
+                ll_cpu = orc.eval_batch(cfg, obs, r_inv, nlay[:n], layers[:n], sig[:n], p.nsmp,
+                                        nthreads=min(physical_cores(), orc.max_threads()))
             d = np.abs(ll_gpu[:n] - ll_cpu)
-            res["parity_in_bench"] = {"n": n, "max_abs_dlogl": float(d.max()),
-                                      "max_rel_dlogl": float((d / np.abs(ll_cpu)).max())}
+            res["parity_in_bench"] = {"n": int(n), "max_abs_dlogl": float(d.max()),
+                                      "max_rel_dlogl": float((d / np.abs(ll_cpu)).max()),
+                                      "within_tolerance": bool(np.all(d <= np.maximum(1e-9, 1e-12 * np.abs(ll_cpu))))}
         eng.close()
         return res
 
     main_res = run(args.workload, args.steps, args.warmup, not args.no_cpu_baseline and world == 1)
+    also_list = args.also if args.also is not None else ("c2,c3,c5,c4common" if world == 1 else "")
     also = {}
-    for wl in [x for x in args.also.split(",") if x]:
-        r = run(wl, max(30, min(200, args.steps // 2)), max(5, min(20, args.warmup // 2)), False)
-        also[wl] = {k: r[k] for k in ("value", "ms_per_step", "config", "roofline", "kernel_ms")}
+    for wl in [x for x in also_list.split(",") if x and x != args.workload]:
+        r = run(wl, max(30, min(200, args.steps)), max(5, min(20, args.warmup)), False)
+        also[wl] = {k: r[k] for k in ("value", "ms_per_step", "ms_per_step_median", "config", "roofline", "kernel_ms",
+                                      "parity_in_bench") if k in r}
     if rank == 0:
+        if "cpu_baseline" in main_res:
+            # the reference's own per-core rate at this shape, from SURVEY.md section 6's probe of the unmodified
+            # reference (amdflang -O2, one core of this container class); ratio = reference / this port, per core
+            probe = {"c2": ("175-205 evals/s/core at 15 layers (nfft 4096, 1 P trace)", None),
+                     "c4": ("29-37 evals/s/core at 30 layers (nfft 4096, 3 traces)", None)}.get(args.workload)
+            if probe:
+                main_res["cpu_baseline"]["reference_probe"] = probe[0]
         out = {"metric": "forward+likelihood evals/sec (whole node)", "value": main_res["value"], "unit": "evals/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",

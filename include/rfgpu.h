@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RFGPU_ABI_VERSION 2
+#define RFGPU_ABI_VERSION 3
 
 typedef struct rf_ctx rf_ctx;
 
@@ -249,11 +249,30 @@ typedef struct rf_post_result {
 int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
 
 /* ---- instrumentation ----------------------------------------------------- */
-/* how rf_eval_batch* will launch: plan[0] = 1 when spectra + trace run as ONE fused kernel
- * (contexts with one forward computation per trace; then ms[0] of rf_profile_read is the
- * fused kernel and ms[1] stays 0), plan[1] = bins per phase chain (0: direct sincos),
- * plan[2] = waves per block of the split spectra kernel, plan[3] = bin-splits per walker
- * at a full batch. */
+/* Launch-plan options.  librfgpu reads NO environment variables; a knob is set here, validated,
+ * and reported by rf_get_launch_plan.  Every option re-partitions or re-orders the same work:
+ * results do not depend on them (tests/test_gpu_parity.py), except "bin_cutoff", which is opt-in
+ * and off by default.  Call between evaluations (the call synchronises the context's stream).
+ *   "fused"            -1 by shape (default) | 0 split spectra -> trace kernels | 1 one fused kernel
+ *   "chain"            -1 by shape (default) | 0, 2, 3, 4, 8 bins per phase chain
+ *   "lpt"              1 (default) longest-first dispatch order | 0
+ *   "order_reuse"      1 (default) a launch prepares the next launch's order | 0 order kernel every time
+ *   "nsplit"           0 by batch size (default) | 1..64 bin-splits per walker (split spectra kernel)
+ *   "waves_per_block"  1..4 (default 4) waves sharing a staged layer stack (split spectra kernel)
+ *   "defer_logl"       -1 by batch size (default) | 0 quadratic form + logL inside the main kernel | 1 follow-up kernels
+ *   "bin_cutoff"       0 (default: every bin like the reference) | tol in (0, 1): bins whose Gaussian filter
+ *                      weight is below tol * flt(1) are not propagated
+ * A library built with -DRFGPU_DIAGNOSTICS (tools/ablate.sh; never the shipped one) also accepts
+ * "ablate" = N: blocks stop after phase N, results are invalid. */
+int rf_set_option(rf_ctx *ctx, const char *name, double value);
+
+/* how rf_eval_batch* will launch, plan[10]:
+ *  [0] 1 when spectra + trace run as ONE fused kernel (contexts with one forward computation per trace;
+ *      then ms[0] of rf_profile_read is the fused kernel and ms[1] stays 0)
+ *  [1] bins per phase chain (0: direct sincos)   [2] waves per block of the split spectra kernel
+ *  [3] bin-splits per walker at a full batch     [4] lpt   [5] order_reuse   [6] defer_logl (-1 / 0 / 1)
+ *  [7] 1 when a bin cut-off is active            [8] number of options away from their defaults
+ *  [9] 0 production build | 1 RFGPU_DIAGNOSTICS build | 2 diagnostics build with "ablate" set (results invalid) */
 int rf_get_launch_plan(const rf_ctx *ctx, int32_t *plan);
 
 /* HIP-event timing (on the streams the kernels are launched on) of the three kernels

@@ -213,14 +213,14 @@ def build_r_inv(nsmp, a_gus, delta, return_rank=False):
 
 def read_sac(path, t_start, t_end):
     """src/params.f90:422-476 read_obs for one file: returns (obs[nsmp], delta, nsmp).
-    SAC: 4-byte records, delta @rec 1, b @rec 6, npts @rec 80, data from rec 159;
-    all header arithmetic in float32 like the reference."""
+    SAC: 4-byte records, delta @rec 1, b @rec 6, npts @rec 80, data from rec 159.
+    t_start / t_end are real(8) (:66), delta4 / t_beg4 default REAL: the mixed expressions of
+    :449-450 are evaluated in double on the float32-valued header fields."""
     raw = np.fromfile(path, dtype="<f4")
     delta4 = np.float32(raw[0])
     t_beg4 = np.float32(raw[5])
-    f32 = np.float32
-    it1 = int(_nint(float((f32(t_start) - t_beg4) / delta4))) + 1   # :449
-    it2 = int(_nint(float((f32(t_end) - t_beg4) / delta4))) + 1     # :450
+    it1 = int(_nint((float(t_start) - float(t_beg4)) / float(delta4))) + 1   # :449
+    it2 = int(_nint((float(t_end) - float(t_beg4)) / float(delta4))) + 1     # :450
     nsmp = it2 - it1 + 1
     data = raw[158 + it1 - 1: 158 + it1 - 1 + nsmp].astype(np.float64)  # :455-458
     return data, float(delta4), nsmp

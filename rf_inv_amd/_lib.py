@@ -6,8 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# RFGPU_LIB selects another build of the same ABI (A/B timing of kernel variants)
-LIB_PATH = os.environ.get("RFGPU_LIB") or os.path.join(_HERE, "lib", "librfgpu.so")
+LIB_PATH = os.path.join(_HERE, "lib", "librfgpu.so")
 
 dp = C.POINTER(C.c_double)
 ip = C.POINTER(C.c_int32)
@@ -88,6 +87,7 @@ SYMBOLS = {
     "rf_post_record": (C.c_int, [_vp, C.c_int32, ip, ip, dp, dp, dp, dp, dp, dp]),
     "rf_post_record_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_post_read": (C.c_int, [_vp, C.POINTER(RFPostResult)]),
+    "rf_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "rf_get_launch_plan": (C.c_int, [_vp, ip]),
     "rf_profile_enable": (C.c_int, [_vp, C.c_int32]),
     "rf_profile_read": (C.c_int, [_vp, dp, C.POINTER(C.c_int64), C.c_int32]),
@@ -96,11 +96,17 @@ SYMBOLS = {
 _lib = None
 
 
-def load():
-    """Load librfgpu.so and type every entry point.  Raises if it is not built."""
-    global _lib
+def load(path=None):
+    """Load librfgpu.so and type every entry point.  Raises if it is not built.
+    `path` (first call only; tools/ab.sh, bench.py --lib): another build of the same ABI for
+    A/B timing -- an explicit argument, never an environment variable."""
+    global _lib, LIB_PATH
     if _lib is not None:
+        if path is not None and os.path.abspath(path) != os.path.abspath(LIB_PATH):
+            raise RuntimeError(f"librfgpu already loaded from {LIB_PATH}")
         return _lib
+    if path is not None:
+        LIB_PATH = os.path.abspath(path)
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             f"{LIB_PATH} is missing: build the HIP extension first "

@@ -53,7 +53,7 @@ struct rf_ctx {
     int *d_order = nullptr;   // [nslots] LPT dispatch order of the current batch
     int *d_order_alt = nullptr;   // [nslots] the order the running launch computes for the next one
     int order_next_nb = 0;    // d_order_alt holds an order for a batch of this size (0: none)
-    bool order_reuse = true;  // RFGPU_ORDER_REUSE=0: a fresh order_kernel before every launch
+    bool order_reuse = true;  // "order_reuse" = 0: a fresh order_kernel before every launch
     // posterior accumulators (row f-3)
     bool have_post = false;
     PostConfig post{};
@@ -62,10 +62,16 @@ struct rf_ctx {
     int *d_post_nlay = nullptr, *d_post_flag = nullptr, *d_post_k = nullptr;
     double *d_post_layers = nullptr, *d_post_scratch = nullptr;
     double *d_post_in = nullptr;   // staging of rf_post_record's host arrays
+    // launch-plan options (rf_set_option; every combination computes the same results)
     bool lpt = true;
-    int nsplit_override = 0;  // RFGPU_NSPLIT
-    int ablate = 0;           // RFGPU_ABLATE: timing diagnostics, stops the trace tail early (results invalid)
-    int defer_logl = -1;      // RFGPU_DEFER_LOGL: -1 = by batch size, 0 / 1 = never / always
+    int nsplit_override = 0;  // "nsplit"
+    int chain_override = -1;  // "chain": -1 = by shape
+    bool fused_allowed = false;   // the context's shape admits the fused kernel
+    int fused_override = -1;  // "fused": -1 = by shape
+    int defer_logl = -1;      // "defer_logl": -1 = by batch size, 0 / 1 = never / always
+    double bin_cutoff = 0.0;  // "bin_cutoff": opt-in filter-support cut-off (0 = off: every bin like the reference)
+    int n_overrides = 0;      // options set away from their defaults (echoed by rf_get_launch_plan)
+    int ablate = 0;           // RFGPU_DIAGNOSTICS builds only ("ablate"): stops the kernel early, results invalid
     double *h_single_in = nullptr, *h_single_out = nullptr;   // pinned staging of the per-call drop-in
     double *d_single_in = nullptr, *d_single_out = nullptr;
     double *single_trace_out = nullptr;   // set by rf_calc_likelihood around its run_batch: extra trace copy
@@ -227,6 +233,22 @@ static int ensure_stage(rf_ctx *c, int nb, int pad)
     return 0;
 }
 
+// Launch plan from the context's shape, then the explicit options on top.
+static void default_plan(rf_ctx *c)
+{
+    // chained phases pay off when a wave owns many 64-bin iterations (nfft 4096: 33); with
+    // few iterations (nfft 256: 3) the direct path with more bin-splits is faster
+    // (measured on MI355X: c4 spectra 4.18 -> 3.17 ms, c2 0.133 -> 0.119 ms, c1 0.035 vs 0.058 ms)
+    const int niter = (c->nh + 63) / 64;
+    c->chain = niter >= 16 ? 4 : 0;
+    c->fused = c->fused_allowed && c->fused_override != 0;
+    // fused kernel, land: chains of 8 when that gives each of the block's four waves whole chunks
+    // (nfft 4096: 4 chunks of 8 iterations + the Nyquist iteration); measured C4 +7 %, C2 +2 % over 4.
+    // Ocean (3 propagated columns): chains of 4 (239 VGPRs; 8 would not fit two waves per SIMD).
+    if (c->fused && c->chain == 4 && c->cfg.sdep <= 0.0 && (niter / 8) >= 4 && (niter / 8) % 4 == 0) c->chain = 8;
+    if (c->chain_override >= 0) c->chain = c->chain_override;
+}
+
 extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
 {
     if (!cfg || !ctx_out) return fail("rf_ctx_create: null argument");
@@ -319,23 +341,7 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     T.domg = 2.0 * pi / (n * cfg->delta);   // forward.f90:241
     T.omg_dc = (double)1.0e-5f;             // forward.f90:247 single-precision literal
     std::vector<double> r_inv_t = transpose_r_inv(c->r_inv, ntrc, nsmp);
-    T.nh_active = nullptr;
-    if (const char *cut = getenv("RFGPU_BIN_CUTOFF")) {
-        // opt-in: skip bins whose filter weight is below cutoff * flt(0) (e.g. 1e-20: their
-        // contribution to any sample is ~1e4 below the FFT's own rounding noise); off by default,
-        // the default path evaluates every bin like the reference
-        const double tol = atof(cut);
-        if (tol > 0.0 && tol < 1.0) {
-            std::vector<int> act(ntrc);
-            for (int t = 0; t < ntrc; ++t) {
-                int last = 0;
-                for (int k = 0; k < nh; ++k)
-                    if (c->flt[(size_t)k + (size_t)nh * t] >= tol * c->flt[(size_t)nh * t]) last = k;
-                act[t] = last + 1;
-            }
-            if (upload(c, act, &T.nh_active)) return cleanup(1);
-        }
-    }
+    T.nh_active = nullptr;   // rf_set_option("bin_cutoff"): opt-in, off by default
     if (upload(c, c->flt, &T.flt) || upload(c, obs, &T.obs) || upload(c, r_inv_t, &T.r_inv_t) ||
         upload(c, rayps, &T.rayps) || upload(c, ipha, &T.ipha) || upload(c, tw, &T.twiddle))
         return cleanup(1);
@@ -378,32 +384,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
 
     if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || trace_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024)
         return cleanup(fail("rf_ctx_create: nfft / nsmp / nlay_max exceed the 160 KiB LDS of a gfx950 CU"));
-    // chained phases pay off when a wave owns many 64-bin iterations (nfft 4096: 33); with
-    // few iterations (nfft 256: 3) the direct path with more bin-splits is faster
-    // (measured on MI355X: c4 spectra 4.18 -> 3.17 ms, c2 0.133 -> 0.119 ms, c1 0.035 vs 0.058 ms)
-    const int niter = (c->nh + 63) / 64;
-    c->chain = niter >= 16 ? 4 : 0;
-    c->fused = (c->nfwd == ntrc) && fused_lds_bytes(n, nsmp, cfg->nlay_max) <= 160 * 1024;
-    const char *env = getenv("RFGPU_FUSED");
-    if (env) c->fused = c->fused && atoi(env) != 0;
-    // fused kernel, land: chains of 8 when that gives each of the block's four waves whole chunks
-    // (nfft 4096: 4 chunks of 8 iterations + the Nyquist iteration); measured C4 +7 %, C2 +2 % over 4.
-    // Ocean (3 propagated columns): chains of 4 (239 VGPRs; 8 would not fit two waves per SIMD).
-    if (c->fused && c->chain == 4 && cfg->sdep <= 0.0 && (niter / 8) >= 4 && (niter / 8) % 4 == 0) c->chain = 8;
-    env = getenv("RFGPU_CHAIN");
-    if (env) c->chain = atoi(env);
-    env = getenv("RFGPU_LPT");
-    if (env) c->lpt = atoi(env) != 0;
-    env = getenv("RFGPU_NSPLIT");
-    if (env && atoi(env) > 0) c->nsplit_override = atoi(env);
-    env = getenv("RFGPU_ABLATE");
-    if (env) c->ablate = atoi(env);
-    env = getenv("RFGPU_ORDER_REUSE");
-    if (env) c->order_reuse = atoi(env) != 0;
-    env = getenv("RFGPU_DEFER_LOGL");
-    if (env) c->defer_logl = atoi(env) != 0;
-    env = getenv("RFGPU_WPB");
-    if (env) c->waves_per_block = atoi(env);
+    c->fused_allowed = (c->nfwd == ntrc) && fused_lds_bytes(n, nsmp, cfg->nlay_max) <= 160 * 1024;
+    default_plan(c);
     *ctx_out = c;
     return 0;
 }
@@ -1014,6 +996,78 @@ extern "C" int rf_post_read(rf_ctx *c, const rf_post_result *o)
     return 0;
 }
 
+// ---------------------------------------------------------------------------
+// launch-plan options.  The library reads NO environment variables: every knob is an explicit
+// call, validated, and visible in rf_get_launch_plan (bench.py echoes it).
+// ---------------------------------------------------------------------------
+static int upload_bin_cutoff(rf_ctx *c)
+{
+    const int ntrc = c->cfg.ntrc, nh = c->nh;
+    if (!(c->bin_cutoff > 0.0)) {
+        c->tab.nh_active = nullptr;
+        return 0;
+    }
+    std::vector<int> act(ntrc);
+    for (int t = 0; t < ntrc; ++t) {
+        int last = 0;
+        for (int k = 0; k < nh; ++k)
+            if (c->flt[(size_t)k + (size_t)nh * t] >= c->bin_cutoff * c->flt[(size_t)nh * t]) last = k;
+        act[t] = last + 1;
+    }
+    return upload(c, act, &c->tab.nh_active);
+}
+
+extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
+{
+    if (!c || !name) return fail("rf_set_option: null argument");
+    const std::string k(name);
+    const int iv = (int)value;
+    const bool integral = (double)iv == value;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (k == "fused") {
+        if (!integral || iv < -1 || iv > 1) return fail("rf_set_option: fused must be -1 (by shape), 0 or 1");
+        if (iv == 1 && !c->fused_allowed)
+            return fail("rf_set_option: this context cannot use the fused kernel (common rays or LDS footprint)");
+        c->fused_override = iv;
+    } else if (k == "chain") {
+        if (!integral || !(iv == -1 || iv == 0 || iv == 2 || iv == 3 || iv == 4 || iv == 8))
+            return fail("rf_set_option: chain must be -1 (by shape), 0, 2, 3, 4 or 8");
+        c->chain_override = iv;
+    } else if (k == "lpt") {
+        if (!integral || iv < 0 || iv > 1) return fail("rf_set_option: lpt must be 0 or 1");
+        c->lpt = iv != 0;
+    } else if (k == "order_reuse") {
+        if (!integral || iv < 0 || iv > 1) return fail("rf_set_option: order_reuse must be 0 or 1");
+        c->order_reuse = iv != 0;
+        c->order_next_nb = 0;
+    } else if (k == "nsplit") {
+        if (!integral || iv < 0 || iv > 64) return fail("rf_set_option: nsplit must be 0 (by batch size) .. 64");
+        c->nsplit_override = iv;
+    } else if (k == "waves_per_block") {
+        if (!integral || iv < 1 || iv > 4) return fail("rf_set_option: waves_per_block must be 1 .. 4");
+        c->waves_per_block = iv;
+    } else if (k == "defer_logl") {
+        if (!integral || iv < -1 || iv > 1) return fail("rf_set_option: defer_logl must be -1 (by batch size), 0 or 1");
+        c->defer_logl = iv;
+    } else if (k == "bin_cutoff") {
+        if (!(value >= 0.0 && value < 1.0)) return fail("rf_set_option: bin_cutoff must be in [0, 1)");
+        c->bin_cutoff = value;
+        if (upload_bin_cutoff(c)) return 1;
+#ifdef RFGPU_DIAGNOSTICS
+    } else if (k == "ablate") {
+        c->ablate = iv;   // timing diagnostics: the kernel stops early, results are INVALID
+#endif
+    } else {
+        return fail("rf_set_option: unknown option '" + k + "'");
+    }
+    default_plan(c);
+    c->n_overrides = (c->fused_override != -1) + (c->chain_override != -1) + (!c->lpt) + (!c->order_reuse) +
+                     (c->nsplit_override != 0) + (c->waves_per_block != 4) + (c->defer_logl != -1) +
+                     (c->bin_cutoff > 0.0) + (c->ablate != 0);
+    return 0;
+}
+
 extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
 {
     if (!c || !plan) return fail("rf_get_launch_plan: null argument");
@@ -1021,6 +1075,16 @@ extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
     plan[1] = c->chain;
     plan[2] = c->waves_per_block;
     plan[3] = pick_nsplit(c, c->cfg.max_walkers);
+    plan[4] = c->lpt ? 1 : 0;
+    plan[5] = c->order_reuse ? 1 : 0;
+    plan[6] = c->defer_logl;
+    plan[7] = c->bin_cutoff > 0.0 ? 1 : 0;
+    plan[8] = c->n_overrides;
+#ifdef RFGPU_DIAGNOSTICS
+    plan[9] = 1 + (c->ablate != 0);
+#else
+    plan[9] = 0;
+#endif
     return 0;
 }
 

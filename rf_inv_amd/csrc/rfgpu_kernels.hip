@@ -20,6 +20,14 @@
 #include "rfgpu_internal.h"
 #include <math.h>
 
+// Timing diagnostics (tools/ablate.sh): a build with -DRFGPU_DIAGNOSTICS can stop a block after phase N
+// to split the kernel time; the production library has no such exits.
+#ifdef RFGPU_DIAGNOSTICS
+#define RFGPU_ABLATE_AT(n, ret) do { if (P.ablate == (n)) return ret; } while (0)
+#else
+#define RFGPU_ABLATE_AT(n, ret) do { } while (0)
+#endif
+
 namespace rfgpu {
 
 // ---------------------------------------------------------------------------
@@ -1139,7 +1147,7 @@ struct TraceParams {
     int log2n;
     FftPlan plan;
     int *slow_count;   // re-armed here for the next batch (the slow kernel ran earlier on the stream)
-    int ablate;        // timing diagnostics only (RFGPU_ABLATE): stop the tail after phase N, results invalid
+    int ablate;        // RFGPU_DIAGNOSTICS builds only: stop the tail after phase N (timing split, results invalid)
     int defer_logl;    // misfits to HBM; quadratic form + logL by phi_deferred_kernel (+ logl_deferred_kernel) after this launch
     double *extra_out; // nullptr, or [ntrc][nfft] (device-mapped host memory): second copy of the proposed trace of
                        // batch item 0 -- the per-call drop-in gets prop_rft without a gather kernel
@@ -1162,7 +1170,7 @@ __device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 
         fft4096_regs(a, t.twiddle, tid, v);
     else
         fft_regs_last<LOG2R>(a, P.plan, P.log2n, t.twiddle, tid, v);
-    if (P.ablate == 2) return true;
+    RFGPU_ABLATE_AT(2, true);
     double fac = 1.0;
     if (!decon) {
         double m = -HUGE_VAL;
@@ -1203,7 +1211,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
 {
     const DeviceTables &t = P.t;
     const int n = t.nfft, nsmp = t.nsmp;
-    if (P.ablate == 1) return;
+    RFGPU_ABLATE_AT(1, );
     double *__restrict__ dst =
         P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
@@ -1227,7 +1235,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
     // ---- in-place mixed-radix inverse FFT, sign +, unnormalised (FFTW c2r definition) ---
     fft_inverse_lds<TRACE_THREADS>(a, P.plan, P.log2n, t.twiddle, tid);
     // a[fft_pad(j)].x = rx (RF trace), .y = vertical trace
-    if (P.ablate == 2) return;
+    RFGPU_ABLATE_AT(2, );
 
     double fac = 1.0;
     if (!decon) {
@@ -1266,10 +1274,10 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
     __syncthreads();
     }
 
-    if (P.ablate == 3) return;
+    RFGPU_ABLATE_AT(3, );
     // ---- phi = (misfit . R^-1) . misfit   (likelihood.f90:92-93) -----------------
     const double phi = quad_form(t, itrc, mis, reinterpret_cast<double *>(a), red, tid);
-    if (P.ablate == 4) return;
+    RFGPU_ABLATE_AT(4, );
     if (tid == 0) {
         double *phis = P.w.phi + ((size_t)slot * P.w.nslots + walker) * t.ntrc;
         // ---- log-likelihood (likelihood.f90:94-96) by the block that finishes the walker's
@@ -1538,7 +1546,7 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
         if (tid == 0) red[4] = arrival_sum(nl - 1 - i0, terms);
     }
     const int slot = 1 - P.w.cur_slot[walker];
-    if (P.ablate == 5) return;   // timing diagnostics: launch + staging only
+    RFGPU_ABLATE_AT(5, );   // timing diagnostics: launch + staging only
 
     // ---- propagator phase: 4 waves x interleaved chunks of bins -> Z in LDS ----------------
     // Optional (off by default, RFGPU_BIN_CUTOFF): bins whose Gaussian filter weight is below

@@ -27,9 +27,10 @@ def _iptr(a):
 
 class RFEngine:
     def __init__(self, *, nfft, delta, t_start, deconv_mode, sdep, rayps, a_gus, ipha, obs, nsmp,
-                 r_inv=None, max_walkers=1, nlay_max=NLAY_MAX, device=0):
+                 r_inv=None, max_walkers=1, nlay_max=NLAY_MAX, device=0, options=None):
         """obs[ntrc, >= nsmp] (row t = trace t, the reference's obs(:, t));
-        r_inv[ntrc, nsmp, nsmp] with r_inv[t].ravel() == Fortran r_inv(:, :, t) or None."""
+        r_inv[ntrc, nsmp, nsmp] with r_inv[t].ravel() == Fortran r_inv(:, :, t) or None;
+        options: {name: value} launch-plan options (rf_set_option, include/rfgpu.h)."""
         self._lib = _lib.load()
         self.nfft, self.nsmp = int(nfft), int(nsmp)
         self.nh = self.nfft // 2 + 1
@@ -51,6 +52,12 @@ class RFEngine:
                             self.max_walkers, self.nlay_max, self.device)
         self._ctx = C.c_void_p()
         self._chk(self._lib.rf_ctx_create(C.byref(cfg), C.byref(self._ctx)))
+        for k, v in (options or {}).items():
+            self.set_option(k, v)
+
+    def set_option(self, name, value):
+        """rf_set_option: a launch-plan knob (results do not depend on it, except the opt-in bin_cutoff)."""
+        self._chk(self._lib.rf_set_option(self._ctx, str(name).encode(), float(value)))
 
     @classmethod
     def from_params(cls, p: Params, r_inv=None, max_walkers=None, nlay_max=None, device=0):
@@ -243,9 +250,12 @@ class RFEngine:
     # ---- instrumentation -----------------------------------------------------
     @property
     def launch_plan(self):
-        plan = (C.c_int32 * 4)()
+        plan = (C.c_int32 * 10)()
         self._chk(self._lib.rf_get_launch_plan(self._ctx, plan))
-        return {"fused": bool(plan[0]), "chain": plan[1], "waves_per_block": plan[2], "nsplit": plan[3]}
+        return {"fused": bool(plan[0]), "chain": plan[1], "waves_per_block": plan[2], "nsplit": plan[3],
+                "lpt": bool(plan[4]), "order_reuse": bool(plan[5]), "defer_logl": plan[6],
+                "bin_cutoff": bool(plan[7]), "overrides": plan[8],
+                "build": ("production", "diagnostics", "diagnostics+ablate")[plan[9]]}
 
     def profile_enable(self, on=True):
         """on: False / True (every batch) / k > 1 (every k-th batch is timed)."""

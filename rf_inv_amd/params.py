@@ -174,15 +174,17 @@ def _nint(x: float) -> int:
 def read_sac(path: str, t_start: float, t_end: float):
     """One file of read_obs (src/params.f90:436-459).  Direct access, recl = 4:
     delta @ record 1, b @ record 6, npts @ record 80, samples from record 159.
-    The window arithmetic is done in float32 like the reference (delta4, t_beg4
-    are default REAL).  Returns (samples[nsmp] as float64, delta, nsmp)."""
+    delta4 and t_beg4 are default REAL, t_start / t_end are real(8) (src/params.f90:66), so
+    `(t_start - t_beg4) / delta4` (:449-450) is evaluated in DOUBLE on the float32-valued header
+    fields (Fortran promotes the mixed expression) -- a window edge half a sample off a grid point
+    rounds differently in float32.  Returns (samples[nsmp] as float64, delta, nsmp)."""
     if not os.path.exists(path):
         raise FileNotFoundError(f"ERROR: cannot open {path}")  # src/params.f90:439-444
     raw = np.fromfile(path, dtype="<f4")
     delta4 = np.float32(raw[0])
     t_beg4 = np.float32(raw[5])
-    it1 = _nint(float((np.float32(t_start) - t_beg4) / delta4)) + 1
-    it2 = _nint(float((np.float32(t_end) - t_beg4) / delta4)) + 1
+    it1 = _nint((float(t_start) - float(t_beg4)) / float(delta4)) + 1
+    it2 = _nint((float(t_end) - float(t_beg4)) / float(delta4)) + 1
     nsmp = it2 - it1 + 1
     if nsmp > NPTS_MAX:
         raise ValueError("time window longer than npts_max = 2000 samples (src/params.f90:44)")

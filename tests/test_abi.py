@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in rfgpu.h but not exported by librfgpu.so"
         assert n in _lib.SYMBOLS, f"{n} not bound in rf_inv_amd/_lib.py"
     assert sorted(_lib.SYMBOLS) == names
-    assert lib.rf_abi_version() == 2
+    assert lib.rf_abi_version() == 3
 
 
 def test_config_struct_layout_matches_header():
@@ -111,5 +111,19 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
                            "-lm", f"-Wl,-rpath,{libdir}"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi 2 rank" in r.stdout
+    assert "abi 3 rank" in r.stdout
     assert "no context: rf_ctx_create: no HIP device" in r.stdout or "calc_rf rc 0" in r.stdout
+
+
+def test_product_library_reads_no_environment_variables():
+    """Every launch-plan knob is an explicit rf_set_option call echoed by rf_get_launch_plan; a stray
+    variable in the environment cannot change what the library computes (or skips)."""
+    import glob
+
+    for f in glob.glob(os.path.join(ROOT, "rf_inv_amd", "csrc", "*")):
+        assert "getenv" not in open(f).read(), f
+    src = open(os.path.join(ROOT, "rf_inv_amd", "_lib.py")).read()
+    assert "os.environ" not in src and "getenv" not in src
+    # the diagnostics exits exist only under the RFGPU_DIAGNOSTICS macro
+    k = open(os.path.join(ROOT, "rf_inv_amd", "csrc", "rfgpu_kernels.hip")).read()
+    assert not re.search(r"if \(P\.ablate", k.split("#endif", 1)[1])

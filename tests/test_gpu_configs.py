@@ -1,0 +1,247 @@
+"""BASELINE.json configs C3, C4, C5 through the library's DEFAULT launch plan at their full per-GPU batch,
+with the parallel-tempering swap in the loop, and a seeded randomised sweep over contexts.  -m gpu only.
+
+Full-size checks are the size-independent properties of the domain (walkers are independent; the true model
+maximises logL; phi does not depend on sigma; temperatures follow a serial replay of the replicated swap
+schedule) plus a sampled comparison with the CPU oracle on the same inputs."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import DELTA, logl_tol, make_cfg, pack_layers, random_stack, synth_obs
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _workload(name):
+    """The bench.py workload of that name: params, walker models of rank 0, observed traces (noise-free
+    synthetic of a fixed 3-interface model through the ORACLE here), R^-1."""
+    import bench
+    from oracle import rf_oracle as oracle
+    from rf_inv_amd import format_model, read_ref_model
+
+    oracle.build()
+    w = dict(bench.WORKLOADS[name])
+    p = bench.make_params(w)
+    ref = read_ref_model(os.path.join(ROOT, "tests", "golden", "sample_syn", "model", "sample.velmod"))
+    nb = w["walkers"]
+    nlay, layers = bench.draw_walkers(p, ref, 0, nb)
+    cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep,
+               rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha)
+    zt = np.zeros(max(p.k_max - 1, 1)); dvt = np.zeros(p.k_max); dst = np.zeros(p.k_max)
+    zt[:3] = [3.1 + p.sdep, 7.7 + p.sdep, 14.2 + p.sdep]; dst[:3] = [-0.6, 0.2, 0.5]; dst[p.k_max - 1] = 0.9
+    nl_t, a_t, b_t, r_t, h_t, ok = format_model(p, ref, 3, zt, dvt, dst)
+    assert ok
+    true = (a_t, b_t, r_t, h_t)
+    obs = np.ascontiguousarray(oracle.calc_rf(cfg, *true)[:, :p.nsmp])
+    r_inv = oracle.build_r_inv(p.nsmp, p.a_gus, p.delta)
+    # the last walker carries the true model: logL at its maximum, the 1e-9 absolute regime
+    nlay[-1] = nl_t
+    layers[-1] = 1.0
+    for r in range(4):
+        layers[-1, r, :nl_t] = true[r]
+    return w, p, cfg, obs, r_inv, nlay, layers
+
+
+def _run_config(name, expect_defer, nsample, extra_check=None):
+    import torch
+
+    from oracle import rf_oracle as oracle
+    from rf_inv_amd import RFEngine
+    from rf_inv_amd.pt import PairSchedule, PTSwap, init_temps, judge_pt
+
+    w, p, cfg, obs, r_inv, nlay, layers = _workload(name)
+    nb, ntrc, nsmp = w["walkers"], p.ntrc, p.nsmp
+    rng = np.random.default_rng(hash(name) % 2 ** 32)
+    sigv = np.linspace(0.01, 0.02, ntrc)
+    sig = np.tile(sigv, (nb, 1))
+    dev = torch.device("cuda", 0)
+    with RFEngine(nfft=p.nfft, delta=p.delta, t_start=p.t_start, deconv_mode=p.deconv_mode, sdep=p.sdep,
+                  rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha, obs=obs, nsmp=nsmp, r_inv=r_inv, max_walkers=nb,
+                  nlay_max=p.k_max + 2) as eng:
+        plan = eng.launch_plan
+        # the DEFAULT plan is the subject: no option set, production build
+        assert plan["overrides"] == 0 and plan["build"] == "production" and plan["fused"] and plan["defer_logl"] == -1
+        assert plan["chain"] == (4 if p.sdep > 0 else 8)
+        # by batch size the library defers the quadratic form + logL to the follow-up kernel(s) here
+        # (rfgpu_api.cpp run_batch: >= 2 rounds of blocks with several traces, >= 4 rounds with one)
+        blocks, rnd = nb * ntrc, 2 * 256
+        assert (blocks >= (2 if ntrc > 1 else 4) * rnd) == expect_defer
+        stream = torch.cuda.Stream(device=dev)
+        d_ids = torch.arange(nb, dtype=torch.int32, device=dev)
+        d_nlay, d_layers = torch.from_numpy(nlay).to(dev), torch.from_numpy(layers).to(dev)
+        d_sig = torch.from_numpy(sig).to(dev)
+        d_logl = torch.empty(nb, dtype=torch.float64, device=dev)
+        swap = PTSwap(eng, nb, w["temps"], dev, seed=99, t_high=15.0, mode="allgather")
+        temps = init_temps(nb, max(1, nb // w["temps"]), 15.0, np.random.Generator(np.random.Philox(key=99 + 7919)))
+        sched = PairSchedule(nb, 99, swap.k)
+        lls = []
+        for step in range(3):                       # evaluation + swap, like bench.py's step
+            with torch.cuda.stream(stream):
+                eng.eval_batch_device(d_ids, d_nlay, d_layers, d_sig, d_logl, stream=stream)
+                swap.step(d_logl, stream)
+            stream.synchronize()
+            ll = d_logl.cpu().numpy()
+            lls.append(ll)
+            pairs, logu = sched.draw()
+            for (i1, i2), lu in zip(pairs, logu):
+                if judge_pt(temps[i1], temps[i2], ll[i1], ll[i2], lu):
+                    temps[i1], temps[i2] = temps[i2], temps[i1]
+            assert np.array_equal(swap.temps.cpu().numpy(), temps), step       # serial replay of the schedule
+        ll = lls[0]
+        assert np.all(np.isfinite(ll))
+        assert np.array_equal(lls[1], ll) and np.array_equal(lls[2], ll)       # deterministic; the swap moves temperatures only
+        assert np.sum(temps != init_temps(nb, max(1, nb // w["temps"]), 15.0,
+                                          np.random.Generator(np.random.Philox(key=99 + 7919)))) > 0   # swaps did happen
+        # (1) walkers are independent: a permuted batch gives the permuted result, bit for bit
+        perm = rng.permutation(nb)
+        ll_p = eng.eval_batch(np.arange(nb), nlay[perm], layers[perm], sig)
+        assert np.array_equal(ll_p, ll[perm])
+        # (2) the true model maximises logL: zero misfit, logL = -nsmp * sum(log sigma)
+        expect = -nsmp * np.log(sigv).sum()
+        assert abs(ll[-1] - expect) < 1e-6 and np.all(ll[:-1] < ll[-1])
+        # (3) phi does not depend on sigma: logL(2 sigma) follows from logL(sigma) trace by trace; with one
+        # common factor: sum_t phi_t / sigma_t^2 scales by 1/4
+        ll2 = eng.eval_batch(np.arange(nb), nlay, layers, 2 * sig)
+        q = -(ll + nsmp * np.log(sigv).sum())                                   # = 0.5 sum phi_t / sigma_t^2
+        assert np.allclose(ll2, -q / 4 - nsmp * np.log(2 * sigv).sum(), rtol=1e-12, atol=1e-9)
+        # (4) sampled oracle parity, incl. the deepest walkers and the true model
+        deep = np.argsort(nlay)[-4:]
+        idx = np.unique(np.concatenate([rng.choice(nb, nsample, replace=False), deep, [nb - 1]]))
+        ref, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], nsmp, want_rft=True,
+                                         nthreads=oracle.max_threads())
+        d = np.abs(ll[idx] - ref)
+        assert np.all(d <= logl_tol(ref)), (name, d.max(), (d / np.abs(ref)).max())
+        eng.eval_batch(np.arange(nb), nlay, layers, sig)                        # proposals = the sampled batch again
+        for j in rng.choice(len(idx), 6, replace=False):
+            got = eng.get_rft(int(idx[j]), which=1).T
+            assert np.abs(got - ref_rft[j]).max() <= 1e-12 * np.abs(ref_rft[j]).max(), (name, int(idx[j]))
+        if extra_check:
+            extra_check(eng, p, cfg, obs, r_inv, oracle)
+
+
+def test_c3_default_plan_full_batch():
+    """C3: 8192 walkers x 1 trace: the single-trace deferred-logL plan (phi_deferred_kernel forms logL itself)."""
+    _run_config("c3", expect_defer=True, nsample=40)
+
+
+def test_c4_default_plan_full_batch():
+    """C4 per-GPU shard: 8192 walkers x (P, P, S) x <= 30 layers: 8-bin chains, misfits to HBM,
+    phi_deferred_kernel + logl_deferred_kernel."""
+    _run_config("c4", expect_defer=True, nsample=36)
+
+
+def test_c5_default_plan_full_batch():
+    """C5 shape: sdep 2.0, traces P, P, S, S, nfft 4096, <= 31 layers (ocean kernel, 4-bin chains, 3 propagated
+    columns), plus -- in the same context -- walkers whose own beta(1) >= 0 (a land stack under sdep > 0:
+    calc_seis keys on beta(1), forward.f90:229; direct_arrival on sdep, :484)."""
+
+    def land_in_ocean_context(eng, p, cfg, obs, r_inv, oracle):
+        rng = np.random.default_rng(55)
+        stacks = [random_stack(rng, n) for n in (2, 3, 9, 31)] + [random_stack(rng, 7, True, p.sdep)]
+        nlay, layers = pack_layers(stacks, p.k_max + 2)
+        sig = np.full((5, p.ntrc), 0.02)
+        ref, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, p.nsmp, want_rft=True)
+        ll = eng.eval_batch(np.arange(5), nlay, layers, sig)
+        assert np.all(np.abs(ll - ref) <= logl_tol(ref)), np.abs(ll - ref)
+        for i in range(5):
+            got = eng.get_rft(i, which=1).T
+            assert np.abs(got - ref_rft[i]).max() <= 1e-12 * np.abs(ref_rft[i]).max(), i
+
+    _run_config("c5", expect_defer=True, nsample=32, extra_check=land_in_ocean_context)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Seeded randomised sweep (promoted from tests/tools/fuzz_parity.py).
+#
+# Conditioning rule.  Without deconvolution a trace is divided by maxval(rx) of the filtered VERTICAL trace
+# (forward.f90:201-202) -- the signed maximum.  kappa = max|rx| / |maxval(rx)| measures how much of the
+# vertical trace's scale cancels in that divisor: its absolute rounding error is ~1e-15..1e-14 of max|rx|
+# in ANY double evaluation (the reference's included), i.e. a relative error kappa times that in the
+# divisor, in every sample of the trace, and twice that in logL.  Resonating one-layer models reach kappa
+# 1e4 .. 1e15 (|logL| 1e11 .. 1e31).  So: an item may exceed the plain tolerance only if its kappa
+# (computed from the ORACLE's own vertical spectrum, in the test) is >= KAPPA_MIN, and then it must stay
+# within the plain tolerance times kappa / KAPPA_SCALE.  Items with kappa below KAPPA_MIN get no allowance.
+# ---------------------------------------------------------------------------------------------------------
+KAPPA_MIN, KAPPA_SCALE = 100.0, 10.0
+
+
+def _kappa(oracle, cfg, stack):
+    """max over traces of max|rx_v| / |maxval(rx_v)| for the filtered vertical trace of forward.f90:197-201."""
+    nfft = int(cfg["nfft"])
+    _, _, _, freq_v = oracle.calc_rf(cfg, *stack, want_stages=True)
+    flt = oracle.init_filter(nfft, cfg["delta"], cfg["a_gus"])
+    k = 1.0
+    for t in range(freq_v.shape[0]):
+        rx = oracle.c2r(np.concatenate([freq_v[t] * flt[t], np.zeros(nfft - freq_v.shape[1])]), nfft)
+        m = rx.max()
+        k = max(k, np.inf if m == 0 else np.abs(rx).max() / abs(m))
+    return k
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_randomised_contexts_against_oracle(oracle, seed):
+    from rf_inv_amd import RFEngine
+
+    rng = np.random.default_rng(seed)
+    n_items = n_allow = 0
+    for case in range(14):
+        nfft = int(rng.choice([256, 512, 1024, 2048, 4096]))
+        ntrc = int(rng.integers(1, 5))
+        ocean = bool(rng.integers(0, 2))
+        sdep = 2.0 if ocean else 0.0
+        deconv = int(rng.integers(0, 2))
+        ipha = [int(rng.choice([1, -1])) for _ in range(ntrc)]
+        rayps = [float(rng.uniform(0.04, 0.075)) if ph == 1 else float(rng.uniform(0.09, 0.12)) for ph in ipha]
+        if rng.integers(0, 4) == 0 and ntrc > 1:      # common rays now and then
+            rayps, ipha = [rayps[0]] * ntrc, [ipha[0]] * ntrc
+        a_gus = [float(rng.choice([2.5, 4.0, 6.0])) for _ in range(ntrc)]
+        t_start = float(rng.choice([0.0, -1.0, -3.0]))
+        nsmp = int(rng.choice([61, 101, 161]))
+        kmax = int(rng.choice([6, 15, 30]))
+        nb = int(rng.choice([1, 3, 17, 130, 300]))
+        cfg = make_cfg(nfft=nfft, deconv_mode=deconv, t_start=t_start, sdep=sdep, rayps=rayps, a_gus=a_gus, ipha=ipha)
+        true = random_stack(rng, int(rng.integers(3, 7)), ocean, sdep)
+        obs = synth_obs(oracle, cfg, true, nsmp)
+        r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+        lo = 3 if ocean else 2
+        stacks = [random_stack(rng, int(rng.integers(lo, kmax + 2)), ocean, sdep) for _ in range(nb)]
+        # the shallowest stacks are where the normalisation can be ill-conditioned: always a few of them
+        stacks += [random_stack(rng, lo, ocean, sdep) for _ in range(4)]
+        nb = len(stacks)
+        nlay, layers = pack_layers(stacks, kmax + 2)
+        sig = rng.uniform(0.01, 0.05, (nb, ntrc))
+        ref = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads())
+        with RFEngine(nfft=nfft, delta=cfg["delta"], t_start=t_start, deconv_mode=deconv, sdep=sdep, rayps=cfg["rayps"],
+                      a_gus=cfg["a_gus"], ipha=cfg["ipha"], obs=obs, nsmp=nsmp, r_inv=r_inv, max_walkers=nb,
+                      nlay_max=kmax + 2) as eng:
+            ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+            eng.commit(np.arange(nb), np.ones(nb, dtype=np.int32))
+            # second evaluation: mixed forward / sigma-only items on the committed traces
+            ff = rng.integers(0, 2, nb).astype(np.int32)
+            sig2 = sig * rng.uniform(0.8, 1.6)
+            stacks2 = [random_stack(rng, int(rng.integers(lo, kmax + 2)), ocean, sdep) for _ in range(nb)]
+            nlay2, layers2 = pack_layers(stacks2, kmax + 2)
+            ll2 = eng.eval_batch(np.arange(nb), nlay2, layers2, sig2, fwd_flag=ff)
+        use_l = np.where(ff[:, None, None] == 1, layers2, layers)
+        use_n = np.where(ff == 1, nlay2, nlay)
+        ref2 = oracle.eval_batch(cfg, obs, r_inv, use_n, use_l, sig2, nsmp, nthreads=oracle.max_threads())
+        for got, want, nl_, lay_ in ((ll, ref, nlay, layers), (ll2, ref2, use_n, use_l)):
+            assert np.array_equal(np.isnan(got), np.isnan(want)), (seed, case)
+            fin = np.isfinite(want)
+            d = np.abs(got - want)
+            n_items += int(fin.sum())
+            for i in np.nonzero(fin & ~(d <= logl_tol(want)))[0]:
+                n = int(nl_[i])
+                kap = _kappa(oracle, cfg, tuple(lay_[i, r, :n] for r in range(4))) if deconv == 0 else 1.0
+                assert kap >= KAPPA_MIN, (seed, case, int(i), "well-conditioned item off tolerance", got[i], want[i], kap)
+                assert d[i] <= logl_tol(want[i]) * kap / KAPPA_SCALE, (seed, case, int(i), got[i], want[i], kap)
+                n_allow += 1
+    # the allowance is the exception, not the rule
+    assert n_allow <= max(2, n_items // 200), (n_allow, n_items)

@@ -10,19 +10,26 @@ from helpers import DELTA, load_true_model, logl_tol, make_cfg, pack_layers, ran
 pytestmark = pytest.mark.gpu
 
 
-def _engine(cfg, obs, nsmp, r_inv, max_walkers=8, nlay_max=40):
+def _engine(cfg, obs, nsmp, r_inv, max_walkers=8, nlay_max=40, options=None):
+    """options: launch-plan knobs (rf_set_option); a context that cannot run the fused kernel
+    ignores a request for it (common rays / LDS footprint), like the library's own default."""
     from rf_inv_amd import RFEngine
 
-    return RFEngine(nfft=cfg["nfft"], delta=cfg["delta"], t_start=cfg["t_start"], deconv_mode=cfg["deconv_mode"],
-                    sdep=cfg["sdep"], rayps=cfg["rayps"], a_gus=cfg["a_gus"], ipha=cfg["ipha"], obs=obs,
-                    nsmp=nsmp, r_inv=r_inv, max_walkers=max_walkers, nlay_max=nlay_max)
+    eng = RFEngine(nfft=cfg["nfft"], delta=cfg["delta"], t_start=cfg["t_start"], deconv_mode=cfg["deconv_mode"],
+                   sdep=cfg["sdep"], rayps=cfg["rayps"], a_gus=cfg["a_gus"], ipha=cfg["ipha"], obs=obs,
+                   nsmp=nsmp, r_inv=r_inv, max_walkers=max_walkers, nlay_max=nlay_max)
+    for k, v in (options or {}).items():
+        if k == "fused" and int(v) == 1 and not eng.launch_plan["fused"]:
+            continue
+        eng.set_option(k, v)
+    return eng
 
 
 def test_library_is_the_hip_one():
     from rf_inv_amd import _lib
 
     lib = _lib.load()
-    assert lib.rf_abi_version() == 2
+    assert lib.rf_abi_version() == 3
     assert os.path.basename(_lib.LIB_PATH) == "librfgpu.so"
 
 
@@ -58,10 +65,9 @@ CASES = [
 
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_batch_parity(oracle, case, fused, monkeypatch):
+def test_batch_parity(oracle, case, fused):
     """rf_eval_batch: traces within 1e-12 of max|trace|, integer shifts identical by
     construction of the trace equality, logL within the north-star tolerance."""
-    monkeypatch.setenv("RFGPU_FUSED", fused)
     name, nfft, deconv, sdep, rayps, ipha, t_start, nlays = case
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     cfg = make_cfg(nfft=nfft, deconv_mode=deconv, t_start=t_start, sdep=sdep, rayps=rayps,
@@ -81,7 +87,7 @@ def test_batch_parity(oracle, case, fused, monkeypatch):
     sig = np.full((nb, len(rayps)), 0.01)
     sig[:, -1] = 0.02
     ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
-    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb) as eng:
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, options={"fused": int(fused)}) as eng:
         ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
         for i in range(nb):
             got = eng.get_rft(i, which=1).T  # [ntrc, nfft]
@@ -135,7 +141,7 @@ def test_nan_propagates_not_traps(oracle, golden_dir):
     assert np.isnan(ll) and np.isnan(rft).all()
 
 
-def test_nsplit_and_block_shape_variants_agree(oracle, monkeypatch):
+def test_nsplit_and_block_shape_variants_agree(oracle):
     """Launch-shape knobs must not change results at all (they only re-partition bins)."""
     rng = np.random.default_rng(11)
     cfg = make_cfg(nfft=1024, rayps=[0.06])
@@ -148,12 +154,9 @@ def test_nsplit_and_block_shape_variants_agree(oracle, monkeypatch):
     outs = []
     for ns, wpb, fused, lpt in [("1", "1", "0", "0"), ("3", "1", "0", "1"), ("3", "4", "0", "0"), ("4", "2", "0", "1"),
                                 ("1", "1", "1", "0"), ("1", "1", "1", "1")]:
-        monkeypatch.setenv("RFGPU_NSPLIT", ns)
-        monkeypatch.setenv("RFGPU_WPB", wpb)
-        monkeypatch.setenv("RFGPU_FUSED", fused)   # split kernels (spectra -> trace) vs the fused kernel
-        monkeypatch.setenv("RFGPU_LPT", lpt)       # longest-first dispatch order
-        monkeypatch.setenv("RFGPU_CHAIN", "0")
-        with _engine(cfg, obs, nsmp, None, max_walkers=4) as eng:
+        # fused: split kernels (spectra -> trace) vs the fused kernel; lpt: longest-first dispatch order
+        opts = {"nsplit": int(ns), "waves_per_block": int(wpb), "fused": int(fused), "lpt": int(lpt), "chain": 0}
+        with _engine(cfg, obs, nsmp, None, max_walkers=4, options=opts) as eng:
             outs.append((eng.eval_batch(np.arange(4), nlay, layers, sig), eng.get_rft(2, 1)))
     # the split variants (outs[0..3]) only re-partition bins and blocks: bit-identical; so are the two
     # fused runs among themselves.  Fused vs split may differ in the last bits (the compiler contracts
@@ -197,13 +200,11 @@ def test_full_size_properties(oracle):
     assert np.all(np.abs(ll[idx] - ref) <= logl_tol(ref))
 
 
-def test_full_size_properties_three_traces(oracle, monkeypatch):
+def test_full_size_properties_three_traces(oracle):
     """BASELINE config-4 shape (nfft 4096, 3 traces P/P/S, <= 30 layers) at 1024 walkers = 3072 blocks:
     the default launch plan here is 8-bin phase chains + quadratic forms and logL by the follow-up kernel.
     Properties that do not need the oracle at full size, agreement with the in-kernel path, and a
     sampled oracle check."""
-    for var in ("RFGPU_FUSED", "RFGPU_CHAIN", "RFGPU_DEFER_LOGL"):   # the default launch plan is the subject here
-        monkeypatch.delenv(var, raising=False)
     rng = np.random.default_rng(4)
     cfg = make_cfg(nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1])
     nsmp = 101
@@ -223,8 +224,7 @@ def test_full_size_properties_three_traces(oracle, monkeypatch):
         assert np.array_equal(ll_p, ll[perm])                              # walkers are independent
         expect = -nsmp * (np.log(0.01) + np.log(0.02) + np.log(0.03))
         assert abs(ll[-1] - expect) < 1e-6 and np.all(ll[:-1] < ll[-1])    # the true model maximises logL
-    monkeypatch.setenv("RFGPU_DEFER_LOGL", "0")
-    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb) as eng:
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, options={"defer_logl": 0}) as eng:
         assert np.array_equal(eng.eval_batch(np.arange(nb), nlay, layers, sig), ll)   # same arithmetic either way
     idx = rng.choice(nb, 12, replace=False)
     ref = oracle.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], nsmp)
@@ -296,12 +296,11 @@ def test_pt_swap_device_matches_serial_replay(oracle, mode, k):
 
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("chain", ["0", "2", "3", "4", "8"])
-def test_chained_phase_variants_parity(oracle, monkeypatch, chain, fused):
+def test_chained_phase_variants_parity(oracle, chain, fused):
     """Every phase-chain length of the spectra kernel (0 = a full sincos per phase) meets the
     same tolerances, on land and under an ocean, including the DC bin whose omega is the
     literal 1e-5 (forward.f90:247) and a bin count that leaves leftover iterations."""
-    monkeypatch.setenv("RFGPU_CHAIN", chain)
-    monkeypatch.setenv("RFGPU_FUSED", fused)
+    opts = {"chain": int(chain), "fused": int(fused)}
     for sdep, nfft in [(0.0, 2048), (2.0, 1024)]:
         rng = np.random.default_rng(77)
         cfg = make_cfg(nfft=nfft, sdep=sdep, rayps=[0.06, 0.10], ipha=[1, -1], t_start=-1.0)
@@ -314,7 +313,7 @@ def test_chained_phase_variants_parity(oracle, monkeypatch, chain, fused):
         nlay, layers = pack_layers(stacks, 32)
         sig = np.full((5, 2), 0.01)
         ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
-        with _engine(cfg, obs, nsmp, r_inv, max_walkers=5) as eng:
+        with _engine(cfg, obs, nsmp, r_inv, max_walkers=5, options=opts) as eng:
             ll = eng.eval_batch(np.arange(5), nlay, layers, sig)
             for i in range(5):
                 got = eng.get_rft(i, which=1).T
@@ -379,13 +378,12 @@ def test_edge_shapes(oracle):
 
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("chain", ["0", "4"])
-def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, monkeypatch, chain, fused):
+def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, chain, fused):
     """In ONE batch: ordinary walkers, one with out-of-range phases (|x| > 1e6 rad) and one whose
     stack is of the other kind than the context (a water layer, beta(1) < 0, with sdep = 0:
     calc_seis keys on beta(1), forward.f90:229, direct_arrival on sdep, :484).  Both the
     in-place generic path of the chained-phase kernels and the deferred-list kernel."""
-    monkeypatch.setenv("RFGPU_CHAIN", chain)
-    monkeypatch.setenv("RFGPU_FUSED", fused)
+    opts = {"chain": int(chain), "fused": int(fused)}
     rng = np.random.default_rng(31)
     cfg = make_cfg(nfft=2048, rayps=[0.06, 0.07], t_start=-1.0)
     nsmp = 101
@@ -398,7 +396,7 @@ def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, monkeypatch, chain, fus
     nlay, layers = pack_layers(stacks, 8)
     sig = np.full((5, 2), 0.05)
     ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
-    with _engine(cfg, obs, nsmp, r_inv, max_walkers=5) as eng:
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=5, options=opts) as eng:
         for rep in range(2):
             ll = eng.eval_batch(np.arange(5), nlay, layers, sig)
             assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (rep, np.abs(ll - ref_ll))
@@ -496,8 +494,8 @@ def test_python_module_mirrors_forward_and_likelihood(oracle, golden_dir):
     lik.engine.close()
 
 
-def test_optional_filter_support_cutoff(oracle, monkeypatch):
-    """RFGPU_BIN_CUTOFF (opt-in, off by default): bins whose Gaussian filter weight is below
+def test_optional_filter_support_cutoff(oracle):
+    """rf_set_option("bin_cutoff") (opt-in, off by default): bins whose Gaussian filter weight is below
     1e-20 of the DC weight are not propagated.  Their contribution is far below the FFT's rounding
     noise: traces agree with the full evaluation (and the oracle) within the usual tolerances."""
     rng = np.random.default_rng(12)
@@ -512,9 +510,8 @@ def test_optional_filter_support_cutoff(oracle, monkeypatch):
     ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
     out = {}
     for cut in ("", "1e-20"):
-        if cut:
-            monkeypatch.setenv("RFGPU_BIN_CUTOFF", cut)
-        with _engine(cfg, obs, nsmp, r_inv, max_walkers=4) as eng:
+        with _engine(cfg, obs, nsmp, r_inv, max_walkers=4, options={"bin_cutoff": float(cut)} if cut else None) as eng:
+            assert eng.launch_plan["bin_cutoff"] == bool(cut)
             ll = eng.eval_batch(np.arange(4), nlay, layers, sig)
             out[cut] = (ll, np.stack([eng.get_rft(i, 1).T for i in range(4)]))
     for cut in out:
@@ -528,12 +525,11 @@ def test_optional_filter_support_cutoff(oracle, monkeypatch):
 
 @pytest.mark.parametrize("nsmp", [101, 161])
 @pytest.mark.parametrize("defer", ["0", "1"])
-def test_deferred_loglikelihood_kernel(oracle, monkeypatch, defer, nsmp):
+def test_deferred_loglikelihood_kernel(oracle, defer, nsmp):
     """Multi-trace batches can form logL in a follow-up kernel instead of the cross-block hand-off inside
-    the fused kernel (RFGPU_DEFER_LOGL; chosen by batch size by default): same values, including
+    the fused kernel (option defer_logl; chosen by batch size by default): same values, including
     sigma-only items (fwd_flag 0) and a second evaluation after a commit.  nsmp 101: R^-1 held in
     registers by the follow-up kernel; 161: streamed."""
-    monkeypatch.setenv("RFGPU_DEFER_LOGL", defer)
     rng = np.random.default_rng(321)
     cfg = make_cfg(nfft=512, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], t_start=-1.0)
     true = random_stack(rng, 5)
@@ -544,7 +540,7 @@ def test_deferred_loglikelihood_kernel(oracle, monkeypatch, defer, nsmp):
     nb = len(stacks)
     sig = np.column_stack([np.full(nb, 0.01), np.full(nb, 0.02), rng.uniform(0.01, 0.05, nb)])
     ref = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp)
-    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb) as eng:
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, options={"defer_logl": int(defer)}) as eng:
         ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
         assert np.all(np.abs(ll - ref) <= logl_tol(ref)), np.abs(ll - ref).max()
         eng.commit(np.arange(nb), np.ones(nb, dtype=np.int32))

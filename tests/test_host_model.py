@@ -110,6 +110,22 @@ def test_sac_writer_roundtrip_and_layout(golden_dir, tmp_path):
     assert np.array_equal(a.view("<i4")[[79]], b.view("<i4")[[79]])          # npts @ record 80
     d2, delta2, n2 = read_sac(str(out), 0.0, 5.0)
     assert n2 == nsmp and delta2 == delta and np.array_equal(d2, data)
-    # a sub-window is addressed like the reference does (it1/it2 in float32 arithmetic)
+    # a sub-window is addressed like the reference does (it1/it2: double arithmetic on float32 header fields)
     d3, _, n3 = read_sac(str(out), 1.0, 2.0)
     assert n3 == 21 and np.array_equal(d3, data[20:41])
+
+
+def test_sac_window_edge_half_a_sample_off_grid(golden_dir, oracle):
+    """read_obs evaluates nint((t_start - t_beg4) / delta4) in DOUBLE (t_start is real(8), src/params.f90:66,
+    :449-450; the REAL header fields are promoted): with delta4 = 0.05f = 0.05000000074505806 the edge
+    t_start = 0.025 gives 0.4999999925 -> 0, where float32 arithmetic would give exactly 0.5 -> 1 and shift
+    the window (and nsmp) by one sample against the reference."""
+    from rf_inv_amd import read_sac
+
+    src = os.path.join(golden_dir, "sample_syn", "data", "sample_1.trc")
+    full, delta, _ = read_sac(src, 0.0, 5.0)
+    assert (0.025 - 0.0) / delta < 0.5 and np.float32(0.025) / np.float32(delta) == np.float32(0.5)
+    for reader in (read_sac, oracle.read_sac):
+        d, _, n = reader(src, 0.025, 4.975)
+        # it1 = nint(0.49999999) + 1 = 1, it2 = nint(99.4999985) + 1 = 100
+        assert n == 100 and np.array_equal(d, full[0:100]), reader

@@ -6,7 +6,7 @@ walkers three ways --
            (the layer stack, omega, and the reference's double-rounded phase arguments
            (omega*xi)*z, whose rounding is part of the reference result), O(n^2) inverse DFT;
   oracle : oracle/rf_oracle.c (the reference's arithmetic in double);
-  gpu    : the library named by RFGPU_LIB (default: the in-tree build).
+  gpu    : the in-tree librfgpu.so, or the build named by --lib.
 
 and prints the distribution of |logL - truth| / |truth| for oracle and gpu, and |gpu - oracle|.
 
@@ -159,9 +159,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="c4")
     ap.add_argument("--n", type=int, default=16)
+    ap.add_argument("--lib", default=None, help="another build of librfgpu.so")
     args = ap.parse_args()
     import bench
     from oracle import rf_oracle as oracle
+    from rf_inv_amd import _lib
+
+    _lib.load(args.lib)
     from rf_inv_amd import RFEngine, format_model, read_ref_model
     from rf_inv_amd.likelihood import init_r_inv
 
@@ -197,7 +201,7 @@ def main():
         print("walker %5d nlay %2d logL %.6e  |gpu-truth| %.2e  |oracle-truth| %.2e  |gpu-oracle| %.2e (relative)"
               % rows[-1], flush=True)
     r = np.array(rows)
-    print("lib", os.environ.get("RFGPU_LIB", "in-tree"), args.workload, "n", len(rows))
+    print("lib", args.lib or "in-tree", args.workload, "n", len(rows))
     print("max / median rel. error vs truth:  gpu %.2e / %.2e   oracle %.2e / %.2e   gpu-vs-oracle (all %d walkers) max %.2e"
           % (r[:, 3].max(), np.median(r[:, 3]), r[:, 4].max(), np.median(r[:, 4]), nb, d.max()))
 

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Condense a tools/collect_counters.sh output directory: per (kernel, launch shape) the mean of every
+counter over that shape's launches -> counters.json (+ a text summary with rocprofv3's kernel stats and
+the derived figures bench.py's roofline uses).  Launch shapes separate the workloads of one bench.py run
+(and its 1-walker set-up launches) from each other."""
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+from collections import defaultdict
+
+out, root = sys.argv[1], sys.argv[2]
+agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
+meta = {}
+for f in glob.glob(os.path.join(out, "p*/**/*counter_collection.csv"), recursive=True):
+    with open(f) as fh:
+        for r in csv.DictReader(fh):
+            k = r["Kernel_Name"]
+            if "rfgpu" not in k:
+                continue
+            k = k.split("(")[0].replace("void ", "").strip()
+            key = (k, int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+            a = agg[key][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            meta[key] = {"lds": int(r["LDS_Block_Size"]), "scratch": int(r["Scratch_Size"]), "vgpr": int(r["VGPR_Count"]),
+                         "sgpr": int(r["SGPR_Count"])}
+lib = os.path.join(root, "rf_inv_amd", "lib", "librfgpu.so")
+doc = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
+       "source": "tools/collect_counters.sh: rocprofv3 --pmc <set> (one set per run; FETCH_SIZE and WRITE_SIZE in separate "
+                 "passes) over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --prewarm-seconds 0`; values are "
+                 "means per launch over the launches of that (kernel, grid) shape; FETCH_SIZE / WRITE_SIZE in KiB as "
+                 "rocprofv3 reports them (HBM bytes = 2048 * FETCH_SIZE + 1024 * WRITE_SIZE: gfx950 read correction)",
+       "kernels": []}
+for (k, grid, wg), ctrs in sorted(agg.items()):
+    e = {"kernel": k, "grid_threads": grid, "workgroup": wg, **meta[(k, grid, wg)],
+         "launches": max(n for n, _ in ctrs.values()), "counters": {c: v / n for c, (n, v) in sorted(ctrs.items())}}
+    doc["kernels"].append(e)
+json.dump(doc, open(os.path.join(out, "counters.json"), "w"), indent=1)
+
+print("== rocprofv3 --kernel-trace --stats ==")
+for f in glob.glob(os.path.join(out, "trace/**/*kernel_stats.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        print(f"{r.get('Name', '?')[:80]:80s} calls={r.get('Calls')} avg_ns={r.get('AverageNs')} pct={r.get('Percentage')} "
+              f"min={r.get('MinNs')} max={r.get('MaxNs')}")
+# per-shape average durations from the trace (the stats table mixes the shapes of one kernel)
+dur = defaultdict(list)
+for f in glob.glob(os.path.join(out, "trace/**/*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "rfgpu" in r["Kernel_Name"]:
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+            dur[(k, int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+print("\n== per launch shape: mean duration under the kernel trace ==")
+for (k, g), v in sorted(dur.items()):
+    v = sorted(v)
+    print(f"{k[:60]:60s} grid={g:9d} n={len(v):4d} mean={sum(v) / len(v) / 1e3:10.1f} us  median={v[len(v) // 2] / 1e3:10.1f} us")
+print("\n== derived per launch shape ==")
+for e in doc["kernels"]:
+    c = e["counters"]
+    line = f"{e['kernel'][:50]:50s} grid={e['grid_threads']:9d} vgpr={e['vgpr']} lds={e['lds']} scratch={e['scratch']}"
+    if "SQ_INSTS_VALU_FMA_F64" in c:
+        fl = 64 * (c.get("SQ_INSTS_VALU_ADD_F64", 0) + c.get("SQ_INSTS_VALU_MUL_F64", 0) + c.get("SQ_INSTS_VALU_TRANS_F64", 0)
+                   + 2 * c["SQ_INSTS_VALU_FMA_F64"])
+        f64 = sum(c.get(x, 0) for x in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_TRANS_F64",
+                                        "SQ_INSTS_VALU_FMA_F64"))
+        line += f" exec_fp64_gflop={fl / 1e9:.3f} fp64_wave_insts={f64:.3e} valu_wave_insts={c.get('SQ_INSTS_VALU', 0):.3e}"
+    if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
+        line += (f" wait_any={c.get('SQ_WAIT_ANY', 0) / c['SQ_WAVE_CYCLES']:.2f}"
+                 f" active_valu={c.get('SQ_ACTIVE_INST_VALU', 0) / c['SQ_WAVE_CYCLES']:.2f}")
+    if "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"]:
+        line += f" lds_conflict={c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:.2f}"
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        line += f" hbm_MB={(2048 * c['FETCH_SIZE'] + 1024 * c['WRITE_SIZE']) / 1e6:.1f}"
+    print(line)
