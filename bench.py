@@ -189,15 +189,31 @@ def physical_cores():
     except OSError:
         n = 0
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    return max(1, min(n or avail, avail))
+    n = min(n or avail, avail)
+    # a container's CPU quota (cgroup v2 cpu.max / v1 cfs_quota) caps what the threads can actually use
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
     """The CPU side of the comparison, on a bounded sample of the same workload: oracle/rf_oracle.c
-    (a scalar fp64 restatement of the reference's arithmetic, kind "port"), one OpenMP thread per
-    PHYSICAL core.  The reference itself cannot be built in this image without stand-ins for FFTW3 /
-    LAPACK, so its own per-core rate is carried as `ref_ratio` from SURVEY.md
-    section 6's probe of the unmodified reference (same shapes) against this port, both single-core."""
+    (a scalar fp64 restatement of the reference's arithmetic, kind "port") in its speed build
+    (-O3 -march=native, same values as the checker build), one OpenMP thread per PHYSICAL core, no
+    allocation inside the evaluation loop.  The reference itself cannot be built in this image without
+    stand-ins for FFTW3 / LAPACK; `ref_ratio` carries its per-core rate relative to
+    this port from the committed single-core comparison at the shapes SURVEY.md section 6 probed the
+    unmodified reference at (profiles/rNN_cpu_port_vs_reference_probe.json)."""
     os.environ.setdefault("OMP_PROC_BIND", "spread")
     os.environ.setdefault("OMP_PLACES", "cores")
     from oracle import rf_oracle as orc
@@ -210,22 +226,32 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
     # parity sample + a first timing on a slice that one pass finishes quickly
     n0 = min(nb, 16 * cores)
     t0 = time.perf_counter()
-    ll = orc.eval_batch(cfg, obs, r_inv, nlay[:n0], layers[:n0], sig[:n0], p.nsmp, nthreads=cores)
+    orc.lib_fast()
+    ll = orc.eval_batch(cfg, obs, r_inv, nlay[:n0], layers[:n0], sig[:n0], p.nsmp, nthreads=cores, fast=True)
     dt0 = time.perf_counter() - t0
     n = int(min(max(n0, budget_s / max(dt0, 1e-3) * n0), 200 * nb))
     idx = np.arange(n) % nb
     t0 = time.perf_counter()
-    ll_all = orc.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], p.nsmp, nthreads=cores)
+    ll_all = orc.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], p.nsmp, nthreads=cores, fast=True)
     dt = time.perf_counter() - t0
     # single-core rate of the port on the same sample (for the per-core comparison with the reference probe)
     n1 = max(8, min(nb, int(2.0 / max(dt / n * cores, 1e-4))))
     t0 = time.perf_counter()
-    orc.eval_batch(cfg, obs, r_inv, nlay[:n1], layers[:n1], sig[:n1], p.nsmp, nthreads=1)
+    orc.eval_batch(cfg, obs, r_inv, nlay[:n1], layers[:n1], sig[:n1], p.nsmp, nthreads=1, fast=True)
     dt1 = time.perf_counter() - t0
+    ratio = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_cpu_port_vs_reference_probe.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            ratio = {"reference_over_port_per_core": {k: v["reference_over_port"] for k, v in d["shapes"].items()},
+                     "measured_on": d.get("cpu_model"), "file": os.path.relpath(f, ROOT)}
+            break
+        except Exception:
+            continue
     base = {"value": n / dt, "unit": "evals/s", "cores": cores, "kind": "port",
-            "per_core": n / dt / cores, "single_core": n1 / dt1,
+            "per_core": n / dt / cores, "single_core": n1 / dt1, "ref_ratio": ratio,
             "sample": f"{n} evals = the rank's walker set cycled ({nb} walkers, mean {float(nlay.mean()):.1f} layers), "
-                      f"oracle/rf_oracle.c (gcc -O2 -ffp-contract=off, OpenMP x{cores} threads = physical cores, "
+                      f"oracle/rf_oracle.c (gcc {' '.join(orc.FAST_FLAGS)}, OpenMP x{cores} threads = physical cores, "
                       f"{dt:.1f} s wall); single-core rate on {n1} evals"}
     nuse = min(nb, n)
     return base, ll_all[:nuse], nuse
@@ -469,7 +495,7 @@ def main():
                            rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha)
                 n = min(nb, parity_n)
                 ll_cpu = orc.eval_batch(cfg, obs, r_inv, nlay[:n], layers[:n], sig[:n], p.nsmp,
-                                        nthreads=min(physical_cores(), orc.max_threads()))
+                                        nthreads=min(physical_cores(), orc.max_threads()))   # the checker build
             d = np.abs(ll_gpu[:n] - ll_cpu)
             res["parity_in_bench"] = {"n": int(n), "max_abs_dlogl": float(d.max()),
                                       "max_rel_dlogl": float((d / np.abs(ll_cpu)).max()),
@@ -485,13 +511,6 @@ def main():
         also[wl] = {k: r[k] for k in ("value", "ms_per_step", "ms_per_step_median", "config", "roofline", "kernel_ms",
                                       "parity_in_bench") if k in r}
     if rank == 0:
-        if "cpu_baseline" in main_res:
-            # the reference's own per-core rate at this shape, from SURVEY.md section 6's probe of the unmodified
-            # reference (amdflang -O2, one core of this container class); ratio = reference / this port, per core
-            probe = {"c2": ("175-205 evals/s/core at 15 layers (nfft 4096, 1 P trace)", None),
-                     "c4": ("29-37 evals/s/core at 30 layers (nfft 4096, 3 traces)", None)}.get(args.workload)
-            if probe:
-                main_res["cpu_baseline"]["reference_probe"] = probe[0]
         out = {"metric": "forward+likelihood evals/sec (whole node)", "value": main_res["value"], "unit": "evals/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",

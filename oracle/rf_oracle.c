@@ -413,6 +413,33 @@ static int rays_common(const rfo_cfg *c)
     return common;
 }
 
+/* scratch of one calc_rf evaluation (the reference keeps these on the stack / in module fftw);
+ * the batched driver allocates one per thread instead of one per evaluation */
+typedef struct {
+    cplx *freq_r, *freq_v, *rff, *cx, *work;
+    double *rx, *rft, *misfits, *phi1;
+} rfo_scratch;
+
+static void scratch_init(rfo_scratch *w, int n, int ntrc, int nsmp)
+{
+    int nh = n / 2 + 1;
+    w->freq_r = (cplx *)malloc(sizeof(cplx) * (size_t)nh);
+    w->freq_v = (cplx *)malloc(sizeof(cplx) * (size_t)nh);
+    w->rff = (cplx *)malloc(sizeof(cplx) * (size_t)nh);
+    w->cx = (cplx *)malloc(sizeof(cplx) * (size_t)nh);
+    w->work = (cplx *)malloc(sizeof(cplx) * (size_t)n);
+    w->rx = (double *)malloc(sizeof(double) * (size_t)n);
+    w->rft = (double *)malloc(sizeof(double) * (size_t)n * (size_t)(ntrc > 0 ? ntrc : 1));
+    w->misfits = (double *)malloc(sizeof(double) * (size_t)(nsmp > 0 ? nsmp : 1));
+    w->phi1 = (double *)malloc(sizeof(double) * (size_t)(nsmp > 0 ? nsmp : 1));
+}
+
+static void scratch_free(rfo_scratch *w)
+{
+    free(w->freq_r); free(w->freq_v); free(w->rff); free(w->cx); free(w->work);
+    free(w->rx); free(w->rft); free(w->misfits); free(w->phi1);
+}
+
 /* src/forward.f90:123-208  calc_rf.  rft is (nfft, ntrc) column-major.
  * flt (nh, ntrc) from rfo_init_filter.  Optional outputs (may be NULL):
  * npre_out[ntrc] (the integer shift), spec_out[(2*nh)*ntrc] cplx = rff then
@@ -420,15 +447,11 @@ static int rays_common(const rfo_cfg *c)
 static void calc_rf_impl(const rfo_cfg *c, const fft_plan *pl, const double *flt,
                          int nlay, const double *alpha, const double *beta,
                          const double *rho, const double *h, double *rft,
-                         int *npre_out, cplx *spec_out)
+                         int *npre_out, cplx *spec_out, rfo_scratch *w)
 {
     int n = c->nfft, nh = n / 2 + 1;
-    cplx *freq_r = (cplx *)malloc(sizeof(cplx) * (size_t)nh);
-    cplx *freq_v = (cplx *)malloc(sizeof(cplx) * (size_t)nh);
-    cplx *rff = (cplx *)malloc(sizeof(cplx) * (size_t)nh);
-    cplx *cx = (cplx *)malloc(sizeof(cplx) * (size_t)nh);
-    cplx *work = (cplx *)malloc(sizeof(cplx) * (size_t)n);
-    double *rx = (double *)malloc(sizeof(double) * (size_t)n);
+    cplx *freq_r = w->freq_r, *freq_v = w->freq_v, *rff = w->rff, *cx = w->cx, *work = w->work;
+    double *rx = w->rx;
     int common = rays_common(c);
     double tp = 0.0;
 
@@ -490,7 +513,6 @@ static void calc_rf_impl(const rfo_cfg *c, const fft_plan *pl, const double *flt
             for (int i = 0; i < n; ++i) out[i] = out[i] / fac_norm;        /* :202 */
         }
     }
-    free(freq_r); free(freq_v); free(rff); free(cx); free(work); free(rx);
 }
 
 /* NOTE on Fortran mod with negative first argument: mod(a, n) keeps the sign
@@ -511,7 +533,10 @@ void rfo_calc_rf(int nfft, int ntrc, int deconv_mode, double delta, double t_sta
     rfo_init_filter(nfft, ntrc, delta, a_gus, flt);
     fft_plan pl;
     fft_plan_init(&pl, nfft);
-    calc_rf_impl(&c, &pl, flt, nlay, alpha, beta, rho, h, rft, npre_out, spec_out);
+    rfo_scratch w;
+    scratch_init(&w, nfft, 0, 0);
+    calc_rf_impl(&c, &pl, flt, nlay, alpha, beta, rho, h, rft, npre_out, spec_out, &w);
+    scratch_free(&w);
     fft_plan_free(&pl);
     free(flt);
 }
@@ -519,12 +544,10 @@ void rfo_calc_rf(int nfft, int ntrc, int deconv_mode, double delta, double t_sta
 /* src/likelihood.f90:84-98: the misfit / quadratic form part of
  * calc_likelihood.  obs has leading dimension ldobs (src/params.f90:413 uses
  * npts_max = 2000), r_inv is (nsmp, nsmp, ntrc) column-major. */
-double rfo_log_likelihood(int nfft, int ntrc, int nsmp, const double *rft,
-                          const double *obs, int ldobs, const double *r_inv,
-                          const double *sig)
+static double log_likelihood_impl(int nfft, int ntrc, int nsmp, const double *rft,
+                                  const double *obs, int ldobs, const double *r_inv,
+                                  const double *sig, double *misfits, double *phi1)
 {
-    double *misfits = (double *)malloc(sizeof(double) * (size_t)nsmp);
-    double *phi1 = (double *)malloc(sizeof(double) * (size_t)nsmp);
     double ll = 0.0;                                                       /* :86 */
     for (int itrc = 0; itrc < ntrc; ++itrc) {
         for (int i = 0; i < nsmp; ++i)
@@ -540,6 +563,16 @@ double rfo_log_likelihood(int nfft, int ntrc, int nsmp, const double *rft,
         for (int j = 0; j < nsmp; ++j) phi += phi1[j] * misfits[j];
         ll = ll - 0.5 * phi / (s * s) - (double)nsmp * log(s);             /* :94-96 */
     }
+    return ll;
+}
+
+double rfo_log_likelihood(int nfft, int ntrc, int nsmp, const double *rft,
+                          const double *obs, int ldobs, const double *r_inv,
+                          const double *sig)
+{
+    double *misfits = (double *)malloc(sizeof(double) * (size_t)nsmp);
+    double *phi1 = (double *)malloc(sizeof(double) * (size_t)nsmp);
+    double ll = log_likelihood_impl(nfft, ntrc, nsmp, rft, obs, ldobs, r_inv, sig, misfits, phi1);
     free(misfits); free(phi1);
     return ll;
 }
@@ -665,20 +698,27 @@ void rfo_eval_batch(int nfft, int ntrc, int nsmp, int deconv_mode, double delta,
     rfo_init_filter(nfft, ntrc, delta, a_gus, flt);
     fft_plan pl;
     fft_plan_init(&pl, nfft);
-#ifdef _OPENMP
     if (nthreads < 1) nthreads = 1;
-#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads)
+    /* one scratch set per thread for the whole batch: no allocation inside the evaluation loop */
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
 #endif
-    for (int b = 0; b < nb; ++b) {
-        const double *L = layers + (size_t)b * 4 * nlay_pad;
-        double *rft = (double *)malloc(sizeof(double) * (size_t)nfft * ntrc);
-        calc_rf_impl(&c, &pl, flt, nlay[b], L, L + nlay_pad, L + 2 * nlay_pad,
-                     L + 3 * nlay_pad, rft, NULL, NULL);
-        logl_out[b] = rfo_log_likelihood(nfft, ntrc, nsmp, rft, obs, ldobs, r_inv,
-                                         sig + (size_t)b * ntrc);
-        if (rft_out)
-            memcpy(rft_out + (size_t)b * nfft * ntrc, rft, sizeof(double) * (size_t)nfft * ntrc);
-        free(rft);
+    {
+        rfo_scratch w;
+        scratch_init(&w, nfft, ntrc, nsmp);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (int b = 0; b < nb; ++b) {
+            const double *L = layers + (size_t)b * 4 * nlay_pad;
+            calc_rf_impl(&c, &pl, flt, nlay[b], L, L + nlay_pad, L + 2 * nlay_pad,
+                         L + 3 * nlay_pad, w.rft, NULL, NULL, &w);
+            logl_out[b] = log_likelihood_impl(nfft, ntrc, nsmp, w.rft, obs, ldobs, r_inv,
+                                              sig + (size_t)b * ntrc, w.misfits, w.phi1);
+            if (rft_out)
+                memcpy(rft_out + (size_t)b * nfft * ntrc, w.rft, sizeof(double) * (size_t)nfft * ntrc);
+        }
+        scratch_free(&w);
     }
     fft_plan_free(&pl);
     free(flt);

@@ -34,18 +34,47 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def _typed(path):
+    h = C.CDLL(path)
+    h.rfo_direct_arrival.restype = C.c_double
+    h.rfo_log_likelihood.restype = C.c_double
+    h.rfo_vp_to_rho.restype = C.c_double
+    h.rfo_vp_to_rho.argtypes = [C.c_double]
+    h.rfo_max_threads.restype = C.c_int
+    return h
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
             build()
-        _lib = C.CDLL(_LIB_PATH)
-        _lib.rfo_direct_arrival.restype = C.c_double
-        _lib.rfo_log_likelihood.restype = C.c_double
-        _lib.rfo_vp_to_rho.restype = C.c_double
-        _lib.rfo_vp_to_rho.argtypes = [C.c_double]
-        _lib.rfo_max_threads.restype = C.c_int
+        _lib = _typed(_LIB_PATH)
     return _lib
+
+
+FAST_FLAGS = ["-O3", "-march=native", "-fno-math-errno", "-fno-trapping-math", "-ffp-contract=off", "-fno-fast-math"]
+_fast = None
+
+
+def lib_fast():
+    """The same source compiled for speed on THIS host (bench.py's cpu_baseline leg only): -O3 -march=native,
+    still no FMA contraction and no fast-math, so it returns bit-identical values (tests/test_oracle_kat.py);
+    built into the temp directory because -march=native must match the machine it runs on."""
+    global _fast
+    if _fast is None:
+        import hashlib
+        import tempfile
+
+        src = os.path.join(_HERE, "rf_oracle.c")
+        tag = hashlib.sha256(open(src, "rb").read() + " ".join(FAST_FLAGS).encode()).hexdigest()[:16]
+        out = os.path.join(tempfile.gettempdir(), f"librf_oracle_fast_{os.getuid()}_{tag}.so")
+        if not os.path.exists(out):
+            tmp = out + f".{os.getpid()}.tmp"
+            subprocess.check_call(["gcc", *FAST_FLAGS, "-fPIC", "-std=c99", "-fopenmp", "-shared", "-o", tmp, src, "-lm"])
+            os.replace(tmp, out)
+        _fast = _typed(out)
+    return _fast
 
 
 def _d(a):
@@ -127,11 +156,11 @@ def log_likelihood(rft, obs, r_inv, sig, nsmp):
                                     C.c_int(obs.shape[1]), pri, ps)
 
 
-def eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=False, nthreads=1):
+def eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=False, nthreads=1, fast=False):
     """nb x calc_likelihood(fwd_flag=.true.)  (src/likelihood.f90:56-101).
 
     layers[nb, 4, nlay_pad] rows = alpha, beta, rho, h;  sig[nb, ntrc].
-    Returns logL[nb] (and rft[nb, ntrc, nfft])."""
+    Returns logL[nb] (and rft[nb, ntrc, nfft]).  fast: the speed build (lib_fast), same values."""
     rayps, prp = _d(cfg["rayps"]); a_gus, pag = _d(cfg["a_gus"]); ipha, pip = _i(cfg["ipha"])
     obs, po = _d(obs); r_inv, pri = _d(r_inv); layers, pl = _d(layers); sig, ps = _d(sig)
     nlay, pn = _i(nlay)
@@ -139,7 +168,7 @@ def eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=False, nthread
     ntrc, nfft = rayps.size, int(cfg["nfft"])
     logl = np.empty(nb)
     rft = np.empty((nb, ntrc, nfft)) if want_rft else None
-    lib().rfo_eval_batch(C.c_int(nfft), C.c_int(ntrc), C.c_int(nsmp),
+    (lib_fast() if fast else lib()).rfo_eval_batch(C.c_int(nfft), C.c_int(ntrc), C.c_int(nsmp),
                          C.c_int(int(cfg["deconv_mode"])), C.c_double(cfg["delta"]),
                          C.c_double(cfg["t_start"]), C.c_double(cfg["sdep"]), prp, pag, pip,
                          po, C.c_int(obs.shape[1]), pri, C.c_int(nb), pn, C.c_int(nlay_pad),

@@ -67,7 +67,8 @@ SYMBOLS = {
     "rf_get_flt": (C.c_int, [_vp, dp]),
     "rf_get_is_ray_common": (C.c_int, [_vp, ip]),
     "rf_get_r_inv": (C.c_int, [_vp, dp]),
-    "rf_compute_r_inv": (C.c_int, [C.c_int32, C.c_double, C.c_double, dp, ip]),
+    "rf_compute_r_inv": (C.c_int, [C.c_int32, C.c_double, C.c_double, dp, ip, dp]),
+    "rf_get_r_inv_info": (C.c_int, [_vp, ip, dp]),
     "rf_set_r_inv": (C.c_int, [_vp, dp]),
     "rf_calc_likelihood_of_trace": (C.c_int, [_vp, dp, dp, dp]),
     "rf_calc_rf": (C.c_int, [_vp, C.c_int32, dp, dp, dp, dp, dp]),
@@ -82,6 +83,13 @@ SYMBOLS = {
     "rf_format_models_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int32, _vp, _vp]),
     "rf_eval_models_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_pt_swap_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rf_comm_probe": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rf_comm_get_unique_id": (C.c_int, [C.c_char_p]),
+    "rf_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int32]),
+    "rf_comm_destroy": (C.c_int, [_vp]),
+    "rf_comm_bcast_i32": (C.c_int, [_vp, ip, C.c_int32, C.c_int32]),
+    "rf_pt_swap_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, dp, ip]),
+    "rf_pt_swap_allgather_device": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "rf_post_create": (C.c_int, [_vp, C.POINTER(RFPostConfig)]),
     "rf_post_reset": (C.c_int, [_vp]),
     "rf_post_record": (C.c_int, [_vp, C.c_int32, ip, ip, dp, dp, dp, dp, dp, dp]),

@@ -21,6 +21,9 @@ static int fail(const std::string &msg)
     g_err = msg;
     return 1;
 }
+namespace rfgpu {
+int comm_fail(const std::string &msg) { return fail(msg); }
+}
 
 #define HIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -30,6 +33,7 @@ static int fail(const std::string &msg)
     } while (0)
 
 struct rf_ctx {
+    rfgpu::CommState *comm = nullptr;   // RCCL communicator of the temperature exchange (rfgpu_comm.cpp), or none
     rf_config cfg{};
     int device = 0;
     int nh = 0, nfwd = 1, ray_common = 1, nslots = 0;
@@ -69,6 +73,7 @@ struct rf_ctx {
     bool fused_allowed = false;   // the context's shape admits the fused kernel
     int fused_override = -1;  // "fused": -1 = by shape
     int defer_logl = -1;      // "defer_logl": -1 = by batch size, 0 / 1 = never / always
+    int prestage = -1;        // "prestage": -1 = by batch size, 0 / 1 = stage inside the fused kernel / by stage_kernel
     double bin_cutoff = 0.0;  // "bin_cutoff": opt-in filter-support cut-off (0 = off: every bin like the reference)
     int n_overrides = 0;      // options set away from their defaults (echoed by rf_get_launch_plan)
     int ablate = 0;           // RFGPU_DIAGNOSTICS builds only ("ablate"): stops the kernel early, results invalid
@@ -79,6 +84,8 @@ struct rf_ctx {
     size_t gather_bytes = 0;
     // host copies of tables
     std::vector<double> flt, r_inv;
+    std::vector<int> r_inv_rank;        // per trace: rank of the library-built pseudo-inverse (-1: caller's r_inv)
+    std::vector<double> r_inv_gap;      // per trace: relative gap at the 1e-3 cut-off (NaN: caller's r_inv)
     std::vector<int> h_order;
     // launch policy
     bool fused = false;       // one launch for spectra + trace (needs one forward computation per trace)
@@ -99,6 +106,12 @@ struct rf_ctx {
     int64_t prof_n[4] = {0, 0, 0, 0};   // batches, spectra / trace / logl kernel launches
 };
 
+namespace rfgpu {
+hipStream_t ctx_stream(rf_ctx *c) { return c->stream; }
+int ctx_device(rf_ctx *c) { return c->device; }
+CommState *&ctx_comm(rf_ctx *c) { return c->comm; }
+}
+
 extern "C" const char *rf_last_error(void) { return g_err.c_str(); }
 extern "C" int rf_abi_version(void) { return RFGPU_ABI_VERSION; }
 
@@ -106,7 +119,8 @@ extern "C" int rf_abi_version(void) { return RFGPU_ABI_VERSION; }
 // init_r_inv for one trace (reference src/likelihood.f90:183-222) with a one-sided
 // Jacobi SVD (Hestenes) in fp64.  r_inv(i,j) column-major.
 // ---------------------------------------------------------------------------
-extern "C" int rf_compute_r_inv(int32_t nsmp, double a_gus, double delta, double *r_inv, int32_t *rank_out)
+extern "C" int rf_compute_r_inv(int32_t nsmp, double a_gus, double delta, double *r_inv, int32_t *rank_out,
+                                double *cut_gap_out)
 {
     if (nsmp <= 0 || !r_inv) return fail("rf_compute_r_inv: bad arguments");
     const int n = nsmp;
@@ -163,6 +177,12 @@ extern "C" int rf_compute_r_inv(int32_t nsmp, double a_gus, double delta, double
     std::sort(sv.begin(), sv.end(), [](const std::pair<double, int> &a, const std::pair<double, int> &b) {
         return a.first > b.first;
     });
+    // relative distance of the nearest singular value to the hard cut-off s > 1e-3 (:214): the rank -- and with
+    // it every value of the pseudo-inverse -- is only as well defined as this gap is wide compared with the
+    // rounding of an SVD (~1e-15 * s_max absolute, ~1e-11 relative to the cut-off for these matrices)
+    double gap = HUGE_VAL;
+    for (int kk = 0; kk < n; ++kk) gap = std::min(gap, std::fabs(sv[kk].first - 1.0e-3) / 1.0e-3);
+    if (cut_gap_out) *cut_gap_out = gap;
     for (int kk = 0; kk < n; ++kk) {
         const double s = sv[kk].first;
         const int k = sv[kk].second;
@@ -307,8 +327,10 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
             }
         }
     }
-    // r_inv: supplied (host dgesvd, bit-identical to the reference build) or built here
+    // r_inv: supplied by the host (its own LAPACK dgesvd, the same products as src/likelihood.f90:212-222) or built here
     c->r_inv.resize((size_t)nsmp * nsmp * ntrc);
+    c->r_inv_rank.assign(ntrc, -1);      // -1 / NaN: r_inv supplied by the caller
+    c->r_inv_gap.assign(ntrc, std::nan(""));
     if (cfg->r_inv) {
         std::memcpy(c->r_inv.data(), cfg->r_inv, sizeof(double) * c->r_inv.size());
     } else {
@@ -317,10 +339,26 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
             for (int u = 0; u < t; ++u)
                 if (cfg->a_gus[u] == cfg->a_gus[t]) same = u;
             double *dst = c->r_inv.data() + (size_t)nsmp * nsmp * t;
-            if (same >= 0)
+            if (same >= 0) {
                 std::memcpy(dst, c->r_inv.data() + (size_t)nsmp * nsmp * same, sizeof(double) * nsmp * nsmp);
-            else if (rf_compute_r_inv(nsmp, cfg->a_gus[t], cfg->delta, dst, nullptr))
-                return cleanup(1);
+                c->r_inv_rank[t] = c->r_inv_rank[same];
+                c->r_inv_gap[t] = c->r_inv_gap[same];
+            }
+            else {
+                int rank = 0;
+                double gap = 0.0;
+                if (rf_compute_r_inv(nsmp, cfg->a_gus[t], cfg->delta, dst, &rank, &gap)) return cleanup(1);
+                if (!(gap >= RF_R_INV_MIN_CUT_GAP)) {
+                    char msg[256];
+                    snprintf(msg, sizeof msg,
+                             "rf_ctx_create: trace %d: a singular value of the noise matrix lies within %.1e (relative) "
+                             "of the 1e-3 rank cut-off (src/likelihood.f90:214): the pseudo-inverse is not well defined; "
+                             "pass the host's own r_inv in rf_config", t + 1, gap);
+                    return cleanup(fail(msg));
+                }
+                c->r_inv_rank[t] = rank;
+                c->r_inv_gap[t] = gap;
+            }
         }
     }
     std::vector<double> obs((size_t)nsmp * ntrc);
@@ -370,6 +408,13 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     (void)hipMemset(p, 0, sizeof(int) * c->nslots);
     if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * ntrc * nsmp)) return cleanup(1);
     c->ws.misfit = (double *)p;
+    // stage_kernel's output (fused path): nlay_max * NCOEF doubles per (walker, forward-trace)
+    if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * c->nfwd * cfg->nlay_max * NCOEF)) return cleanup(1);
+    c->ws.gcoef = (double *)p;
+    if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * c->nfwd * GTAIL)) return cleanup(1);
+    c->ws.gtail = (double *)p;
+    if (dev_alloc(c, &p, sizeof(int) * (size_t)c->nslots * c->nfwd)) return cleanup(1);
+    c->ws.gflag = (int *)p;
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->d_order = (int *)p;
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
@@ -382,7 +427,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     c->slow_list = (int *)p + 1;   // [nslots * nfwd]
     (void)hipMemset(p, 0, sizeof(int));
 
-    if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || trace_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024)
+    if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || trace_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024 ||
+        sizeof(double) * (size_t)(5 * ((nsmp + 1) & ~1) + 8) > 160 * 1024)   // phi_kernel (host-owned traces)
         return cleanup(fail("rf_ctx_create: nfft / nsmp / nlay_max exceed the 160 KiB LDS of a gfx950 CU"));
     c->fused_allowed = (c->nfwd == ntrc) && fused_lds_bytes(n, nsmp, cfg->nlay_max) <= 160 * 1024;
     default_plan(c);
@@ -393,6 +439,7 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
 extern "C" int rf_ctx_destroy(rf_ctx *c)
 {
     if (!c) return 0;
+    (void)rf_comm_destroy(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (void *p : c->owned) (void)hipFree(p);
@@ -417,6 +464,15 @@ extern "C" int rf_get_is_ray_common(const rf_ctx *c, int32_t *flag)
 {
     if (!c || !flag) return fail("rf_get_is_ray_common: null argument");
     *flag = c->ray_common;
+    return 0;
+}
+extern "C" int rf_get_r_inv_info(const rf_ctx *c, int32_t *rank, double *cut_gap)
+{
+    if (!c) return fail("rf_get_r_inv_info: null context");
+    for (int t = 0; t < c->cfg.ntrc; ++t) {
+        if (rank) rank[t] = c->r_inv_rank[t];
+        if (cut_gap) cut_gap[t] = c->r_inv_gap[t];
+    }
     return 0;
 }
 extern "C" int rf_get_r_inv(const rf_ctx *c, double *r_inv)
@@ -516,8 +572,13 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         const long long blocks = (long long)b.nb * c->cfg.ntrc, round = 2LL * c->num_cu;
         const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl
                           : (c->cfg.ntrc > 1 ? blocks >= 2 * round : blocks >= 4 * round));
+        // constants of the propagator by stage_kernel once the batch fills the chip (every block would otherwise
+        // stage its item on its own critical path); tiny batches (the per-call drop-in) keep the single launch
+        const int prestage = c->prestage >= 0 ? c->prestage : blocks >= c->num_cu;
+        if (prestage) launch_stage(c->tab, b, c->ws, s);
         hipEvent_t e = prof_begin(c, 0, s);
-        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, c->single_trace_out, s);
+        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, c->single_trace_out,
+                     prestage, s);
         if (e) (void)hipEventRecord(e, s);
         if (defer) launch_logl_deferred(c->tab, b, c->ws, s);
     } else {
@@ -1050,6 +1111,9 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     } else if (k == "defer_logl") {
         if (!integral || iv < -1 || iv > 1) return fail("rf_set_option: defer_logl must be -1 (by batch size), 0 or 1");
         c->defer_logl = iv;
+    } else if (k == "prestage") {
+        if (!integral || iv < -1 || iv > 1) return fail("rf_set_option: prestage must be -1 (by batch size), 0 or 1");
+        c->prestage = iv;
     } else if (k == "bin_cutoff") {
         if (!(value >= 0.0 && value < 1.0)) return fail("rf_set_option: bin_cutoff must be in [0, 1)");
         c->bin_cutoff = value;
@@ -1064,7 +1128,7 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     default_plan(c);
     c->n_overrides = (c->fused_override != -1) + (c->chain_override != -1) + (!c->lpt) + (!c->order_reuse) +
                      (c->nsplit_override != 0) + (c->waves_per_block != 4) + (c->defer_logl != -1) +
-                     (c->bin_cutoff > 0.0) + (c->ablate != 0);
+                     (c->prestage != -1) + (c->bin_cutoff > 0.0) + (c->ablate != 0);
     return 0;
 }
 

@@ -6,8 +6,12 @@
 
 namespace rfgpu {
 
+struct CommState;   // rfgpu_comm.cpp
+
 // doubles of per-layer coefficients staged in LDS (see stage_layer_coef)
 constexpr int NCOEF = 24;
+// doubles per (batch item, forward-trace) of walker constants written by stage_kernel
+constexpr int GTAIL = 24;
 
 struct DeviceTables {
     int nfft, nh, ntrc, nfwd, nsmp, deconv_mode, ray_common;
@@ -41,6 +45,9 @@ struct WalkerState {
     int *meta_slot;   // [nslots] per batch item: destination half of the proposal
     int *done;        // [nslots] per batch item: traces finished (last one forms logL), self-resetting
     double *misfit;   // [nslots][ntrc][nsmp] per batch item: misfits handed to the deferred phi / logL kernel
+    double *gcoef;    // [nslots * nfwd][nlay_max][NCOEF] per batch item: stage_kernel's per-layer constants
+    double *gtail;    // [nslots * nfwd][GTAIL]           ... walker constants + direct-arrival time
+    int *gflag;       // [nslots * nfwd]                  ... bit 0 sea, bit 1 phases beyond the fast sincos range
     int nslots;
 };
 
@@ -56,7 +63,9 @@ void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 // fused K1+K2 (contexts with one forward computation per trace)
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
-                  int ablate, int defer_logl, int *order_next, double *extra_out, hipStream_t s);
+                  int ablate, int defer_logl, int *order_next, double *extra_out, int prestaged, hipStream_t s);
+// K0: per-(item, forward-trace) constants of the propagator, once per batch item (fused path, large batches)
+void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 // logL of a batch launched with defer_logl (one thread per batch item, after the fused kernel)
 void launch_logl_deferred(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 size_t phi_deferred_lds_bytes(int nsmp);

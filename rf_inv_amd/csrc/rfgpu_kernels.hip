@@ -19,6 +19,7 @@
 // consumes (1, 2 and, under an ocean, 4) are propagated.
 #include "rfgpu_internal.h"
 #include <math.h>
+#include <atomic>
 
 // Timing diagnostics (tools/ablate.sh): a build with -DRFGPU_DIAGNOSTICS can stop a block after phase N
 // to split the kernel time; the production library has no such exits.
@@ -29,6 +30,23 @@
 #endif
 
 namespace rfgpu {
+
+// Dynamic LDS beyond 64 KiB must be opted into per kernel and per device.  Every kernel that can need it is
+// opted in ONCE to the CU's whole 160 KiB (the launch's own size decides residency, not this ceiling): the
+// same value from every thread, so concurrent contexts on different host threads cannot shrink each other's
+// limit, and nothing is set on the launch path afterwards.
+struct LdsOptIn {
+    std::atomic<unsigned> done{0};   // bit per device ordinal (mod 32)
+    void operator()(const void *fn)
+    {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const unsigned bit = 1u << (dev & 31);
+        if (done.load(std::memory_order_acquire) & bit) return;
+        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done.fetch_or(bit, std::memory_order_release);
+    }
+};
 
 // ---------------------------------------------------------------------------
 // small complex helpers (same operation order as the oracle's c_mul)
@@ -785,15 +803,130 @@ __global__ __launch_bounds__(64) void spectra_slow_kernel(SpectraParams P)
 
 size_t spectra_lds_bytes(int nlay_pad) { return sizeof(double) * ((size_t)nlay_pad * (NCOEF + 1) + 24); }
 
+// ---------------------------------------------------------------------------
+// K0  stage_kernel: the per-(walker, forward-trace) constants of K1 computed ONCE per batch item by a
+// wide, shallow launch instead of by every block that works on the item.  Inside the fused kernel the
+// staging sat on each block's critical path (a dependent chain of divisions, square roots and three
+// sincos per layer executed by a few lanes while the rest of the block waited: ~4 us per block, 9 % of
+// the C4 launch); here one lane per layer does all four parts of stage_walker, a wave per
+// (item, forward-trace), and the fused kernel starts with a coalesced 6 KB copy.
+// Output per bf = item * nfwd + f (global, same image as the LDS one described above K1):
+//   gcoef[bf][nlay_pad][NCOEF]   layers ilay0 .. nl-2
+//   gtail[bf][GTAIL]             tail[0..16], [17] direct-arrival time (forward.f90:474-519)
+//   gflag[bf]                    bit 0: sea (beta(1) < 0), bit 1: a phase beyond the Cody-Waite range
+// ---------------------------------------------------------------------------
+struct StageParams {
+    DeviceTables t;
+    BatchArgs b;
+    double *gcoef, *gtail;
+    int *gflag;
+};
+
+__global__ __launch_bounds__(256) void stage_kernel(StageParams S)
+{
+    extern __shared__ double lds[];                 // [4][nlay_pad] direct-arrival terms, one row per wave
+    const int pad = S.b.nlay_pad;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bf = blockIdx.x * 4 + wave;
+    const bool live = bf < S.b.nb * S.t.nfwd;
+    const int ib = live ? bf / S.t.nfwd : 0, f = live ? bf % S.t.nfwd : 0;
+    const bool run = live && (!S.b.fwd_flag || S.b.fwd_flag[ib] == 1);
+    double *terms = lds + (size_t)wave * pad;
+    bool big = false;
+    int nl = 2;
+    if (run) {
+        const double *L = S.b.layers + (size_t)ib * 4 * pad;
+        nl = S.b.nlay[ib];
+        const double p = S.t.rayps[f];
+        const bool sea = L[pad] < 0.0;              // beta(1) < 0  (forward.f90:229)
+        const int ilay0 = sea ? 1 : 0;
+        const bool solid = nl - 1 > ilay0;          // at least one solid layer above the half-space
+        const double omg_max = (double)(S.t.nh - 1) * S.t.domg;
+        const double omg_nyq = (double)(S.t.nfft / 2) * S.t.domg;
+        double *coef = S.gcoef + (size_t)bf * pad * NCOEF;
+        double *tail = S.gtail + (size_t)bf * GTAIL;
+        const double *vel = (S.t.ipha[f] == 1) ? L : L + pad;   // alpha for P, beta for S (:157,161)
+        const int i0 = S.t.sdep > 0.0 ? 1 : 0;                  // keyed on sdep (:484)
+        for (int l = lane; l < pad - 1; l += 64) {
+            const double a0 = L[l], b0 = L[pad + l], r0 = L[2 * pad + l], h0 = L[3 * pad + l];
+            const double a1 = L[l + 1], b1 = L[pad + l + 1], r1 = L[2 * pad + l + 1];
+            double *c = coef + (size_t)l * NCOEF;
+            if (l >= ilay0 && l < nl - 1) {
+                const bool below = l + 1 < nl - 1;
+                const LayerHalf ue = layer_half(b0, b0, r0, p), ux = layer_half(a0, b0, r0, p);
+                const LayerHalf we = layer_half(b1, b1, r1, p), wx = layer_half(a1, b1, r1, p);
+                stage_interface(c + 3, 0, ue, below ? &we : nullptr);
+                stage_interface(c + 7, 1, ux, below ? &wx : nullptr);
+                double sn, cn;
+                sincos_cw((omg_nyq * ux.slow) * h0, sn, cn);    // phases of the Nyquist bin (forward.f90:397-400)
+                c[0] = ux.slow;
+                c[2] = h0;
+                stage_phase(c + 11, c + 15, S.t.domg, ux.slow, h0);
+                c[19] = sn;
+                c[20] = cn;
+                sincos_cw((omg_nyq * ue.slow) * h0, sn, cn);
+                c[1] = ue.slow;
+                stage_phase(c + 13, c + 17, S.t.domg, ue.slow, h0);
+                c[21] = sn;
+                c[22] = cn;
+                c[23] = 0.0;
+                big |= fabs(omg_max * ux.slow * h0) >= SINCOS_CW_LIMIT || fabs(omg_max * ue.slow * h0) >= SINCOS_CW_LIMIT;
+            }
+            if (l == nl - 2) {
+                LayerBasis last;
+                if (solid) last = layer_basis(a0, b0, r0, p);
+                stage_halfspace(tail, a1, b1, r1, p, solid ? &last : nullptr);
+            }
+            if (l == (solid ? ilay0 : 0)) {
+                LayerBasis top;
+                if (solid) top = layer_basis(a0, b0, r0, p);
+                stage_start(tail + 11, solid ? &top : nullptr);
+            }
+            if (l == 0 && sea) {
+                const double xiw = vertical_slowness(a0, p);   // forward.f90:431
+                tail[8] = xiw;
+                tail[9] = h0;
+                tail[10] = r0 / xiw;
+                big |= fabs(omg_max * xiw * h0) >= SINCOS_CW_LIMIT;
+            }
+            // direct_arrival (forward.f90:474-519): the independent per-layer terms, summed in order below
+            if (l >= i0 && l < nl - 1) terms[l - i0] = arrival_term(h0, vel[l], p);
+        }
+    }
+    const bool any_big = __any(big);
+    __syncthreads();
+    if (run && lane == 0) {
+        const double *L = S.b.layers + (size_t)ib * 4 * pad;
+        const int i0 = S.t.sdep > 0.0 ? 1 : 0;
+        S.gtail[(size_t)bf * GTAIL + 17] = arrival_sum(nl - 1 - i0, terms);
+        S.gflag[bf] = (L[pad] < 0.0 ? 1 : 0) | (any_big ? 2 : 0);
+    }
+}
+
+void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
+{
+    StageParams S{t, b, w.gcoef, w.gtail, w.gflag};
+    const unsigned nbf = (unsigned)(b.nb * t.nfwd);
+    hipLaunchKernelGGL(stage_kernel, dim3((nbf + 3) / 4), dim3(256), sizeof(double) * 4 * (size_t)b.nlay_pad, s, S);
+}
+
+template <int BK, int NCOL>
+static void launch_spectra_one(dim3 grid, dim3 block, size_t lds, hipStream_t s, const SpectraParams &P)
+{
+    static LdsOptIn opt;     // nlay_max 200 (the reference's limit) needs 40 KB; deeper contexts more than 64
+    opt(reinterpret_cast<const void *>(spectra_kernel<BK, NCOL>));
+    hipLaunchKernelGGL((spectra_kernel<BK, NCOL>), grid, block, lds, s, P);
+}
+
 template <int NCOL>
 static void launch_spectra_ncol(int chain, dim3 grid, dim3 block, size_t lds, hipStream_t s, const SpectraParams &P)
 {
     switch (chain) {
-    case 2: hipLaunchKernelGGL((spectra_kernel<2, NCOL>), grid, block, lds, s, P); break;
-    case 3: hipLaunchKernelGGL((spectra_kernel<3, NCOL>), grid, block, lds, s, P); break;
-    case 4: hipLaunchKernelGGL((spectra_kernel<4, NCOL>), grid, block, lds, s, P); break;
-    case 8: hipLaunchKernelGGL((spectra_kernel<8, NCOL>), grid, block, lds, s, P); break;
-    default: hipLaunchKernelGGL((spectra_kernel<0, NCOL>), grid, block, lds, s, P); break;
+    case 2: launch_spectra_one<2, NCOL>(grid, block, lds, s, P); break;
+    case 3: launch_spectra_one<3, NCOL>(grid, block, lds, s, P); break;
+    case 4: launch_spectra_one<4, NCOL>(grid, block, lds, s, P); break;
+    case 8: launch_spectra_one<8, NCOL>(grid, block, lds, s, P); break;
+    default: launch_spectra_one<0, NCOL>(grid, block, lds, s, P); break;
     }
 }
 
@@ -812,6 +945,8 @@ void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, in
     else
         launch_spectra_ncol<2>(chain, grid, block, lds, s, P);
     if (chain == 2 || chain == 3 || chain == 4 || chain == 8) return;   // generic path handled in place
+    static LdsOptIn opt_slow;
+    opt_slow(reinterpret_cast<const void *>(spectra_slow_kernel));
     hipLaunchKernelGGL(spectra_slow_kernel, dim3(512), dim3(64), lds, s, P);
 }
 
@@ -1472,6 +1607,7 @@ struct FusedParams {
     SpectraParams sp;   // t, b, nsplit (= waves per block), meta pointers unused
     TraceParams tp;     // t, b, w, log2n, plan, slow_count
     int *order_next;    // nullptr, or: block 0 sorts this batch's items by depth for the NEXT launch
+    int prestaged;      // stage_kernel ran for this batch: copy its output instead of staging in the block
 };
 
 __device__ __forceinline__ void order_block(int nb, const int *nlay, const int *fwd_flag, int *order, int *hist,
@@ -1530,20 +1666,38 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
     const int ipha = t.ipha[itrc];
     const bool decon = t.deconv_mode == 1;
 
-    // ---- stage the layer stack, direct-arrival time --------------------------------------
+    // ---- the layer stack's constants and the direct-arrival time: copied from stage_kernel's output
+    // (large batches), or staged here (small batches, where one more launch would cost more than it saves)
     int nl, ilay0;
-    bool sea;
-    const bool big = stage_walker(F.sp, ib, itrc, coef, tail, nl, ilay0, sea);
-    if (!decon) {
+    bool sea, big;
+    if (P.w.gcoef && F.prestaged) {
+        const int bfi = ib * t.ntrc + itrc;
         const int pad = P.b.nlay_pad;
-        const double *L = P.b.layers + (size_t)ib * 4 * pad;
-        const double *vel = (ipha == 1) ? L : L + pad;            // alpha for P, beta for S (:157,161)
-        const int i0 = t.sdep > 0.0 ? 1 : 0;                      // keyed on sdep (:484)
-        double *terms = tail + 24;
-        for (int i = i0 + tid; i < nl - 1; i += TRACE_THREADS)
-            terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], t.rayps[itrc]);
+        nl = P.b.nlay[ib];
+        const int fl = P.w.gflag[bfi];
+        sea = fl & 1;
+        big = fl & 2;
+        ilay0 = sea ? 1 : 0;
+        const double2 *__restrict__ gc = reinterpret_cast<const double2 *>(P.w.gcoef + (size_t)bfi * pad * NCOEF);
+        double2 *lc = reinterpret_cast<double2 *>(coef);
+        for (int i = ilay0 * (NCOEF / 2) + tid; i < (nl - 1) * (NCOEF / 2); i += TRACE_THREADS) lc[i] = gc[i];
+        const double *__restrict__ gt = P.w.gtail + (size_t)bfi * GTAIL;
+        if (tid < 17) tail[tid] = gt[tid];
+        if (tid == 17) red[4] = gt[17];
         __syncthreads();
-        if (tid == 0) red[4] = arrival_sum(nl - 1 - i0, terms);
+    } else {
+        big = stage_walker(F.sp, ib, itrc, coef, tail, nl, ilay0, sea);
+        if (!decon) {
+            const int pad = P.b.nlay_pad;
+            const double *L = P.b.layers + (size_t)ib * 4 * pad;
+            const double *vel = (ipha == 1) ? L : L + pad;            // alpha for P, beta for S (:157,161)
+            const int i0 = t.sdep > 0.0 ? 1 : 0;                      // keyed on sdep (:484)
+            double *terms = tail + 24;
+            for (int i = i0 + tid; i < nl - 1; i += TRACE_THREADS)
+                terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], t.rayps[itrc]);
+            __syncthreads();
+            if (tid == 0) red[4] = arrival_sum(nl - 1 - i0, terms);
+        }
     }
     const int slot = 1 - P.w.cur_slot[walker];
     RFGPU_ABLATE_AT(5, );   // timing diagnostics: launch + staging only
@@ -1610,46 +1764,39 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
     trace_tail(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
 }
 
+template <int BK, int NCOL>
+static void launch_fused_one(dim3 grid, size_t lds, hipStream_t s, const FusedParams &F)
+{
+    static LdsOptIn opt;
+    opt(reinterpret_cast<const void *>(fused_kernel<BK, NCOL>));
+    hipLaunchKernelGGL((fused_kernel<BK, NCOL>), grid, dim3(TRACE_THREADS), lds, s, F);
+}
+
 template <int NCOL>
 static void launch_fused_ncol(int chain, dim3 grid, size_t lds, hipStream_t s, const FusedParams &F)
 {
-    const dim3 block(TRACE_THREADS);
     switch (chain) {
-    case 2: hipLaunchKernelGGL((fused_kernel<2, NCOL>), grid, block, lds, s, F); break;
-    case 3: hipLaunchKernelGGL((fused_kernel<3, NCOL>), grid, block, lds, s, F); break;
-    case 4: hipLaunchKernelGGL((fused_kernel<4, NCOL>), grid, block, lds, s, F); break;
-    case 8: hipLaunchKernelGGL((fused_kernel<8, NCOL>), grid, block, lds, s, F); break;
-    default: hipLaunchKernelGGL((fused_kernel<0, NCOL>), grid, block, lds, s, F); break;
+    case 2: launch_fused_one<2, NCOL>(grid, lds, s, F); break;
+    case 3: launch_fused_one<3, NCOL>(grid, lds, s, F); break;
+    case 4: launch_fused_one<4, NCOL>(grid, lds, s, F); break;
+    case 8: launch_fused_one<8, NCOL>(grid, lds, s, F); break;
+    default: launch_fused_one<0, NCOL>(grid, lds, s, F); break;
     }
 }
 
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
-                  int ablate, int defer_logl, int *order_next, double *extra_out, hipStream_t s)
+                  int ablate, int defer_logl, int *order_next, double *extra_out, int prestaged, hipStream_t s)
 {
     FusedParams F{};
     F.order_next = order_next;
+    F.prestaged = prestaged;
     F.sp = SpectraParams{t, b, nullptr, TRACE_THREADS / 64, nullptr, slow_count, w.meta_tp, w.meta_slot, w.cur_slot};
     F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count, ablate, defer_logl, extra_out};
     while ((1 << F.tp.log2n) < t.nfft) ++F.tp.log2n;
     F.tp.plan = make_fft_plan(F.tp.log2n);
     const size_t lds = fused_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
-    static size_t lds_set_dev[16][2][5] = {};   // the attribute is per device and per kernel
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    size_t (&lds_set)[2][5] = lds_set_dev[dev & 15];
-    const int ci = chain == 2 ? 1 : chain == 3 ? 2 : chain == 4 ? 3 : chain == 8 ? 4 : 0;
-    const int ni = t.sdep > 0.0 ? 1 : 0;
-    if (lds > lds_set[ni][ci]) {   // dynamic LDS beyond 64 KiB must be opted into, per kernel
-        static const void *const fns[2][5] = {
-            {(const void *)fused_kernel<0, 2>, (const void *)fused_kernel<2, 2>, (const void *)fused_kernel<3, 2>,
-             (const void *)fused_kernel<4, 2>, (const void *)fused_kernel<8, 2>},
-            {(const void *)fused_kernel<0, 3>, (const void *)fused_kernel<2, 3>, (const void *)fused_kernel<3, 3>,
-             (const void *)fused_kernel<4, 3>, (const void *)fused_kernel<8, 3>}};
-        (void)hipFuncSetAttribute(fns[ni][ci], hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set[ni][ci] = lds;
-    }
     const dim3 grid((unsigned)(b.nb * t.ntrc) + (order_next ? 1u : 0u));
-    if (ni)
+    if (t.sdep > 0.0)
         launch_fused_ncol<3>(chain, grid, lds, s, F);
     else
         launch_fused_ncol<2>(chain, grid, lds, s, F);
@@ -1677,7 +1824,9 @@ __global__ __launch_bounds__(TRACE_THREADS) void phi_kernel(DeviceTables t, Walk
 
 void launch_phi(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s)
 {
-    const size_t lds = sizeof(double) * (size_t)(5 * ((t.nsmp + 1) & ~1) + 8);
+    const size_t lds = sizeof(double) * (size_t)(5 * ((t.nsmp + 1) & ~1) + 8);   // 80 KB at the reference's npts_max = 2000
+    static LdsOptIn opt;
+    opt(reinterpret_cast<const void *>(phi_kernel));
     hipLaunchKernelGGL(phi_kernel, dim3((unsigned)t.ntrc), dim3(TRACE_THREADS), lds, s, t, w, walker);
 }
 
@@ -1693,15 +1842,8 @@ void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec
     while ((1 << P.log2n) < t.nfft) ++P.log2n;
     P.plan = make_fft_plan(P.log2n);
     const size_t lds = trace_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
-    static size_t lds_set_dev[16] = {};   // the attribute is per device
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    size_t &lds_set = lds_set_dev[dev & 15];
-    if (lds > lds_set) {  // dynamic LDS beyond 64 KiB must be opted into
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(trace_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        lds_set = lds;
-    }
+    static LdsOptIn opt;
+    opt(reinterpret_cast<const void *>(trace_kernel));
     hipLaunchKernelGGL(trace_kernel, dim3((unsigned)(b.nb * t.ntrc)), dim3(TRACE_THREADS), lds, s, P);
 }
 

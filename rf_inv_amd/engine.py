@@ -108,6 +108,14 @@ class RFEngine:
         self._chk(self._lib.rf_get_r_inv(self._ctx, _dptr(out)))
         return out
 
+    @property
+    def r_inv_info(self):
+        """(rank[ntrc], cut_gap[ntrc]) of the library-built pseudo-inverse (-1 / NaN for a supplied r_inv)."""
+        rank = np.zeros(self.ntrc, dtype=np.int32)
+        gap = np.zeros(self.ntrc)
+        self._chk(self._lib.rf_get_r_inv_info(self._ctx, _iptr(rank), _dptr(gap)))
+        return rank, gap
+
     # ---- single evaluations ---------------------------------------------
     def calc_rf(self, nlay, alpha, beta, rho, h):
         """rft(nfft, ntrc) -- src/forward.f90:123-208."""
@@ -269,12 +277,13 @@ class RFEngine:
                 "spectra_launches": n[1], "trace_launches": n[2], "logl_launches": n[3]}
 
 
-def compute_r_inv(nsmp, a_gus, delta):
+def compute_r_inv(nsmp, a_gus, delta, with_gap=False):
     """librfgpu's own init_r_inv (one-sided Jacobi SVD): returns (r_inv[nsmp, nsmp]
-    with .ravel() == Fortran column-major r_inv(:, :), rank)."""
+    with .ravel() == Fortran column-major r_inv(:, :), rank[, relative gap at the 1e-3 cut-off])."""
     lib = _lib.load()
     out = np.empty((nsmp, nsmp))
     rank = C.c_int32()
-    if lib.rf_compute_r_inv(int(nsmp), float(a_gus), float(delta), _dptr(out), C.byref(rank)):
+    gap = C.c_double()
+    if lib.rf_compute_r_inv(int(nsmp), float(a_gus), float(delta), _dptr(out), C.byref(rank), C.byref(gap)):
         raise RFGPUError(lib.rf_last_error().decode())
-    return out, rank.value
+    return (out, rank.value, gap.value) if with_gap else (out, rank.value)

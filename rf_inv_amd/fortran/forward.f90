@@ -84,14 +84,23 @@ contains
   end subroutine init_forward
 
   !---------------------------------------------------------------------
-  ! n, ntrc and rayps are accepted for interface compatibility; like every
-  ! call site of the reference they must be params' nfft, ntrc, rayps.
+  ! n, ntrc and rayps are part of the reference's interface; like every call site of the
+  ! reference (src/likelihood.f90:78-79, src/forward_test.f90:63) they must be params' nfft, ntrc
+  ! and rayps -- the engine was created from those -- and anything else is refused, not ignored.
   subroutine calc_rf(chain_id, nlay, n, ntrc, rayps, alpha, beta, rho, h, rft)
+    use params, only: p_nfft => nfft, p_ntrc => ntrc, p_rayps => rayps
     integer, intent(in) :: nlay, n, ntrc, chain_id
     real(8), intent(in) :: rayps(ntrc)
     real(8), intent(in) :: alpha(nlay), beta(nlay), rho(nlay), h(nlay)
     real(8), intent(out) :: rft(n, ntrc)
 
+    if (n /= p_nfft .or. ntrc /= p_ntrc) then
+       write(0,*) "ERROR: calc_rf called with n, ntrc =", n, ntrc, " but the engine was set up for", p_nfft, p_ntrc
+       call rfgpu_check(1_c_int, "calc_rf argument check")
+    else if (any(rayps(1:ntrc) /= p_rayps(1:ntrc))) then
+       write(0,*) "ERROR: calc_rf called with ray parameters other than params' rayps"
+       call rfgpu_check(1_c_int, "calc_rf argument check")
+    end if
     call rfgpu_check(rf_calc_rf(rf_ctx, int(nlay, c_int32_t), alpha, beta, rho, h, rft), "rf_calc_rf")
   end subroutine calc_rf
 

@@ -113,8 +113,15 @@ contains
        call dgesvd('A', 'A', nsmp, nsmp, cov, nsmp, sv, u, nsmp, vt, nsmp, work, size(work), info)
        deallocate(work)
        if (info /= 0) call rfgpu_check(int(info, c_int), "dgesvd")
+       ! matmul(transpose(vt), diag) of src/likelihood.f90:221 with diag(i,i) = 1.d0 / s(i) or 0 (:212-219):
+       ! column i of the product is transpose(vt)(:, i) TIMES the reciprocal (not divided by s(i): that
+       ! rounds differently); the zero off-diagonal terms of the reference's sum add exact zeros
        do i = 1, nsmp
-          scaled_v(:, i) = merge(vt(i, :) / sv(i), 0.d0, sv(i) > 1.0d-3)
+          if (sv(i) > 1.0d-3) then
+             scaled_v(:, i) = vt(i, :) * (1.d0 / sv(i))
+          else
+             scaled_v(:, i) = 0.d0
+          end if
        end do
        pinv(:, :, jt) = matmul(scaled_v, transpose(u))
     end do

@@ -44,6 +44,8 @@ module rfgpu_c
      type(c_ptr) :: amp_out_of_range
   end type rf_post_result
 
+  integer, parameter :: RF_COMM_ID_BYTES = 128
+
   interface
      integer(c_int) function rf_ctx_create(cfg, ctx_out) bind(C, name="rf_ctx_create")
        import :: c_int, c_ptr, rf_config
@@ -162,6 +164,47 @@ module rfgpu_c
        real(c_double), intent(in) :: z(*), dvp(*), dvs(*), sig(*), logl(*)
        type(c_ptr), value :: temps
      end function rf_post_record
+
+     ! ---- temperature exchange over RCCL (include/rfgpu.h, "multi-GPU") ----
+     integer(c_int) function rf_comm_probe(ctx, device_key) bind(C, name="rf_comm_probe")
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int64_t), intent(out) :: device_key
+     end function rf_comm_probe
+
+     integer(c_int) function rf_comm_get_unique_id(id) bind(C, name="rf_comm_get_unique_id")
+       import :: c_int, c_int8_t
+       integer(c_int8_t), intent(out) :: id(*)
+     end function rf_comm_get_unique_id
+
+     integer(c_int) function rf_comm_init(ctx, id, rank, nranks) bind(C, name="rf_comm_init")
+       import :: c_int, c_ptr, c_int8_t, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int8_t), intent(in) :: id(*)
+       integer(c_int32_t), value :: rank, nranks
+     end function rf_comm_init
+
+     integer(c_int) function rf_comm_destroy(ctx) bind(C, name="rf_comm_destroy")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+     end function rf_comm_destroy
+
+     integer(c_int) function rf_comm_bcast_i32(ctx, buf, n, root) bind(C, name="rf_comm_bcast_i32")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), intent(inout) :: buf(*)
+       integer(c_int32_t), value :: n, root
+     end function rf_comm_bcast_i32
+
+     integer(c_int) function rf_pt_swap_exchange(ctx, peer, judge, temp, logl, log_u, new_temp, accepted) &
+          & bind(C, name="rf_pt_swap_exchange")
+       import :: c_int, c_ptr, c_int32_t, c_double
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: peer, judge
+       real(c_double), value :: temp, logl, log_u
+       real(c_double), intent(out) :: new_temp
+       integer(c_int32_t), intent(out) :: accepted
+     end function rf_pt_swap_exchange
 
      integer(c_int) function rf_post_read(ctx, res) bind(C, name="rf_post_read")
        import :: c_int, c_ptr, rf_post_result

@@ -13,7 +13,7 @@ int main(void)
     double *r = (double *)malloc(sizeof(double) * NSMP * NSMP);
     int32_t rank = -1;
     if (rf_abi_version() != RFGPU_ABI_VERSION) return 2;
-    if (rf_compute_r_inv(NSMP, 4.0, 0.05, r, &rank) != 0) return 3;
+    if (rf_compute_r_inv(NSMP, 4.0, 0.05, r, &rank, NULL) != 0) return 3;
     /* symmetric to rounding, finite, positive rank */
     double asym = 0.0;
     for (int i = 0; i < NSMP; ++i)

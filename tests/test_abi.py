@@ -127,3 +127,64 @@ def test_product_library_reads_no_environment_variables():
     # the diagnostics exits exist only under the RFGPU_DIAGNOSTICS macro
     k = open(os.path.join(ROOT, "rf_inv_amd", "csrc", "rfgpu_kernels.hip")).read()
     assert not re.search(r"if \(P\.ablate", k.split("#endif", 1)[1])
+
+
+@pytest.mark.parametrize("a_gus", [2.5, 4.0, 8.0])
+@pytest.mark.parametrize("nsmp", [61, 101, 401])
+def test_builtin_r_inv_agrees_with_lapack_in_rank_and_values(oracle, a_gus, nsmp):
+    """librfgpu's one-sided Jacobi SVD against LAPACK dgesvd (the reference's route, src/likelihood.f90:196-222)
+    across filter widths and window lengths: same rank at the hard 1e-3 cut, values to 1e-11, and a reported gap
+    at the cut that is wide compared with SVD rounding (so the rank cannot depend on the SVD algorithm)."""
+    from rf_inv_amd.engine import compute_r_inv
+
+    delta = float(np.float32(0.05))
+    r, rank, gap = compute_r_inv(nsmp, a_gus, delta, with_gap=True)
+    ref, ranks = oracle.build_r_inv(nsmp, [a_gus], delta, return_rank=True)
+    assert rank == ranks[0]
+    assert np.abs(r - ref[0]).max() <= 1e-11 * np.abs(ref[0]).max()
+    assert gap > 1e-3
+
+
+def _a_gus_with_singular_value_on_the_cut(nsmp, delta):
+    """Bisect the filter width until a singular value of the noise matrix sits on the 1e-3 cut-off."""
+    from rf_inv_amd.engine import compute_r_inv
+
+    lo, hi = 4.0, 4.2
+    rank_lo = compute_r_inv(nsmp, lo, delta)[1]
+    assert compute_r_inv(nsmp, hi, delta)[1] > rank_lo
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        _, rank, gap = compute_r_inv(nsmp, mid, delta, with_gap=True)
+        if gap < 1e-9:
+            return mid, gap
+        if rank > rank_lo:
+            hi = mid
+        else:
+            lo = mid
+    return mid, gap
+
+
+def test_r_inv_gap_reports_a_singular_value_on_the_cut():
+    """The rank of the pseudo-inverse flips where a singular value crosses 1e-3; rf_compute_r_inv reports how
+    close the nearest one is, so that a caller (and rf_ctx_create) can refuse an ill-defined R^-1."""
+    delta = float(np.float32(0.05))
+    a, gap = _a_gus_with_singular_value_on_the_cut(61, delta)
+    assert gap < 1e-7
+
+
+@pytest.mark.gpu
+def test_ctx_create_refuses_to_build_an_ill_defined_r_inv():
+    from rf_inv_amd import RFEngine, RFGPUError
+
+    delta = float(np.float32(0.05))
+    a, gap = _a_gus_with_singular_value_on_the_cut(61, delta)
+    kw = dict(nfft=256, delta=delta, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=np.array([0.06]),
+              ipha=np.array([1], dtype=np.int32), obs=np.zeros((1, 61)), nsmp=61, max_walkers=1)
+    with pytest.raises(RFGPUError, match="rank cut-off"):
+        RFEngine(a_gus=np.array([a]), **kw)
+    with RFEngine(a_gus=np.array([4.0]), **kw) as eng:          # the ordinary case reports rank and gap
+        rank, g = eng.r_inv_info
+        assert rank[0] == 25 and g[0] > 0.1
+    with RFEngine(a_gus=np.array([a]), r_inv=np.zeros((1, 61, 61)), **kw) as eng:   # the host's own r_inv is taken as is
+        rank, g = eng.r_inv_info
+        assert rank[0] == -1 and np.isnan(g[0])

@@ -109,7 +109,9 @@ def test_hip_matches_reflectivity_solution(case, fused):
         got = eng.calc_rf(nlay, *model[1:])[:, 0]
     _check(got, _expected(model, ipha, p, dec), (case[0][0], fused))
     if ipha == -1 and dec == 0:
-        assert got.min() == -1.0
+        # the kernel forms the S trace and the vertical trace it is normalised by as the two channels of ONE complex
+        # transform (different roundings of the same sequence): -1 to rounding, not bit for bit like the oracle
+        assert abs(got.min() + 1.0) <= 1e-14
 
 
 @pytest.mark.gpu

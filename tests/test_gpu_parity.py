@@ -63,7 +63,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("fused", ["1", "0", "1p"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_batch_parity(oracle, case, fused):
     """rf_eval_batch: traces within 1e-12 of max|trace|, integer shifts identical by
@@ -87,7 +87,9 @@ def test_batch_parity(oracle, case, fused):
     sig = np.full((nb, len(rayps)), 0.01)
     sig[:, -1] = 0.02
     ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
-    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, options={"fused": int(fused)}) as eng:
+    # "1p": fused kernel fed by stage_kernel (the plan of large batches) forced on this small one
+    opts = {"fused": 1, "prestage": 1} if fused == "1p" else {"fused": int(fused), "prestage": 0}
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, options=opts) as eng:
         ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
         for i in range(nb):
             got = eng.get_rft(i, which=1).T  # [ntrc, nfft]
@@ -376,14 +378,17 @@ def test_edge_shapes(oracle):
         assert np.all(eng.get_rft(2, 0) == 0.0)
 
 
+@pytest.mark.parametrize("prestage", [0, 1])
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("chain", ["0", "4"])
-def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, chain, fused):
+def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, chain, fused, prestage):
     """In ONE batch: ordinary walkers, one with out-of-range phases (|x| > 1e6 rad) and one whose
     stack is of the other kind than the context (a water layer, beta(1) < 0, with sdep = 0:
     calc_seis keys on beta(1), forward.f90:229, direct_arrival on sdep, :484).  Both the
     in-place generic path of the chained-phase kernels and the deferred-list kernel."""
-    opts = {"chain": int(chain), "fused": int(fused)}
+    # prestage: the layer constants from stage_kernel (incl. its "out of range" / "other kind" flags) or staged
+    # inside the fused kernel's blocks
+    opts = {"chain": int(chain), "fused": int(fused), "prestage": prestage}
     rng = np.random.default_rng(31)
     cfg = make_cfg(nfft=2048, rayps=[0.06, 0.07], t_start=-1.0)
     nsmp = 101

@@ -222,3 +222,22 @@ def test_water_level_decon_against_numpy_restatement(oracle, golden_dir, ipha):
     want = y * np.conj(x) / np.maximum(amp, 0.001 * amp.max())
     assert np.abs(rff[0] - want).max() <= 1e-13 * np.abs(want).max()
     assert np.array_equal(fv[0], freq_v) and npre[0] == 20  # tp = 0 in deconvolution mode
+
+
+def test_speed_build_of_the_oracle_returns_identical_values(oracle):
+    """bench.py times the oracle compiled -O3 -march=native (oracle.lib_fast: still no FMA contraction, no
+    fast-math); the checker build is -O2.  Same source, same values, bit for bit -- incl. S traces, the ocean
+    branch and deconvolution."""
+    from helpers import DELTA, make_cfg, pack_layers, random_stack
+
+    rng = np.random.default_rng(8)
+    for sdep, dec in ((0.0, 0), (2.0, 1)):
+        cfg = make_cfg(nfft=1024, deconv_mode=dec, sdep=sdep, t_start=-1.0, rayps=[0.06, 0.10], ipha=[1, -1])
+        stacks = [random_stack(rng, int(n), sdep > 0, sdep) for n in (3, 8, 21)]
+        nlay, layers = pack_layers(stacks, 23)
+        obs = rng.normal(size=(2, 101)) * 0.1
+        r_inv = oracle.build_r_inv(101, cfg["a_gus"], DELTA)
+        sig = np.full((3, 2), 0.02)
+        a, ra = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, 101, want_rft=True)
+        b, rb = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, 101, want_rft=True, nthreads=2, fast=True)
+        assert np.array_equal(a, b) and np.array_equal(ra, rb)

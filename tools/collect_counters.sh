@@ -20,17 +20,26 @@ filter() { # keep the counters this rocprofv3 knows
   for c in "$@"; do grep -qw "$c" $OUT/available.txt && keep="$keep $c"; done
   echo $keep
 }
-i=0
-for set in "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" \
-           "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
-           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
+i=0; fails=0
+# small sets (a failed pass costs one short run, and a set that faults is easy to single out); every pass under its
+# own timeout -- a faulted rocprofv3 otherwise waits for ever on its incomplete dispatches
+for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
+           "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64" \
+           "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
+           "SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   use=$(filter $set)
   [ -z "$use" ] && continue
-  rocprofv3 --pmc $use --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 3 --warmup 1 $BARGS > $OUT/p$i.json 2> $OUT/p$i.log
+  timeout -k 10 ${PASS_TIMEOUT:-240} rocprofv3 --pmc $use --output-format csv -d $OUT/p$i -- python3 $R/bench.py --steps 3 --warmup 1 $BARGS > $OUT/p$i.json 2> $OUT/p$i.log
+  rc=$?
+  echo "pass $i [$use] rc=$rc" >> $OUT/passes.txt
+  if [ $rc -ne 0 ]; then fails=$((fails+1)); else fails=0; fi
+  [ $fails -ge 2 ] && { echo "two passes in a row failed: stopping" >> $OUT/passes.txt; break; }
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 50 --warmup 5 $BARGS > $OUT/bench_trace.json 2> $OUT/trace.log
+timeout -k 10 ${PASS_TIMEOUT:-240} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 50 --warmup 5 $BARGS > $OUT/bench_trace.json 2> $OUT/trace.log
 python3 $R/tools/summarize_counters.py $OUT $R > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 cp $OUT/trace/*/*kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null
