@@ -278,6 +278,8 @@ def main():
     ap.add_argument("--lib", default=None, help="another build of librfgpu.so (A/B timing); echoed in config.lib")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not time the dominant kernel with HIP events")
     ap.add_argument("--copy-logl", action="store_true", help="always read logL back with an async copy")
+    ap.add_argument("--dump-state", default=None, metavar="PATH.npz",
+                    help="rank 0 writes every rank's final temperatures and logL (tests replay the swap schedule)")
     args = ap.parse_args()
 
     stray = sorted(k for k in os.environ if k.startswith("RFGPU_") and k not in ENV_ALLOWED)
@@ -410,10 +412,26 @@ def main():
         prof = eng.profile_read()
         step_ms = np.array([a.elapsed_time(b) for a, b in marks])
         if world > 1:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         ll_gpu = h_logl.numpy().copy()
+        if args.dump_state and workload == args.workload:
+            t_loc = swap.temps.clone() if swap is not None else torch.ones(nb, dtype=torch.float64, device=dev)
+            l_loc = torch.from_numpy(ll_gpu).to(dev)
+            if world > 1:
+                on_host = backend != "nccl"
+                src_t, src_l = (t_loc.cpu(), l_loc.cpu()) if on_host else (t_loc, l_loc)
+                all_t = [torch.empty_like(src_t) for _ in range(world)]
+                all_l = [torch.empty_like(src_l) for _ in range(world)]
+                dist.all_gather(all_t, src_t)
+                dist.all_gather(all_l, src_l)
+            else:
+                all_t, all_l = [t_loc], [l_loc]
+            if rank == 0:
+                np.savez(args.dump_state, temps=np.stack([t.cpu().numpy() for t in all_t]),
+                         logl=np.stack([t.cpu().numpy() for t in all_l]), swap_steps=n_pre + warmup + steps,
+                         pairs_per_step=swap.k if swap is not None else 0)
         plan = eng.launch_plan
         assert plan["build"] == "production" or overrides or args.lib, plan
         assert np.all(np.isfinite(ll_gpu)), "non-finite logL in the benchmark batch"

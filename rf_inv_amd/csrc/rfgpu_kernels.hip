@@ -43,7 +43,12 @@ struct LdsOptIn {
         (void)hipGetDevice(&dev);
         const unsigned bit = 1u << (dev & 31);
         if (done.load(std::memory_order_acquire) & bit) return;
-        (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // the ceiling is the CU's LDS minus the kernel's static allocation
+        hipFuncAttributes attr{};
+        size_t stat = 0;
+        if (hipFuncGetAttributes(&attr, fn) == hipSuccess) stat = attr.sharedSizeBytes;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024 - stat)) != hipSuccess)
+            (void)hipGetLastError();   // leave no sticky error behind: a launch that needs the room reports it itself
         done.fetch_or(bit, std::memory_order_release);
     }
 };

@@ -255,6 +255,53 @@ class RFEngine:
                                               accepted.data_ptr() if accepted is not None else None,
                                               st.cuda_stream))
 
+    # ---- temperature exchange over RCCL (rfgpu_comm.cpp; one process per GPU) -----------------
+    @staticmethod
+    def comm_unique_id():
+        """rank 0: the 128-byte RCCL id every rank passes to comm_init (distribute it with whatever the
+        host already has: torch.distributed, MPI, a file)."""
+        lib = _lib.load()
+        buf = C.create_string_buffer(128)
+        if lib.rf_comm_get_unique_id(buf):
+            raise RFGPUError(lib.rf_last_error().decode())
+        return buf.raw
+
+    def comm_probe(self):
+        """(usable, device_key): can this rank join an RCCL communicator, and on which physical GPU it sits."""
+        key = C.c_int64()
+        rc = self._lib.rf_comm_probe(self._ctx, C.byref(key))
+        return rc == 0, key.value
+
+    def comm_init(self, unique_id: bytes, rank: int, nranks: int):
+        self._chk(self._lib.rf_comm_init(self._ctx, unique_id, int(rank), int(nranks)))
+
+    def comm_destroy(self):
+        self._chk(self._lib.rf_comm_destroy(self._ctx))
+
+    def comm_bcast_i32(self, values, root=0):
+        v = np.ascontiguousarray(values, dtype=np.int32)
+        self._chk(self._lib.rf_comm_bcast_i32(self._ctx, _iptr(v), v.size, int(root)))
+        return v
+
+    def pt_swap_exchange(self, peer, judge, temp, logl, log_u):
+        """The cross-rank swap of src/pt_mcmc.f90:542-571 as one grouped ncclSend + ncclRecv: returns
+        (temperature this rank's chain holds afterwards, accepted)."""
+        t = C.c_double()
+        acc = C.c_int32()
+        self._chk(self._lib.rf_pt_swap_exchange(self._ctx, int(peer), int(bool(judge)), float(temp), float(logl),
+                                                float(log_u), C.byref(t), C.byref(acc)))
+        return t.value, bool(acc.value)
+
+    def pt_swap_allgather_device(self, pairs, log_u, temps, logl, stream=None):
+        """K disjoint pairs of GLOBAL walker ids: one ncclAllGather of (T, logL) + the swap kernel; temps[nchains]
+        (this rank's, torch float64 on the device) is updated in place."""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(temps.device)
+        self._chk(self._lib.rf_pt_swap_allgather_device(self._ctx, temps.numel(), pairs.shape[0], pairs.data_ptr(),
+                                                        log_u.data_ptr(), temps.data_ptr(), logl.data_ptr(),
+                                                        st.cuda_stream))
+
     # ---- instrumentation -----------------------------------------------------
     @property
     def launch_plan(self):

@@ -129,7 +129,14 @@ class PTSwap:
         global id = rank * nchains + chain (src/pt_mcmc.f90:508-511)."""
         self._local[0].copy_(self.temps)
         self._local[1].copy_(logl)
-        self.dist.all_gather_into_tensor(self._gather, self._local)
+        if self.device.type == "cuda" and self.dist.get_backend() == "gloo":
+            # functional mode (several ranks on ONE GPU, where RCCL cannot form a communicator): gloo moves host
+            # tensors, so stage through the host; the RCCL path below never leaves the device
+            h_all = self.torch.empty(self._gather.shape, dtype=self.torch.float64)
+            self.dist.all_gather_into_tensor(h_all, self._local.cpu())
+            self._gather.copy_(h_all)
+        else:
+            self.dist.all_gather_into_tensor(self._gather, self._local)
         g = self._gather.view(self.world, 2, self.nchains)
         return g[:, 0, :].reshape(-1).contiguous(), g[:, 1, :].reshape(-1).contiguous()
 

@@ -6,6 +6,7 @@ maximises logL; phi does not depend on sigma; temperatures follow a serial repla
 schedule) plus a sampled comparison with the CPU oracle on the same inputs."""
 import os
 import sys
+import zlib
 
 import numpy as np
 import pytest
@@ -58,7 +59,7 @@ def _run_config(name, expect_defer, nsample, extra_check=None):
 
     w, p, cfg, obs, r_inv, nlay, layers = _workload(name)
     nb, ntrc, nsmp = w["walkers"], p.ntrc, p.nsmp
-    rng = np.random.default_rng(hash(name) % 2 ** 32)
+    rng = np.random.default_rng(zlib.crc32(name.encode()))
     sigv = np.linspace(0.01, 0.02, ntrc)
     sig = np.tile(sigv, (nb, 1))
     dev = torch.device("cuda", 0)
@@ -245,3 +246,51 @@ def test_randomised_contexts_against_oracle(oracle, seed):
                 n_allow += 1
     # the allowance is the exception, not the rule
     assert n_allow <= max(2, n_items // 200), (n_allow, n_items)
+
+
+def test_bench_two_ranks_on_one_gpu_swap_matches_serial_replay(tmp_path):
+    """bench.py's N > 1 path end to end: launched as two ranks (torch.distributed.run) that share the one GPU, with
+    gloo as the process-group backend (RCCL cannot put two ranks on one device) -- sharding, barrier, max-over-ranks
+    timing, the all-gather temperature exchange and the JSON line.  The final temperatures of both ranks equal a
+    serial replay of the replicated swap schedule on the logL values the run produced."""
+    import json
+    import socket
+    import subprocess
+
+    from rf_inv_amd.pt import PairSchedule, init_temps, judge_pt
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dump = tmp_path / "state.npz"
+    nb, ntemps, steps, warm = 256, 8, 5, 1
+    env = dict(os.environ, RFGPU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c3",
+           "--walkers", str(nb), "--steps", str(steps), "--warmup", str(warm), "--prewarm-seconds", "0",
+           "--no-cpu-baseline", "--also", "", "--dump-state", str(dump)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == steps
+    assert abs(d["value"] - 2 * nb * steps / (d["ms_per_step"] * 1e-3 * steps)) < 1e-6 * d["value"]
+    assert d["config"]["parallelism"] == "walkers sharded x2"
+    st = np.load(dump)
+    temps, logl = st["temps"], st["logl"]
+    assert temps.shape == (2, nb) and int(st["swap_steps"]) == 8 + warm + steps
+    ref = np.concatenate([init_temps(nb, max(1, nb // ntemps), 15.0,
+                                     np.random.Generator(np.random.Philox(key=1234 + 7919 * (rk + 1)))) for rk in range(2)])
+    start = ref.copy()
+    sched = PairSchedule(2 * nb, 1234, int(st["pairs_per_step"]))
+    ll = logl.reshape(-1)                       # the same models every step: logL is the same every step
+    for _ in range(int(st["swap_steps"])):
+        pairs, logu = sched.draw()
+        for (i1, i2), lu in zip(pairs, logu):
+            if judge_pt(ref[i1], ref[i2], ll[i1], ll[i2], lu):
+                ref[i1], ref[i2] = ref[i2], ref[i1]
+    assert np.array_equal(temps.reshape(-1), ref)
+    assert np.sum(ref != start) > 0             # swaps (also across the two ranks' blocks) did happen
+    cross = [(a, b) for a, b in np.argwhere(ref[:, None] == start[None, :]) if (a < nb) != (b < nb)]
+    assert len(cross) > 0

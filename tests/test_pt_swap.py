@@ -87,3 +87,45 @@ def test_judge_pt_rule():
     # hotter chain with higher likelihood always swaps (del_s >= 0 >= log u)
     assert judge_pt(1.0, 4.0, -10.0, -5.0, np.log(0.999))
     assert not judge_pt(1.0, 4.0, -5.0, -50.0, np.log(0.5))
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_entry_points_on_one_rank():
+    """The C-ABI temperature exchange over RCCL (rfgpu_comm.cpp) on a communicator of ONE rank -- all a one-GPU box
+    can form (RCCL refuses two ranks on one device): id, init, broadcast, the grouped send/receive with itself as
+    the peer, and the all-gather form against rf_pt_swap_device.  Multi-rank behaviour is by construction only until
+    a multi-GPU node runs it."""
+    from rf_inv_amd import RFEngine
+    from rf_inv_amd.pt import PairSchedule, judge_pt
+
+    nch = 64
+    delta = float(np.float32(0.05))
+    with RFEngine(nfft=256, delta=delta, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=np.array([0.06]),
+                  a_gus=np.array([4.0]), ipha=np.array([1], dtype=np.int32), obs=np.zeros((1, 101)), nsmp=101,
+                  max_walkers=nch) as eng:
+        ok, key = eng.comm_probe()
+        assert ok and key >= 0
+        eng.comm_init(RFEngine.comm_unique_id(), 0, 1)
+        assert list(eng.comm_bcast_i32([7, 11, 13, 17])) == [7, 11, 13, 17]
+        # self-exchange: both "sides" are this rank's chain; the rule is judge_pt with chain 1 = chain 2
+        t_new, acc = eng.pt_swap_exchange(0, True, 2.5, -10.0, np.log(0.3))
+        assert t_new == 2.5 and acc == judge_pt(2.5, 2.5, -10.0, -10.0, np.log(0.3))
+        dev = torch.device("cuda", 0)
+        rng = np.random.default_rng(3)
+        temps = np.exp(rng.random(nch) * np.log(15.0))
+        ll = -100.0 * rng.random(nch)
+        sched = PairSchedule(nch, 5, 8)
+        d_t = torch.from_numpy(temps.copy()).to(dev)
+        d_t2 = d_t.clone()
+        d_l = torch.from_numpy(ll).to(dev)
+        for _ in range(5):
+            pairs, logu = sched.draw()
+            d_p, d_u = torch.from_numpy(pairs).to(dev), torch.from_numpy(logu).to(dev)
+            eng.pt_swap_allgather_device(d_p, d_u, d_t, d_l)
+            eng.pt_swap_device(d_p, d_u, d_t2, d_l)
+            for (i1, i2), lu in zip(pairs, logu):
+                if judge_pt(temps[i1], temps[i2], ll[i1], ll[i2], lu):
+                    temps[i1], temps[i2] = temps[i2], temps[i1]
+            torch.cuda.synchronize()
+            assert np.array_equal(d_t.cpu().numpy(), temps) and np.array_equal(d_t2.cpu().numpy(), temps)
+        eng.comm_destroy()
