@@ -40,7 +40,8 @@ typedef struct rf_ctx rf_ctx;
 /* Everything `init_forward` / `init_likelihood` read from `module params`
  * (reference src/params.f90:34-96) plus capacity hints. */
 typedef struct rf_config {
-    int32_t nfft;        /* params nfft; power of two, >= 8                      */
+    int32_t nfft;        /* params nfft >= 8.  Powers of two: in-LDS FFT (any size up to 8192).  Any other
+                            length (FFTW plans any n, src/fftw.f90:44): direct DFT, up to ~3300 samples */
     int32_t ntrc;        /* params ntrc                                         */
     int32_t nsmp;        /* params nsmp (src/params.f90:449-451)                */
     int32_t deconv_mode; /* params deconv_mode: 0 = normalise by vertical, 1 = water-level decon */
@@ -301,7 +302,6 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
  *   "nsplit"           0 by batch size (default) | 1..64 bin-splits per walker (split spectra kernel)
  *   "waves_per_block"  1..4 (default 4) waves sharing a staged layer stack (split spectra kernel)
  *   "defer_logl"       -1 by batch size (default) | 0 quadratic form + logL inside the main kernel | 1 follow-up kernels
- *   "prestage"         -1 by batch size (default) | 0 layer constants staged inside the fused kernel | 1 by stage_kernel
  *   "bin_cutoff"       0 (default: every bin like the reference) | tol in (0, 1): bins whose Gaussian filter
  *                      weight is below tol * flt(1) are not propagated
  * A library built with -DRFGPU_DIAGNOSTICS (tools/ablate.sh; never the shipped one) also accepts

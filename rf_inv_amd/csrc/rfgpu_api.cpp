@@ -73,7 +73,6 @@ struct rf_ctx {
     bool fused_allowed = false;   // the context's shape admits the fused kernel
     int fused_override = -1;  // "fused": -1 = by shape
     int defer_logl = -1;      // "defer_logl": -1 = by batch size, 0 / 1 = never / always
-    int prestage = -1;        // "prestage": -1 = by batch size, 0 / 1 = stage inside the fused kernel / by stage_kernel
     double bin_cutoff = 0.0;  // "bin_cutoff": opt-in filter-support cut-off (0 = off: every bin like the reference)
     int n_overrides = 0;      // options set away from their defaults (echoed by rf_get_launch_plan)
     int ablate = 0;           // RFGPU_DIAGNOSTICS builds only ("ablate"): stops the kernel early, results invalid
@@ -274,7 +273,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (!cfg || !ctx_out) return fail("rf_ctx_create: null argument");
     *ctx_out = nullptr;
     const int n = cfg->nfft;
-    if (n < 8 || (n & (n - 1))) return fail("rf_ctx_create: nfft must be a power of two >= 8");
+    if (n < 8) return fail("rf_ctx_create: nfft must be >= 8");
+    const bool pow2 = (n & (n - 1)) == 0;
     if (cfg->ntrc < 1 || cfg->nsmp < 1 || cfg->nsmp > n) return fail("rf_ctx_create: bad ntrc / nsmp");
     if (cfg->deconv_mode != 0 && cfg->deconv_mode != 1) return fail("rf_ctx_create: deconv_mode must be 0 or 1");
     if (!cfg->rayps || !cfg->a_gus || !cfg->ipha || !cfg->obs) return fail("rf_ctx_create: null table");
@@ -364,8 +364,9 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     std::vector<double> obs((size_t)nsmp * ntrc);
     for (int t = 0; t < ntrc; ++t)
         for (int i = 0; i < nsmp; ++i) obs[(size_t)i + (size_t)nsmp * t] = cfg->obs[(size_t)i + (size_t)cfg->ldobs * t];
-    std::vector<double2> tw((size_t)n / 2);
-    for (int k = 0; k < n / 2; ++k) {
+    // exp(+2 pi i k / n): half a turn for the power-of-two FFT, the full turn for the direct DFT of any other n
+    std::vector<double2> tw(pow2 ? (size_t)n / 2 : (size_t)n);
+    for (size_t k = 0; k < tw.size(); ++k) {
         const long double a = 2.0L * 3.14159265358979323846264338327950288L * k / n;
         tw[k] = make_double2((double)cosl(a), (double)sinl(a));
     }
@@ -383,6 +384,11 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (upload(c, c->flt, &T.flt) || upload(c, obs, &T.obs) || upload(c, r_inv_t, &T.r_inv_t) ||
         upload(c, rayps, &T.rayps) || upload(c, ipha, &T.ipha) || upload(c, tw, &T.twiddle))
         return cleanup(1);
+    T.twiddle_any = nullptr;
+    if (!pow2) {
+        T.twiddle_any = T.twiddle;
+        T.twiddle = nullptr;
+    }
 
     // walker state
     void *p;
@@ -399,10 +405,6 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->ws.prop_fwd = (int *)p;
     (void)hipMemset(p, 0, sizeof(int) * c->nslots);
-    if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * c->nfwd)) return cleanup(1);
-    c->ws.meta_tp = (double *)p;
-    if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
-    c->ws.meta_slot = (int *)p;
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->ws.done = (int *)p;
     (void)hipMemset(p, 0, sizeof(int) * c->nslots);
@@ -427,10 +429,13 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     c->slow_list = (int *)p + 1;   // [nslots * nfwd]
     (void)hipMemset(p, 0, sizeof(int));
 
+    if (!pow2 && trace_anyn_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024)
+        return cleanup(fail("rf_ctx_create: an nfft that is not a power of two is transformed by a direct DFT whose tables "
+                            "must fit the 160 KiB LDS of a CU (nfft up to ~3300); use a power of two for longer series"));
     if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || trace_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024 ||
         sizeof(double) * (size_t)(5 * ((nsmp + 1) & ~1) + 8) > 160 * 1024)   // phi_kernel (host-owned traces)
         return cleanup(fail("rf_ctx_create: nfft / nsmp / nlay_max exceed the 160 KiB LDS of a gfx950 CU"));
-    c->fused_allowed = (c->nfwd == ntrc) && fused_lds_bytes(n, nsmp, cfg->nlay_max) <= 160 * 1024;
+    c->fused_allowed = pow2 && (c->nfwd == ntrc) && fused_lds_bytes(n, nsmp, cfg->nlay_max) <= 160 * 1024;
     default_plan(c);
     *ctx_out = c;
     return 0;
@@ -558,6 +563,8 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
     } else {
         c->order_next_nb = 0;
     }
+    // the per-(item, forward-trace) constants of the propagator, once per batch item, for whichever plan follows
+    launch_stage(c->tab, b, c->ws, s);
     if (c->fused) {
         // several traces per walker and at least two rounds of blocks: the block ends with the trace store;
         // misfits go to HBM (808 B per trace) and two small follow-up kernels form the quadratic forms -- the
@@ -572,13 +579,8 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         const long long blocks = (long long)b.nb * c->cfg.ntrc, round = 2LL * c->num_cu;
         const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl
                           : (c->cfg.ntrc > 1 ? blocks >= 2 * round : blocks >= 4 * round));
-        // constants of the propagator by stage_kernel once the batch fills the chip (every block would otherwise
-        // stage its item on its own critical path); tiny batches (the per-call drop-in) keep the single launch
-        const int prestage = c->prestage >= 0 ? c->prestage : blocks >= c->num_cu;
-        if (prestage) launch_stage(c->tab, b, c->ws, s);
         hipEvent_t e = prof_begin(c, 0, s);
-        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, c->single_trace_out,
-                     prestage, s);
+        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, c->single_trace_out, s);
         if (e) (void)hipEventRecord(e, s);
         if (defer) launch_logl_deferred(c->tab, b, c->ws, s);
     } else {
@@ -1111,9 +1113,6 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     } else if (k == "defer_logl") {
         if (!integral || iv < -1 || iv > 1) return fail("rf_set_option: defer_logl must be -1 (by batch size), 0 or 1");
         c->defer_logl = iv;
-    } else if (k == "prestage") {
-        if (!integral || iv < -1 || iv > 1) return fail("rf_set_option: prestage must be -1 (by batch size), 0 or 1");
-        c->prestage = iv;
     } else if (k == "bin_cutoff") {
         if (!(value >= 0.0 && value < 1.0)) return fail("rf_set_option: bin_cutoff must be in [0, 1)");
         c->bin_cutoff = value;
@@ -1128,7 +1127,7 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     default_plan(c);
     c->n_overrides = (c->fused_override != -1) + (c->chain_override != -1) + (!c->lpt) + (!c->order_reuse) +
                      (c->nsplit_override != 0) + (c->waves_per_block != 4) + (c->defer_logl != -1) +
-                     (c->prestage != -1) + (c->bin_cutoff > 0.0) + (c->ablate != 0);
+                     (c->bin_cutoff > 0.0) + (c->ablate != 0);
     return 0;
 }
 

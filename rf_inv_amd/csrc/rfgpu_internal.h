@@ -21,7 +21,8 @@ struct DeviceTables {
     const double *r_inv_t;  // [ntrc][nsmp*nsmp]  r_inv(i,j) at [i*nsmp + j] (transposed image)
     const double *rayps;    // [ntrc]
     const int *ipha;        // [ntrc]
-    const double2 *twiddle; // [nfft/2]  exp(+2 pi i k / nfft)
+    const double2 *twiddle; // [nfft/2]  exp(+2 pi i k / nfft) (power-of-two nfft: the in-LDS FFT)
+    const double2 *twiddle_any; // [nfft] exp(+2 pi i k / nfft) for any other nfft (direct DFT, trace_anyn_kernel), else nullptr
     const int *nh_active;   // [ntrc] bins with a non-negligible filter weight, or nullptr (all bins)
 };
 
@@ -41,8 +42,6 @@ struct WalkerState {
     double *phi;      // [2][nslots][ntrc]
     int *cur_slot;    // [nslots] 0/1: which half holds the current trace
     int *prop_fwd;    // [nslots] last proposal ran the forward model
-    double *meta_tp;  // [nslots * nfwd] per batch item: direct-arrival time (spectra -> trace kernel)
-    int *meta_slot;   // [nslots] per batch item: destination half of the proposal
     int *done;        // [nslots] per batch item: traces finished (last one forms logL), self-resetting
     double *misfit;   // [nslots][ntrc][nsmp] per batch item: misfits handed to the deferred phi / logL kernel
     double *gcoef;    // [nslots * nfwd][nlay_max][NCOEF] per batch item: stage_kernel's per-layer constants
@@ -63,8 +62,8 @@ void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 // fused K1+K2 (contexts with one forward computation per trace)
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
-                  int ablate, int defer_logl, int *order_next, double *extra_out, int prestaged, hipStream_t s);
-// K0: per-(item, forward-trace) constants of the propagator, once per batch item (fused path, large batches)
+                  int ablate, int defer_logl, int *order_next, double *extra_out, hipStream_t s);
+// K0: per-(item, forward-trace) constants of the propagator, once per batch item, in front of K1 / the fused kernel
 void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 // logL of a batch launched with defer_logl (one thread per batch item, after the fused kernel)
 void launch_logl_deferred(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
@@ -129,6 +128,7 @@ void launch_post_record(const PostConfig &c, const PostState &st, const PostBatc
 void launch_post_mark_unused(const PostConfig &c, const PostState &st, hipStream_t s);
 
 size_t spectra_lds_bytes(int nlay_pad);
+size_t trace_anyn_lds_bytes(int nfft, int nsmp, int nlay_pad);
 size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad);
 
 } // namespace rfgpu

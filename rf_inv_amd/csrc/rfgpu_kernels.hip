@@ -186,7 +186,7 @@ __device__ __forceinline__ LayerBasis layer_basis(double alpha, double beta, dou
 
 // c[3..10] = G = W_next^T U_this: the change of eigen-coordinates across the interface below the
 // layer (two 2x2 blocks: (a_p, b_s) and (b_p, a_s)); identity after the last solid layer.  Staged in
-// four independent parts so that the four waves of a block share the latency (stage_walker):
+// four independent parts so that the lanes of stage_kernel's wave share the latency:
 //   part 0: the (a_p, b_s) block, c[3..6]   (needs the S slownesses only)
 //   part 1: the (b_p, a_s) block, c[7..10]  (needs the P slownesses only)
 //   part 2: xi, h and the P phase constants;  part 3: eta and the S phase constants
@@ -209,7 +209,20 @@ __device__ __forceinline__ LayerHalf layer_half(double vslow, double beta, doubl
 // part 0 (slow = eta) writes c[3..6]; part 1 (slow = xi) writes c[7..10]; the two blocks have the
 // same entries up to their order: block 0 = (a_p'<-a_p, a_p'<-b_s, b_s'<-a_p, b_s'<-b_s),
 // block 1 = (b_p'<-b_p, b_p'<-a_s, a_s'<-b_p, a_s'<-a_s)
-__device__ __forceinline__ void stage_interface(double *g, int part, const LayerHalf &u, const LayerHalf *w)
+//
+// Gauge.  Scaling all four eigen-coordinates of a layer by one number leaves the rotations alone and rescales G;
+// the entry a_p'<-a_p of block 0 and the entry a_s'<-a_s of block 1 are the SAME number d (interface_diag: it
+// does not contain a vertical slowness), so dividing G by d makes both exactly 1 and saves two multiplications
+// per propagated column, bin and layer in the chained-phase loop (apply_layer_trig_unit).  The product of the
+// d's of a walker is folded into the half-space rows (stage_halfspace), so the boundary condition sees the
+// unscaled product.  `unit` is decided per walker (walker_gauge): every d within [1/16, 16] and their product
+// within 2^+-600; otherwise the walker keeps the plain G and takes the generic path.
+__device__ __forceinline__ double interface_diag(const LayerHalf &u, const LayerHalf &w)
+{
+    return fma(w.tb2p, u.p, (u.rho / w.rho) * u.bp);
+}
+
+__device__ __forceinline__ void stage_interface(double *g, int part, const LayerHalf &u, const LayerHalf *w, bool unit)
 {
     if (!w) {
         g[0] = 1.0; g[1] = 0.0; g[2] = 0.0; g[3] = 1.0;
@@ -217,10 +230,17 @@ __device__ __forceinline__ void stage_interface(double *g, int part, const Layer
     }
     const double pr = w->p / w->rho;            // p / rho'
     const double m = u.tb2p * u.rho;            // 2 b^2 rho p
-    const double diag_a = fma(w->tb2p, u.p, (u.rho / w->rho) * u.bp);
-    const double off_a = u.slow * (w->tb2p - m / w->rho);
-    const double off_b = (w->bp * u.p - pr * (u.rho * u.bp)) / w->slow;
-    const double diag_b = u.slow * (w->bp + pr * m) / w->slow;
+    double diag_a = interface_diag(u, *w);
+    double off_a = u.slow * (w->tb2p - m / w->rho);
+    double off_b = (w->bp * u.p - pr * (u.rho * u.bp)) / w->slow;
+    double diag_b = u.slow * (w->bp + pr * m) / w->slow;
+    if (unit) {
+        const double inv = 1.0 / diag_a;
+        diag_a = 1.0;
+        off_a *= inv;
+        off_b *= inv;
+        diag_b *= inv;
+    }
     if (part == 0) {
         g[0] = diag_a; g[1] = off_a; g[2] = off_b; g[3] = diag_b;
     } else {
@@ -228,11 +248,35 @@ __device__ __forceinline__ void stage_interface(double *g, int part, const Layer
     }
 }
 
+// The walker's gauge, by one wave (every lane returns the same values): scale = product of interface_diag over
+// the interfaces between solid layers ilay0 .. nl-2, unit = the gauge is usable (see above).  L: the walker's
+// layer rows [4][pad].
+__device__ __forceinline__ double walker_gauge(const double *L, int pad, int nl, int ilay0, double p, int lane, bool &unit)
+{
+    double prod = 1.0;
+    bool ok = true;
+    for (int l0 = ilay0; l0 + 1 < nl - 1; l0 += 64) {
+        const int l = l0 + lane;
+        double d = 1.0;
+        if (l + 1 < nl - 1) {
+            const LayerHalf u = layer_half(L[pad + l], L[pad + l], L[2 * pad + l], p);
+            const LayerHalf w = layer_half(L[pad + l + 1], L[pad + l + 1], L[2 * pad + l + 1], p);
+            d = interface_diag(u, w);
+            ok = ok && fabs(d) >= 0.0625 && fabs(d) <= 16.0;      // (false for NaN)
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) d *= __shfl_xor(d, o, 64);
+        prod *= d;
+    }
+    unit = __all(ok) && fabs(prod) > 0x1p-600 && fabs(prod) < 0x1p600;
+    return unit ? prod : 1.0;
+}
+
 // tail[0..7]: rows 3 and 4 of E^-1 (forward.f90:370-377) times T = diag(1, i, w, i w), expressed in
 // the eigen-coordinates of the last solid layer (`last`; nullptr: no solid layer, physical
 // coordinates).  Row r: re = g[0] v[0] + g[1] v[3], im = g[2] v[1] + g[3] v[2] (halfspace_row).
 __device__ __forceinline__ void stage_halfspace(double *g, double alpha, double beta, double rho, double p,
-                                                const LayerBasis *last)
+                                                const LayerBasis *last, double scale)
 {
     const double eta = vertical_slowness(beta, p);
     const double xi = vertical_slowness(alpha, p);
@@ -250,11 +294,12 @@ __device__ __forceinline__ void stage_halfspace(double *g, double alpha, double 
         const double *q = e + 4 * r;
         double *o = g + 4 * r;
         if (last) {
+            // (scale: the walker's gauge, 1 when the plain G is staged)
             const double m = last->tb2p * last->rho, rb = last->rho * last->bp;
-            o[0] = fma(q[0], last->p, q[1] * rb);               // a_p
-            o[1] = last->eta * (q[0] - q[1] * m);               // b_s
-            o[2] = last->xi * (q[2] - q[3] * m);                // b_p
-            o[3] = fma(q[2], last->p, q[3] * rb);               // a_s
+            o[0] = scale * fma(q[0], last->p, q[1] * rb);       // a_p
+            o[1] = scale * (last->eta * (q[0] - q[1] * m));     // b_s
+            o[2] = scale * (last->xi * (q[2] - q[3] * m));      // b_p
+            o[3] = scale * fma(q[2], last->p, q[3] * rb);       // a_s
         } else {
             o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; o[3] = q[3];
         }
@@ -363,6 +408,27 @@ __device__ __forceinline__ void apply_layer_trig(ColState<NCOL> &s, const double
     }
 }
 
+// the same with the walker's gauge applied (stage_interface, unit): c[3] = c[10] = 1 exactly
+template <int NCOL>
+__device__ __forceinline__ void apply_layer_trig_unit(ColState<NCOL> &s, const double *__restrict__ c, double sx,
+                                                      double cx, double se, double ce)
+{
+    const double g1 = c[4], g2 = c[5], g3 = c[6], g4 = c[7], g5 = c[8], g6 = c[9];
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) {
+        const double ap = s.v[j][0], bp = s.v[j][1], as = s.v[j][2], bs = s.v[j][3];
+        const double rap = fma(cx, ap, -(sx * bp));
+        const double rbp = fma(sx, ap, cx * bp);
+        const double ras = fma(ce, as, -(se * bs));
+        const double rbs = fma(se, as, ce * bs);
+        s.v[j][0] = fma(g1, rbs, rap);
+        s.v[j][3] = fma(g3, rbs, g2 * rap);
+        s.v[j][1] = fma(g5, ras, g4 * rbp);
+        s.v[j][2] = fma(g6, rbp, ras);
+    }
+}
+
+// FAST: the walker's constants carry the unit gauge (the fast paths run only for such walkers)
 template <int NCOL, bool FAST>
 __device__ __forceinline__ void apply_layer(ColState<NCOL> &s, const double *__restrict__ c, double omg)
 {
@@ -370,7 +436,10 @@ __device__ __forceinline__ void apply_layer(ColState<NCOL> &s, const double *__r
     // argument formed exactly like the reference: (omega * xi) * z  (forward.f90:397-400)
     phase_sincos<FAST>((omg * c[0]) * c[2], sx, cx);
     phase_sincos<FAST>((omg * c[1]) * c[2], se, ce);
-    apply_layer_trig<NCOL>(s, c, sx, cx, se, ce);
+    if (FAST)
+        apply_layer_trig_unit<NCOL>(s, c, sx, cx, se, ce);
+    else
+        apply_layer_trig<NCOL>(s, c, sx, cx, se, ce);
 }
 
 // T_rj = sum_k (E^-1 T)(r,k) B_kj  for r = 3 (g[0..3]) or 4 (g[4..7])
@@ -426,11 +495,7 @@ struct SpectraParams {
     int nsplit;
     int *slow_list;   // [nslots * nfwd] (walker, trace) pairs deferred to spectra_slow_kernel
     int *slow_count;  // [1] reset by logl_kernel
-    // per-batch-item scalars prepared for trace_kernel so that it starts with one memory
-    // round trip instead of a dependent chain of them
-    double *meta_tp;  // [nb * nfwd] direct-arrival time of the forward trace
-    int *meta_slot;   // [nb] which half of the walker's trace buffer receives the proposal
-    const int *cur_slot;
+    WalkerState w;    // stage_kernel's constants (gcoef, gtail, gflag)
 };
 
 // One wave (64 lanes) per (walker, forward-trace, bin-split).  Lanes own frequency
@@ -505,22 +570,20 @@ __device__ __forceinline__ void spectra_iter_nyquist(const SpectraParams &P, con
     init_cols<NCOL>(st, tail);
     for (int l = ilay0; l < nl - 1; ++l) {
         const double *c = coef + l * NCOEF;
-        apply_layer_trig<NCOL>(st, c, c[19], c[20], c[21], c[22]);
+        apply_layer_trig_unit<NCOL>(st, c, c[19], c[20], c[21], c[22]);
     }
     double2 ur, uz;
     finish_bin<NCOL, true>(st, tail, omg, ipha, ur, uz);
     sink(k, ur, uz);
 }
 
-// eps = arg - k * phi, phi = (hi, lo): the rounding perturbation of the reference's
-// argument (omega*xi)*z relative to the exact multiple k*phi.  (arg - k*phi_hi) is exact
-// (Sterbenz), the product k*phi is error-free through fma.
+// eps = arg - k * phi, phi = (hi, lo): the rounding perturbation of the reference's argument (omega*xi)*z
+// relative to the exact multiple k*phi.  k*phi_hi - arg is formed by ONE fma and is exact: the 65-bit product and
+// the 53-bit argument agree to a few ulps, so their difference has ~15 significant bits; the second fma adds
+// k*phi_lo with a single rounding (2^-53 of eps).  Two instructions.
 __device__ __forceinline__ double phase_eps(double arg, double kd, double phi_hi, double phi_lo)
 {
-    const double p = kd * phi_hi;
-    double e = fma(kd, phi_hi, -p);
-    e = fma(kd, phi_lo, e);
-    return (arg - p) - e;
+    return -fma(kd, phi_lo, fma(kd, phi_hi, -arg));
 }
 
 // BK consecutive 64-bin iterations per lane (bins k0, k0+64, ...): "chained phases".
@@ -572,7 +635,7 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
         const double ax0 = (omg0l * xi) * h, ae0 = (omg0l * eta) * h;
         sincos_cw(ax0, sx, cx);
         sincos_cw(ae0, se, ce);
-        apply_layer_trig<NCOL>(st[0], c, sx, cx, se, ce);
+        apply_layer_trig_unit<NCOL>(st[0], c, sx, cx, se, ce);
         // exact-angle start of the chain: remove the first bin's own perturbation.  The DC
         // bin's omega is the literal 1e-5 (not 0 * domg): its chain starts from angle 0.
         const double ex0 = phase_eps(ax0, kd0l, c[11], c[12]);
@@ -592,8 +655,8 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
             const double omgm = LEAN ? kdm * P.t.domg : omg[m];
             const double ex = phase_eps((omgm * xi) * h, kdm, c[11], c[12]);
             const double ee = phase_eps((omgm * eta) * h, kdm, c[13], c[14]);
-            apply_layer_trig<NCOL>(st[m], c, fma(cEx, ex, sEx), fma(-sEx, ex, cEx), fma(cEe, ee, sEe),
-                                   fma(-sEe, ee, cEe));
+            apply_layer_trig_unit<NCOL>(st[m], c, fma(cEx, ex, sEx), fma(-sEx, ex, cEx), fma(cEe, ee, sEe),
+                                        fma(-sEe, ee, cEe));
         }
     }
 #pragma unroll
@@ -631,89 +694,25 @@ __device__ __forceinline__ void spectra_body(const SpectraParams &P, const doubl
     }
 }
 
-// Stages the layer stack of (walker ib, forward-trace f) into LDS (all threads of the
-// block); returns true (block-uniform) when some phase of the walker leaves the
-// Cody-Waite range of sincos_cw.
-__device__ __forceinline__ bool stage_walker(const SpectraParams &P, int ib, int f, double *coef, double *tail,
-                                             int &nl, int &ilay0, bool &sea)
+// Copies stage_kernel's constants of (batch item ib, forward-trace f) into the block's LDS image (all threads of
+// the block; coalesced 16-byte loads, ~6 KB at 30 layers).  Returns true (block-uniform) when the walker must take
+// the generic path (a phase beyond the Cody-Waite range of sincos_cw, or no unit gauge).  tail[17] = the
+// direct-arrival time of the forward trace.
+__device__ __forceinline__ bool load_staged(const WalkerState &w, const BatchArgs &b, int nfwd, int ib, int f, double *coef,
+                                            double *tail, int &nl, int &ilay0, bool &sea)
 {
-    const int pad = P.b.nlay_pad;
-    const double *L = P.b.layers + (size_t)ib * 4 * pad;
-    // every load below is independent of nlay (padding entries of the stack are readable): the layer
-    // values travel in the same memory round trip as the layer count
-    nl = P.b.nlay[ib];
-    const double p = P.t.rayps[f];
-    const double beta1 = L[pad];
-    const double omg_max = (double)(P.t.nh - 1) * P.t.domg;
-    const double omg_nyq = (double)(P.t.nfft / 2) * P.t.domg;
-    bool big = false;
-    // four independent parts per layer (stage_interface) + the walker constants: one part per wave
-    // when the block has four, so the block waits for the longest part, not for their sum
-    const int nw = blockDim.x >> 6, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    for (int part = wave; part < 4; part += nw) {
-        const double *V = (part == 1 || part == 2) ? L : L + pad;   // parts 1, 2: alpha (xi); 0, 3: beta (eta)
-        for (int l = lane; l < pad - 1; l += 64) {
-            // this layer and the one below it
-            const double v0 = V[l], a0 = L[l], b0 = L[pad + l], r0 = L[2 * pad + l], h0 = L[3 * pad + l];
-            const double v1 = V[l + 1], a1 = L[l + 1], b1 = L[pad + l + 1], r1 = L[2 * pad + l + 1];
-            sea = beta1 < 0.0;       // beta(1) < 0  (forward.f90:229)
-            ilay0 = sea ? 1 : 0;
-            const bool solid = nl - 1 > ilay0;          // at least one solid layer above the half-space
-            double *c = coef + l * NCOEF;
-            if (l >= ilay0 && l < nl - 1) {
-                if (part < 2) {
-                    const LayerHalf u = layer_half(v0, b0, r0, p);
-                    if (l + 1 < nl - 1) {
-                        const LayerHalf w = layer_half(v1, b1, r1, p);
-                        stage_interface(c + 3 + 4 * part, part, u, &w);
-                    } else {
-                        stage_interface(c + 3 + 4 * part, part, u, nullptr);
-                    }
-                } else {
-                    const double slow = vertical_slowness(v0, p);
-                    // phases of the Nyquist bin, argument formed like the reference (forward.f90:397-400)
-                    double sn, cn;
-                    sincos_cw((omg_nyq * slow) * h0, sn, cn);
-                    if (part == 2) {
-                        c[0] = slow;
-                        c[2] = h0;
-                        stage_phase(c + 11, c + 15, P.t.domg, slow, h0);
-                        c[19] = sn;
-                        c[20] = cn;
-                    } else {
-                        c[1] = slow;
-                        stage_phase(c + 13, c + 17, P.t.domg, slow, h0);
-                        c[21] = sn;
-                        c[22] = cn;
-                        c[23] = 0.0;
-                    }
-                    big |= fabs(omg_max * slow * h0) >= SINCOS_CW_LIMIT;
-                }
-            }
-            // walker constants, by the lanes of the lighter parts that already hold the layers involved
-            if (part == 2 && l == nl - 2) {
-                // half-space = layer l + 1; the last solid layer (if any) = layer l
-                LayerBasis last;
-                if (solid) last = layer_basis(a0, b0, r0, p);
-                stage_halfspace(tail, a1, b1, r1, p, solid ? &last : nullptr);
-            }
-            if (part == 3 && l == (solid ? ilay0 : 0)) {
-                LayerBasis top;
-                if (solid) top = layer_basis(a0, b0, r0, p);
-                stage_start(tail + 11, solid ? &top : nullptr);
-            }
-            if (part == 3 && l == 0 && sea) {
-                const double xiw = vertical_slowness(a0, p);   // forward.f90:431
-                tail[8] = xiw;
-                tail[9] = h0;
-                tail[10] = r0 / xiw;
-                big |= fabs(omg_max * xiw * h0) >= SINCOS_CW_LIMIT;
-            }
-        }
-    }
-    sea = beta1 < 0.0;
+    const int bfi = ib * nfwd + f, pad = b.nlay_pad;
+    nl = b.nlay[ib];
+    const int fl = w.gflag[bfi];
+    sea = fl & 1;                     // beta(1) < 0  (forward.f90:229)
     ilay0 = sea ? 1 : 0;
-    return __syncthreads_or(big);
+    const double2 *__restrict__ gc = reinterpret_cast<const double2 *>(w.gcoef + (size_t)bfi * pad * NCOEF);
+    double2 *lc = reinterpret_cast<double2 *>(coef);
+    for (int i = ilay0 * (NCOEF / 2) + (int)threadIdx.x; i < (nl - 1) * (NCOEF / 2); i += blockDim.x) lc[i] = gc[i];
+    const double *__restrict__ gt = w.gtail + (size_t)bfi * GTAIL;
+    if (threadIdx.x < GTAIL) tail[threadIdx.x] = gt[threadIdx.x];
+    __syncthreads();
+    return (fl & 2) != 0;
 }
 
 // WPB waves per block share one staged layer stack; wave w of block b works on split
@@ -738,23 +737,7 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
     double *tail = lds + (size_t)P.b.nlay_pad * NCOEF;
     int nl, ilay0;
     bool sea;
-    const bool big = stage_walker(P, ib, f, coef, tail, nl, ilay0, sea);
-    if (blockIdx.x % nblk == 0) {
-        // direct_arrival (forward.f90:474-519) for trace_kernel: per-layer terms by separate
-        // threads, strictly sequential in-order sum (it feeds nint(): bit-exact bookkeeping)
-        const int pad = P.b.nlay_pad;
-        const double *L = P.b.layers + (size_t)ib * 4 * pad;
-        const double *vel = (P.t.ipha[f] == 1) ? L : L + pad;   // alpha for P, beta for S (:157,161)
-        const int i0 = P.t.sdep > 0.0 ? 1 : 0;                  // keyed on sdep (:484)
-        double *terms = tail + 24;
-        for (int i = i0 + (int)threadIdx.x; i < nl - 1; i += blockDim.x)
-            terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], P.t.rayps[f]);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            P.meta_tp[ib * P.t.nfwd + f] = arrival_sum(nl - 1 - i0, terms);
-            if (f == 0) P.meta_slot[ib] = 1 - P.cur_slot[P.b.walker_ids[ib]];
-        }
-    }
+    const bool big = load_staged(P.w, P.b, P.t.nfwd, ib, f, coef, tail, nl, ilay0, sea);
     const int ipha = P.t.ipha[f];
     double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
     const GlobalSink sink{out_r, out_r + P.t.nh, P.t.nh};
@@ -795,7 +778,7 @@ __global__ __launch_bounds__(64) void spectra_slow_kernel(SpectraParams P)
         int nl, ilay0;
         bool sea;
         __syncthreads();
-        stage_walker(P, ib, f, coef, tail, nl, ilay0, sea);
+        load_staged(P.w, P.b, P.t.nfwd, ib, f, coef, tail, nl, ilay0, sea);
         const int ipha = P.t.ipha[f];
         double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
         const GlobalSink sink{out_r, out_r + P.t.nh, P.t.nh};
@@ -809,16 +792,20 @@ __global__ __launch_bounds__(64) void spectra_slow_kernel(SpectraParams P)
 size_t spectra_lds_bytes(int nlay_pad) { return sizeof(double) * ((size_t)nlay_pad * (NCOEF + 1) + 24); }
 
 // ---------------------------------------------------------------------------
-// K0  stage_kernel: the per-(walker, forward-trace) constants of K1 computed ONCE per batch item by a
-// wide, shallow launch instead of by every block that works on the item.  Inside the fused kernel the
-// staging sat on each block's critical path (a dependent chain of divisions, square roots and three
-// sincos per layer executed by a few lanes while the rest of the block waited: ~4 us per block, 9 % of
-// the C4 launch); here one lane per layer does all four parts of stage_walker, a wave per
-// (item, forward-trace), and the fused kernel starts with a coalesced 6 KB copy.
-// Output per bf = item * nfwd + f (global, same image as the LDS one described above K1):
+// K0  stage_kernel: the per-(walker, forward-trace) constants of K1, computed ONCE per batch item by a wide,
+// shallow launch in front of the spectra / fused kernel -- not by every block that works on the item, on its
+// critical path (a dependent chain of divisions, square roots and three sincos per layer: ~4 us per block,
+// 4.5 % of a C4 launch).  One wave per (item, forward-trace); its lanes take (layer, part) pairs, the four
+// parts of a layer being independent (stage_interface), so the wave waits for one part's chain, not for four:
+//   part 0: the (a_p, b_s) block of G, c[3..6]    (S slownesses)     part 2: xi, h and the P phase constants
+//   part 1: the (b_p, a_s) block of G, c[7..10]   (P slownesses)     part 3: eta and the S phase constants
+// Every consumer copies the same image, so the fused and the split launch plans -- and a chain evaluated alone
+// or in a batch -- see identical constants.
+// Output per bf = item * nfwd + f (global; the LDS image described above K1):
 //   gcoef[bf][nlay_pad][NCOEF]   layers ilay0 .. nl-2
 //   gtail[bf][GTAIL]             tail[0..16], [17] direct-arrival time (forward.f90:474-519)
-//   gflag[bf]                    bit 0: sea (beta(1) < 0), bit 1: a phase beyond the Cody-Waite range
+//   gflag[bf]                    bit 0: sea (beta(1) < 0), bit 1: generic path (a phase beyond the Cody-Waite
+//                                range, or no unit gauge: walker_gauge)
 // ---------------------------------------------------------------------------
 struct StageParams {
     DeviceTables t;
@@ -850,53 +837,72 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
         const double omg_nyq = (double)(S.t.nfft / 2) * S.t.domg;
         double *coef = S.gcoef + (size_t)bf * pad * NCOEF;
         double *tail = S.gtail + (size_t)bf * GTAIL;
-        const double *vel = (S.t.ipha[f] == 1) ? L : L + pad;   // alpha for P, beta for S (:157,161)
-        const int i0 = S.t.sdep > 0.0 ? 1 : 0;                  // keyed on sdep (:484)
-        for (int l = lane; l < pad - 1; l += 64) {
-            const double a0 = L[l], b0 = L[pad + l], r0 = L[2 * pad + l], h0 = L[3 * pad + l];
-            const double a1 = L[l + 1], b1 = L[pad + l + 1], r1 = L[2 * pad + l + 1];
+        bool unit;
+        const double gauge = walker_gauge(L, pad, nl, ilay0, p, lane, unit);
+        big = !unit;
+        for (int w0 = 0; w0 < 4 * (pad - 1); w0 += 64) {
+            const int l = (w0 + lane) >> 2, part = lane & 3;
+            if (l >= pad - 1) continue;
+            const double *V = (part == 1 || part == 2) ? L : L + pad;   // parts 1, 2: alpha (xi); 0, 3: beta (eta)
+            // this layer and the one below it
+            const double v0 = V[l], a0 = L[l], b0 = L[pad + l], r0 = L[2 * pad + l], h0 = L[3 * pad + l];
+            const double v1 = V[l + 1], a1 = L[l + 1], b1 = L[pad + l + 1], r1 = L[2 * pad + l + 1];
             double *c = coef + (size_t)l * NCOEF;
             if (l >= ilay0 && l < nl - 1) {
-                const bool below = l + 1 < nl - 1;
-                const LayerHalf ue = layer_half(b0, b0, r0, p), ux = layer_half(a0, b0, r0, p);
-                const LayerHalf we = layer_half(b1, b1, r1, p), wx = layer_half(a1, b1, r1, p);
-                stage_interface(c + 3, 0, ue, below ? &we : nullptr);
-                stage_interface(c + 7, 1, ux, below ? &wx : nullptr);
-                double sn, cn;
-                sincos_cw((omg_nyq * ux.slow) * h0, sn, cn);    // phases of the Nyquist bin (forward.f90:397-400)
-                c[0] = ux.slow;
-                c[2] = h0;
-                stage_phase(c + 11, c + 15, S.t.domg, ux.slow, h0);
-                c[19] = sn;
-                c[20] = cn;
-                sincos_cw((omg_nyq * ue.slow) * h0, sn, cn);
-                c[1] = ue.slow;
-                stage_phase(c + 13, c + 17, S.t.domg, ue.slow, h0);
-                c[21] = sn;
-                c[22] = cn;
-                c[23] = 0.0;
-                big |= fabs(omg_max * ux.slow * h0) >= SINCOS_CW_LIMIT || fabs(omg_max * ue.slow * h0) >= SINCOS_CW_LIMIT;
+                if (part < 2) {
+                    const LayerHalf u = layer_half(v0, b0, r0, p);
+                    if (l + 1 < nl - 1) {
+                        const LayerHalf w = layer_half(v1, b1, r1, p);
+                        stage_interface(c + 3 + 4 * part, part, u, &w, unit);
+                    } else {
+                        stage_interface(c + 3 + 4 * part, part, u, nullptr, unit);
+                    }
+                } else {
+                    const double slow = vertical_slowness(v0, p);
+                    // phases of the Nyquist bin, argument formed like the reference (forward.f90:397-400)
+                    double sn, cn;
+                    sincos_cw((omg_nyq * slow) * h0, sn, cn);
+                    if (part == 2) {
+                        c[0] = slow;
+                        c[2] = h0;
+                        stage_phase(c + 11, c + 15, S.t.domg, slow, h0);
+                        c[19] = sn;
+                        c[20] = cn;
+                    } else {
+                        c[1] = slow;
+                        stage_phase(c + 13, c + 17, S.t.domg, slow, h0);
+                        c[21] = sn;
+                        c[22] = cn;
+                        c[23] = 0.0;
+                    }
+                    big |= fabs(omg_max * slow * h0) >= SINCOS_CW_LIMIT;
+                }
             }
-            if (l == nl - 2) {
+            // walker constants, by the lanes of the lighter parts that already hold the layers involved
+            if (part == 2 && l == nl - 2) {
+                // half-space = layer l + 1; the last solid layer (if any) = layer l
                 LayerBasis last;
                 if (solid) last = layer_basis(a0, b0, r0, p);
-                stage_halfspace(tail, a1, b1, r1, p, solid ? &last : nullptr);
+                stage_halfspace(tail, a1, b1, r1, p, solid ? &last : nullptr, gauge);
             }
-            if (l == (solid ? ilay0 : 0)) {
+            if (part == 3 && l == (solid ? ilay0 : 0)) {
                 LayerBasis top;
                 if (solid) top = layer_basis(a0, b0, r0, p);
                 stage_start(tail + 11, solid ? &top : nullptr);
             }
-            if (l == 0 && sea) {
+            if (part == 3 && l == 0 && sea) {
                 const double xiw = vertical_slowness(a0, p);   // forward.f90:431
                 tail[8] = xiw;
                 tail[9] = h0;
                 tail[10] = r0 / xiw;
                 big |= fabs(omg_max * xiw * h0) >= SINCOS_CW_LIMIT;
             }
-            // direct_arrival (forward.f90:474-519): the independent per-layer terms, summed in order below
-            if (l >= i0 && l < nl - 1) terms[l - i0] = arrival_term(h0, vel[l], p);
         }
+        // direct_arrival (forward.f90:474-519): the independent per-layer terms by separate lanes, summed
+        // strictly in layer order below (it feeds nint(): bit-exact bookkeeping)
+        const double *vel = (S.t.ipha[f] == 1) ? L : L + pad;   // alpha for P, beta for S (:157,161)
+        const int i0 = S.t.sdep > 0.0 ? 1 : 0;                  // keyed on sdep (:484)
+        for (int i = i0 + lane; i < nl - 1; i += 64) terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], p);
     }
     const bool any_big = __any(big);
     __syncthreads();
@@ -939,7 +945,7 @@ static void launch_spectra_ncol(int chain, dim3 grid, dim3 block, size_t lds, hi
 void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit, int chain,
                     int waves_per_block, int *slow_list, int *slow_count, const WalkerState &w, hipStream_t s)
 {
-    SpectraParams P{t, b, spec, nsplit, slow_list, slow_count, w.meta_tp, w.meta_slot, w.cur_slot};
+    SpectraParams P{t, b, spec, nsplit, slow_list, slow_count, w};
     int wpb = waves_per_block < 1 ? 1 : (waves_per_block > 4 ? 4 : waves_per_block);
     if (wpb > nsplit) wpb = nsplit;
     const int nblk = (nsplit + wpb - 1) / wpb;
@@ -984,6 +990,14 @@ __device__ __forceinline__ double block_max(double v, double *red)
 
 // Fortran nint: round half away from zero
 __device__ __forceinline__ int f_nint(double x) { return (int)(x >= 0.0 ? floor(x + 0.5) : -floor(0.5 - x)); }
+
+// the reference's mod(x, n) of the shift maps (forward.f90:179,188) for in-range shifts: into [0, n)
+__device__ __forceinline__ int wrap_index(int x, int n)
+{
+    if ((n & (n - 1)) == 0) return x & (n - 1);
+    const int r = x % n;
+    return r < 0 ? r + n : r;
+}
 
 __device__ __noinline__ int calc_npre(double t_start, double tp, double delta, int ipha)
 {
@@ -1347,7 +1361,8 @@ __device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 
 // the follow-up kernels).  Shared by trace_kernel (Z filled from the spectra in HBM) and
 // fused_kernel (Z filled straight from the propagator registers).
 __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, double *mis, double *red, int ib,
-                                           int itrc, int walker, int ipha, bool decon, double tp, int slot, int tid)
+                                           int itrc, int walker, int ipha, bool decon, double tp, int slot, int tid,
+                                           bool transformed = false)
 {
     const DeviceTables &t = P.t;
     const int n = t.nfft, nsmp = t.nsmp;
@@ -1357,7 +1372,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
     double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
     double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
-    if (TRACE_THREADS == 256 && n >= 512 && n <= 4096) {
+    if (TRACE_THREADS == 256 && n >= 512 && n <= 4096 && !transformed) {
         // nfft 512 .. 4096: the last pass has exactly one butterfly (radix nfft / 256) per thread; its
         // outputs stay in registers for the vertical maximum, the shift and the store -- one LDS write
         // pass, two LDS read passes and a barrier less than the general path below.  Same values, same
@@ -1373,7 +1388,8 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
         __syncthreads();
     } else {
     // ---- in-place mixed-radix inverse FFT, sign +, unnormalised (FFTW c2r definition) ---
-    fft_inverse_lds<TRACE_THREADS>(a, P.plan, P.log2n, t.twiddle, tid);
+    // (transformed: `a` already holds the time series -- the direct DFT of trace_anyn_kernel)
+    if (!transformed) fft_inverse_lds<TRACE_THREADS>(a, P.plan, P.log2n, t.twiddle, tid);
     // a[fft_pad(j)].x = rx (RF trace), .y = vertical trace
     RFGPU_ABLATE_AT(2, );
 
@@ -1389,13 +1405,12 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
     for (int i = tid + 1; i <= n; i += TRACE_THREADS) {
         int j;
         double val;
-        // n is a power of two: the reference's mod(x, n) = x & (n - 1), also for negative x
         if (ipha == 1) {
-            j = (n - npre + i) & (n - 1);                            // forward.f90:179
+            j = wrap_index(n - npre + i, n);                         // forward.f90:179
             if (j == 0) j = n;
             val = a[fft_pad(j - 1)].x;
         } else {
-            j = (n + npre - i + 1) & (n - 1);                        // forward.f90:188
+            j = wrap_index(n + npre - i + 1, n);                     // forward.f90:188
             if (j == 0) j = n;
             val = -a[fft_pad(j - 1)].x;
         }
@@ -1489,9 +1504,9 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
         }
         wlvl = 0.001 * block_max(m, red);            // forward.f90:460, pcnt = 0.001 (:149)
     }
-    // direct-arrival time and destination half were prepared by spectra_kernel
-    const double tp = decon ? 0.0 : P.w.meta_tp[ib * t.nfwd + f];
-    const int slot = P.w.meta_slot[ib];
+    // direct-arrival time: stage_kernel; destination = the half that does not hold the walker's current trace
+    const double tp = decon ? 0.0 : P.w.gtail[(size_t)(ib * t.nfwd + f) * GTAIL + 17];
+    const int slot = 1 - P.w.cur_slot[walker];
 
     // ---- Z = RF*flt + i * (V*flt), Hermitian-extended, written digit-reversed ----
     // The spectra come from HBM: each thread first issues the loads of FILL_CHUNK bins
@@ -1540,6 +1555,115 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
     __syncthreads();
 
     trace_tail(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
+}
+
+// ---------------------------------------------------------------------------
+// trace_anyn_kernel: K2 for an nfft that is NOT a power of two (FFTW plans any length, src/fftw.f90:44;
+// the reference accepts any nfft, src/params.f90:179).  Same steps as trace_kernel; the c2r step is the
+// DEFINITION of the unnormalised inverse real DFT (Hermitian extension of bins 0 .. n/2, imaginary parts
+// of the DC and -- for even n -- Nyquist bins ignored) summed directly from an LDS twiddle table:
+// O(n^2) per trace instead of O(n log n), which is fine for the rare sizes that need it (n = 1000:
+// ~2e6 FMA per trace) and keeps every other stage shared.  Split launch plan only.
+// ---------------------------------------------------------------------------
+__host__ __device__ inline size_t anyn_spec_offset(int nfft, int nsmp, int nlay_pad)
+{
+    return trace_work_doubles(nfft, nsmp, nlay_pad) + (size_t)(((nsmp + 1) & ~1) + 8);   // doubles: after a | mis | red
+}
+
+size_t trace_anyn_lds_bytes(int nfft, int nsmp, int nlay_pad)
+{
+    const size_t nh = (size_t)nfft / 2 + 1;
+    return sizeof(double) * anyn_spec_offset(nfft, nsmp, nlay_pad) + sizeof(double2) * (2 * nh + (size_t)nfft);
+}
+
+__global__ __launch_bounds__(TRACE_THREADS) void trace_anyn_kernel(TraceParams P)
+{
+    extern __shared__ double2 lds2[];
+    const DeviceTables &t = P.t;
+    const int n = t.nfft, nh = t.nh, nsmp = t.nsmp;
+    double2 *a = lds2;
+    double *mis = reinterpret_cast<double *>(a) + trace_work_doubles(n, nsmp, P.b.nlay_pad);
+    double *red = mis + ((nsmp + 1) & ~1);
+    double2 *zr = reinterpret_cast<double2 *>(reinterpret_cast<double *>(a) + anyn_spec_offset(n, nsmp, P.b.nlay_pad));
+    double2 *zv = zr + nh;                               // filtered RF and vertical spectra, bins 0 .. nh-1
+    double2 *tw = zv + nh;                               // exp(+2 pi i k / n), k = 0 .. n-1
+
+    const int tid = threadIdx.x;
+    const int itrc = blockIdx.x % t.ntrc;
+    const int ib = P.b.order ? P.b.order[blockIdx.x / t.ntrc] : blockIdx.x / t.ntrc;
+    if (blockIdx.x == 0 && tid == 0) *P.slow_count = 0;
+    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
+        if (itrc == 0 && tid == 0 && P.b.fwd_flag[ib] < 0) {
+            P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
+            P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
+        } else if (itrc == 0 && tid == 0) {
+            const int wk = P.b.walker_ids[ib];
+            const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * t.ntrc;
+            P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
+            P.w.prop_fwd[wk] = 0;
+        }
+        return;
+    }
+    const int walker = P.b.walker_ids[ib];
+    const int f = t.ray_common ? 0 : itrc;
+    const int ipha = t.ipha[itrc];
+    const double2 *__restrict__ sr = P.spec + ((size_t)(ib * t.nfwd + f) * 2) * nh;   // freq_r
+    const double2 *__restrict__ sv = sr + nh;                                          // freq_v
+    const double *__restrict__ flt = t.flt + (size_t)itrc * nh;
+    const bool decon = t.deconv_mode == 1;
+    const double2 *num = (ipha == 1) ? sr : sv;      // forward.f90:148-163
+    const double2 *den = (ipha == 1) ? sv : sr;      // decon only
+    double wlvl = 0.0;
+    if (decon) {
+        double m = -HUGE_VAL;
+        for (int k = tid; k < nh; k += TRACE_THREADS) {
+            const double2 x = den[k];
+            m = fmax(m, x.x * x.x + x.y * x.y);      // forward.f90:458
+        }
+        wlvl = 0.001 * block_max(m, red);            // forward.f90:460, pcnt = 0.001 (:149)
+    }
+    const double tp = decon ? 0.0 : P.w.gtail[(size_t)(ib * t.nfwd + f) * GTAIL + 17];
+    const int slot = 1 - P.w.cur_slot[walker];
+    for (int k = tid; k < n; k += TRACE_THREADS) tw[k] = t.twiddle_any[k];
+    for (int k = tid; k < nh; k += TRACE_THREADS) {
+        double2 r = num[k];
+        const double fk = flt[k];
+        double2 V = make_double2(0.0, 0.0);
+        if (decon) {
+            const double2 x = den[k];
+            const double amp = x.x * x.x + x.y * x.y;
+            const double dd = fmax(amp, wlvl);                       // forward.f90:464
+            const double2 yx = cmul(r, make_double2(x.x, -x.y));
+            r = make_double2(yx.x / dd, yx.y / dd);
+        } else {
+            V = make_double2(sv[k].x * fk, sv[k].y * fk);            // forward.f90:198
+        }
+        zr[k] = make_double2(r.x * fk, r.y * fk);                    // forward.f90:168
+        zv[k] = V;
+    }
+    __syncthreads();
+    // x[j] = X0 + [n even] (-1)^j X_{n/2} + 2 sum_{0 < k < n/2} Re(X_k e^{+2 pi i j k / n})
+    const int kmax = (n - 1) / 2;
+    for (int j = tid; j < n; j += TRACE_THREADS) {
+        double xr = zr[0].x, xv = zv[0].x;
+        if ((n & 1) == 0) {
+            const double sg = (j & 1) ? -1.0 : 1.0;
+            xr = fma(sg, zr[n / 2].x, xr);
+            xv = fma(sg, zv[n / 2].x, xv);
+        }
+        double sr2 = 0.0, sv2 = 0.0;
+        int idx = 0;
+        for (int k = 1; k <= kmax; ++k) {
+            idx += j;
+            if (idx >= n) idx -= n;
+            const double2 w = tw[idx], R = zr[k], V = zv[k];
+            sr2 += R.x * w.x - R.y * w.y;
+            sv2 += V.x * w.x - V.y * w.y;
+        }
+        a[fft_pad(j)] = make_double2(fma(2.0, sr2, xr), fma(2.0, sv2, xv));
+    }
+    __syncthreads();
+    trace_tail(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid, true);
 }
 
 // ---------------------------------------------------------------------------
@@ -1612,7 +1736,6 @@ struct FusedParams {
     SpectraParams sp;   // t, b, nsplit (= waves per block), meta pointers unused
     TraceParams tp;     // t, b, w, log2n, plan, slow_count
     int *order_next;    // nullptr, or: block 0 sorts this batch's items by depth for the NEXT launch
-    int prestaged;      // stage_kernel ran for this batch: copy its output instead of staging in the block
 };
 
 __device__ __forceinline__ void order_block(int nb, const int *nlay, const int *fwd_flag, int *order, int *hist,
@@ -1671,39 +1794,10 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
     const int ipha = t.ipha[itrc];
     const bool decon = t.deconv_mode == 1;
 
-    // ---- the layer stack's constants and the direct-arrival time: copied from stage_kernel's output
-    // (large batches), or staged here (small batches, where one more launch would cost more than it saves)
+    // ---- the layer stack's constants and the direct-arrival time: stage_kernel's output, one coalesced copy
     int nl, ilay0;
-    bool sea, big;
-    if (P.w.gcoef && F.prestaged) {
-        const int bfi = ib * t.ntrc + itrc;
-        const int pad = P.b.nlay_pad;
-        nl = P.b.nlay[ib];
-        const int fl = P.w.gflag[bfi];
-        sea = fl & 1;
-        big = fl & 2;
-        ilay0 = sea ? 1 : 0;
-        const double2 *__restrict__ gc = reinterpret_cast<const double2 *>(P.w.gcoef + (size_t)bfi * pad * NCOEF);
-        double2 *lc = reinterpret_cast<double2 *>(coef);
-        for (int i = ilay0 * (NCOEF / 2) + tid; i < (nl - 1) * (NCOEF / 2); i += TRACE_THREADS) lc[i] = gc[i];
-        const double *__restrict__ gt = P.w.gtail + (size_t)bfi * GTAIL;
-        if (tid < 17) tail[tid] = gt[tid];
-        if (tid == 17) red[4] = gt[17];
-        __syncthreads();
-    } else {
-        big = stage_walker(F.sp, ib, itrc, coef, tail, nl, ilay0, sea);
-        if (!decon) {
-            const int pad = P.b.nlay_pad;
-            const double *L = P.b.layers + (size_t)ib * 4 * pad;
-            const double *vel = (ipha == 1) ? L : L + pad;            // alpha for P, beta for S (:157,161)
-            const int i0 = t.sdep > 0.0 ? 1 : 0;                      // keyed on sdep (:484)
-            double *terms = tail + 24;
-            for (int i = i0 + tid; i < nl - 1; i += TRACE_THREADS)
-                terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], t.rayps[itrc]);
-            __syncthreads();
-            if (tid == 0) red[4] = arrival_sum(nl - 1 - i0, terms);
-        }
-    }
+    bool sea;
+    const bool big = load_staged(P.w, P.b, t.ntrc, ib, itrc, coef, tail, nl, ilay0, sea);
     const int slot = 1 - P.w.cur_slot[walker];
     RFGPU_ABLATE_AT(5, );   // timing diagnostics: launch + staging only
 
@@ -1733,7 +1827,7 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
         spectra_body<BK, NCOL, true>(sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
     }
     __syncthreads();
-    const double tp = decon ? 0.0 : red[4];
+    const double tp = decon ? 0.0 : tail[17];
 
     if (decon) {
         // water_level_decon (forward.f90:447-470) in place: slot(k) holds the numerator,
@@ -1790,12 +1884,11 @@ static void launch_fused_ncol(int chain, dim3 grid, size_t lds, hipStream_t s, c
 }
 
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
-                  int ablate, int defer_logl, int *order_next, double *extra_out, int prestaged, hipStream_t s)
+                  int ablate, int defer_logl, int *order_next, double *extra_out, hipStream_t s)
 {
     FusedParams F{};
     F.order_next = order_next;
-    F.prestaged = prestaged;
-    F.sp = SpectraParams{t, b, nullptr, TRACE_THREADS / 64, nullptr, slow_count, w.meta_tp, w.meta_slot, w.cur_slot};
+    F.sp = SpectraParams{t, b, nullptr, TRACE_THREADS / 64, nullptr, slow_count, w};
     F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count, ablate, defer_logl, extra_out};
     while ((1 << F.tp.log2n) < t.nfft) ++F.tp.log2n;
     F.tp.plan = make_fft_plan(F.tp.log2n);
@@ -1844,6 +1937,13 @@ void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec
                   int *slow_count, hipStream_t s)
 {
     TraceParams P{t, b, spec, w, 0, {}, slow_count, 0, 0, nullptr};
+    if (t.twiddle_any) {   // nfft is not a power of two: direct-DFT variant
+        static LdsOptIn opt_any;
+        opt_any(reinterpret_cast<const void *>(trace_anyn_kernel));
+        hipLaunchKernelGGL(trace_anyn_kernel, dim3((unsigned)(b.nb * t.ntrc)), dim3(TRACE_THREADS),
+                           trace_anyn_lds_bytes(t.nfft, t.nsmp, b.nlay_pad), s, P);
+        return;
+    }
     while ((1 << P.log2n) < t.nfft) ++P.log2n;
     P.plan = make_fft_plan(P.log2n);
     const size_t lds = trace_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);

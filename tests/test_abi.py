@@ -65,9 +65,9 @@ def test_no_cpu_fallback_ctx_create_fails_loudly_without_gpu():
 def test_ctx_create_argument_validation():
     from rf_inv_amd import RFEngine, RFGPUError
 
-    with pytest.raises(RFGPUError, match="power of two"):
-        RFEngine(nfft=250, delta=0.05, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=[0.06], a_gus=[4.0],
-                 ipha=[1], obs=np.zeros((1, 101)), nsmp=101)
+    with pytest.raises(RFGPUError, match="nfft must be >= 8"):
+        RFEngine(nfft=6, delta=0.05, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=[0.06], a_gus=[4.0],
+                 ipha=[1], obs=np.zeros((1, 3)), nsmp=3)
     with pytest.raises(RFGPUError, match="ipha"):
         RFEngine(nfft=256, delta=0.05, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=[0.06], a_gus=[4.0],
                  ipha=[0], obs=np.zeros((1, 101)), nsmp=101)

