@@ -63,6 +63,10 @@ void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w
 // fused K1+K2 (contexts with one forward computation per trace)
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
                   int ablate, int defer_logl, int *order_next, double *extra_out, hipStream_t s);
+// the fused kernel with 512-thread blocks (nfft 4096, land): see fused8_kernel
+void launch_fused8(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int defer_logl,
+                   int *order_next, double *extra_out, hipStream_t s);
+size_t fused8_lds_bytes(int nsmp, int nlay_pad);
 // K0: per-(item, forward-trace) constants of the propagator, once per batch item, in front of K1 / the fused kernel
 void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 // logL of a batch launched with defer_logl (one thread per batch item, after the fused kernel)

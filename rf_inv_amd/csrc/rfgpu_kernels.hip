@@ -371,6 +371,13 @@ __device__ __forceinline__ void sincos_cw(double x, double &sn, double &cs)
     cs = ((q + 1) & 2) ? -cc : cc;
 }
 
+// Wave-uniform constants read straight from stage_kernel's global image go through the SCALAR data path
+// (s_load into SGPRs; a VALU instruction takes one of them as an operand) when the pointer lives in the constant
+// address space: no LDS copy, no ds_read per layer and ~38 fewer VGPRs per lane in the chained-phase loop than
+// the LDS broadcast -- which is what removed its register-shuffling moves (34 v_mov_b64 per layer at 8 bins).
+typedef const double __attribute__((address_space(4))) *KPtr;
+__device__ __forceinline__ KPtr as_scalar_ptr(const double *p) { return (KPtr)(uintptr_t)p; }
+
 template <int NCOL>
 struct ColState {
     double v[NCOL][4];
@@ -389,8 +396,8 @@ __device__ __forceinline__ void phase_sincos(double x, double &sn, double &cs)
 // one layer applied to NCOL columns held in the layer's eigen-coordinates (a_p, b_p, a_s, b_s):
 // rotate the P pair by the layer's P phase and the S pair by its S phase, then change to the
 // next layer's coordinates (c[3..10])
-template <int NCOL>
-__device__ __forceinline__ void apply_layer_trig(ColState<NCOL> &s, const double *__restrict__ c, double sx,
+template <int NCOL, class CP = const double *>
+__device__ __forceinline__ void apply_layer_trig(ColState<NCOL> &s, CP c, double sx,
                                                  double cx, double se, double ce)
 {
     const double g0 = c[3], g1 = c[4], g2 = c[5], g3 = c[6], g4 = c[7], g5 = c[8], g6 = c[9], g7 = c[10];
@@ -409,28 +416,32 @@ __device__ __forceinline__ void apply_layer_trig(ColState<NCOL> &s, const double
 }
 
 // the same with the walker's gauge applied (stage_interface, unit): c[3] = c[10] = 1 exactly
-template <int NCOL>
-__device__ __forceinline__ void apply_layer_trig_unit(ColState<NCOL> &s, const double *__restrict__ c, double sx,
+template <int NCOL, class CP = const double *>
+__device__ __forceinline__ void apply_layer_trig_unit(ColState<NCOL> &s, CP c, double sx,
                                                       double cx, double se, double ce)
 {
     const double g1 = c[4], g2 = c[5], g3 = c[6], g4 = c[7], g5 = c[8], g6 = c[9];
 #pragma unroll
     for (int j = 0; j < NCOL; ++j) {
         const double ap = s.v[j][0], bp = s.v[j][1], as = s.v[j][2], bs = s.v[j][3];
-        const double rap = fma(cx, ap, -(sx * bp));
-        const double rbp = fma(sx, ap, cx * bp);
-        const double ras = fma(ce, as, -(se * bs));
-        const double rbs = fma(se, as, ce * bs);
+        // Operation order chosen for the register allocator, not the reader: each rotated value stays live past the
+        // fma that adds it to a state slot, so hipcc emits that fma in its three-address form; written the other
+        // way round it picks v_fmac and copies the addend into the slot first (4 v_mov_b64 per bin: 6 % of the loop)
+        const double u1 = sx * ap, u2 = sx * bp, u3 = se * as, u4 = se * bs;
+        const double rap = fma(cx, ap, -u2);
+        const double rbp = fma(cx, bp, u1);
+        const double ras = fma(ce, as, -u4);
+        const double rbs = fma(ce, bs, u3);
         s.v[j][0] = fma(g1, rbs, rap);
-        s.v[j][3] = fma(g3, rbs, g2 * rap);
-        s.v[j][1] = fma(g5, ras, g4 * rbp);
+        s.v[j][3] = fma(g2, rap, g3 * rbs);
         s.v[j][2] = fma(g6, rbp, ras);
+        s.v[j][1] = fma(g5, ras, g4 * rbp);
     }
 }
 
 // FAST: the walker's constants carry the unit gauge (the fast paths run only for such walkers)
-template <int NCOL, bool FAST>
-__device__ __forceinline__ void apply_layer(ColState<NCOL> &s, const double *__restrict__ c, double omg)
+template <int NCOL, bool FAST, class CP = const double *>
+__device__ __forceinline__ void apply_layer(ColState<NCOL> &s, CP c, double omg)
 {
     double sx, cx, se, ce;
     // argument formed exactly like the reference: (omega * xi) * z  (forward.f90:397-400)
@@ -443,13 +454,14 @@ __device__ __forceinline__ void apply_layer(ColState<NCOL> &s, const double *__r
 }
 
 // T_rj = sum_k (E^-1 T)(r,k) B_kj  for r = 3 (g[0..3]) or 4 (g[4..7])
-__device__ __forceinline__ double2 halfspace_row(const double *g, const double *v)
+template <class CP = const double *>
+__device__ __forceinline__ double2 halfspace_row(CP g, const double *v)
 {
     return make_double2(fma(g[1], v[3], g[0] * v[0]), fma(g[3], v[2], g[2] * v[1]));
 }
 
-template <int NCOL, bool FAST>
-__device__ __forceinline__ void finish_bin(const ColState<NCOL> &s, const double *tail, double omg,
+template <int NCOL, bool FAST, class CP = const double *>
+__device__ __forceinline__ void finish_bin(const ColState<NCOL> &s, CP tail, double omg,
                                            int ipha, double2 &ur, double2 &uz)
 {
     const double2 t31 = halfspace_row(tail, s.v[0]);
@@ -503,10 +515,10 @@ struct SpectraParams {
 // in LDS as precomputed coefficients and broadcast to all lanes; the 4x4 chain runs in
 // registers.
 
-template <int NCOL>
-__device__ __forceinline__ void init_cols(ColState<NCOL> &st, const double *tail)
+template <int NCOL, class CP = const double *>
+__device__ __forceinline__ void init_cols(ColState<NCOL> &st, CP tail)
 {
-    const double *t = tail + 11;   // stage_start
+    const CP t = tail + 11;   // stage_start
 #pragma unroll
     for (int j = 0; j < NCOL; ++j)
 #pragma unroll
@@ -542,8 +554,8 @@ struct GlobalSink {
 };
 
 // one 64-bin iteration, every phase by a full sincos evaluation
-template <int NCOL, bool FAST, class Sink>
-__device__ __forceinline__ void spectra_iter_direct(const SpectraParams &P, const double *coef, const double *tail,
+template <int NCOL, bool FAST, class Sink, class CP = const double *>
+__device__ __forceinline__ void spectra_iter_direct(const SpectraParams &P, CP coef, CP tail,
                                                     int nl, int ilay0, int ipha, const Sink &sink, int it, int lane)
 {
     const int k = it * 64 + lane;
@@ -560,8 +572,8 @@ __device__ __forceinline__ void spectra_iter_direct(const SpectraParams &P, cons
 // The iteration that holds the Nyquist bin has one active lane (nfft / 2 is a multiple of 64): a whole
 // wave walks the layer stack for it, so its sines and cosines come from the staged constants
 // (same function, same argument as spectra_iter_direct would use: identical values).
-template <int NCOL, class Sink>
-__device__ __forceinline__ void spectra_iter_nyquist(const SpectraParams &P, const double *coef, const double *tail,
+template <int NCOL, class Sink, class CP = const double *>
+__device__ __forceinline__ void spectra_iter_nyquist(const SpectraParams &P, CP coef, CP tail,
                                                      int nl, int ilay0, int ipha, const Sink &sink, int it, int lane)
 {
     const int k = it * 64 + lane;
@@ -569,7 +581,7 @@ __device__ __forceinline__ void spectra_iter_nyquist(const SpectraParams &P, con
     ColState<NCOL> st;
     init_cols<NCOL>(st, tail);
     for (int l = ilay0; l < nl - 1; ++l) {
-        const double *c = coef + l * NCOEF;
+        const CP c = coef + l * NCOEF;
         apply_layer_trig_unit<NCOL>(st, c, c[19], c[20], c[21], c[22]);
     }
     double2 ur, uz;
@@ -593,8 +605,8 @@ __device__ __forceinline__ double phase_eps(double arg, double kd, double phi_hi
 // rounding is part of the reference result -- is recovered to first order from
 // eps = arg - k phi (|eps| < 1e-9, second order < 1e-18).  ~13 instructions per extra
 // sincos instead of ~45.  Chain length <= BK-1 rotations (error growth ~1 ulp per step).
-template <int BK, int NCOL, class Sink>
-__device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, const double *coef, const double *tail,
+template <int BK, int NCOL, class Sink, class CP = const double *>
+__device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP coef, CP tail,
                                                     int nl, int ilay0, int ipha, const Sink &sink, int it0, int lane)
 {
     // long chains (and the 3-column ocean kernel) keep only the first bin's index and rebuild k, omega
@@ -617,7 +629,7 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
     const bool dc = k0 == 0;
 #pragma unroll LEAN ? 1 : 2
     for (int l = ilay0; l < nl - 1; ++l) {
-        const double *c = coef + l * NCOEF;
+        const CP c = coef + l * NCOEF;
         const double xi = c[0], eta = c[1], h = c[2];
         const double Cx = c[15], Sx = c[16], Ce = c[17], Se = c[18];
         double sx, cx, se, ce;
@@ -672,8 +684,8 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, cons
 // the bins of one (walker, forward-trace) assigned to `split` of P.nsplit:
 // full chunks of BK iterations go through the chained-phase path, the remaining
 // iterations (and everything when BK == 0) through the direct path.
-template <int BK, int NCOL, bool FAST, class Sink>
-__device__ __forceinline__ void spectra_body(const SpectraParams &P, const double *coef, const double *tail,
+template <int BK, int NCOL, bool FAST, class Sink, class CP = const double *>
+__device__ __forceinline__ void spectra_body(const SpectraParams &P, CP coef, CP tail,
                                              int nl, int ilay0, int ipha, const Sink &sink, int split, int lane)
 {
     const int niter = (P.t.nh + 63) / 64;
@@ -1242,26 +1254,32 @@ static FftPlan make_fft_plan(int log2n)
 __device__ __forceinline__ double quad_form(const DeviceTables &t, int itrc, const double *mis, double *part,
                                             double *red, int tid)
 {
+    // (blocks of more than four waves -- fused8_kernel -- leave the arithmetic to waves 0..3: the same partition
+    // of the rows and the same summation order as in a 256-thread block and in phi_deferred_kernel)
     const int nsmp = t.nsmp;
     const double *__restrict__ RT = t.r_inv_t + (size_t)itrc * nsmp * nsmp;
     const int wv = tid >> 6, lane = tid & 63;
     const int rows = (nsmp + 3) >> 2;
     const int r0 = wv * rows, r1 = min(nsmp, r0 + rows);
     __syncthreads();                                          // `part` may alias a buffer still being read
-    for (int j = lane; j < nsmp; j += 64) {
-        double acc = 0.0;
+    if (wv < 4) {
+        for (int j = lane; j < nsmp; j += 64) {
+            double acc = 0.0;
 #pragma unroll 8
-        for (int i = r0; i < r1; ++i) acc = fma(mis[i], RT[(size_t)i * nsmp + j], acc);
-        part[wv * nsmp + j] = acc;
+            for (int i = r0; i < r1; ++i) acc = fma(mis[i], RT[(size_t)i * nsmp + j], acc);
+            part[wv * nsmp + j] = acc;
+        }
     }
     __syncthreads();
     double acc = 0.0;
-    for (int j = tid; j < nsmp; j += TRACE_THREADS) {
-        const double phi1 = ((part[j] + part[nsmp + j]) + part[2 * nsmp + j]) + part[3 * nsmp + j];
-        acc = fma(phi1, mis[j], acc);
+    if (wv < 4) {
+        for (int j = tid; j < nsmp; j += TRACE_THREADS) {
+            const double phi1 = ((part[j] + part[nsmp + j]) + part[2 * nsmp + j]) + part[3 * nsmp + j];
+            acc = fma(phi1, mis[j], acc);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) red[wv] = acc;
     }
-    acc = wave_sum(acc);
-    if (lane == 0) red[wv] = acc;
     __syncthreads();
     return (red[0] + red[1]) + (red[2] + red[3]);
 }
@@ -1794,10 +1812,23 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
     const int ipha = t.ipha[itrc];
     const bool decon = t.deconv_mode == 1;
 
-    // ---- the layer stack's constants and the direct-arrival time: stage_kernel's output, one coalesced copy
-    int nl, ilay0;
-    bool sea;
-    const bool big = load_staged(P.w, P.b, t.ntrc, ib, itrc, coef, tail, nl, ilay0, sea);
+    // ---- the layer stack's constants and the direct-arrival time: stage_kernel's output.  The fast paths read
+    // them through the scalar data path straight from the global image; only a walker on the generic path (rare)
+    // copies the image into LDS first
+    const int bfi = ib * t.ntrc + itrc;
+    const int nl = P.b.nlay[ib];
+    const int stage_flags = P.w.gflag[bfi];
+    const bool sea = stage_flags & 1;             // beta(1) < 0  (forward.f90:229)
+    const bool big = (stage_flags & 2) != 0;
+    const int ilay0 = sea ? 1 : 0;
+    const bool generic = big || sea != (NCOL == 3);
+    const KPtr gcoef = as_scalar_ptr(P.w.gcoef + (size_t)bfi * P.b.nlay_pad * NCOEF);
+    const KPtr gtail = as_scalar_ptr(P.w.gtail + (size_t)bfi * GTAIL);
+    if (generic) {
+        int nl2, il2;
+        bool sea2;
+        (void)load_staged(P.w, P.b, t.ntrc, ib, itrc, coef, tail, nl2, il2, sea2);
+    }
     const int slot = 1 - P.w.cur_slot[walker];
     RFGPU_ABLATE_AT(5, );   // timing diagnostics: launch + staging only
 
@@ -1818,16 +1849,16 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
     const int lane_m = (64 - lane) & 63;
     const LdsSink sink{a, side, t.flt + (size_t)itrc * nh, P.plan, P.log2n, n, nh_eff, ipha, decon, r16x3,
                        ((lane & 15) << 8) + ((lane >> 4) << 4), ((lane_m & 15) << 8) + ((lane_m >> 4) << 4)};
-    if (big || sea != (NCOL == 3)) {
+    if (generic) {
         if (sea)
-            spectra_body<0, 3, false>(sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
+            spectra_body<0, 3, false>(sp, (const double *)coef, (const double *)tail, nl, ilay0, ipha, sink, wave, lane);
         else
-            spectra_body<0, 2, false>(sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
+            spectra_body<0, 2, false>(sp, (const double *)coef, (const double *)tail, nl, ilay0, ipha, sink, wave, lane);
     } else {
-        spectra_body<BK, NCOL, true>(sp, coef, tail, nl, ilay0, ipha, sink, wave, lane);
+        spectra_body<BK, NCOL, true>(sp, gcoef, gtail, nl, ilay0, ipha, sink, wave, lane);
     }
     __syncthreads();
-    const double tp = decon ? 0.0 : tail[17];
+    const double tp = decon ? 0.0 : gtail[17];
 
     if (decon) {
         // water_level_decon (forward.f90:447-470) in place: slot(k) holds the numerator,
@@ -1861,6 +1892,326 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
         __syncthreads();
     }
     trace_tail(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
+}
+
+// ---------------------------------------------------------------------------
+// fused8_kernel: the fused kernel for nfft = 4096 on land (every land BASELINE shape) with 512-thread blocks:
+// EIGHT waves per (walker, trace), each propagating one 4-bin phase chain (+ the Nyquist iteration on the last),
+// then a four-pass radix-8 FFT with one butterfly per thread and pass, the last pass left in registers.
+//
+// Why: the 256-thread kernel holds two blocks = two waves per SIMD (76 KB of LDS and ~240 VGPRs each); while a
+// block is in its latency-bound tail the other computes with ONE wave per SIMD, and a single wave issues an
+// fp64 instruction only every ~10 cycles (tools/fp64_peak.hip).  Here the constants of the chained-phase loop
+// live in SGPRs (scalar loads from stage_kernel's image), the 4-bin chain needs ~120 VGPRs and the radix-8
+// butterflies 32 + 28, so the kernel fits 128 VGPRs: two 8-wave blocks per CU = FOUR waves per SIMD, and a
+// block in its tail still leaves two.  A block's tail is also twice as parallel.  LDS: the FFT array only
+// (70.7 KB) -- walkers on the generic path copy their constants over the misfit / reduction area's neighbour
+// (rare; their code may spill, it is off the hot path).
+//
+// Same arithmetic as fused_kernel per bin and layer; the FFT factorisation differs (8^4 instead of 16^3), so
+// traces differ from the 256-thread kernel's in the last bits (both within 1e-12 of the oracle).
+// LDS index padding i + (i >> 4) + (i >> 9): the first term keeps the stride-1 pass (8 contiguous elements per
+// lane) conflict-free, the second spreads the digit-reversed fill (consecutive bins land 512 elements apart).
+// ---------------------------------------------------------------------------
+constexpr int W8_THREADS = 512;
+__host__ __device__ inline int w8_pad(int i) { return i + (i >> 4) + (i >> 9); }
+
+// position (unpadded) of bin k in the digit-reversed input order of four radix-8 DIT passes
+__device__ __forceinline__ int w8_pos(int k)
+{
+    return ((k & 7) << 9) | (((k >> 3) & 7) << 6) | (((k >> 6) & 7) << 3) | (k >> 9);
+}
+
+struct W8Sink {
+    double2 *a;                 // padded, digit-reversed FFT array
+    double2 *side;              // [2] denominators of the DC and Nyquist bins (decon only)
+    const double *__restrict__ flt;
+    int nh, ipha;
+    bool decon;
+    int lane_pos, lane_pos_m;   // digit-reversed contribution of the lane and of its mirror lane (64 - lane) & 63
+    __device__ __forceinline__ int pos_of(int k) const
+    {
+        const int it = k >> 6;                              // k = lane + 64 it
+        return w8_pad(lane_pos + ((it & 7) << 3) + (it >> 3));
+    }
+    __device__ __forceinline__ int pos_of_mirror(int k) const   // position of bin 4096 - k, 0 < k < 2048
+    {
+        const int it = (k & 63) ? 63 - (k >> 6) : 64 - (k >> 6);
+        return w8_pad(lane_pos_m + ((it & 7) << 3) + (it >> 3));
+    }
+    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz) const
+    {
+        if (k >= nh) return;
+        const double2 fr = make_double2(ur.x, -ur.y);    // freq_r = conjg(ur)   forward.f90:145
+        const double2 fv = make_double2(-uz.x, uz.y);    // freq_v = -conjg(uz)  forward.f90:146
+        const double2 num = ipha == 1 ? fr : fv;         // forward.f90:148-163
+        const int pk = pos_of(k);
+        const bool self = (k == 0 || k == 2048);
+        if (decon) {
+            const double2 den = ipha == 1 ? fv : fr;
+            a[pk] = num;
+            if (self)
+                side[k == 0 ? 0 : 1] = den;
+            else
+                a[pos_of_mirror(k)] = den;
+        } else {
+            const double fk = flt[k];
+            const double2 R = make_double2(num.x * fk, num.y * fk);   // forward.f90:168
+            const double2 V = make_double2(fv.x * fk, fv.y * fk);     // forward.f90:198
+            if (self) {
+                a[pk] = make_double2(R.x, V.x);          // c2r ignores Im of the DC and Nyquist bins
+            } else {
+                a[pk] = make_double2(R.x - V.y, R.y + V.x);
+                a[pos_of_mirror(k)] = make_double2(R.x + V.y, V.x - R.y);
+            }
+        }
+    }
+};
+
+// one in-place radix-8 DIT pass of the 4096-point inverse transform, one butterfly per thread
+template <int SL>   // log2 of the stride: 0, 3, 6
+__device__ __forceinline__ void w8_pass(double2 *a, const double2 *__restrict__ tw, int tid)
+{
+    constexpr int STRIDE = 1 << SL;
+    const int jp = tid & (STRIDE - 1);
+    const int base = ((tid >> SL) << (SL + 3)) + jp;
+    double2 v[8], w[8];
+    if (SL > 0) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) w[k] = tw[((jp * k) << (9 - SL)) & 2047];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(base + (k << SL))];
+    if (SL > 0) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const bool neg = ((jp * k) << (9 - SL)) >= 2048;   // exp(i(t + pi)) = -exp(it)
+            const double2 wk = neg ? make_double2(-w[k].x, -w[k].y) : w[k];
+            v[k] = cmul(v[k], wk);
+        }
+    }
+    dft_regs<3>(v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[w8_pad(base + (bitrev_small<3>(k) << SL))] = v[k];
+}
+
+size_t fused8_lds_bytes(int nsmp, int nlay_pad)
+{
+    // FFT array | misfits | reductions | side | (generic path only) layer constants
+    return sizeof(double2) * (size_t)(w8_pad(4095) + 2) + sizeof(double) * (size_t)(((nsmp + 1) & ~1) + 8) +
+           sizeof(double2) * 2 + spectra_lds_bytes(nlay_pad);
+}
+
+template <int NCOL>
+__global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
+{
+    extern __shared__ double2 lds2[];
+    const TraceParams &P = F.tp;
+    const DeviceTables &t = P.t;
+    constexpr int n = 4096, nh = 2049;
+    const int nsmp = t.nsmp;
+    double2 *a = lds2;
+    double *mis = reinterpret_cast<double *>(a + ((w8_pad(4095) + 2) & ~1));
+    double *red = mis + ((nsmp + 1) & ~1);
+    double2 *side = reinterpret_cast<double2 *>(red + 8);
+    double *coef = reinterpret_cast<double *>(side + 2);          // generic path only
+    double *tail = coef + (size_t)P.b.nlay_pad * NCOEF;
+
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    if (F.order_next && bid == P.b.nb * t.ntrc) {
+        // the dispatch order of the next launch (see fused_kernel)
+        int *w = reinterpret_cast<int *>(lds2);
+        order_block(P.b.nb, P.b.nlay, P.b.fwd_flag, F.order_next, w, w + 256, w + 512);
+        return;
+    }
+    const int itrc = bid % t.ntrc;            // == forward-trace index here (nfwd == ntrc)
+    const int ib = P.b.order ? P.b.order[bid / t.ntrc] : bid / t.ntrc;
+    if (bid == 0 && tid == 0) *P.slow_count = 0;
+    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
+        // 0: sigma-only proposal (likelihood.f90:81); < 0: no evaluation at all (see fused_kernel)
+        if (itrc == 0 && tid == 0 && P.b.fwd_flag[ib] < 0) {
+            P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
+            P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
+        } else if (itrc == 0 && tid == 0) {
+            const int wk = P.b.walker_ids[ib];
+            const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * t.ntrc;
+            P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
+            P.w.prop_fwd[wk] = 0;
+        }
+        return;
+    }
+    const int walker = P.b.walker_ids[ib];
+    const int ipha = t.ipha[itrc];
+    const bool decon = t.deconv_mode == 1;
+
+    const int bfi = ib * t.ntrc + itrc;
+    const int nl = P.b.nlay[ib];
+    const int stage_flags = P.w.gflag[bfi];
+    const bool sea = stage_flags & 1;             // beta(1) < 0  (forward.f90:229)
+    const int ilay0 = sea ? 1 : 0;
+    const bool generic = (stage_flags & 2) != 0 || sea != (NCOL == 3);
+    const KPtr gcoef = as_scalar_ptr(P.w.gcoef + (size_t)bfi * P.b.nlay_pad * NCOEF);
+    const KPtr gtail = as_scalar_ptr(P.w.gtail + (size_t)bfi * GTAIL);
+    const int slot = 1 - P.w.cur_slot[walker];
+
+    // ---- propagator phase: 8 waves x one 4-bin chain each -> Z in LDS ------------------------------------
+    const int nh_eff = (t.nh_active && !decon) ? t.nh_active[itrc] : nh;
+    SpectraParams sp = F.sp;
+    sp.t.nh = nh_eff;
+    sp.nsplit = W8_THREADS / 64;
+    for (int k = nh_eff + tid; k < nh; k += W8_THREADS) {
+        a[w8_pad(w8_pos(k))] = make_double2(0.0, 0.0);
+        if (k != 0 && k != 2048) a[w8_pad(w8_pos(n - k))] = make_double2(0.0, 0.0);
+    }
+    const int wave = tid >> 6, lane = tid & 63;
+    const int lane_m = (64 - lane) & 63;
+    const W8Sink sink{a, side, t.flt + (size_t)itrc * nh, nh_eff, ipha, decon,
+                      ((lane & 7) << 9) + ((lane >> 3) << 6), ((lane_m & 7) << 9) + ((lane_m >> 3) << 6)};
+    if (generic) {
+        int nl2, il2;
+        bool sea2;
+        (void)load_staged(P.w, P.b, t.ntrc, ib, itrc, coef, tail, nl2, il2, sea2);
+        if (sea)
+            spectra_body<0, 3, false>(sp, (const double *)coef, (const double *)tail, nl, ilay0, ipha, sink, wave, lane);
+        else
+            spectra_body<0, 2, false>(sp, (const double *)coef, (const double *)tail, nl, ilay0, ipha, sink, wave, lane);
+    } else {
+        spectra_body<4, NCOL, true>(sp, gcoef, gtail, nl, ilay0, ipha, sink, wave, lane);
+    }
+    __syncthreads();
+    const double tp = decon ? 0.0 : gtail[17];
+
+    if (decon) {
+        // water_level_decon (forward.f90:447-470) in place: slot(k) holds the numerator, slot(n-k) the denominator
+        double m = -HUGE_VAL;
+        for (int k = tid; k < nh; k += W8_THREADS) {
+            const bool self = (k == 0 || k == 2048);
+            const double2 x = self ? side[k == 0 ? 0 : 1] : a[w8_pad(w8_pos(n - k))];
+            m = fmax(m, x.x * x.x + x.y * x.y);                   // forward.f90:458
+        }
+        m = wave_max(m);
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        double mm = red[0];
+#pragma unroll
+        for (int w = 1; w < W8_THREADS / 64; ++w) mm = fmax(mm, red[w]);
+        const double wlvl = 0.001 * mm;                           // forward.f90:460, pcnt = 0.001 (:149)
+        const double *__restrict__ flt = t.flt + (size_t)itrc * nh;
+        for (int k = tid; k < nh; k += W8_THREADS) {
+            const bool self = (k == 0 || k == 2048);
+            const int pk = w8_pad(w8_pos(k));
+            const int pnk = self ? pk : w8_pad(w8_pos(n - k));
+            const double2 y = a[pk];
+            const double2 x = self ? side[k == 0 ? 0 : 1] : a[pnk];
+            const double amp = x.x * x.x + x.y * x.y;
+            const double dd = fmax(amp, wlvl);                    // forward.f90:464
+            const double2 yx = cmul(y, make_double2(x.x, -x.y));
+            const double fk = flt[k];
+            const double2 R = make_double2(yx.x / dd * fk, yx.y / dd * fk);
+            if (self) {
+                a[pk] = make_double2(R.x, 0.0);
+            } else {
+                a[pk] = R;
+                a[pnk] = make_double2(R.x, -R.y);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- inverse FFT: radix-8 passes of stride 1, 8, 64 through LDS, the last (stride 512) in registers -------
+    const double2 *__restrict__ tw = t.twiddle;
+    w8_pass<0>(a, tw, tid);
+    __syncthreads();
+    w8_pass<3>(a, tw, tid);
+    __syncthreads();
+    w8_pass<6>(a, tw, tid);
+    __syncthreads();
+    double2 v[8];
+    {
+        double2 w[8];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) w[k] = tw[(tid * k) & 2047];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(tid + (k << 9))];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const bool neg = (tid * k) >= 2048;
+            const double2 wk = neg ? make_double2(-w[k].x, -w[k].y) : w[k];
+            v[k] = cmul(v[k], wk);
+        }
+        dft_regs<3>(v);                    // v[k] = sample tid + (bitrev3(k) << 9): .x RF trace, .y vertical trace
+    }
+    double fac = 1.0;
+    if (!decon) {
+        double m = -HUGE_VAL;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m = fmax(m, v[k].y);
+        m = wave_max(m);
+        __syncthreads();
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        fac = red[0];                                                // maxval(rx) forward.f90:201
+#pragma unroll
+        for (int w = 1; w < W8_THREADS / 64; ++w) fac = fmax(fac, red[w]);
+    }
+    double *__restrict__ dst = P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
+    const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
+    double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
+    double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
+    const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int j = tid + (bitrev_small<3>(k) << 9) + 1;           // 1-based sample of rx
+        // invert rft(i) = rx(mod(n - npre + i, n)) (forward.f90:179) and rft(i) = -rx(mod(n + npre - i + 1, n)) (:188)
+        int i = (ipha == 1 ? j + npre : n + npre + 1 - j) & (n - 1);
+        if (i == 0) i = n;
+        double val = ipha == 1 ? v[k].x : -v[k].x;
+        if (!decon) val = val / fac;                                 // forward.f90:202
+        __builtin_nontemporal_store(val, &dst[i - 1]);
+        if (xout) xout[i - 1] = val;
+        if (i <= nsmp) {
+            const double m = val - obs[i - 1];                       // likelihood.f90:88
+            if (P.defer_logl)
+                mis_g[i - 1] = m;
+            else
+                mis[i - 1] = m;
+        }
+    }
+    if (P.defer_logl) return;   // quadratic form and logL: phi_deferred_kernel (+ logl_deferred_kernel)
+    __syncthreads();
+    // ---- phi = (misfit . R^-1) . misfit (likelihood.f90:92-93) and logL, as in trace_tail ------------------
+    const double phi = quad_form(t, itrc, mis, reinterpret_cast<double *>(a), red, tid);
+    if (tid == 0) {
+        double *phis = P.w.phi + ((size_t)slot * P.w.nslots + walker) * t.ntrc;
+        bool last = true;
+        if (t.ntrc > 1) {
+            __hip_atomic_store(phis + itrc, phi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            last = atomicAdd(P.w.done + ib, 1) == t.ntrc - 1;
+            if (last) P.w.done[ib] = 0;
+        } else {
+            phis[itrc] = phi;
+        }
+        if (last) {
+            P.b.logl[ib] = logl_from_phi(phis, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, t.ntrc > 1);
+            P.w.prop_fwd[walker] = 1;
+        }
+    }
+}
+
+void launch_fused8(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int defer_logl,
+                   int *order_next, double *extra_out, hipStream_t s)
+{
+    FusedParams F{};
+    F.order_next = order_next;
+    F.sp = SpectraParams{t, b, nullptr, W8_THREADS / 64, nullptr, slow_count, w};
+    F.tp = TraceParams{t, b, nullptr, w, 12, {}, slow_count, 0, defer_logl, extra_out};
+    const size_t lds = fused8_lds_bytes(t.nsmp, b.nlay_pad);
+    const dim3 grid((unsigned)(b.nb * t.ntrc) + (order_next ? 1u : 0u));
+    static LdsOptIn opt;
+    opt(reinterpret_cast<const void *>(fused8_kernel<2>));
+    hipLaunchKernelGGL((fused8_kernel<2>), grid, dim3(W8_THREADS), lds, s, F);
 }
 
 template <int BK, int NCOL>

@@ -436,7 +436,7 @@ def test_mixed_kinds_and_huge_phase_in_one_batch(oracle, chain, fused):
 def test_walker_without_unit_gauge_takes_the_generic_path(oracle):
     """The fast paths divide every interface's change of eigen-coordinates by its common diagonal entry
     d = 2 b'^2 p^2 + (rho / rho')(1 - 2 b^2 p^2) (the gauge of stage_interface).  A walker for which some d leaves
-    [1/16, 16] -- here density contrasts of 40 and of 35 across one interface (d ~ 36 and ~ 30 / 0.08) -- keeps the
+    [1/16, 16] -- here density contrasts of 40 and of 35 across one interface (d ~ 36 and d ~ 30) -- keeps the
     plain constants and is evaluated by the generic path; results
     agree with the oracle either way, in one batch with ordinary walkers."""
     rng = np.random.default_rng(77)
@@ -448,8 +448,7 @@ def test_walker_without_unit_gauge_takes_the_generic_path(oracle):
     stacks = [random_stack(rng, 6) for _ in range(5)]
     stacks[1][2][2] = 40.0 * stacks[1][2][3]                   # rho contrast across one interface: d ~ 40
     a, b, r, h = stacks[3]
-    b[1], b[2], r[1], r[2] = 6.2, 3.0, 0.08, 3.0               # a very light layer between ordinary ones: d ~ 30 and ~ 0.08
-    a[1] = 11.0
+    r[1] = 0.08                                                # a very light layer between ordinary ones: d ~ 30 (p = 0.06) and ~ 23 (p = 0.125)
     nlay, layers = pack_layers(stacks, 8)
     sig = np.full((5, 2), 0.05)
     ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
