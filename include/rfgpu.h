@@ -302,19 +302,21 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
  *   "nsplit"           0 by batch size (default) | 1..64 bin-splits per walker (split spectra kernel)
  *   "waves_per_block"  1..4 (default 4) waves sharing a staged layer stack (split spectra kernel)
  *   "defer_logl"       -1 by batch size (default) | 0 quadratic form + logL inside the main kernel | 1 follow-up kernels
+ *   "block_threads"    0 by batch size (default) | 256 fused_kernel | 512 fused8_kernel (nfft 4096 on land only)
  *   "bin_cutoff"       0 (default: every bin like the reference) | tol in (0, 1): bins whose Gaussian filter
  *                      weight is below tol * flt(1) are not propagated
  * A library built with -DRFGPU_DIAGNOSTICS (tools/ablate.sh; never the shipped one) also accepts
  * "ablate" = N: blocks stop after phase N, results are invalid. */
 int rf_set_option(rf_ctx *ctx, const char *name, double value);
 
-/* how rf_eval_batch* will launch, plan[10]:
+/* how rf_eval_batch* will launch, plan[12]:
  *  [0] 1 when spectra + trace run as ONE fused kernel (contexts with one forward computation per trace;
  *      then ms[0] of rf_profile_read is the fused kernel and ms[1] stays 0)
  *  [1] bins per phase chain (0: direct sincos)   [2] waves per block of the split spectra kernel
  *  [3] bin-splits per walker at a full batch     [4] lpt   [5] order_reuse   [6] defer_logl (-1 / 0 / 1)
  *  [7] 1 when a bin cut-off is active            [8] number of options away from their defaults
- *  [9] 0 production build | 1 RFGPU_DIAGNOSTICS build | 2 diagnostics build with "ablate" set (results invalid) */
+ *  [9] 0 production build | 1 RFGPU_DIAGNOSTICS build | 2 diagnostics build with "ablate" set (results invalid)
+ *  [10] the "block_threads" option (0 = by batch size)   [11] threads per block of the fused kernel at a full batch */
 int rf_get_launch_plan(const rf_ctx *ctx, int32_t *plan);
 
 /* HIP-event timing (on the streams the kernels are launched on) of the three kernels

@@ -73,6 +73,8 @@ struct rf_ctx {
     bool fused_allowed = false;   // the context's shape admits the fused kernel
     int fused_override = -1;  // "fused": -1 = by shape
     int defer_logl = -1;      // "defer_logl": -1 = by batch size, 0 / 1 = never / always
+    int block_threads = 0;    // "block_threads": 0 = by batch size, 256 / 512 = fused_kernel / fused8_kernel
+    int fused8_max_rounds = 0;   // batches of up to this many rounds of blocks (2 blocks per CU) take fused8_kernel
     double bin_cutoff = 0.0;  // "bin_cutoff": opt-in filter-support cut-off (0 = off: every bin like the reference)
     int n_overrides = 0;      // options set away from their defaults (echoed by rf_get_launch_plan)
     int ablate = 0;           // RFGPU_DIAGNOSTICS builds only ("ablate"): stops the kernel early, results invalid
@@ -538,6 +540,19 @@ static int pick_nsplit(const rf_ctx *c, int nb)
     return ns;
 }
 
+// 512-thread blocks (fused8_kernel: nfft 4096, land, default phase chains) or 256-thread blocks (fused_kernel).
+// The 8-wave block executes ~13 % more instructions per bin and layer (4-bin phase chains: twice the anchors of
+// 8-bin chains) but keeps four waves per SIMD and halves a block's latency-bound tail: it wins while the launch is
+// a few rounds of blocks (latency-bound: C2), the 4-wave block once the chip is saturated with work (C3, C4).
+static bool use_fused8(const rf_ctx *c, long long blocks)
+{
+    const bool can = c->fused && c->cfg.nfft == 4096 && c->cfg.sdep <= 0.0 && c->chain_override < 0 && c->ablate == 0 &&
+                     fused8_lds_bytes(c->cfg.nsmp, c->cfg.nlay_max) <= 80 * 1024;
+    if (!can || c->block_threads == 256) return false;
+    if (c->block_threads == 512) return true;
+    return blocks <= (long long)c->fused8_max_rounds * 2 * c->num_cu;
+}
+
 static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
 {
     if (b_in.nb <= 0) return 0;
@@ -580,7 +595,10 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl
                           : (c->cfg.ntrc > 1 ? blocks >= 2 * round : blocks >= 4 * round));
         hipEvent_t e = prof_begin(c, 0, s);
-        launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, c->single_trace_out, s);
+        if (use_fused8(c, blocks))
+            launch_fused8(c->tab, b, c->ws, c->slow_count, defer, order_next, c->single_trace_out, s);
+        else
+            launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, c->single_trace_out, s);
         if (e) (void)hipEventRecord(e, s);
         if (defer) launch_logl_deferred(c->tab, b, c->ws, s);
     } else {
@@ -1113,6 +1131,10 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     } else if (k == "defer_logl") {
         if (!integral || iv < -1 || iv > 1) return fail("rf_set_option: defer_logl must be -1 (by batch size), 0 or 1");
         c->defer_logl = iv;
+    } else if (k == "block_threads") {
+        if (!integral || !(iv == 0 || iv == 256 || iv == 512))
+            return fail("rf_set_option: block_threads must be 0 (by batch size), 256 or 512");
+        c->block_threads = iv;
     } else if (k == "bin_cutoff") {
         if (!(value >= 0.0 && value < 1.0)) return fail("rf_set_option: bin_cutoff must be in [0, 1)");
         c->bin_cutoff = value;
@@ -1127,7 +1149,7 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     default_plan(c);
     c->n_overrides = (c->fused_override != -1) + (c->chain_override != -1) + (!c->lpt) + (!c->order_reuse) +
                      (c->nsplit_override != 0) + (c->waves_per_block != 4) + (c->defer_logl != -1) +
-                     (c->bin_cutoff > 0.0) + (c->ablate != 0);
+                     (c->block_threads != 0) + (c->bin_cutoff > 0.0) + (c->ablate != 0);
     return 0;
 }
 
@@ -1148,6 +1170,8 @@ extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
 #else
     plan[9] = 0;
 #endif
+    plan[10] = c->block_threads;
+    plan[11] = use_fused8(c, (long long)c->cfg.max_walkers * c->cfg.ntrc) ? 512 : 256;
     return 0;
 }
 

@@ -605,14 +605,15 @@ __device__ __forceinline__ double phase_eps(double arg, double kd, double phi_hi
 // rounding is part of the reference result -- is recovered to first order from
 // eps = arg - k phi (|eps| < 1e-9, second order < 1e-18).  ~13 instructions per extra
 // sincos instead of ~45.  Chain length <= BK-1 rotations (error growth ~1 ulp per step).
-template <int BK, int NCOL, class Sink, class CP = const double *>
+template <int BK, int NCOL, class Sink, class CP = const double *, bool TIGHT = false>
 __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP coef, CP tail,
                                                     int nl, int ilay0, int ipha, const Sink &sink, int it0, int lane)
 {
     // long chains (and the 3-column ocean kernel) keep only the first bin's index and rebuild k, omega
     // of the others where they are used (2 instructions per bin and layer; the values are the same
     // doubles) to stay within the register budget of two waves per SIMD
-    constexpr bool LEAN = BK >= 8 || (NCOL == 3 && BK >= 4);
+    // (TIGHT: the 128-VGPR budget of fused8_kernel)
+    constexpr bool LEAN = TIGHT || BK >= 8 || (NCOL == 3 && BK >= 4);
     ColState<NCOL> st[BK];
     double omg[LEAN ? 1 : BK], kd[LEAN ? 1 : BK];
     const int k0 = it0 * 64 + lane;
@@ -684,7 +685,7 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
 // the bins of one (walker, forward-trace) assigned to `split` of P.nsplit:
 // full chunks of BK iterations go through the chained-phase path, the remaining
 // iterations (and everything when BK == 0) through the direct path.
-template <int BK, int NCOL, bool FAST, class Sink, class CP = const double *>
+template <int BK, int NCOL, bool FAST, class Sink, class CP = const double *, bool TIGHT = false>
 __device__ __forceinline__ void spectra_body(const SpectraParams &P, CP coef, CP tail,
                                              int nl, int ilay0, int ipha, const Sink &sink, int split, int lane)
 {
@@ -693,7 +694,7 @@ __device__ __forceinline__ void spectra_body(const SpectraParams &P, CP coef, CP
     if (BK > 1 && FAST) {
         const int nchunk = niter / BK;
         for (int ch = split; ch < nchunk; ch += P.nsplit)
-            spectra_chunk_chain<(BK > 1 ? BK : 2), NCOL>(P, coef, tail, nl, ilay0, ipha, sink, ch * BK, lane);
+            spectra_chunk_chain<(BK > 1 ? BK : 2), NCOL, Sink, CP, TIGHT>(P, coef, tail, nl, ilay0, ipha, sink, ch * BK, lane);
         it_direct0 = nchunk * BK;
     }
     // leftover iterations: spread from the last split downwards (the chunk loop loads
@@ -745,24 +746,30 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
     const int ib = P.b.order ? P.b.order[bf / P.t.nfwd] : bf / P.t.nfwd;
     if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) return;
 
-    double *coef = lds;
-    double *tail = lds + (size_t)P.b.nlay_pad * NCOEF;
-    int nl, ilay0;
-    bool sea;
-    const bool big = load_staged(P.w, P.b, P.t.nfwd, ib, f, coef, tail, nl, ilay0, sea);
+    // stage_kernel's constants: the fast paths read them through the scalar data path; only a walker on the generic
+    // path (rare) copies the image into LDS
+    const int bfi = ib * P.t.nfwd + f;   // (walker, forward-trace) index in batch order
+    const int nl = P.b.nlay[ib];
+    const int stage_flags = P.w.gflag[bfi];
+    const bool sea = stage_flags & 1;    // beta(1) < 0  (forward.f90:229)
+    const int ilay0 = sea ? 1 : 0;
     const int ipha = P.t.ipha[f];
     double2 *out_r = P.spec + ((size_t)(ib * P.t.nfwd + f) * 2) * P.t.nh;
     const GlobalSink sink{out_r, out_r + P.t.nh, P.t.nh};
-    const int bfi = ib * P.t.nfwd + f;   // (walker, forward-trace) index in batch order
-    if (big || sea != (NCOL == 3)) {
-        // rare: out-of-range phases or a layer stack of the other kind (land / ocean)
+    if ((stage_flags & 2) != 0 || sea != (NCOL == 3)) {
+        // rare: out-of-range phases, no unit gauge, or a layer stack of the other kind (land / ocean)
         if (BK > 1) {
             // the chained-phase kernels have the registers to spare: generic path in place
+            double *coef = lds;
+            double *tail = lds + (size_t)P.b.nlay_pad * NCOEF;
+            int nl2, il2;
+            bool sea2;
+            (void)load_staged(P.w, P.b, P.t.nfwd, ib, f, coef, tail, nl2, il2, sea2);
             if (split >= P.nsplit) return;
             if (sea)
-                spectra_body<0, 3, false>(P, coef, tail, nl, ilay0, ipha, sink, split, lane);
+                spectra_body<0, 3, false>(P, (const double *)coef, (const double *)tail, nl, ilay0, ipha, sink, split, lane);
             else
-                spectra_body<0, 2, false>(P, coef, tail, nl, ilay0, ipha, sink, split, lane);
+                spectra_body<0, 2, false>(P, (const double *)coef, (const double *)tail, nl, ilay0, ipha, sink, split, lane);
         } else if (blockIdx.x % nblk == 0 && threadIdx.x == 0) {
             // the lean direct kernel (4 waves/SIMD) defers to spectra_slow_kernel via the list
             P.slow_list[atomicAdd(P.slow_count, 1)] = bfi;
@@ -770,7 +777,9 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
         return;
     }
     if (split >= P.nsplit) return;
-    spectra_body<BK, NCOL, true>(P, coef, tail, nl, ilay0, ipha, sink, split, lane);
+    const KPtr gcoef = as_scalar_ptr(P.w.gcoef + (size_t)bfi * P.b.nlay_pad * NCOEF);
+    const KPtr gtail = as_scalar_ptr(P.w.gtail + (size_t)bfi * GTAIL);
+    spectra_body<BK, NCOL, true>(P, gcoef, gtail, nl, ilay0, ipha, sink, split, lane);
 }
 
 // walkers whose phases exceed the Cody-Waite range (|x| >= 1e6 rad): same body with ocml's
@@ -2077,7 +2086,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
         else
             spectra_body<0, 2, false>(sp, (const double *)coef, (const double *)tail, nl, ilay0, ipha, sink, wave, lane);
     } else {
-        spectra_body<4, NCOL, true>(sp, gcoef, gtail, nl, ilay0, ipha, sink, wave, lane);
+        spectra_body<4, NCOL, true, W8Sink, KPtr, true>(sp, gcoef, gtail, nl, ilay0, ipha, sink, wave, lane);
     }
     __syncthreads();
     const double tp = decon ? 0.0 : gtail[17];

@@ -115,8 +115,10 @@ def test_hip_matches_reflectivity_solution(case, fused):
 
 
 @pytest.mark.gpu
-def test_hip_c4_traces_match_reflectivity_solution():
-    """The C4 trace set (P .06, P .08, S .10; nfft 4096, 8-bin phase chains) on a 12-layer stack, batched entry."""
+@pytest.mark.parametrize("block_threads", [256, 512])
+def test_hip_c4_traces_match_reflectivity_solution(block_threads):
+    """The C4 trace set (P .06, P .08, S .10; nfft 4096) on 2 .. 29-layer stacks, batched entry: the 4-wave fused kernel
+    (8-bin phase chains, radix-16 FFT) and the 8-wave one (4-bin chains, radix-8 FFT)."""
     from rf_inv_amd import RFEngine
 
     rng = np.random.default_rng(404)
@@ -127,8 +129,9 @@ def test_hip_c4_traces_match_reflectivity_solution():
     nlay, layers = pack_layers(stacks, 32)
     with RFEngine(nfft=4096, delta=DELTA, t_start=T_START, deconv_mode=0, sdep=0.0, rayps=rayps,
                   a_gus=np.full(3, A_GUS), ipha=ipha, obs=np.zeros((3, 101)), nsmp=101, max_walkers=4,
-                  nlay_max=32) as eng:
+                  nlay_max=32, options={"block_threads": block_threads}) as eng:
         assert eng.launch_plan["fused"] and eng.launch_plan["chain"] == 8
+        assert eng.launch_plan["block_threads_full_batch"] == block_threads
         eng.eval_batch(np.arange(4), nlay, layers, np.full((4, 3), 0.01))
         for i, st in enumerate(stacks):
             got = eng.get_rft(i, which=1)

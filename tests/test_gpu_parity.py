@@ -168,9 +168,11 @@ def test_nsplit_and_block_shape_variants_agree(oracle):
     assert np.abs(outs[4][1] - outs[0][1]).max() <= 1e-13 * np.abs(outs[0][1]).max()
 
 
-def test_full_size_properties(oracle):
+@pytest.mark.parametrize("block_threads", [256, 512])
+def test_full_size_properties(oracle, block_threads):
     """BASELINE config-2 shape (nfft 4096, 15 layers, 1024 walkers): properties that do
-    not need the oracle at full size + a sampled oracle check."""
+    not need the oracle at full size + a sampled oracle check; with the 4-wave fused_kernel (radix-16 FFT) and
+    the 8-wave fused8_kernel (4-bin chains, radix-8 FFT)."""
     rng = np.random.default_rng(2)
     cfg = make_cfg(nfft=4096, rayps=[0.06])
     nsmp = 101
@@ -181,7 +183,7 @@ def test_full_size_properties(oracle):
     stacks = [random_stack(rng, int(rng.integers(2, 16))) for _ in range(nb - 1)] + [true]
     nlay, layers = pack_layers(stacks, 16)
     sig = np.full((nb, 1), 0.01)
-    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb) as eng:
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, options={"block_threads": block_threads}) as eng:
         ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
         # (1) permutation invariance: walkers are independent
         perm = rng.permutation(nb)
@@ -229,6 +231,52 @@ def test_full_size_properties_three_traces(oracle):
     idx = rng.choice(nb, 12, replace=False)
     ref = oracle.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], nsmp)
     assert np.all(np.abs(ll[idx] - ref) <= logl_tol(ref)), np.abs(ll[idx] - ref).max()
+
+
+@pytest.mark.parametrize("deconv", [0, 1])
+def test_eight_wave_fused_kernel(oracle, deconv):
+    """fused8_kernel (512-thread blocks: nfft 4096, land) on every branch it carries: P and S traces, with and without
+    water-level deconvolution, a walker on the generic path (out-of-range phases; a water layer in a land context),
+    in-kernel and deferred quadratic forms, sigma-only items after a commit, and the per-call entry -- against the
+    oracle, and against the 4-wave kernel to rounding."""
+    rng = np.random.default_rng(88 + deconv)
+    cfg = make_cfg(nfft=4096, deconv_mode=deconv, rayps=[0.06, 0.10], ipha=[1, -1], t_start=-2.0, a_gus=[4.0, 2.5])
+    nsmp = 101
+    true = random_stack(rng, 5)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, int(n)) for n in (2, 3, 8, 17, 30, 12, 12)] + [true]
+    stacks[5][3][3] = 2.5e5                        # out-of-range phases
+    stacks[6] = random_stack(rng, 12, ocean=True)  # beta(1) < 0 with sdep = 0
+    nlay, layers = pack_layers(stacks, 32)
+    nb = len(stacks)
+    sig = np.column_stack([np.full(nb, 0.01), np.full(nb, 0.03)])
+    ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True, nthreads=4)
+    res = {}
+    for bt in (256, 512):
+        for defer in (0, 1):
+            with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=32,
+                         options={"block_threads": bt, "defer_logl": defer}) as eng:
+                assert eng.launch_plan["block_threads_full_batch"] == bt
+                ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+                rft = np.stack([eng.get_rft(i, which=1).T for i in range(nb)])
+                assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (bt, defer, np.abs(ll - ref_ll).max())
+                for i in range(nb):
+                    assert np.abs(rft[i] - ref_rft[i]).max() <= 1e-11 * np.abs(ref_rft[i]).max(), (bt, i)
+                eng.commit(np.arange(nb), np.ones(nb, dtype=np.int32))
+                ff = (np.arange(nb) % 2).astype(np.int32)
+                ll2 = eng.eval_batch(np.arange(nb), nlay[::-1].copy(), layers[::-1].copy(), 2 * sig, fwd_flag=ff)
+                use_l = np.where(ff[:, None, None] == 1, layers[::-1], layers)
+                use_n = np.where(ff == 1, nlay[::-1], nlay)
+                ref2 = oracle.eval_batch(cfg, obs, r_inv, use_n, use_l, 2 * sig, nsmp, nthreads=4)
+                assert np.all(np.abs(ll2 - ref2) <= logl_tol(ref2)), (bt, defer, np.abs(ll2 - ref2).max())
+                one, rft1 = eng.calc_likelihood(0, True, int(nlay[3]), *[layers[3, r, :nlay[3]] for r in range(4)], sig[3])
+                assert abs(one - ref_ll[3]) <= logl_tol(ref_ll[3])
+                assert np.abs(rft1.T - ref_rft[3]).max() <= 1e-12 * np.abs(ref_rft[3]).max()
+                res[(bt, defer)] = (ll, rft)
+    assert np.array_equal(res[(512, 0)][0], res[(512, 1)][0])        # same arithmetic in-kernel and deferred
+    d = np.abs(res[(512, 0)][1] - res[(256, 0)][1]).max(axis=(1, 2)) / np.abs(res[(256, 0)][1]).max(axis=(1, 2))
+    assert d.max() <= 1e-12
 
 
 def test_r_inv_builtin_matches_lapack(oracle):
