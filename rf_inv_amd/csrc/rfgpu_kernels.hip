@@ -861,9 +861,10 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
         bool unit;
         const double gauge = walker_gauge(L, pad, nl, ilay0, p, lane, unit);
         big = !unit;
-        for (int w0 = 0; w0 < 4 * (pad - 1); w0 += 64) {
+        // (layer, part) pairs of the walker's own nl - 1 layers above the half-space: a 16-layer walker is one pass
+        for (int w0 = 0; w0 < 4 * (nl - 1); w0 += 64) {
             const int l = (w0 + lane) >> 2, part = lane & 3;
-            if (l >= pad - 1) continue;
+            if (l >= nl - 1) continue;
             const double *V = (part == 1 || part == 2) ? L : L + pad;   // parts 1, 2: alpha (xi); 0, 3: beta (eta)
             // this layer and the one below it
             const double v0 = V[l], a0 = L[l], b0 = L[pad + l], r0 = L[2 * pad + l], h0 = L[3 * pad + l];

@@ -236,7 +236,7 @@ def test_full_size_properties_three_traces(oracle):
 @pytest.mark.parametrize("deconv", [0, 1])
 def test_eight_wave_fused_kernel(oracle, deconv):
     """fused8_kernel (512-thread blocks: nfft 4096, land) on every branch it carries: P and S traces, with and without
-    water-level deconvolution, a walker on the generic path (out-of-range phases; a water layer in a land context),
+    water-level deconvolution, walkers on the generic path (out-of-range phases; no unit gauge),
     in-kernel and deferred quadratic forms, sigma-only items after a commit, and the per-call entry -- against the
     oracle, and against the 4-wave kernel to rounding."""
     rng = np.random.default_rng(88 + deconv)
@@ -247,7 +247,7 @@ def test_eight_wave_fused_kernel(oracle, deconv):
     r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
     stacks = [random_stack(rng, int(n)) for n in (2, 3, 8, 17, 30, 12, 12)] + [true]
     stacks[5][3][3] = 2.5e5                        # out-of-range phases
-    stacks[6] = random_stack(rng, 12, ocean=True)  # beta(1) < 0 with sdep = 0
+    stacks[6][2][4] = 40.0 * stacks[6][2][5]       # density contrast of 40 across an interface: no unit gauge
     nlay, layers = pack_layers(stacks, 32)
     nb = len(stacks)
     sig = np.column_stack([np.full(nb, 0.01), np.full(nb, 0.03)])
