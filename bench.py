@@ -442,9 +442,10 @@ def main():
         # its own forward computation, else spectra_kernel (then trace_kernel follows it)
         kernel_ms = prof["spectra_ms"] / n_l if prof["launches"] else None
         f_dom = f_tot if plan["fused"] else f_spec
-        kname = "rfgpu::fused_kernel" if plan["fused"] else "rfgpu::spectra_kernel"
+        bt = plan["block_threads_full_batch"]      # 512: fused8_kernel (launches of up to four rounds of blocks)
+        kname = ("rfgpu::fused8_kernel" if bt == 512 else "rfgpu::fused_kernel") if plan["fused"] else "rfgpu::spectra_kernel"
         if plan["fused"]:
-            grid_threads = 256 * (nb * p.ntrc + (1 if (plan["lpt"] and plan["order_reuse"] and nb >= 512) else 0))
+            grid_threads = bt * (nb * p.ntrc + (1 if (plan["lpt"] and plan["order_reuse"] and nb >= 512) else 0))
         else:
             grid_threads = None   # split path: matched by name only (nsplit decides the grid)
         ctr = committed_counters(kname, grid_threads) if grid_threads else None
