@@ -231,16 +231,13 @@ __device__ __forceinline__ void stage_interface(double *g, int part, const Layer
     const double pr = w->p / w->rho;            // p / rho'
     const double m = u.tb2p * u.rho;            // 2 b^2 rho p
     double diag_a = interface_diag(u, *w);
-    double off_a = u.slow * (w->tb2p - m / w->rho);
-    double off_b = (w->bp * u.p - pr * (u.rho * u.bp)) / w->slow;
-    double diag_b = u.slow * (w->bp + pr * m) / w->slow;
-    if (unit) {
-        const double inv = 1.0 / diag_a;
-        diag_a = 1.0;
-        off_a *= inv;
-        off_b *= inv;
-        diag_b *= inv;
-    }
+    // the unit gauge's 1 / d rides on the two divisors the entries have anyway (no division of its own)
+    const double ga = unit ? diag_a : 1.0;
+    double off_a = u.slow * (w->tb2p - m / w->rho) / ga;
+    const double ws = w->slow * ga;
+    double off_b = (w->bp * u.p - pr * (u.rho * u.bp)) / ws;
+    double diag_b = u.slow * (w->bp + pr * m) / ws;
+    if (unit) diag_a = 1.0;
     if (part == 0) {
         g[0] = diag_a; g[1] = off_a; g[2] = off_b; g[3] = diag_b;
     } else {
@@ -880,23 +877,18 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
                         stage_interface(c + 3 + 4 * part, part, u, nullptr, unit);
                     }
                 } else {
+                    // parts 2 (P) and 3 (S) run the SAME instructions on different inputs and store at offsets
+                    // that differ by a constant: the two halves of the wave do not diverge
+                    const int s = part - 2;
                     const double slow = vertical_slowness(v0, p);
                     // phases of the Nyquist bin, argument formed like the reference (forward.f90:397-400)
                     double sn, cn;
                     sincos_cw((omg_nyq * slow) * h0, sn, cn);
-                    if (part == 2) {
-                        c[0] = slow;
-                        c[2] = h0;
-                        stage_phase(c + 11, c + 15, S.t.domg, slow, h0);
-                        c[19] = sn;
-                        c[20] = cn;
-                    } else {
-                        c[1] = slow;
-                        stage_phase(c + 13, c + 17, S.t.domg, slow, h0);
-                        c[21] = sn;
-                        c[22] = cn;
-                        c[23] = 0.0;
-                    }
+                    c[s] = slow;
+                    c[2 + 21 * s] = s ? 0.0 : h0;      // c[2] = h (part 2), c[23] = pad (part 3)
+                    stage_phase(c + 11 + 2 * s, c + 15 + 2 * s, S.t.domg, slow, h0);
+                    c[19 + 2 * s] = sn;
+                    c[20 + 2 * s] = cn;
                     big |= fabs(omg_max * slow * h0) >= SINCOS_CW_LIMIT;
                 }
             }
