@@ -55,16 +55,20 @@
  *       log-likelihood.  Provenance caveat: that number comes from the
  *       surveyor's probe build (FFT/LAPACK link shims), not from a fixture the
  *       reference ships.
- * Branches with NO reference-derived known answers: S-phase traces and
- * water-level deconvolution.  They are restated from the cited lines and
- * checked by (a) an independent numpy restatement (oracle/rf_oracle.py:
- * calc_seis_numpy; tests/test_oracle_kat.py water-level test), (b) a
- * physics known answer that does not come from the reference: for a
- * homogeneous half-space u_r/u_z must equal the classic free-surface
- * apparent-angle relations for P and for SV incidence
- * (test_homogeneous_halfspace_apparent_angle), which exercises the S
- * boundary-condition lines.  They remain "parity unpinned" by reference
- * outputs -- see DESIGN.md.
+ * Branches with NO reference-GENERATED known answers: S-phase traces and
+ * water-level deconvolution (the reference ships no such fixture and its
+ * forward module cannot be built here).  They are pinned by an INDEPENDENT
+ * formulation instead (tests/analytic_layered.py, tests/test_analytic_pins.py):
+ * the receiver function of a layer stack by the reflectivity method --
+ * scattering matrices from numerically solved boundary conditions, Kennett's
+ * addition rules, the reverberation operator; no propagator product -- plus
+ * the textbook receiver-function processing, with the reference's integer
+ * quirks listed one by one.  This file and the HIP path both agree with it to
+ * 1e-11 of the trace scale for P and S, with and without deconvolution,
+ * 2..29 layers, on models where the water level clips bins.  Also kept: an
+ * independent numpy restatement (calc_seis_numpy) and the half-space
+ * apparent-angle relations (tests/test_oracle_kat.py).  With respect to
+ * reference OUTPUTS these two branches remain "parity unpinned".
  */
 #include <math.h>
 #include <stdlib.h>

@@ -8,7 +8,7 @@ namespace rfgpu {
 
 struct CommState;   // rfgpu_comm.cpp
 
-// doubles of per-layer coefficients staged in LDS (see stage_layer_coef)
+// doubles of per-layer constants written by stage_kernel (layout: the comment above K1 in rfgpu_kernels.hip)
 constexpr int NCOEF = 24;
 // doubles per (batch item, forward-trace) of walker constants written by stage_kernel
 constexpr int GTAIL = 24;

@@ -116,11 +116,13 @@ __device__ __noinline__ double arrival_sum(int n, const double *terms)
 // blocks, 8 instructions, wave-uniform coefficients.  The phases are the reference's own doubles
 // (w xi) h.  Only the columns the boundary condition consumes are propagated (1, 2; ocean: + 4).
 //
-// LDS image per (walker, forward-trace), staged once per block:
+// Constants per (batch item, forward-trace), written once per batch item by stage_kernel (K0) into a global image
+// (gcoef / gtail of WalkerState).  The fast paths read it through the scalar data path (KPtr); a walker on the
+// generic path copies it into LDS (load_staged).
 //   coef[l][0..NCOEF-1]  per solid layer l (0-based, l < nlay-1):
 //      0 xi   1 eta   2 h
 //      3..10  G: a_p'<-(a_p, b_s), b_s'<-(a_p, b_s), b_p'<-(b_p, a_s), a_s'<-(b_p, a_s)
-//             (identity below the last solid layer)
+//             (identity below the last solid layer; in the unit gauge c[3] = c[10] = 1, see stage_interface)
 //     11,12 phi_xi  = domg*xi*h  as a double-double (hi, lo)   } phase per bin of the layer and
 //     13,14 phi_eta = domg*eta*h as a double-double            } cos/sin of 64 bins of phase:
 //     15,16 cos, sin(64 phi_xi)   17,18 cos, sin(64 phi_eta)   } the chained-phase path (below)
@@ -130,7 +132,7 @@ __device__ __noinline__ double arrival_sum(int n, const double *terms)
 //   tail[0..7]   rows 3,4 of E^-1 T of the half-space in the last solid layer's eigen-coordinates
 //   tail[8..10]  water layer: xi_w, h_w, rho_w / xi_w
 //   tail[11..16] unit columns 1, 2, 4 in the top solid layer's eigen-coordinates (stage_start)
-//   tail[24..]   per-layer direct-arrival terms
+//   tail[17]     direct-arrival time of the forward trace (forward.f90:474-519)
 __device__ __forceinline__ void sincos_cw(double x, double &sn, double &cs);
 
 // vertical slowness sqrt(1/v^2 - p^2) exactly as the reference's double arithmetic forms it
@@ -830,11 +832,13 @@ struct StageParams {
     BatchArgs b;
     double *gcoef, *gtail;
     int *gflag;
+    int via_lds;
 };
 
 __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
 {
-    extern __shared__ double lds[];                 // [4][nlay_pad] direct-arrival terms, one row per wave
+    extern __shared__ double lds[];                 // [4][nlay_pad] direct-arrival terms, one row per wave, then
+                                                    // (S.via_lds) [4][nlay_pad * NCOEF + GTAIL] the waves' images
     const int pad = S.b.nlay_pad;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bf = blockIdx.x * 4 + wave;
@@ -842,19 +846,24 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
     const int ib = live ? bf / S.t.nfwd : 0, f = live ? bf % S.t.nfwd : 0;
     const bool run = live && (!S.b.fwd_flag || S.b.fwd_flag[ib] == 1);
     double *terms = lds + (size_t)wave * pad;
+    // The constants are assembled in LDS and leave as whole 16-byte-per-lane rows: written straight to the global
+    // image they are 8- to 32-byte pieces scattered over every layer's 192-byte record (partial-line writes:
+    // 128 MB of them per C4 launch took as long as the arithmetic).  Contexts whose images do not fit 64 KB of
+    // LDS (nlay_max > 78) write directly.
+    double *img = S.via_lds ? lds + 4 * (size_t)pad + (size_t)wave * ((size_t)pad * NCOEF + GTAIL) : nullptr;
     bool big = false;
-    int nl = 2;
+    int nl = 2, ilay0 = 0;
     if (run) {
         const double *L = S.b.layers + (size_t)ib * 4 * pad;
         nl = S.b.nlay[ib];
         const double p = S.t.rayps[f];
         const bool sea = L[pad] < 0.0;              // beta(1) < 0  (forward.f90:229)
-        const int ilay0 = sea ? 1 : 0;
+        ilay0 = sea ? 1 : 0;
         const bool solid = nl - 1 > ilay0;          // at least one solid layer above the half-space
         const double omg_max = (double)(S.t.nh - 1) * S.t.domg;
         const double omg_nyq = (double)(S.t.nfft / 2) * S.t.domg;
-        double *coef = S.gcoef + (size_t)bf * pad * NCOEF;
-        double *tail = S.gtail + (size_t)bf * GTAIL;
+        double *coef = img ? img : S.gcoef + (size_t)bf * pad * NCOEF;
+        double *tail = img ? img + (size_t)pad * NCOEF : S.gtail + (size_t)bf * GTAIL;
         bool unit;
         const double gauge = walker_gauge(L, pad, nl, ilay0, p, lane, unit);
         big = !unit;
@@ -920,6 +929,13 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
     }
     const bool any_big = __any(big);
     __syncthreads();
+    if (run && img) {
+        // layers ilay0 .. nl-2 and the walker constants, 16 bytes per lane, contiguous
+        const double2 *src = reinterpret_cast<const double2 *>(img);
+        double2 *dst = reinterpret_cast<double2 *>(S.gcoef + (size_t)bf * pad * NCOEF);
+        for (int i = ilay0 * (NCOEF / 2) + lane; i < (nl - 1) * (NCOEF / 2); i += 64) dst[i] = src[i];
+        if (lane < 17) S.gtail[(size_t)bf * GTAIL + lane] = img[(size_t)pad * NCOEF + lane];
+    }
     if (run && lane == 0) {
         const double *L = S.b.layers + (size_t)ib * 4 * pad;
         const int i0 = S.t.sdep > 0.0 ? 1 : 0;
@@ -930,9 +946,12 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
 
 void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
 {
-    StageParams S{t, b, w.gcoef, w.gtail, w.gflag};
+    const size_t lds_img = sizeof(double) * 4 * ((size_t)b.nlay_pad * (NCOEF + 1) + GTAIL);
+    const int via_lds = lds_img <= 64 * 1024;
+    StageParams S{t, b, w.gcoef, w.gtail, w.gflag, via_lds};
     const unsigned nbf = (unsigned)(b.nb * t.nfwd);
-    hipLaunchKernelGGL(stage_kernel, dim3((nbf + 3) / 4), dim3(256), sizeof(double) * 4 * (size_t)b.nlay_pad, s, S);
+    hipLaunchKernelGGL(stage_kernel, dim3((nbf + 3) / 4), dim3(256),
+                       via_lds ? lds_img : sizeof(double) * 4 * (size_t)b.nlay_pad, s, S);
 }
 
 template <int BK, int NCOL>
@@ -1835,7 +1854,7 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
     RFGPU_ABLATE_AT(5, );   // timing diagnostics: launch + staging only
 
     // ---- propagator phase: 4 waves x interleaved chunks of bins -> Z in LDS ----------------
-    // Optional (off by default, RFGPU_BIN_CUTOFF): bins whose Gaussian filter weight is below
+    // Optional (off by default, rf_set_option "bin_cutoff"): bins whose Gaussian filter weight is below
     // cutoff * flt(0) are not propagated; their Z entries are zero.  Only without deconvolution
     // (the water level needs the maximum over every bin).
     const int nh_eff = (t.nh_active && !decon) ? t.nh_active[itrc] : nh;
