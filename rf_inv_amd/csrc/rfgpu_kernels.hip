@@ -20,6 +20,7 @@
 #include "rfgpu_internal.h"
 #include <math.h>
 #include <atomic>
+#include <type_traits>
 
 // Timing diagnostics (tools/ablate.sh): a build with -DRFGPU_DIAGNOSTICS can stop a block after phase N
 // to split the kernel time; the production library has no such exits.
@@ -438,6 +439,47 @@ __device__ __forceinline__ void apply_layer_trig_unit(ColState<NCOL> &s, CP c, d
     }
 }
 
+// The constants of one layer that the chained-phase loop uses, as values: the loop fetches the NEXT layer's set while
+// it works on the current one (scalar loads have no other latency hiding: a wave that waits for its s_load at the
+// top of every layer idles a few hundred cycles per layer).
+struct LayerK {
+    double xi, eta, h;
+    double g1, g2, g3, g4, g5, g6;              // c[4..9]: G in the unit gauge (c[3] = c[10] = 1)
+    double px_hi, px_lo, pe_hi, pe_lo;          // c[11..14]
+    double Cx, Sx, Ce, Se;                      // c[15..18]
+};
+
+template <class CP>
+__device__ __forceinline__ LayerK load_layer_k(CP c)
+{
+    LayerK k;
+    k.xi = c[0]; k.eta = c[1]; k.h = c[2];
+    k.g1 = c[4]; k.g2 = c[5]; k.g3 = c[6]; k.g4 = c[7]; k.g5 = c[8]; k.g6 = c[9];
+    k.px_hi = c[11]; k.px_lo = c[12]; k.pe_hi = c[13]; k.pe_lo = c[14];
+    k.Cx = c[15]; k.Sx = c[16]; k.Ce = c[17]; k.Se = c[18];
+    return k;
+}
+
+template <int NCOL>
+__device__ __forceinline__ void apply_layer_trig_unit(ColState<NCOL> &s, const LayerK &k, double sx, double cx, double se,
+                                                      double ce)
+{
+#pragma unroll
+    for (int j = 0; j < NCOL; ++j) {
+        const double ap = s.v[j][0], bp = s.v[j][1], as = s.v[j][2], bs = s.v[j][3];
+        // (same operation order as the pointer form above)
+        const double u1 = sx * ap, u2 = sx * bp, u3 = se * as, u4 = se * bs;
+        const double rap = fma(cx, ap, -u2);
+        const double rbp = fma(cx, bp, u1);
+        const double ras = fma(ce, as, -u4);
+        const double rbs = fma(ce, bs, u3);
+        s.v[j][0] = fma(k.g1, rbs, rap);
+        s.v[j][3] = fma(k.g2, rap, k.g3 * rbs);
+        s.v[j][2] = fma(k.g6, rbp, ras);
+        s.v[j][1] = fma(k.g5, ras, k.g4 * rbp);
+    }
+}
+
 // FAST: the walker's constants carry the unit gauge (the fast paths run only for such walkers)
 template <int NCOL, bool FAST, class CP = const double *>
 __device__ __forceinline__ void apply_layer(ColState<NCOL> &s, CP c, double omg)
@@ -546,7 +588,9 @@ struct GlobalSink {
     double2 *__restrict__ out_r;
     double2 *__restrict__ out_v;
     int nh;
-    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz) const
+    // (the sinks that apply the Gaussian filter hand out its weight ahead of the bin: see LdsSink)
+    __device__ __forceinline__ double weight(int) const { return 1.0; }
+    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz, double) const
     {
         store_bin(out_r, out_v, k, nh, ur, uz);
     }
@@ -560,12 +604,13 @@ __device__ __forceinline__ void spectra_iter_direct(const SpectraParams &P, CP c
     const int k = it * 64 + lane;
     // forward.f90:245-248: omega = (iomg-1) * domg, DC bin uses the single literal 1.0e-5
     const double omg = k == 0 ? P.t.omg_dc : (double)k * P.t.domg;
+    const double wgt = sink.weight(k);
     ColState<NCOL> st;
     init_cols<NCOL>(st, tail);
     for (int l = ilay0; l < nl - 1; ++l) apply_layer<NCOL, FAST>(st, coef + l * NCOEF, omg);
     double2 ur, uz;
     finish_bin<NCOL, FAST>(st, tail, omg, ipha, ur, uz);
-    sink(k, ur, uz);
+    sink(k, ur, uz, wgt);
 }
 
 // The iteration that holds the Nyquist bin has one active lane (nfft / 2 is a multiple of 64): a whole
@@ -577,6 +622,7 @@ __device__ __forceinline__ void spectra_iter_nyquist(const SpectraParams &P, CP 
 {
     const int k = it * 64 + lane;
     const double omg = (double)k * P.t.domg;
+    const double wgt = sink.weight(k);
     ColState<NCOL> st;
     init_cols<NCOL>(st, tail);
     for (int l = ilay0; l < nl - 1; ++l) {
@@ -585,7 +631,7 @@ __device__ __forceinline__ void spectra_iter_nyquist(const SpectraParams &P, CP 
     }
     double2 ur, uz;
     finish_bin<NCOL, true>(st, tail, omg, ipha, ur, uz);
-    sink(k, ur, uz);
+    sink(k, ur, uz, wgt);
 }
 
 // eps = arg - k * phi, phi = (hi, lo): the rounding perturbation of the reference's argument (omega*xi)*z
@@ -608,41 +654,53 @@ template <int BK, int NCOL, class Sink, class CP = const double *, bool TIGHT = 
 __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP coef, CP tail,
                                                     int nl, int ilay0, int ipha, const Sink &sink, int it0, int lane)
 {
-    // long chains (and the 3-column ocean kernel) keep only the first bin's index and rebuild k, omega
-    // of the others where they are used (2 instructions per bin and layer; the values are the same
-    // doubles) to stay within the register budget of two waves per SIMD
-    // (TIGHT: the 128-VGPR budget of fused8_kernel)
-    constexpr bool LEAN = TIGHT || BK >= 8 || (NCOL == 3 && BK >= 4);
+    // Register budget (two waves per SIMD: 256 VGPRs; TIGHT: the 128 of fused8_kernel).  Short chains hold k and
+    // omega of every bin; the 8-bin land kernel holds the omegas and rebuilds k (one exact addition per bin and
+    // layer); the 3-column ocean kernel and the TIGHT chains keep only the first bin's index and rebuild both
+    // where they are used (the values are the same doubles).
+    constexpr bool LEAN = TIGHT || (NCOL == 3 && BK >= 4) || (NCOL != 2 && BK >= 8);
+    constexpr bool KEEP_KD = !LEAN && BK < 8;
     ColState<NCOL> st[BK];
-    double omg[LEAN ? 1 : BK], kd[LEAN ? 1 : BK];
+    double omg[LEAN ? 1 : BK], kd[KEEP_KD ? BK : 1];
     const int k0 = it0 * 64 + lane;
-    const double kd0 = (double)k0;
-    const double omg0 = k0 == 0 ? P.t.omg_dc : kd0 * P.t.domg;
 #pragma unroll
     for (int m = 0; m < BK; ++m) {
         if (!LEAN) {
-            kd[m] = (double)(k0 + 64 * m);
-            omg[m] = (k0 + 64 * m) == 0 ? P.t.omg_dc : kd[m] * P.t.domg;
+            const double kdm = (double)(k0 + 64 * m);
+            if (KEEP_KD) kd[m] = kdm;
+            omg[m] = (k0 + 64 * m) == 0 ? P.t.omg_dc : kdm * P.t.domg;
         }
         init_cols<NCOL>(st[m], tail);
     }
     const bool dc = k0 == 0;
-#pragma unroll LEAN ? 1 : 2
+    constexpr int LAYER_UNROLL = (LEAN || BK >= 8) ? 1 : 2;
+    // Scalar-cache prefetch of the next layer's record (three 64-byte lines): by the next iteration it sits in the
+    // scalar cache and that iteration's s_loads, which the wave waits for before it can do anything, are hits.
+    // Inline asm because the compiler sinks an ordinary load down to its use; tied to the first bin's index (a VGPR
+    // operand the iteration needs at once) so that it stays at the top.  The three destination registers are
+    // loop-carried ("+s"): reserved for the whole loop, never read; the wait after the loop retires the last loads
+    // before the registers are handed back.
+    unsigned touch0 = 0, touch1 = 0, touch2 = 0;
+    int kk = k0;
+#pragma unroll LAYER_UNROLL
     for (int l = ilay0; l < nl - 1; ++l) {
-        const CP c = coef + l * NCOEF;
-        const double xi = c[0], eta = c[1], h = c[2];
-        const double Cx = c[15], Sx = c[16], Ce = c[17], Se = c[18];
+        const LayerK c = load_layer_k(coef + l * NCOEF);
+        // (wave-uniform address; under register pressure the compiler may hold it in VGPRs, and it does not
+        // legalise an inline asm's "s" operand by itself)
+        const uint64_t an = (uint64_t)(uintptr_t)(coef + (l + 1 < nl - 1 ? l + 1 : l) * NCOEF);
+        const uint64_t cn = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(an >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)an);
+        static_assert(std::is_same<CP, KPtr>::value, "the chained-phase path reads stage_kernel's image through SGPRs");
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80"
+                     : "+s"(touch0), "+s"(touch1), "+s"(touch2), "+v"(kk)
+                     : "s"(cn));
+        const double xi = c.xi, eta = c.eta, h = c.h;
         double sx, cx, se, ce;
-        // long chains: k and omega of the first bin are rebuilt from the bin index in every layer
-        // (the empty asm keeps the compiler from hoisting them back into registers that it would
+        // k and omega of the first bin: long chains rebuild them from the bin index in every layer (kk went
+        // through the asm above, which keeps the compiler from hoisting them back into registers that it would
         // then have to spill: 4 instructions per layer against 8 scratch reloads)
-        double kd0l = kd0, omg0l = omg0;
-        if (LEAN) {
-            int kk = k0;
-            asm volatile("" : "+v"(kk));
-            kd0l = (double)kk;
-            omg0l = kk == 0 ? P.t.omg_dc : kd0l * P.t.domg;
-        }
+        const double kd0l = (double)kk;
+        const double omg0l = LEAN ? (kk == 0 ? P.t.omg_dc : kd0l * P.t.domg) : omg[0];
         // first bin: direct evaluation of the reference's argument
         const double ax0 = (omg0l * xi) * h, ae0 = (omg0l * eta) * h;
         sincos_cw(ax0, sx, cx);
@@ -650,8 +708,8 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
         apply_layer_trig_unit<NCOL>(st[0], c, sx, cx, se, ce);
         // exact-angle start of the chain: remove the first bin's own perturbation.  The DC
         // bin's omega is the literal 1e-5 (not 0 * domg): its chain starts from angle 0.
-        const double ex0 = phase_eps(ax0, kd0l, c[11], c[12]);
-        const double ee0 = phase_eps(ae0, kd0l, c[13], c[14]);
+        const double ex0 = phase_eps(ax0, kd0l, c.px_hi, c.px_lo);
+        const double ee0 = phase_eps(ae0, kd0l, c.pe_hi, c.pe_lo);
         double cEx = dc ? 1.0 : fma(sx, ex0, cx);
         double sEx = dc ? 0.0 : fma(-cx, ex0, sx);
         double cEe = dc ? 1.0 : fma(se, ee0, ce);
@@ -659,25 +717,31 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
 #pragma unroll
         for (int m = 1; m < BK; ++m) {
             const double tx = cEx, te = cEe;
-            cEx = fma(tx, Cx, -(sEx * Sx));
-            sEx = fma(sEx, Cx, tx * Sx);
-            cEe = fma(te, Ce, -(sEe * Se));
-            sEe = fma(sEe, Ce, te * Se);
-            const double kdm = LEAN ? kd0l + (double)(64 * m) : kd[m];    // exact: small integers
+            cEx = fma(tx, c.Cx, -(sEx * c.Sx));
+            sEx = fma(sEx, c.Cx, tx * c.Sx);
+            cEe = fma(te, c.Ce, -(sEe * c.Se));
+            sEe = fma(sEe, c.Ce, te * c.Se);
+            const double kdm = KEEP_KD ? kd[m] : kd0l + (double)(64 * m);    // exact: small integers
             const double omgm = LEAN ? kdm * P.t.domg : omg[m];
-            const double ex = phase_eps((omgm * xi) * h, kdm, c[11], c[12]);
-            const double ee = phase_eps((omgm * eta) * h, kdm, c[13], c[14]);
+            const double ex = phase_eps((omgm * xi) * h, kdm, c.px_hi, c.px_lo);
+            const double ee = phase_eps((omgm * eta) * h, kdm, c.pe_hi, c.pe_lo);
             apply_layer_trig_unit<NCOL>(st[m], c, fma(cEx, ex, sEx), fma(-sEx, ex, cEx), fma(cEe, ee, sEe),
                                         fma(-sEe, ee, cEe));
         }
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch0), "+s"(touch1), "+s"(touch2));
+    // the bins' filter weights: every load is in flight before the first boundary condition is evaluated (the
+    // chain's registers are free by now); loaded where they are used, each bin waited for its own
+    double wgt[BK];
+#pragma unroll
+    for (int m = 0; m < BK; ++m) wgt[m] = sink.weight(k0 + 64 * m);
 #pragma unroll
     for (int m = 0; m < BK; ++m) {
         const int km = k0 + 64 * m;
         const double omgm = km == 0 ? P.t.omg_dc : (double)km * P.t.domg;
         double2 ur, uz;
         finish_bin<NCOL, true>(st[m], tail, omgm, ipha, ur, uz);
-        sink(km, ur, uz);
+        sink(km, ur, uz, wgt[m]);
     }
 }
 
@@ -690,7 +754,7 @@ __device__ __forceinline__ void spectra_body(const SpectraParams &P, CP coef, CP
 {
     const int niter = (P.t.nh + 63) / 64;
     int it_direct0 = 0;
-    if (BK > 1 && FAST) {
+    if constexpr (BK > 1 && FAST) {
         const int nchunk = niter / BK;
         for (int ch = split; ch < nchunk; ch += P.nsplit)
             spectra_chunk_chain<(BK > 1 ? BK : 2), NCOL, Sink, CP, TIGHT>(P, coef, tail, nl, ilay0, ipha, sink, ch * BK, lane);
@@ -832,13 +896,11 @@ struct StageParams {
     BatchArgs b;
     double *gcoef, *gtail;
     int *gflag;
-    int via_lds;
 };
 
 __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
 {
-    extern __shared__ double lds[];                 // [4][nlay_pad] direct-arrival terms, one row per wave, then
-                                                    // (S.via_lds) [4][nlay_pad * NCOEF + GTAIL] the waves' images
+    extern __shared__ double lds[];                 // [4][nlay_pad] direct-arrival terms, one row per wave
     const int pad = S.b.nlay_pad;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bf = blockIdx.x * 4 + wave;
@@ -846,24 +908,22 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
     const int ib = live ? bf / S.t.nfwd : 0, f = live ? bf % S.t.nfwd : 0;
     const bool run = live && (!S.b.fwd_flag || S.b.fwd_flag[ib] == 1);
     double *terms = lds + (size_t)wave * pad;
-    // The constants are assembled in LDS and leave as whole 16-byte-per-lane rows: written straight to the global
-    // image they are 8- to 32-byte pieces scattered over every layer's 192-byte record (partial-line writes:
-    // 128 MB of them per C4 launch took as long as the arithmetic).  Contexts whose images do not fit 64 KB of
-    // LDS (nlay_max > 78) write directly.
-    double *img = S.via_lds ? lds + 4 * (size_t)pad + (size_t)wave * ((size_t)pad * NCOEF + GTAIL) : nullptr;
+    // The lanes store their pieces straight into the global image.  (Assembling the image in LDS and writing whole
+    // rows was measured: no faster -- the kernel is bound by its divisions and square roots, not by its stores --
+    // and the 64 KB of LDS per block halved the occupancy.)
     bool big = false;
-    int nl = 2, ilay0 = 0;
+    int nl = 2;
     if (run) {
         const double *L = S.b.layers + (size_t)ib * 4 * pad;
         nl = S.b.nlay[ib];
         const double p = S.t.rayps[f];
         const bool sea = L[pad] < 0.0;              // beta(1) < 0  (forward.f90:229)
-        ilay0 = sea ? 1 : 0;
+        const int ilay0 = sea ? 1 : 0;
         const bool solid = nl - 1 > ilay0;          // at least one solid layer above the half-space
         const double omg_max = (double)(S.t.nh - 1) * S.t.domg;
         const double omg_nyq = (double)(S.t.nfft / 2) * S.t.domg;
-        double *coef = img ? img : S.gcoef + (size_t)bf * pad * NCOEF;
-        double *tail = img ? img + (size_t)pad * NCOEF : S.gtail + (size_t)bf * GTAIL;
+        double *coef = S.gcoef + (size_t)bf * pad * NCOEF;
+        double *tail = S.gtail + (size_t)bf * GTAIL;
         bool unit;
         const double gauge = walker_gauge(L, pad, nl, ilay0, p, lane, unit);
         big = !unit;
@@ -929,13 +989,6 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
     }
     const bool any_big = __any(big);
     __syncthreads();
-    if (run && img) {
-        // layers ilay0 .. nl-2 and the walker constants, 16 bytes per lane, contiguous
-        const double2 *src = reinterpret_cast<const double2 *>(img);
-        double2 *dst = reinterpret_cast<double2 *>(S.gcoef + (size_t)bf * pad * NCOEF);
-        for (int i = ilay0 * (NCOEF / 2) + lane; i < (nl - 1) * (NCOEF / 2); i += 64) dst[i] = src[i];
-        if (lane < 17) S.gtail[(size_t)bf * GTAIL + lane] = img[(size_t)pad * NCOEF + lane];
-    }
     if (run && lane == 0) {
         const double *L = S.b.layers + (size_t)ib * 4 * pad;
         const int i0 = S.t.sdep > 0.0 ? 1 : 0;
@@ -946,12 +999,9 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
 
 void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
 {
-    const size_t lds_img = sizeof(double) * 4 * ((size_t)b.nlay_pad * (NCOEF + 1) + GTAIL);
-    const int via_lds = lds_img <= 64 * 1024;
-    StageParams S{t, b, w.gcoef, w.gtail, w.gflag, via_lds};
+    StageParams S{t, b, w.gcoef, w.gtail, w.gflag};
     const unsigned nbf = (unsigned)(b.nb * t.nfwd);
-    hipLaunchKernelGGL(stage_kernel, dim3((nbf + 3) / 4), dim3(256),
-                       via_lds ? lds_img : sizeof(double) * 4 * (size_t)b.nlay_pad, s, S);
+    hipLaunchKernelGGL(stage_kernel, dim3((nbf + 3) / 4), dim3(256), sizeof(double) * 4 * (size_t)b.nlay_pad, s, S);
 }
 
 template <int BK, int NCOL>
@@ -1738,7 +1788,10 @@ struct LdsSink {
         const int it = (k & 63) ? 63 - (k >> 6) : 64 - (k >> 6);
         return fft_pad(lane_pos_m + ((it & 3) << 6) + (it >> 2));
     }
-    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz) const
+    // Gaussian filter weight of bin k (forward.f90:168,198), fetched by the caller before the bin's boundary
+    // condition is evaluated; deconvolution applies the filter after the water level (no weight here)
+    __device__ __forceinline__ double weight(int k) const { return (!decon && k < nh) ? flt[k] : 0.0; }
+    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz, double fk) const
     {
         if (k >= nh) return;
         const double2 fr = make_double2(ur.x, -ur.y);    // freq_r = conjg(ur)   forward.f90:145
@@ -1755,7 +1808,6 @@ struct LdsSink {
             else
                 a[pos_of_mirror(k)] = den;
         } else {
-            const double fk = flt[k];
             const double2 R = make_double2(num.x * fk, num.y * fk);   // forward.f90:168
             const double2 V = make_double2(fv.x * fk, fv.y * fk);     // forward.f90:198
             if (self) {
@@ -1960,7 +2012,10 @@ struct W8Sink {
         const int it = (k & 63) ? 63 - (k >> 6) : 64 - (k >> 6);
         return w8_pad(lane_pos_m + ((it & 7) << 3) + (it >> 3));
     }
-    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz) const
+    // Gaussian filter weight of bin k (forward.f90:168,198), fetched by the caller before the bin's boundary
+    // condition is evaluated; deconvolution applies the filter after the water level (no weight here)
+    __device__ __forceinline__ double weight(int k) const { return (!decon && k < nh) ? flt[k] : 0.0; }
+    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz, double fk) const
     {
         if (k >= nh) return;
         const double2 fr = make_double2(ur.x, -ur.y);    // freq_r = conjg(ur)   forward.f90:145
@@ -1976,7 +2031,6 @@ struct W8Sink {
             else
                 a[pos_of_mirror(k)] = den;
         } else {
-            const double fk = flt[k];
             const double2 R = make_double2(num.x * fk, num.y * fk);   // forward.f90:168
             const double2 V = make_double2(fv.x * fk, fv.y * fk);     // forward.f90:198
             if (self) {
