@@ -568,7 +568,7 @@ __device__ __forceinline__ void init_cols(ColState<NCOL> &st, CP tail)
     st.v[0][3] = t[1];
     st.v[1][1] = t[2];
     st.v[1][2] = t[3];
-    if (NCOL == 3) {
+    if constexpr (NCOL == 3) {
         st.v[2][0] = t[4];
         st.v[2][3] = t[5];
     }
@@ -643,6 +643,83 @@ __device__ __forceinline__ double phase_eps(double arg, double kd, double phi_hi
     return -fma(kd, phi_lo, fma(kd, phi_hi, -arg));
 }
 
+// ---------------------------------------------------------------------------
+// Anchor table of fused8_kernel.  The chain of a lane starts at bin k0 = 64 BK ch + lane (ch: the wave's chunk),
+// so the exact-angle pair it starts from factors into a part every wave of the block shares and a wave-uniform part:
+//     E(k0 phi) = E(64 BK ch phi) * E(lane phi),        E(x) = (cos x, sin x).
+// The block computes both factors ONCE per (layer, phase) -- 64 + nchunk evaluations of sincos_cw instead of one per
+// lane and wave -- into LDS, in the space of the FFT array, which nothing else uses until the bins are deposited
+// (a barrier separates the two uses).  Row (l - ilay0, phase) holds ANCHOR_ROW double2 entries (cos, sin):
+// [0, 64) the lane factors, [64, 64 + nchunk) the chunk factors (entry 64 and entry 0 are exactly (1, 0)).
+// Each entry is the sine and cosine of the real number j * phi, phi = (hi, lo): the rounded product's sincos,
+// corrected to first order by the product's rounding error and j * lo (|err| < 1e-13).
+// ---------------------------------------------------------------------------
+constexpr int ANCHOR_ROW = 72;
+
+__device__ __forceinline__ double2 exact_angle(double mult, double phi_hi, double phi_lo)
+{
+    const double x = mult * phi_hi;
+    const double err = fma(mult, phi_lo, fma(mult, phi_hi, -x));   // (mult * phi) - x: the inner fma is exact
+    double s, c;
+    sincos_cw(x, s, c);
+    return make_double2(fma(-s, err, c), fma(c, err, s));
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src)   // src: wave-uniform
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)b, src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+// gc: stage_kernel's image of this (item, trace); nsolid <= 64.  Lane i of every wave fetches the four phase doubles
+// of solid layer i -- ONE round trip to memory for the whole table -- and the passes below take them from there.
+// Lane factors: a whole-wave pass per layer (both phases: two independent evaluations); wave 0 takes half a share
+// (its chunk holds the DC bin, whose first-bin evaluation is longer: spectra_chunk_chain).  Chunk factors of all
+// layers: packed 64 to a pass.
+template <int THREADS>
+__device__ __forceinline__ void build_anchor_table(double2 *tab, const double *__restrict__ gc, int nsolid, int ilay0,
+                                                   int nchunk, int chunk_bins, int tid)
+{
+    constexpr int NW = THREADS / 64;
+    const int wave = tid >> 6, lane = tid & 63;
+    double xh = 0.0, xl = 0.0, eh = 0.0, el = 0.0;
+    if (lane < nsolid) {
+        const double *q = gc + (size_t)(ilay0 + lane) * NCOEF + 11;
+        xh = q[0]; xl = q[1]; eh = q[2]; el = q[3];
+    }
+    const double m = (double)lane;
+    for (int li = 0; li < nsolid; ++li) {
+        const int c = li % (2 * NW - 1);
+        const int owner = c < NW - 1 ? c + 1 : (c == NW - 1 ? 0 : c - NW + 1);
+        if (owner != wave) continue;
+        double2 *row = tab + 2 * li * ANCHOR_ROW + lane;
+        row[0] = exact_angle(m, readlane_f64(xh, li), readlane_f64(xl, li));
+        row[ANCHOR_ROW] = exact_angle(m, readlane_f64(eh, li), readlane_f64(el, li));
+    }
+    const int per = 2 * nchunk, nfac = nsolid * per;
+    for (int p = wave; p * 64 < nfac; p += NW) {
+        const int q = min(p * 64 + lane, nfac - 1);
+        const int li = q / per, rem = q - li * per;
+        const int phs = rem >= nchunk ? 1 : 0, ch = rem - phs * nchunk;
+        const double axh = __shfl(xh, li, 64), axl = __shfl(xl, li, 64), aeh = __shfl(eh, li, 64), ael = __shfl(el, li, 64);
+        const double2 e = exact_angle((double)(ch * chunk_bins), phs ? aeh : axh, phs ? ael : axl);
+        if (p * 64 + lane < nfac) tab[(2 * li + phs) * ANCHOR_ROW + 64 + ch] = e;
+    }
+}
+
+// (cos, sin)(x) for |x| < 2^-8 by its series (error < 5e-18): the DC bin's phase is omega_dc xi h with the
+// single-precision literal omega_dc = 1e-5 (forward.f90:247), far too large for a first-order correction of the
+// chain's angle 0 and far too small to be worth a range reduction.  stage_kernel sends walkers with a larger DC
+// phase (a layer thousands of kilometres thick) to the generic path.
+constexpr double DC_PHASE_LIMIT = 0x1p-8;
+__device__ __forceinline__ void sincos_small(double x, double &sn, double &cs)
+{
+    const double z = x * x;
+    cs = fma(z, fma(z, 1.0 / 24.0, -0.5), 1.0);
+    sn = fma(x * z, fma(z, 1.0 / 120.0, -1.0 / 6.0), x);
+}
+
 // BK consecutive 64-bin iterations per lane (bins k0, k0+64, ...): "chained phases".
 // For each layer only the first bin pays a full sincos; the exact-angle pair
 // (cos, sin)(k phi) then advances by the wave-uniform rotation (cos, sin)(64 phi) of the
@@ -650,9 +727,14 @@ __device__ __forceinline__ double phase_eps(double arg, double kd, double phi_hi
 // rounding is part of the reference result -- is recovered to first order from
 // eps = arg - k phi (|eps| < 1e-9, second order < 1e-18).  ~13 instructions per extra
 // sincos instead of ~45.  Chain length <= BK-1 rotations (error growth ~1 ulp per step).
-template <int BK, int NCOL, class Sink, class CP = const double *, bool TIGHT = false>
+// TABLE (fused8_kernel): the chain's starting pair comes from the block's anchor table (one complex product) and
+// the first bin is corrected like every other; its only special case is the DC bin (lane 0 of chunk 0).  A barrier
+// separates the layer loop (table reads) from the deposit of the bins, which overwrites the table: every wave of
+// the block runs exactly one chunk in this mode.
+template <int BK, int NCOL, class Sink, class CP = const double *, bool TIGHT = false, bool TABLE = false>
 __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP coef, CP tail,
-                                                    int nl, int ilay0, int ipha, const Sink &sink, int it0, int lane)
+                                                    int nl, int ilay0, int ipha, const Sink &sink, int it0, int lane,
+                                                    const double2 *tab = nullptr)
 {
     // Register budget (two waves per SIMD: 256 VGPRs; TIGHT: the 128 of fused8_kernel).  Short chains hold k and
     // omega of every bin; the 8-bin land kernel holds the omegas and rebuilds k (one exact addition per bin and
@@ -682,6 +764,8 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
     // before the registers are handed back.
     unsigned touch0 = 0, touch1 = 0, touch2 = 0;
     int kk = k0;
+    const double2 *trow = TABLE ? tab + lane : nullptr;                 // lane factor of (layer, phase) row r: trow[r * ANCHOR_ROW]
+    const double2 *tfac = TABLE ? tab + 64 + it0 / BK : nullptr;        // chunk factor of row r: tfac[r * ANCHOR_ROW]
 #pragma unroll LAYER_UNROLL
     for (int l = ilay0; l < nl - 1; ++l) {
         const LayerK c = load_layer_k(coef + l * NCOEF);
@@ -695,25 +779,49 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
                      : "+s"(touch0), "+s"(touch1), "+s"(touch2), "+v"(kk)
                      : "s"(cn));
         const double xi = c.xi, eta = c.eta, h = c.h;
-        double sx, cx, se, ce;
         // k and omega of the first bin: long chains rebuild them from the bin index in every layer (kk went
         // through the asm above, which keeps the compiler from hoisting them back into registers that it would
         // then have to spill: 4 instructions per layer against 8 scratch reloads)
         const double kd0l = (double)kk;
         const double omg0l = LEAN ? (kk == 0 ? P.t.omg_dc : kd0l * P.t.domg) : omg[0];
-        // first bin: direct evaluation of the reference's argument
+        // first bin: the reference's argument
         const double ax0 = (omg0l * xi) * h, ae0 = (omg0l * eta) * h;
-        sincos_cw(ax0, sx, cx);
-        sincos_cw(ae0, se, ce);
-        apply_layer_trig_unit<NCOL>(st[0], c, sx, cx, se, ce);
-        // exact-angle start of the chain: remove the first bin's own perturbation.  The DC
-        // bin's omega is the literal 1e-5 (not 0 * domg): its chain starts from angle 0.
         const double ex0 = phase_eps(ax0, kd0l, c.px_hi, c.px_lo);
         const double ee0 = phase_eps(ae0, kd0l, c.pe_hi, c.pe_lo);
-        double cEx = dc ? 1.0 : fma(sx, ex0, cx);
-        double sEx = dc ? 0.0 : fma(-cx, ex0, sx);
-        double cEe = dc ? 1.0 : fma(se, ee0, ce);
-        double sEe = dc ? 0.0 : fma(-ce, ee0, se);
+        double cEx, sEx, cEe, sEe;
+        if constexpr (TABLE) {
+            // exact-angle start of the chain: chunk factor * lane factor
+            const int r = 2 * (l - ilay0) * ANCHOR_ROW;
+            const double2 bx = trow[r], be = trow[r + ANCHOR_ROW];
+            const double2 fx = tfac[r], fe = tfac[r + ANCHOR_ROW];
+            cEx = fma(fx.x, bx.x, -(fx.y * bx.y));
+            sEx = fma(fx.y, bx.x, fx.x * bx.y);
+            cEe = fma(fe.x, be.x, -(fe.y * be.y));
+            sEe = fma(fe.y, be.x, fe.x * be.y);
+            double sx = fma(cEx, ex0, sEx), cx = fma(-sEx, ex0, cEx), se = fma(cEe, ee0, sEe), ce = fma(-sEe, ee0, cEe);
+            if (it0 == 0) {
+                // (wave-uniform) the DC bin: angle 0 + the phase of omega_dc, by series
+                double s1, c1, s2, c2;
+                sincos_small(ax0, s1, c1);
+                sincos_small(ae0, s2, c2);
+                sx = dc ? s1 : sx;
+                cx = dc ? c1 : cx;
+                se = dc ? s2 : se;
+                ce = dc ? c2 : ce;
+            }
+            apply_layer_trig_unit<NCOL>(st[0], c, sx, cx, se, ce);
+        } else {
+            // direct evaluation; then the exact-angle start of the chain: remove the first bin's own
+            // perturbation.  The DC bin's omega is the literal 1e-5 (not 0 * domg): its chain starts from angle 0.
+            double sx, cx, se, ce;
+            sincos_cw(ax0, sx, cx);
+            sincos_cw(ae0, se, ce);
+            apply_layer_trig_unit<NCOL>(st[0], c, sx, cx, se, ce);
+            cEx = dc ? 1.0 : fma(sx, ex0, cx);
+            sEx = dc ? 0.0 : fma(-cx, ex0, sx);
+            cEe = dc ? 1.0 : fma(se, ee0, ce);
+            sEe = dc ? 0.0 : fma(-ce, ee0, se);
+        }
 #pragma unroll
         for (int m = 1; m < BK; ++m) {
             const double tx = cEx, te = cEe;
@@ -730,6 +838,7 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch0), "+s"(touch1), "+s"(touch2));
+    if constexpr (TABLE) __syncthreads();   // every wave is done with the table: the deposits below overwrite it
     // the bins' filter weights: every load is in flight before the first boundary condition is evaluated (the
     // chain's registers are free by now); loaded where they are used, each bin waited for its own
     double wgt[BK];
@@ -748,16 +857,22 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
 // the bins of one (walker, forward-trace) assigned to `split` of P.nsplit:
 // full chunks of BK iterations go through the chained-phase path, the remaining
 // iterations (and everything when BK == 0) through the direct path.
-template <int BK, int NCOL, bool FAST, class Sink, class CP = const double *, bool TIGHT = false>
+template <int BK, int NCOL, bool FAST, class Sink, class CP = const double *, bool TIGHT = false, bool TABLE = false>
 __device__ __forceinline__ void spectra_body(const SpectraParams &P, CP coef, CP tail,
-                                             int nl, int ilay0, int ipha, const Sink &sink, int split, int lane)
+                                             int nl, int ilay0, int ipha, const Sink &sink, int split, int lane,
+                                             const double2 *tab = nullptr)
 {
     const int niter = (P.t.nh + 63) / 64;
     int it_direct0 = 0;
     if constexpr (BK > 1 && FAST) {
         const int nchunk = niter / BK;
-        for (int ch = split; ch < nchunk; ch += P.nsplit)
-            spectra_chunk_chain<(BK > 1 ? BK : 2), NCOL, Sink, CP, TIGHT>(P, coef, tail, nl, ilay0, ipha, sink, ch * BK, lane);
+        if constexpr (TABLE) {
+            // (the caller checked nchunk == P.nsplit: one chunk per wave, see spectra_chunk_chain)
+            spectra_chunk_chain<BK, NCOL, Sink, CP, TIGHT, true>(P, coef, tail, nl, ilay0, ipha, sink, split * BK, lane, tab);
+        } else {
+            for (int ch = split; ch < nchunk; ch += P.nsplit)
+                spectra_chunk_chain<(BK > 1 ? BK : 2), NCOL, Sink, CP, TIGHT>(P, coef, tail, nl, ilay0, ipha, sink, ch * BK, lane);
+        }
         it_direct0 = nchunk * BK;
     }
     // leftover iterations: spread from the last split downwards (the chunk loop loads
@@ -958,7 +1073,7 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
                     stage_phase(c + 11 + 2 * s, c + 15 + 2 * s, S.t.domg, slow, h0);
                     c[19 + 2 * s] = sn;
                     c[20 + 2 * s] = cn;
-                    big |= fabs(omg_max * slow * h0) >= SINCOS_CW_LIMIT;
+                    big |= fabs(omg_max * slow * h0) >= SINCOS_CW_LIMIT || !(fabs(S.t.omg_dc * slow * h0) < DC_PHASE_LIMIT);
                 }
             }
             // walker constants, by the lanes of the lighter parts that already hold the layers involved
@@ -1422,6 +1537,8 @@ __device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 
         fac = block_max(m, red);                                     // maxval(rx) forward.f90:201
     }
     const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
+    // one reciprocal per thread instead of a division per sample (each sample within 1 ulp of the quotient)
+    const double rfac = 1.0 / fac;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
         const int j = tid + (bitrev_small<LOG2R>(k) << 8) + 1;       // 1-based sample of rx
@@ -1431,7 +1548,7 @@ __device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 
         int i = (ipha == 1 ? j + npre : n + npre + 1 - j) & (n - 1);
         if (i == 0) i = n;
         double val = ipha == 1 ? v[k].x : -v[k].x;
-        if (!decon) val = val / fac;                                 // forward.f90:202
+        if (!decon) val = val * rfac;                                // forward.f90:202 (see rfac)
         __builtin_nontemporal_store(val, &dst[i - 1]);   // written once, read rarely: keep it out of L2
         if (xout) xout[i - 1] = val;
         if (i <= nsmp) {
@@ -1491,6 +1608,8 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
 
     // ---- time shift (+ reverse/negate for S), normalise, store, misfit ----------
     const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
+    // one reciprocal per thread instead of a division per sample (each sample within 1 ulp of the quotient)
+    const double rfac = 1.0 / fac;
     for (int i = tid + 1; i <= n; i += TRACE_THREADS) {
         int j;
         double val;
@@ -1503,7 +1622,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
             if (j == 0) j = n;
             val = -a[fft_pad(j - 1)].x;
         }
-        if (!decon) val = val / fac;                                 // forward.f90:202
+        if (!decon) val = val * rfac;                                // forward.f90:202 (see rfac)
         dst[i - 1] = val;
         if (xout) xout[i - 1] = val;
         if (i <= nsmp) {
@@ -2152,7 +2271,17 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
         else
             spectra_body<0, 2, false>(sp, (const double *)coef, (const double *)tail, nl, ilay0, ipha, sink, wave, lane);
     } else {
-        spectra_body<4, NCOL, true, W8Sink, KPtr, true>(sp, gcoef, gtail, nl, ilay0, ipha, sink, wave, lane);
+        // chains start from the block's anchor table (spectra_chunk_chain) when the walker's layers fit it
+        const int nsolid = nl - 1 - ilay0;
+        const int cap = ((w8_pad(4095) + 2) & ~1) / (2 * ANCHOR_ROW);
+        if (nsolid >= 1 && nsolid <= cap && nh_eff == nh) {
+            build_anchor_table<W8_THREADS>(a, P.w.gcoef + (size_t)bfi * P.b.nlay_pad * NCOEF, nsolid, ilay0, W8_THREADS / 64,
+                                           64 * 4, tid);
+            __syncthreads();
+            spectra_body<4, NCOL, true, W8Sink, KPtr, true, true>(sp, gcoef, gtail, nl, ilay0, ipha, sink, wave, lane, a);
+        } else {
+            spectra_body<4, NCOL, true, W8Sink, KPtr, true>(sp, gcoef, gtail, nl, ilay0, ipha, sink, wave, lane);
+        }
     }
     __syncthreads();
     const double tp = decon ? 0.0 : gtail[17];
@@ -2235,6 +2364,8 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
     double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
     double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
     const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
+    // one reciprocal per thread instead of a division per sample (each sample within 1 ulp of the quotient)
+    const double rfac = 1.0 / fac;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int j = tid + (bitrev_small<3>(k) << 9) + 1;           // 1-based sample of rx
@@ -2242,7 +2373,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
         int i = (ipha == 1 ? j + npre : n + npre + 1 - j) & (n - 1);
         if (i == 0) i = n;
         double val = ipha == 1 ? v[k].x : -v[k].x;
-        if (!decon) val = val / fac;                                 // forward.f90:202
+        if (!decon) val = val * rfac;                                // forward.f90:202 (see rfac)
         __builtin_nontemporal_store(val, &dst[i - 1]);
         if (xout) xout[i - 1] = val;
         if (i <= nsmp) {

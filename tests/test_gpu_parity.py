@@ -510,6 +510,34 @@ def test_walker_without_unit_gauge_takes_the_generic_path(oracle):
                 assert np.abs(got - ref_rft[i]).max() <= 1e-11 * np.abs(ref_rft[i]).max(), (fused, i)
 
 
+def test_dc_bin_phase_by_series_and_its_limit(oracle):
+    """The 512-thread fused kernel starts its phase chains from the block's anchor table and evaluates the DC bin's
+    phase omega_dc * xi * h (omega_dc = the single-precision literal 1e-5, forward.f90:247) by its series, valid
+    below 2^-8 rad; stage_kernel sends walkers with a larger DC phase to the generic path.  Layers 1500 km (series)
+    and 4000 km thick (beyond the limit: 1e-5 * 0.14 * 4000 ~ 5.6e-3) next to ordinary walkers, nfft 4096 on both
+    block sizes: every result agrees with the oracle."""
+    rng = np.random.default_rng(91)
+    cfg = make_cfg(nfft=4096, rayps=[0.06], ipha=[1], t_start=0.0)
+    nsmp = 101
+    true = random_stack(rng, 4)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, 6) for _ in range(6)]
+    stacks[1][3][1] = 1500.0
+    stacks[4][3][2] = 4000.0
+    nlay, layers = pack_layers(stacks, 8)
+    sig = np.full((6, 1), 0.05)
+    ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True)
+    assert np.all(np.isfinite(ref_ll))
+    for bt in (512, 256):
+        with _engine(cfg, obs, nsmp, r_inv, max_walkers=6, options={"block_threads": bt}) as eng:
+            ll = eng.eval_batch(np.arange(6), nlay, layers, sig)
+            assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (bt, np.abs(ll - ref_ll))
+            for i in range(6):
+                got = eng.get_rft(i, which=1).T
+                assert np.abs(got - ref_rft[i]).max() <= 1e-11 * np.abs(ref_rft[i]).max(), (bt, i)
+
+
 def test_make_syn_reproduces_the_shipped_sample(oracle, golden_dir, tmp_path):
     """rf_inv_amd.make_syn on true.velmod (land) regenerates the reference's shipped
     sample_{1,2}.trc payloads byte for byte (float32 samples)."""
