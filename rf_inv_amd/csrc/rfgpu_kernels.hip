@@ -81,6 +81,17 @@ __device__ __forceinline__ void cdiv2(double2 a1, double2 a2, double2 b, double2
     x2 = make_double2((sel ? a2.x + a2.y * r : a2.x * r + a2.y) * t, (sel ? a2.y - a2.x * r : a2.y * r - a2.x) * t);
 }
 
+// The fast paths' form of the same two quotients: a conj(b) / |b|^2 with one reciprocal -- 27 instructions instead of
+// 51, no selects.  Smith's range reduction protects |b| beyond 1e154 or below 1e-154, which the boundary-condition
+// determinant of a walker on the fast paths (unit gauge, phases below 1e6 rad) never reaches; the generic path keeps
+// cdiv2.  Each quotient within 3 ulp of the exact one (Smith: 2.5).
+__device__ __forceinline__ void cdiv2_norm(double2 a1, double2 a2, double2 b, double2 &x1, double2 &x2)
+{
+    const double t = 1.0 / fma(b.x, b.x, b.y * b.y);
+    x1 = make_double2(fma(a1.x, b.x, a1.y * b.y) * t, fma(a1.y, b.x, -(a1.x * b.y)) * t);
+    x2 = make_double2(fma(a2.x, b.x, a2.y * b.y) * t, fma(a2.y, b.x, -(a2.x * b.y)) * t);
+}
+
 // direct_arrival (forward.f90:474-519).  Its result feeds nint() (integer bookkeeping
 // must be bit-exact), so no FMA contraction anywhere and the SUM stays strictly
 // sequential in layer order; only the independent per-layer terms h(i)*sqrt(1/v(i)^2-p^2)
@@ -501,6 +512,15 @@ __device__ __forceinline__ double2 halfspace_row(CP g, const double *v)
     return make_double2(fma(g[1], v[3], g[0] * v[0]), fma(g[3], v[2], g[2] * v[1]));
 }
 
+template <bool FAST>
+__device__ __forceinline__ void cdivq(double2 a1, double2 a2, double2 b, double2 &x1, double2 &x2)
+{
+    if constexpr (FAST)
+        cdiv2_norm(a1, a2, b, x1, x2);
+    else
+        cdiv2(a1, a2, b, x1, x2);
+}
+
 template <int NCOL, bool FAST, class CP = const double *>
 __device__ __forceinline__ void finish_bin(const ColState<NCOL> &s, CP tail, double omg,
                                            int ipha, double2 &ur, double2 &uz)
@@ -517,9 +537,9 @@ __device__ __forceinline__ void finish_bin(const ColState<NCOL> &s, CP tail, dou
         // free surface (forward.f90:267-275)
         const double2 denom = csub(cmul(sl31, sl42), cmul(sl32, sl41));
         if (ipha >= 0)
-            cdiv2(sl42, cneg(sl41), denom, ur, uz);
+            cdivq<FAST>(sl42, cneg(sl41), denom, ur, uz);
         else
-            cdiv2(cneg(sl32), sl31, denom, ur, uz);
+            cdivq<FAST>(cneg(sl32), sl31, denom, ur, uz);
     } else {
         // sea floor (forward.f90:276-287).  sl(r,4) = -(i/w) T_r4 and
         // lq21 = -(rho_w w / xi_w) sin: the w cancels in sl(r,4) * lq21.
@@ -535,9 +555,9 @@ __device__ __forceinline__ void finish_bin(const ColState<NCOL> &s, CP tail, dou
         // the reference divides uz by d2 = b sl41 - a sl31 = -d1 (exactly): same quotient as -num / d1
         const double2 d1 = csub(cmul(a, sl31), cmul(b, sl41));
         if (ipha >= 0)
-            cdiv2(a, make_double2(-(cw * sl41.x), -(cw * sl41.y)), d1, ur, uz);
+            cdivq<FAST>(a, make_double2(-(cw * sl41.x), -(cw * sl41.y)), d1, ur, uz);
         else
-            cdiv2(cneg(b), make_double2(cw * sl31.x, cw * sl31.y), d1, ur, uz);
+            cdivq<FAST>(cneg(b), make_double2(cw * sl31.x, cw * sl31.y), d1, ur, uz);
     }
 }
 
@@ -755,32 +775,16 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
         init_cols<NCOL>(st[m], tail);
     }
     const bool dc = k0 == 0;
-    constexpr int LAYER_UNROLL = (LEAN || BK >= 8) ? 1 : 2;
-    // Scalar-cache prefetch of the next layer's record (three 64-byte lines): by the next iteration it sits in the
-    // scalar cache and that iteration's s_loads, which the wave waits for before it can do anything, are hits.
-    // Inline asm because the compiler sinks an ordinary load down to its use; tied to the first bin's index (a VGPR
-    // operand the iteration needs at once) so that it stays at the top.  The three destination registers are
-    // loop-carried ("+s"): reserved for the whole loop, never read; the wait after the loop retires the last loads
-    // before the registers are handed back.
-    unsigned touch0 = 0, touch1 = 0, touch2 = 0;
     int kk = k0;
     const double2 *trow = TABLE ? tab + lane : nullptr;                 // lane factor of (layer, phase) row r: trow[r * ANCHOR_ROW]
     const double2 *tfac = TABLE ? tab + 64 + it0 / BK : nullptr;        // chunk factor of row r: tfac[r * ANCHOR_ROW]
-#pragma unroll LAYER_UNROLL
-    for (int l = ilay0; l < nl - 1; ++l) {
-        const LayerK c = load_layer_k(coef + l * NCOEF);
-        // (wave-uniform address; under register pressure the compiler may hold it in VGPRs, and it does not
-        // legalise an inline asm's "s" operand by itself)
-        const uint64_t an = (uint64_t)(uintptr_t)(coef + (l + 1 < nl - 1 ? l + 1 : l) * NCOEF);
-        const uint64_t cn = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(an >> 32)) << 32) |
-                            (unsigned)__builtin_amdgcn_readfirstlane((int)an);
-        static_assert(std::is_same<CP, KPtr>::value, "the chained-phase path reads stage_kernel's image through SGPRs");
-        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80"
-                     : "+s"(touch0), "+s"(touch1), "+s"(touch2), "+v"(kk)
-                     : "s"(cn));
+    static_assert(std::is_same<CP, KPtr>::value, "the chained-phase path reads stage_kernel's image through SGPRs");
+
+    // one layer applied to the BK bins of the lane, constants c
+    auto layer_step = [&](const LayerK &c, int l) {
         const double xi = c.xi, eta = c.eta, h = c.h;
-        // k and omega of the first bin: long chains rebuild them from the bin index in every layer (kk went
-        // through the asm above, which keeps the compiler from hoisting them back into registers that it would
+        // k and omega of the first bin: long chains rebuild them from the bin index in every layer (kk goes
+        // through the loop's asm, which keeps the compiler from hoisting them back into registers that it would
         // then have to spill: 4 instructions per layer against 8 scratch reloads)
         const double kd0l = (double)kk;
         const double omg0l = LEAN ? (kk == 0 ? P.t.omg_dc : kd0l * P.t.domg) : omg[0];
@@ -836,6 +840,38 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
             apply_layer_trig_unit<NCOL>(st[m], c, fma(cEx, ex, sEx), fma(-sEx, ex, cEx), fma(cEe, ee, sEe),
                                         fma(-sEe, ee, cEe));
         }
+    };
+    // (wave-uniform address of a layer's record; under register pressure the compiler may hold the base in VGPRs,
+    // and it does not legalise an inline asm's "s" operand by itself)
+    auto record_of = [&](int l) -> uint64_t {
+        const uint64_t an = (uint64_t)(uintptr_t)(coef + l * NCOEF);
+        return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(an >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)an);
+    };
+    constexpr int LAYER_UNROLL = (LEAN || BK >= 8) ? 1 : 2;
+    // Scalar-cache prefetch of the next layer's record (three 64-byte lines): by the next iteration it sits in the
+    // scalar cache and that iteration's s_loads, which the wave waits for before it can do anything, are hits.
+    // (Fetching the next layer's constants themselves into a second register set a layer ahead -- 17 s_loads by
+    // inline asm, loop unrolled by two -- was measured: 13 % slower at C4; the scalar moves and loads it adds
+    // compete with the loop's own issue.)
+    // Inline asm because the compiler sinks an ordinary load down to its use; tied to the first bin's index (a VGPR
+    // operand the iteration needs at once) so that it stays at the top.  The three destination registers are
+    // loop-carried ("+s"): reserved for the whole loop, never read; the wait after the loop retires the last loads
+    // before the registers are handed back.
+    unsigned touch0 = 0, touch1 = 0, touch2 = 0;
+#pragma unroll LAYER_UNROLL
+    for (int l = ilay0; l < nl - 1; ++l) {
+        LayerK c = load_layer_k(coef + l * NCOEF);
+        // (every constant through one empty asm: the compiler then issues all the loads together and waits once;
+        // left alone it sometimes splits them around the first uses and the wave waits twice per layer, +3 %)
+        asm volatile("" : "+s"(c.xi), "+s"(c.eta), "+s"(c.h), "+s"(c.g1), "+s"(c.g2), "+s"(c.g3), "+s"(c.g4), "+s"(c.g5),
+                     "+s"(c.g6), "+s"(c.px_hi), "+s"(c.px_lo), "+s"(c.pe_hi), "+s"(c.pe_lo), "+s"(c.Cx), "+s"(c.Sx),
+                     "+s"(c.Ce), "+s"(c.Se));
+        const uint64_t cn = record_of(l + 1 < nl - 1 ? l + 1 : l);
+        asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %4, 0x40\n\ts_load_dword %2, %4, 0x80"
+                     : "+s"(touch0), "+s"(touch1), "+s"(touch2), "+v"(kk)
+                     : "s"(cn));
+        layer_step(c, l);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch0), "+s"(touch1), "+s"(touch2));
     if constexpr (TABLE) __syncthreads();   // every wave is done with the table: the deposits below overwrite it
