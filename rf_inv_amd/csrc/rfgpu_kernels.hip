@@ -259,15 +259,18 @@ __device__ __forceinline__ void stage_interface(double *g, int part, const Layer
     }
 }
 
-// The walker's gauge, by one wave (every lane returns the same values): scale = product of interface_diag over
-// the interfaces between solid layers ilay0 .. nl-2, unit = the gauge is usable (see above).  L: the walker's
-// layer rows [4][pad].
-__device__ __forceinline__ double walker_gauge(const double *L, int pad, int nl, int ilay0, double p, int lane, bool &unit)
+// The walker's gauge, by the G lanes (G = 16, 32 or 64, aligned) that stage one (item, trace) -- every one of them
+// returns the same values: scale = product of interface_diag over the interfaces between solid layers
+// ilay0 .. nl-2, unit = the gauge is usable (see above).  L: the walker's layer rows [4][pad]; sl: lane within
+// the group; group_mask: the group's lanes within the wave.
+template <int G>
+__device__ __forceinline__ double walker_gauge(const double *L, int pad, int nl, int ilay0, double p, int sl,
+                                               unsigned long long group_mask, bool &unit)
 {
     double prod = 1.0;
     bool ok = true;
-    for (int l0 = ilay0; l0 + 1 < nl - 1; l0 += 64) {
-        const int l = l0 + lane;
+    for (int l0 = ilay0; l0 + 1 < nl - 1; l0 += G) {
+        const int l = l0 + sl;
         double d = 1.0;
         if (l + 1 < nl - 1) {
             const LayerHalf u = layer_half(L[pad + l], L[pad + l], L[2 * pad + l], p);
@@ -276,10 +279,11 @@ __device__ __forceinline__ double walker_gauge(const double *L, int pad, int nl,
             ok = ok && fabs(d) >= 0.0625 && fabs(d) <= 16.0;      // (false for NaN)
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) d *= __shfl_xor(d, o, 64);
+        for (int o = G / 2; o > 0; o >>= 1) d *= __shfl_xor(d, o, 64);
         prod *= d;
     }
-    unit = __all(ok) && fabs(prod) > 0x1p-600 && fabs(prod) < 0x1p600;
+    const bool all_ok = (__ballot(ok) & group_mask) == (__ballot(true) & group_mask);
+    unit = all_ok && fabs(prod) > 0x1p-600 && fabs(prod) < 0x1p600;
     return unit ? prod : 1.0;
 }
 
@@ -1030,17 +1034,21 @@ size_t spectra_lds_bytes(int nlay_pad) { return sizeof(double) * ((size_t)nlay_p
 // K0  stage_kernel: the per-(walker, forward-trace) constants of K1, computed ONCE per batch item by a wide,
 // shallow launch in front of the spectra / fused kernel -- not by every block that works on the item, on its
 // critical path (a dependent chain of divisions, square roots and three sincos per layer: ~4 us per block,
-// 4.5 % of a C4 launch).  One wave per (item, forward-trace); its lanes take (layer, part) pairs, the four
-// parts of a layer being independent (stage_interface), so the wave waits for one part's chain, not for four:
+// 4.5 % of a C4 launch).  A group of G lanes (16, 32 or 64: the smallest that holds the context's layers) per
+// (item, forward-trace), one LAYER per lane; the four independent parts of a layer (stage_interface),
 //   part 0: the (a_p, b_s) block of G, c[3..6]    (S slownesses)     part 2: xi, h and the P phase constants
 //   part 1: the (b_p, a_s) block of G, c[7..10]   (P slownesses)     part 3: eta and the S phase constants
+// run one after the other, each by every lane at once -- no lane waits while another part's code runs, and the
+// 64 / G groups of a wave execute the same instructions on different items.  (One lane per (layer, part) pair with
+// a wave per item, as before: the wave ran the interface code and the phase code one after the other with half
+// its lanes idle each time, twice for more than 16 layers -- 2.3x the instructions per item at C4, 4x at C2.)
 // Every consumer copies the same image, so the fused and the split launch plans -- and a chain evaluated alone
 // or in a batch -- see identical constants.
 // Output per bf = item * nfwd + f (global; the LDS image described above K1):
 //   gcoef[bf][nlay_pad][NCOEF]   layers ilay0 .. nl-2
 //   gtail[bf][GTAIL]             tail[0..16], [17] direct-arrival time (forward.f90:474-519)
 //   gflag[bf]                    bit 0: sea (beta(1) < 0), bit 1: generic path (a phase beyond the Cody-Waite
-//                                range, or no unit gauge: walker_gauge)
+//                                range, a DC phase beyond its series, or no unit gauge: walker_gauge)
 // ---------------------------------------------------------------------------
 struct StageParams {
     DeviceTables t;
@@ -1049,19 +1057,22 @@ struct StageParams {
     int *gflag;
 };
 
+template <int G>
 __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
 {
-    extern __shared__ double lds[];                 // [4][nlay_pad] direct-arrival terms, one row per wave
+    extern __shared__ double lds[];                 // [waves][64 / G][nlay_pad] direct-arrival terms, one row per group
+    constexpr int NG = 64 / G;                      // groups per wave
     const int pad = S.b.nlay_pad;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int bf = blockIdx.x * 4 + wave;
+    const int grp = lane / G, sl = lane % G;
+    const int bf = (blockIdx.x * (blockDim.x >> 6) + wave) * NG + grp;
     const bool live = bf < S.b.nb * S.t.nfwd;
     const int ib = live ? bf / S.t.nfwd : 0, f = live ? bf % S.t.nfwd : 0;
     const bool run = live && (!S.b.fwd_flag || S.b.fwd_flag[ib] == 1);
-    double *terms = lds + (size_t)wave * pad;
+    const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)) << (grp * G);
+    double *terms = lds + (size_t)(wave * NG + grp) * pad;
     // The lanes store their pieces straight into the global image.  (Assembling the image in LDS and writing whole
-    // rows was measured: no faster -- the kernel is bound by its divisions and square roots, not by its stores --
-    // and the 64 KB of LDS per block halved the occupancy.)
+    // rows was measured: no faster -- the kernel is bound by its divisions and square roots, not by its stores.)
     bool big = false;
     int nl = 2;
     if (run) {
@@ -1076,55 +1087,54 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
         double *coef = S.gcoef + (size_t)bf * pad * NCOEF;
         double *tail = S.gtail + (size_t)bf * GTAIL;
         bool unit;
-        const double gauge = walker_gauge(L, pad, nl, ilay0, p, lane, unit);
+        const double gauge = walker_gauge<G>(L, pad, nl, ilay0, p, sl, group_mask, unit);
         big = !unit;
-        // (layer, part) pairs of the walker's own nl - 1 layers above the half-space: a 16-layer walker is one pass
-        for (int w0 = 0; w0 < 4 * (nl - 1); w0 += 64) {
-            const int l = (w0 + lane) >> 2, part = lane & 3;
-            if (l >= nl - 1) continue;
-            const double *V = (part == 1 || part == 2) ? L : L + pad;   // parts 1, 2: alpha (xi); 0, 3: beta (eta)
+        // the walker's nl - 1 layers above the half-space, one per lane
+        for (int l = sl; l < nl - 1; l += G) {
             // this layer and the one below it
-            const double v0 = V[l], a0 = L[l], b0 = L[pad + l], r0 = L[2 * pad + l], h0 = L[3 * pad + l];
-            const double v1 = V[l + 1], a1 = L[l + 1], b1 = L[pad + l + 1], r1 = L[2 * pad + l + 1];
+            const double a0 = L[l], b0 = L[pad + l], r0 = L[2 * pad + l], h0 = L[3 * pad + l];
+            const double a1 = L[l + 1], b1 = L[pad + l + 1], r1 = L[2 * pad + l + 1];
             double *c = coef + (size_t)l * NCOEF;
-            if (l >= ilay0 && l < nl - 1) {
-                if (part < 2) {
-                    const LayerHalf u = layer_half(v0, b0, r0, p);
+            if (l >= ilay0) {
+#pragma unroll
+                for (int part = 0; part < 2; ++part) {
+                    // part 0: beta (eta), part 1: alpha (xi)
+                    const LayerHalf u = layer_half(part ? a0 : b0, b0, r0, p);
                     if (l + 1 < nl - 1) {
-                        const LayerHalf w = layer_half(v1, b1, r1, p);
+                        const LayerHalf w = layer_half(part ? a1 : b1, b1, r1, p);
                         stage_interface(c + 3 + 4 * part, part, u, &w, unit);
                     } else {
                         stage_interface(c + 3 + 4 * part, part, u, nullptr, unit);
                     }
-                } else {
-                    // parts 2 (P) and 3 (S) run the SAME instructions on different inputs and store at offsets
-                    // that differ by a constant: the two halves of the wave do not diverge
-                    const int s = part - 2;
-                    const double slow = vertical_slowness(v0, p);
+                }
+#pragma unroll
+                for (int sph = 0; sph < 2; ++sph) {
+                    // sph 0: the P phase (part 2), 1: the S phase (part 3)
+                    const double slow = vertical_slowness(sph ? b0 : a0, p);
                     // phases of the Nyquist bin, argument formed like the reference (forward.f90:397-400)
                     double sn, cn;
                     sincos_cw((omg_nyq * slow) * h0, sn, cn);
-                    c[s] = slow;
-                    c[2 + 21 * s] = s ? 0.0 : h0;      // c[2] = h (part 2), c[23] = pad (part 3)
-                    stage_phase(c + 11 + 2 * s, c + 15 + 2 * s, S.t.domg, slow, h0);
-                    c[19 + 2 * s] = sn;
-                    c[20 + 2 * s] = cn;
+                    c[sph] = slow;
+                    c[2 + 21 * sph] = sph ? 0.0 : h0;      // c[2] = h (part 2), c[23] = pad (part 3)
+                    stage_phase(c + 11 + 2 * sph, c + 15 + 2 * sph, S.t.domg, slow, h0);
+                    c[19 + 2 * sph] = sn;
+                    c[20 + 2 * sph] = cn;
                     big |= fabs(omg_max * slow * h0) >= SINCOS_CW_LIMIT || !(fabs(S.t.omg_dc * slow * h0) < DC_PHASE_LIMIT);
                 }
             }
-            // walker constants, by the lanes of the lighter parts that already hold the layers involved
-            if (part == 2 && l == nl - 2) {
+            // walker constants, by the lanes that already hold the layers involved
+            if (l == nl - 2) {
                 // half-space = layer l + 1; the last solid layer (if any) = layer l
                 LayerBasis last;
                 if (solid) last = layer_basis(a0, b0, r0, p);
                 stage_halfspace(tail, a1, b1, r1, p, solid ? &last : nullptr, gauge);
             }
-            if (part == 3 && l == (solid ? ilay0 : 0)) {
+            if (l == (solid ? ilay0 : 0)) {
                 LayerBasis top;
                 if (solid) top = layer_basis(a0, b0, r0, p);
                 stage_start(tail + 11, solid ? &top : nullptr);
             }
-            if (part == 3 && l == 0 && sea) {
+            if (l == 0 && sea) {
                 const double xiw = vertical_slowness(a0, p);   // forward.f90:431
                 tail[8] = xiw;
                 tail[9] = h0;
@@ -1136,11 +1146,11 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
         // strictly in layer order below (it feeds nint(): bit-exact bookkeeping)
         const double *vel = (S.t.ipha[f] == 1) ? L : L + pad;   // alpha for P, beta for S (:157,161)
         const int i0 = S.t.sdep > 0.0 ? 1 : 0;                  // keyed on sdep (:484)
-        for (int i = i0 + lane; i < nl - 1; i += 64) terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], p);
+        for (int i = i0 + sl; i < nl - 1; i += G) terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], p);
     }
-    const bool any_big = __any(big);
+    const bool any_big = (__ballot(big) & group_mask) != 0;
     __syncthreads();
-    if (run && lane == 0) {
+    if (run && sl == 0) {
         const double *L = S.b.layers + (size_t)ib * 4 * pad;
         const int i0 = S.t.sdep > 0.0 ? 1 : 0;
         S.gtail[(size_t)bf * GTAIL + 17] = arrival_sum(nl - 1 - i0, terms);
@@ -1148,11 +1158,29 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
     }
 }
 
+template <int G>
+static void launch_stage_g(const StageParams &S, unsigned nbf, int nlay_pad, hipStream_t s)
+{
+    constexpr unsigned NG = 64 / G;
+    const unsigned nwave = (nbf + NG - 1) / NG;
+    // small batches: one wave per block, so that the few waves spread over the CUs
+    const unsigned wpb = nwave <= 2048 ? 1 : 4;
+    hipLaunchKernelGGL(stage_kernel<G>, dim3((nwave + wpb - 1) / wpb), dim3(64 * wpb),
+                       sizeof(double) * wpb * NG * (size_t)nlay_pad, s, S);
+}
+
 void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
 {
     StageParams S{t, b, w.gcoef, w.gtail, w.gflag};
     const unsigned nbf = (unsigned)(b.nb * t.nfwd);
-    hipLaunchKernelGGL(stage_kernel, dim3((nbf + 3) / 4), dim3(256), sizeof(double) * 4 * (size_t)b.nlay_pad, s, S);
+    // lanes per (item, trace): the layers above the half-space of the deepest walker the context allows
+    const int nsolid_max = b.nlay_pad - 1;
+    if (nsolid_max <= 16)
+        launch_stage_g<16>(S, nbf, b.nlay_pad, s);
+    else if (nsolid_max <= 32)
+        launch_stage_g<32>(S, nbf, b.nlay_pad, s);
+    else
+        launch_stage_g<64>(S, nbf, b.nlay_pad, s);
 }
 
 template <int BK, int NCOL>
