@@ -366,12 +366,15 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     std::vector<double> obs((size_t)nsmp * ntrc);
     for (int t = 0; t < ntrc; ++t)
         for (int i = 0; i < nsmp; ++i) obs[(size_t)i + (size_t)nsmp * t] = cfg->obs[(size_t)i + (size_t)cfg->ldobs * t];
-    // exp(+2 pi i k / n): half a turn for the power-of-two FFT, the full turn for the direct DFT of any other n
-    std::vector<double2> tw(pow2 ? (size_t)n / 2 : (size_t)n);
+    // exp(+2 pi i k / n), the full turn.  Power-of-two n (the in-LDS FFT): the second half is the exact negative of
+    // the first, so that a butterfly reads its twiddle straight from the table (no sign select).
+    std::vector<double2> tw((size_t)n);
     for (size_t k = 0; k < tw.size(); ++k) {
         const long double a = 2.0L * 3.14159265358979323846264338327950288L * k / n;
         tw[k] = make_double2((double)cosl(a), (double)sinl(a));
     }
+    if (pow2)
+        for (size_t k = 0; k < (size_t)n / 2; ++k) tw[k + (size_t)n / 2] = make_double2(-tw[k].x, -tw[k].y);
     std::vector<double> rayps(cfg->rayps, cfg->rayps + ntrc);
     std::vector<int> ipha(cfg->ipha, cfg->ipha + ntrc);
 

@@ -21,7 +21,7 @@ struct DeviceTables {
     const double *r_inv_t;  // [ntrc][nsmp*nsmp]  r_inv(i,j) at [i*nsmp + j] (transposed image)
     const double *rayps;    // [ntrc]
     const int *ipha;        // [ntrc]
-    const double2 *twiddle; // [nfft/2]  exp(+2 pi i k / nfft) (power-of-two nfft: the in-LDS FFT)
+    const double2 *twiddle; // [nfft]  exp(+2 pi i k / nfft), the full turn (power-of-two nfft: the in-LDS FFT)
     const double2 *twiddle_any; // [nfft] exp(+2 pi i k / nfft) for any other nfft (direct DFT, trace_anyn_kernel), else nullptr
     const int *nh_active;   // [ntrc] bins with a non-negligible filter weight, or nullptr (all bins)
 };

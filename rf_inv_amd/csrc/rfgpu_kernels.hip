@@ -1354,13 +1354,6 @@ __device__ __forceinline__ void dft_regs(double2 (&v)[1 << LOG2R])
     }
 }
 
-// twiddle exp(+2 pi i t / n) for 0 <= t < n from the half table tw[0 .. n/2)
-__device__ __forceinline__ double2 tw_full(const double2 *__restrict__ tw, int t, int half_n)
-{
-    const double2 w = tw[t & (half_n - 1)];
-    return t >= half_n ? make_double2(-w.x, -w.y) : w;
-}
-
 template <int LOG2R, int THREADS>
 __device__ __forceinline__ void fft_pass(double2 *a, int log2n, int stride_log2, const double2 *__restrict__ tw,
                                          int tid)
@@ -1377,17 +1370,13 @@ __device__ __forceinline__ void fft_pass(double2 *a, int log2n, int stride_log2,
         // whole pass pays one global round trip, not R-1 of them
         if (stride_log2 > 0) {
 #pragma unroll
-            for (int k = 1; k < R; ++k) w[k] = tw[((jp * k) << tw_mul_log2) & ((n >> 1) - 1)];
+            for (int k = 1; k < R; ++k) w[k] = tw[(unsigned)((jp * k) << tw_mul_log2)];   // (< n: the table holds the full turn)
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) v[k] = a[fft_pad(base + (k << stride_log2))];
         if (stride_log2 > 0) {
 #pragma unroll
-            for (int k = 1; k < R; ++k) {
-                const bool neg = ((jp * k) << tw_mul_log2) >= (n >> 1);   // exp(i(t + pi)) = -exp(it)
-                const double2 wk = neg ? make_double2(-w[k].x, -w[k].y) : w[k];
-                v[k] = cmul(v[k], wk);
-            }
+            for (int k = 1; k < R; ++k) v[k] = cmul(v[k], w[k]);
         }
         dft_regs<LOG2R>(v);
 #pragma unroll
@@ -1401,13 +1390,12 @@ __device__ __forceinline__ void fft_pass(double2 *a, int log2n, int stride_log2,
 // v[k] is sample tid + (bitrev4(k) << 8).  Same operations as fft_pass, pass by pass.
 __device__ __forceinline__ void fft4096_regs(double2 *a, const double2 *__restrict__ tw, int tid, double2 (&v)[16])
 {
-    constexpr int HALF = 2048;
     double2 w2[16], w3[16];
     const int jp = tid & 15;
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w2[k] = tw[((jp * k) << 4) & (HALF - 1)];
+    for (int k = 1; k < 16; ++k) w2[k] = tw[(unsigned)((jp * k) << 4)];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w3[k] = tw[(tid * k) & (HALF - 1)];
+    for (int k = 1; k < 16; ++k) w3[k] = tw[(unsigned)(tid * k)];
     fft_pass<4, TRACE_THREADS>(a, 12, 0, tw, tid);          // pass 1: stride 1, no twiddles
     __syncthreads();
     {                                                       // pass 2: stride 16
@@ -1415,11 +1403,7 @@ __device__ __forceinline__ void fft4096_regs(double2 *a, const double2 *__restri
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = a[fft_pad(base + (k << 4))];
 #pragma unroll
-        for (int k = 1; k < 16; ++k) {
-            const bool neg = ((jp * k) << 4) >= HALF;       // exp(i(t + pi)) = -exp(it)
-            const double2 wk = neg ? make_double2(-w2[k].x, -w2[k].y) : w2[k];
-            v[k] = cmul(v[k], wk);
-        }
+        for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], w2[k]);
         dft_regs<4>(v);
 #pragma unroll
         for (int k = 0; k < 16; ++k) a[fft_pad(base + (bitrev_small<4>(k) << 4))] = v[k];
@@ -1428,11 +1412,7 @@ __device__ __forceinline__ void fft4096_regs(double2 *a, const double2 *__restri
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = a[fft_pad(tid + (k << 8))];   // pass 3: stride 256
 #pragma unroll
-    for (int k = 1; k < 16; ++k) {
-        const bool neg = (tid * k) >= HALF;
-        const double2 wk = neg ? make_double2(-w3[k].x, -w3[k].y) : w3[k];
-        v[k] = cmul(v[k], wk);
-    }
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], w3[k]);
     dft_regs<4>(v);
 }
 
@@ -1453,15 +1433,11 @@ __device__ __forceinline__ void fft_regs_last(double2 *a, const FftPlan &pl, int
     }
     double2 w[R];
 #pragma unroll
-    for (int k = 1; k < R; ++k) w[k] = tw[(tid * k) & ((n >> 1) - 1)];
+    for (int k = 1; k < R; ++k) w[k] = tw[(unsigned)(tid * k)];
 #pragma unroll
     for (int k = 0; k < R; ++k) v[k] = a[fft_pad(tid + (k << 8))];
 #pragma unroll
-    for (int k = 1; k < R; ++k) {
-        const bool neg = (tid * k) >= (n >> 1);   // exp(i(t + pi)) = -exp(it)
-        const double2 wk = neg ? make_double2(-w[k].x, -w[k].y) : w[k];
-        v[k] = cmul(v[k], wk);
-    }
+    for (int k = 1; k < R; ++k) v[k] = cmul(v[k], w[k]);
     dft_regs<LOG2R>(v);
 }
 
@@ -2236,17 +2212,13 @@ __device__ __forceinline__ void w8_pass(double2 *a, const double2 *__restrict__ 
     double2 v[8], w[8];
     if (SL > 0) {
 #pragma unroll
-        for (int k = 1; k < 8; ++k) w[k] = tw[((jp * k) << (9 - SL)) & 2047];
+        for (int k = 1; k < 8; ++k) w[k] = tw[(unsigned)((jp * k) << (9 - SL))];   // (< 4096: the table holds the full turn)
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(base + (k << SL))];
     if (SL > 0) {
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            const bool neg = ((jp * k) << (9 - SL)) >= 2048;   // exp(i(t + pi)) = -exp(it)
-            const double2 wk = neg ? make_double2(-w[k].x, -w[k].y) : w[k];
-            v[k] = cmul(v[k], wk);
-        }
+        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
     }
     dft_regs<3>(v);
 #pragma unroll
@@ -2399,15 +2371,11 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
     {
         double2 w[8];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) w[k] = tw[(tid * k) & 2047];
+        for (int k = 1; k < 8; ++k) w[k] = tw[(unsigned)(tid * k)];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(tid + (k << 9))];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            const bool neg = (tid * k) >= 2048;
-            const double2 wk = neg ? make_double2(-w[k].x, -w[k].y) : w[k];
-            v[k] = cmul(v[k], wk);
-        }
+        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
         dft_regs<3>(v);                    // v[k] = sample tid + (bitrev3(k) << 9): .x RF trace, .y vertical trace
     }
     double fac = 1.0;
