@@ -1577,26 +1577,28 @@ __device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 
         fac = block_max(m, red);                                     // maxval(rx) forward.f90:201
     }
     const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
-    // one reciprocal per thread instead of a division per sample (each sample within 1 ulp of the quotient)
-    const double rfac = 1.0 / fac;
+    // one reciprocal per thread instead of a division per sample (each sample within 1 ulp of the quotient); it
+    // carries the sign of the S map (decon: fac = 1, the product is exact)
+    const double rfac = (ipha == 1 ? 1.0 : -1.0) / fac;
+    // The reference's maps rft(i) = rx(mod(n - npre + i, n)) (forward.f90:179) and rft(i) = -rx(mod(n + npre - i + 1, n))
+    // (:188), index 0 standing for n, inverted: sample j (1-based) of rx lands at i = j + npre (P) or n + npre + 1 - j
+    // (S), taken mod n with 0 -> n; 0-based that is (j - 1 + npre) mod n and (npre - j) mod n -- n is a power of
+    // two, so the reference's mod is a mask, also for negative arguments.
+    const unsigned mask = (unsigned)(n - 1);
+    const int at0 = ipha == 1 ? tid + npre : npre - tid - 1;        // sample j = tid + 1
+    const int step = ipha == 1 ? 256 : -256;
 #pragma unroll
     for (int k = 0; k < R; ++k) {
-        const int j = tid + (bitrev_small<LOG2R>(k) << 8) + 1;       // 1-based sample of rx
-        // invert the reference's maps rft(i) = rx(mod(n - npre + i, n)) (forward.f90:179) and
-        // rft(i) = -rx(mod(n + npre - i + 1, n)) (:188), index 0 standing for n
-        // n is a power of two: mod(x, n) of the reference = x & (n - 1), also for negative x
-        int i = (ipha == 1 ? j + npre : n + npre + 1 - j) & (n - 1);
-        if (i == 0) i = n;
-        double val = ipha == 1 ? v[k].x : -v[k].x;
-        if (!decon) val = val * rfac;                                // forward.f90:202 (see rfac)
-        __builtin_nontemporal_store(val, &dst[i - 1]);   // written once, read rarely: keep it out of L2
-        if (xout) xout[i - 1] = val;
-        if (i <= nsmp) {
-            const double m = val - obs[i - 1];                       // likelihood.f90:88
+        const unsigned i0 = (unsigned)(at0 + step * bitrev_small<LOG2R>(k)) & mask;   // 0-based sample of rft
+        const double val = v[k].x * rfac;                            // forward.f90:202 (see rfac)
+        __builtin_nontemporal_store(val, &dst[i0]);   // written once, read rarely: keep it out of L2
+        if (xout) xout[i0] = val;
+        if (i0 < (unsigned)nsmp) {
+            const double m = val - obs[i0];                          // likelihood.f90:88
             if (P.defer_logl)
-                mis_g[i - 1] = m;
+                mis_g[i0] = m;
             else
-                mis[i - 1] = m;
+                mis[i0] = m;
         }
     }
     return P.defer_logl != 0;   // quadratic form and logL: phi_deferred_kernel (+ logl_deferred_kernel), after this launch
@@ -2396,24 +2398,22 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
     double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
     double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
     const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
-    // one reciprocal per thread instead of a division per sample (each sample within 1 ulp of the quotient)
-    const double rfac = 1.0 / fac;
+    // (the same store loop as tail_in_registers: one signed reciprocal per thread, 0-based masked sample index)
+    const double rfac = (ipha == 1 ? 1.0 : -1.0) / fac;
+    const int at0 = ipha == 1 ? tid + npre : npre - tid - 1;        // sample j = tid + 1
+    const int step = ipha == 1 ? 512 : -512;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const int j = tid + (bitrev_small<3>(k) << 9) + 1;           // 1-based sample of rx
-        // invert rft(i) = rx(mod(n - npre + i, n)) (forward.f90:179) and rft(i) = -rx(mod(n + npre - i + 1, n)) (:188)
-        int i = (ipha == 1 ? j + npre : n + npre + 1 - j) & (n - 1);
-        if (i == 0) i = n;
-        double val = ipha == 1 ? v[k].x : -v[k].x;
-        if (!decon) val = val * rfac;                                // forward.f90:202 (see rfac)
-        __builtin_nontemporal_store(val, &dst[i - 1]);
-        if (xout) xout[i - 1] = val;
-        if (i <= nsmp) {
-            const double m = val - obs[i - 1];                       // likelihood.f90:88
+        const unsigned i0 = (unsigned)(at0 + step * bitrev_small<3>(k)) & 4095u;      // 0-based sample of rft
+        const double val = v[k].x * rfac;                            // forward.f90:202 (see rfac)
+        __builtin_nontemporal_store(val, &dst[i0]);
+        if (xout) xout[i0] = val;
+        if (i0 < (unsigned)nsmp) {
+            const double m = val - obs[i0];                          // likelihood.f90:88
             if (P.defer_logl)
-                mis_g[i - 1] = m;
+                mis_g[i0] = m;
             else
-                mis[i - 1] = m;
+                mis[i0] = m;
         }
     }
     if (P.defer_logl) return;   // quadratic form and logL: phi_deferred_kernel (+ logl_deferred_kernel)
