@@ -760,12 +760,12 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
                                                     int nl, int ilay0, int ipha, const Sink &sink, int it0, int lane,
                                                     const double2 *tab = nullptr)
 {
-    // Register budget (two waves per SIMD: 256 VGPRs; TIGHT: the 128 of fused8_kernel).  Short chains hold k and
-    // omega of every bin; the 8-bin land kernel holds the omegas and rebuilds k (one exact addition per bin and
-    // layer); the 3-column ocean kernel and the TIGHT chains keep only the first bin's index and rebuild both
-    // where they are used (the values are the same doubles).
-    constexpr bool LEAN = TIGHT || (NCOL == 3 && BK >= 4) || (NCOL != 2 && BK >= 8);
-    constexpr bool KEEP_KD = !LEAN && BK < 8;
+    // Register budget (two waves per SIMD: 256 VGPRs; TIGHT: the 128 of fused8_kernel).  Short 2-column chains hold
+    // k and omega of every bin; the 8-bin land kernel and the 3-column ocean kernels hold the omegas and rebuild k
+    // (one exact addition per bin and layer); the TIGHT chains (and the 8-bin ocean chain nothing selects) keep only
+    // the first bin's index and rebuild both where they are used (the values are the same doubles).
+    constexpr bool LEAN = TIGHT || (NCOL != 2 && BK >= 8);
+    constexpr bool KEEP_KD = !LEAN && BK < 8 && NCOL == 2;
     ColState<NCOL> st[BK];
     double omg[LEAN ? 1 : BK], kd[KEEP_KD ? BK : 1];
     const int k0 = it0 * 64 + lane;

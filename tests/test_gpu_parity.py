@@ -245,17 +245,19 @@ def test_eight_wave_fused_kernel(oracle, deconv):
     true = random_stack(rng, 5)
     obs = synth_obs(oracle, cfg, true, nsmp)
     r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
-    stacks = [random_stack(rng, int(n)) for n in (2, 3, 8, 17, 30, 12, 12)] + [true]
+    # (40 layers: more than the anchor table of the 512-thread kernel holds -- that walker's chains start from a
+    # direct sincos like the 4-wave kernel's)
+    stacks = [random_stack(rng, int(n)) for n in (2, 3, 8, 17, 30, 12, 12, 40)] + [true]
     stacks[5][3][3] = 2.5e5                        # out-of-range phases
     stacks[6][2][4] = 40.0 * stacks[6][2][5]       # density contrast of 40 across an interface: no unit gauge
-    nlay, layers = pack_layers(stacks, 32)
+    nlay, layers = pack_layers(stacks, 42)
     nb = len(stacks)
     sig = np.column_stack([np.full(nb, 0.01), np.full(nb, 0.03)])
     ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True, nthreads=4)
     res = {}
     for bt in (256, 512):
         for defer in (0, 1):
-            with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=32,
+            with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=42,
                          options={"block_threads": bt, "defer_logl": defer}) as eng:
                 assert eng.launch_plan["block_threads_full_batch"] == bt
                 ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
