@@ -852,7 +852,6 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
         return ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(an >> 32)) << 32) |
                (unsigned)__builtin_amdgcn_readfirstlane((int)an);
     };
-    constexpr int LAYER_UNROLL = (LEAN || BK >= 8) ? 1 : 2;
     // Scalar-cache prefetch of the next layer's record (three 64-byte lines): by the next iteration it sits in the
     // scalar cache and that iteration's s_loads, which the wave waits for before it can do anything, are hits.
     // (Fetching the next layer's constants themselves into a second register set a layer ahead -- 17 s_loads by
@@ -863,7 +862,7 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
     // loop-carried ("+s"): reserved for the whole loop, never read; the wait after the loop retires the last loads
     // before the registers are handed back.
     unsigned touch0 = 0, touch1 = 0, touch2 = 0;
-#pragma unroll LAYER_UNROLL
+#pragma unroll 1
     for (int l = ilay0; l < nl - 1; ++l) {
         LayerK c = load_layer_k(coef + l * NCOEF);
         // (every constant through one empty asm: the compiler then issues all the loads together and waits once;
@@ -1424,7 +1423,6 @@ __device__ __forceinline__ void fft_regs_last(double2 *a, const FftPlan &pl, int
                                               int tid, double2 (&v)[1 << LOG2R])
 {
     constexpr int R = 1 << LOG2R;
-    const int n = 1 << log2n;
     int stride_log2 = 0;
     for (int p = 0; p + 1 < pl.npass; ++p) {
         fft_pass<4, TRACE_THREADS>(a, log2n, stride_log2, tw, tid);   // these sizes: radix 16 before the last
