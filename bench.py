@@ -263,6 +263,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c4", choices=sorted(WORKLOADS))
+    ap.add_argument("--debug-steps", action="store_true", help="stderr: the event-timed step durations of the timed region")
     ap.add_argument("--walkers", type=int, default=0, help="override walkers per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--swap", default="allgather", choices=["allgather", "p2p"],
@@ -372,31 +373,21 @@ def main():
                         swap.step(d_logl, stream)
                     h_logl.copy_(d_logl, non_blocking=True)
 
-        # ---- pre-warm by TIME (clock ramp, allocator, dispatch order of the running batch), then --warmup steps
-        t_pre = time.perf_counter()
-        n_pre = 0
-        while True:
-            for _ in range(8):
-                step()
-            n_pre += 8
-            torch.cuda.synchronize(dev)
-            if time.perf_counter() - t_pre >= args.prewarm_seconds:
-                break
-        for _ in range(warmup):
-            step()
-        barrier()
-        # HIP events (library side, on the launch stream) around the dominant kernel, and torch events on the same
-        # stream around whole steps, both on every `every`-th step of the timed region: an event pair costs ~4 us of
-        # stream time -- at C2 (0.09 ms steps) timing every step would slow the loop it measures by ~8 %
-        every = 1 if steps <= 16 else min(8, max(1, steps // 8))
-        eng.profile_enable(0 if args.no_kernel_events else every)
-        marks = []
+        # ---- pre-warm by TIME (clock ramp, allocator, dispatch order of the running batch), then --warmup steps.
+        # Nothing that leaves the GPU idle for milliseconds may sit between the last warm-up step and the timed
+        # region -- the clocks drop within a few ms of idleness and take tens of ms of work to come back (a
+        # gc.collect() there cost the first 20 timed steps 15 %): the collector is run and disabled, and the event
+        # machinery switched on, BEFORE the pre-warm; only the barrier separates warm-up and timed steps.
         import gc
 
         gc.collect()
         gc.disable()            # no collector pause inside the (possibly short) timed region
-        t0 = time.perf_counter()
-        for i in range(steps):
+        # HIP events (library side, on the launch stream) around the dominant kernel, and torch events on the same
+        # stream around whole steps, both on every `every`-th step of the timed region: an event pair costs ~4 us of
+        # stream time -- at C2 (0.09 ms steps) timing every step would slow the loop it measures by ~8 %
+        every = 1 if steps <= 16 else min(8, max(1, steps // 8))
+        marks = []
+        def timed_step(i, marks):
             if i % every == 0:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(stream)
@@ -405,12 +396,45 @@ def main():
                 marks.append((e0, e1))
             else:
                 step()
+
+        # (the pre-warm and the warm-up run the very code of the timed loop, events included: on a fresh box the first
+        # pass through any code path pages it in from the image -- a 10 ms stall if that happens inside the timed
+        # region.  The library-side kernel events are exercised once, flushed -- a synchronisation -- and switched on
+        # again, which costs nothing, right before the timed region.)
+        eng.profile_enable(0 if args.no_kernel_events else every)
+        scratch = []
+        for i in range(8):
+            timed_step(i, scratch)
+        torch.cuda.synchronize(dev)
+        eng.profile_enable(False)
+        eng.profile_read()
+        t_pre = time.perf_counter()
+        n_pre = 8
+        while True:
+            scratch = []
+            for i in range(8):
+                timed_step(i, scratch)
+            n_pre += 8
+            torch.cuda.synchronize(dev)
+            _ = [a.elapsed_time(b) for a, b in scratch]
+            if time.perf_counter() - t_pre >= args.prewarm_seconds:
+                break
+        scratch = []
+        for i in range(warmup):
+            timed_step(i, scratch)
+        barrier()
+        eng.profile_enable(0 if args.no_kernel_events else every)
+        t0 = time.perf_counter()
+        for i in range(steps):
+            timed_step(i, marks)
         barrier()
         dt = time.perf_counter() - t0
         gc.enable()
         eng.profile_enable(False)
         prof = eng.profile_read()
         step_ms = np.array([a.elapsed_time(b) for a, b in marks])
+        if args.debug_steps:
+            print("step_ms", workload, np.round(step_ms, 3).tolist(), "dt", dt, file=sys.stderr)
         if world > 1:
             t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

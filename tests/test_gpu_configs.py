@@ -279,7 +279,7 @@ def test_bench_two_ranks_on_one_gpu_swap_matches_serial_replay(tmp_path):
     assert d["config"]["parallelism"] == "walkers sharded x2"
     st = np.load(dump)
     temps, logl = st["temps"], st["logl"]
-    assert temps.shape == (2, nb) and int(st["swap_steps"]) == 8 + warm + steps
+    assert temps.shape == (2, nb) and int(st["swap_steps"]) == 16 + warm + steps
     ref = np.concatenate([init_temps(nb, max(1, nb // ntemps), 15.0,
                                      np.random.Generator(np.random.Philox(key=1234 + 7919 * (rk + 1)))) for rk in range(2)])
     start = ref.copy()
