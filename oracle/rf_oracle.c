@@ -65,7 +65,11 @@
  * the textbook receiver-function processing, with the reference's integer
  * quirks listed one by one.  This file and the HIP path both agree with it to
  * 1e-11 of the trace scale for P and S, with and without deconvolution,
- * 2..29 layers, on models where the water level clips bins.  Also kept: an
+ * 2..29 layers, on models where the water level clips bins; and, with the
+ * free surface replaced by the sea floor's boundary conditions solved
+ * together with the acoustic waves of the water column, for the ocean-bottom
+ * case (layer_matrix_liq and the sea-floor rows, forward.f90:276-287,
+ * 424-442) -- which therefore no longer rests on (3) alone.  Also kept: an
  * independent numpy restatement (calc_seis_numpy) and the half-space
  * apparent-angle relations (tests/test_oracle_kat.py).  With respect to
  * reference OUTPUTS these two branches remain "parity unpinned".

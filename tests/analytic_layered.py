@@ -15,6 +15,13 @@ The receiver-function processing on top is the textbook definition (Langston 197
 water-level deconvolution; unit-height Gaussian pulse), written against physical time, with the reference's
 integer quirks listed explicitly in `REFERENCE_QUIRKS` -- each one cites the reference line it comes from.
 
+An ocean (the reference marks it with beta(1) < 0: src/forward.f90:229, model.f90:203-206) is a FLUID layer on top
+of the solid stack with the receiver on the sea floor: the traction-free surface is replaced by the sea floor's
+own boundary conditions -- no shear traction, continuous vertical displacement and normal traction -- solved
+numerically together with the acoustic up- and down-going waves of the water column under a pressure-free sea
+surface.  (The reference instead multiplies a 2x2 liquid-layer propagator into rows of the solid chain,
+src/forward.f90:276-287, 424-442.)
+
 Conventions here: z positive DOWN, time dependence exp(-i w t) while solving; at the end the spectra are
 conjugated (numpy / FFTW synthesise with exp(+i w t)) and the vertical component is flipped to positive UP,
 the receiver-function convention (direct P positive on both components).
@@ -57,10 +64,39 @@ def _wave_vectors(w, p, alpha, beta, rho):
     return np.stack(cols, axis=-1), xi, eta
 
 
+def _sea_floor_reflection(w, p, F1, alpha_w, rho_w, depth):
+    """R[nw, 2, 2]: downgoing (P, SV) amplitudes in the top solid layer per unit upgoing (P, SV) wave hitting
+    the sea floor from below, under a water column of the given depth with a pressure-free surface.
+    Acoustic plane waves of unit displacement amplitude along their slowness vector: u_z = alpha_w s,
+    t_zz = i w lambda_w (p u_x + s u_z) with lambda_w = rho_w alpha_w^2; the sea floor is z = 0, the sea surface
+    z = -depth.  Unknowns per incident wave: the two reflected solid waves and the upgoing acoustic amplitude."""
+    nw = w.size
+    xi_w = np.sqrt(1.0 / alpha_w ** 2 - p * p + 0j)
+    lam_w = rho_w * alpha_w ** 2
+    uz_up, uz_dn = alpha_w * (-xi_w), alpha_w * xi_w
+    tzz = 1j * w * lam_w * alpha_w * (p * p + xi_w * xi_w)          # the same for both directions
+    # pressure-free sea surface: up exp(i w xi_w depth) + down exp(-i w xi_w depth) = 0
+    down_per_up = -np.exp(2j * w * xi_w * depth)
+    wz = uz_up + uz_dn * down_per_up                                 # water column at the sea floor, per unit U
+    wt = tzz * (1.0 + down_per_up)
+    A = np.zeros((nw, 3, 3), complex)
+    A[:, 0, :2] = F1[:, 2, 2:]                                       # t_xz of the reflected waves = -t_xz incident
+    A[:, 1, :2] = F1[:, 1, 2:]                                       # u_z continuous
+    A[:, 1, 2] = -wz
+    A[:, 2, :2] = F1[:, 3, 2:]                                       # t_zz continuous
+    A[:, 2, 2] = -wt
+    rhs = -np.stack([F1[:, 2, :2], F1[:, 1, :2], F1[:, 3, :2]], axis=1)
+    return np.linalg.solve(A, rhs)[:, :2, :]
+
+
 def surface_response(w, p, ipha, alpha, beta, rho, h):
-    """(u_x, u_z)[nw] at the free surface (z down, exp(-iwt)) for a unit upgoing P (ipha = 1) or SV (ipha = -1)
-    wave incident from the half-space = last entry of alpha/beta/rho; h[:-1] are the layer thicknesses.
-    The incident wave's phase is zero at the deepest interface."""
+    """(u_x, u_z)[nw] at the free surface -- under an ocean (beta[0] < 0): of the solid at the sea floor -- (z down,
+    exp(-iwt)) for a unit upgoing P (ipha = 1) or SV (ipha = -1) wave incident from the half-space = last entry of
+    alpha/beta/rho; h[:-1] are the layer thicknesses.  The incident wave's phase is zero at the deepest interface."""
+    water = None
+    if beta[0] < 0:                                  # ocean: layer 0 is water, the receiver sits on the sea floor
+        water = (alpha[0], rho[0], h[0])
+        alpha, beta, rho, h = alpha[1:], beta[1:], rho[1:], h[1:]
     n = len(alpha)
     F = [_wave_vectors(w, p, alpha[i], beta[i], rho[i]) for i in range(n)]
     nw = w.size
@@ -84,7 +120,10 @@ def surface_response(w, p, ipha, alpha, beta, rho, h):
         R_D = E @ R_D @ E
         T_U = E @ T_U
     F1 = F[0][0]
-    R_F = -np.linalg.solve(F1[:, 2:, 2:], F1[:, 2:, :2])                   # traction-free surface
+    if water is None:
+        R_F = -np.linalg.solve(F1[:, 2:, 2:], F1[:, 2:, :2])               # traction-free surface
+    else:
+        R_F = _sea_floor_reflection(w, p, F1, *water)
     e = np.zeros((nw, 2, 1), complex)
     e[:, 0 if ipha == 1 else 1, 0] = 1.0
     v_up = np.linalg.solve(eye - R_D @ R_F, T_U @ e)
@@ -111,6 +150,8 @@ def receiver_function(nfft, delta, t_start, a_gus, rayp, ipha, deconv, alpha, be
     def synth(spec):           # unnormalised real inverse DFT (imaginary parts of DC / Nyquist have no effect)
         return np.fft.irfft(spec, nfft) * nfft
 
+    solid = slice(1, None) if beta[0] < 0 else slice(None)     # the direct wave reaches the sea floor, not the sea surface
+    alpha, beta, h = alpha[solid], beta[solid], h[solid]
     xi = np.sqrt(1.0 / alpha ** 2 - rayp ** 2)
     eta = np.sqrt(1.0 / beta ** 2 - rayp ** 2)
     if deconv:

@@ -11,7 +11,12 @@ oracle (CPU, `-m "not gpu"`) and the HIP path (`-m gpu`) must reproduce it:
     normalisation of an S trace by the VERTICAL maximum (:197-203);
   * water-level deconvolution: R/V for P, V/R for S (:148-153), level 0.001 of the maximum over the nh bins
     (:447-470), no direct-arrival shift (tp = 0) -- on models where the level really clips bins;
-  * P incidence and several layers as a control.
+  * P incidence and several layers as a control;
+  * an ocean over the stack with the receiver on the sea floor (the reference's OBS case, `sdep > 0`): the
+    liquid-layer matrix and the sea-floor rows of the boundary condition (forward.f90:276-287, 424-442), the
+    direct-arrival time without the water layer (:484), P and S, with and without deconvolution -- from the sea
+    floor's boundary conditions solved together with the acoustic waves of the water column, not from a
+    liquid-layer propagator.
 
 Agreement is at rounding level (1e-12 of the trace scale), far inside the 1e-9 logL tolerance.
 """
@@ -36,6 +41,15 @@ MODELS += [
 ]
 CASES = [(m, ipha, p, dec) for m in MODELS for ipha, p in ((1, 0.06), (-1, 0.10)) for dec in (0, 1)]
 IDS = [f"{m[0]}-{'P' if ipha == 1 else 'S'}-{'decon' if dec else 'norm'}" for m, ipha, p, dec in CASES]
+
+# ocean-bottom models: the reference's water layer (alpha 1.5, rho 1.0, beta < 0 as the marker, thickness = sdep)
+# on top of random crustal stacks; nlay 2 = water directly on the half-space
+SDEP = 2.0
+OCEAN_MODELS = [("obs%d" % n, *random_stack(_rng, n, ocean=True, sdep=SDEP)) for n in (2, 3, 5, 8)]
+OCEAN_MODELS.append(("deep_water", np.array([1.5, 5.5, 7.9]), np.array([-999.0, 3.1, 4.4]), np.array([1.0, 2.6, 3.3]),
+                     np.array([5.0, 12.0, 999.0])))
+OCEAN_CASES = [(m, ipha, p, dec) for m in OCEAN_MODELS for ipha, p in ((1, 0.06), (-1, 0.10)) for dec in (0, 1)]
+OCEAN_IDS = [f"{m[0]}-{'P' if ipha == 1 else 'S'}-{'decon' if dec else 'norm'}" for m, ipha, p, dec in OCEAN_CASES]
 
 
 def _expected(model, ipha, p, dec, nfft=NFFT, **kw):
@@ -77,6 +91,26 @@ def test_oracle_matches_reflectivity_solution(oracle, case):
         assert np.abs(other - got).max() > 1e-3 * np.abs(got).max()
 
 
+@pytest.mark.parametrize("case", OCEAN_CASES, ids=OCEAN_IDS)
+def test_oracle_matches_sea_floor_reflectivity_solution(oracle, case):
+    model, ipha, p, dec = case
+    sdep = float(model[4][0])
+    cfg = make_cfg(nfft=NFFT, deconv_mode=dec, t_start=T_START, rayps=[p], a_gus=[A_GUS], ipha=[ipha], sdep=sdep)
+    got = oracle.calc_rf(cfg, *model[1:])[0]
+    _check(got, _expected(model, ipha, p, dec), case[0][0])
+
+
+def test_sea_floor_solution_differs_from_the_land_one():
+    """The ocean pin is not vacuous: the same solid stack without its water column is a different trace, and so is
+    a water column of another depth."""
+    m = OCEAN_MODELS[2]
+    wet = _expected(m, 1, 0.06, 0)
+    dry = al.receiver_function(NFFT, DELTA, T_START, A_GUS, 0.06, 1, 0, *[x[1:] for x in m[1:]])
+    assert np.abs(wet - dry).max() > 1e-2 * np.abs(wet).max()
+    deeper = (m[0], m[1], m[2], m[3], np.concatenate([[3.0], m[4][1:]]))
+    assert np.abs(_expected(deeper, 1, 0.06, 0) - wet).max() > 1e-3 * np.abs(wet).max()
+
+
 def test_s_trace_is_offset_by_one_sample_like_the_reference(oracle):
     """forward.f90:188: j = mod(nfft + npre - i + 1, nfft) puts lag t_start + i * delta into the 1-based sample i
     -- the lag that nominally belongs to sample i + 1 (the P map of :179 has no such offset).  The physical
@@ -112,6 +146,45 @@ def test_hip_matches_reflectivity_solution(case, fused):
         # the kernel forms the S trace and the vertical trace it is normalised by as the two channels of ONE complex
         # transform (different roundings of the same sequence): -1 to rounding, not bit for bit like the oracle
         assert abs(got.min() + 1.0) <= 1e-14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("case", OCEAN_CASES, ids=OCEAN_IDS)
+def test_hip_matches_sea_floor_reflectivity_solution(case, fused):
+    """The ocean-bottom known answers straight through the C ABI (3-column kernels), fused and split launch plans."""
+    from rf_inv_amd import RFEngine
+
+    model, ipha, p, dec = case
+    nlay = len(model[1])
+    with RFEngine(nfft=NFFT, delta=DELTA, t_start=T_START, deconv_mode=dec, sdep=float(model[4][0]), rayps=np.array([p]),
+                  a_gus=np.array([A_GUS]), ipha=np.array([ipha], dtype=np.int32), obs=np.zeros((1, 101)), nsmp=101,
+                  max_walkers=1, nlay_max=nlay + 2, options={"fused": fused}) as eng:
+        got = eng.calc_rf(nlay, *model[1:])[:, 0]
+    _check(got, _expected(model, ipha, p, dec), (case[0][0], fused))
+
+
+@pytest.mark.gpu
+def test_hip_c5_traces_match_sea_floor_reflectivity_solution():
+    """The C5 trace set (P .06, P .08, S .10, S .12; nfft 4096; 2 km of water) on 2 .. 31-layer stacks through the
+    batched entry and the library's default plan (4-bin ocean chains)."""
+    from rf_inv_amd import RFEngine
+    from helpers import pack_layers
+
+    rng = np.random.default_rng(505)
+    stacks = [random_stack(rng, n, ocean=True, sdep=SDEP) for n in (2, 3, 9, 31)]
+    rayps, ipha = np.array([0.06, 0.08, 0.10, 0.12]), np.array([1, 1, -1, -1], dtype=np.int32)
+    nlay, layers = pack_layers(stacks, 32)
+    with RFEngine(nfft=4096, delta=DELTA, t_start=T_START, deconv_mode=0, sdep=SDEP, rayps=rayps,
+                  a_gus=np.full(4, A_GUS), ipha=ipha, obs=np.zeros((4, 101)), nsmp=101, max_walkers=4,
+                  nlay_max=32) as eng:
+        assert eng.launch_plan["fused"]
+        eng.eval_batch(np.arange(4), nlay, layers, np.full((4, 4), 0.01))
+        for i, st in enumerate(stacks):
+            got = eng.get_rft(i, which=1)
+            for t in range(4):
+                want = al.receiver_function(4096, DELTA, T_START, A_GUS, rayps[t], int(ipha[t]), 0, *st)
+                _check(got[:, t], want, (i, t))
 
 
 @pytest.mark.gpu
