@@ -111,6 +111,45 @@ def test_sea_floor_solution_differs_from_the_land_one():
     assert np.abs(_expected(deeper, 1, 0.06, 0) - wet).max() > 1e-3 * np.abs(wet).max()
 
 
+COMMON_A = (4.0, 2.5, 1.5)
+COMMON_CASES = [(ipha, p, dec, ocean) for ipha, p in ((1, 0.06), (-1, 0.10)) for dec in (0, 1) for ocean in (0, 1)]
+
+
+def _common_model(ocean):
+    return OCEAN_MODELS[2] if ocean else MODELS[3]
+
+
+@pytest.mark.parametrize("ipha,p,dec,ocean", COMMON_CASES)
+def test_oracle_single_fwd_mode_matches_reflectivity_solution(oracle, ipha, p, dec, ocean):
+    """Common ray geometry (forward.f90:59-91, 141): ONE forward computation feeds every trace, which differ by their
+    Gaussian filter only -- each must equal the single-trace known answer of its own filter width."""
+    model = _common_model(ocean)
+    cfg = make_cfg(nfft=NFFT, deconv_mode=dec, t_start=T_START, rayps=[p] * 3, a_gus=list(COMMON_A), ipha=[ipha] * 3,
+                   sdep=float(model[4][0]) if ocean else 0.0)
+    got = oracle.calc_rf(cfg, *model[1:])
+    for t, a in enumerate(COMMON_A):
+        want = al.receiver_function(NFFT, DELTA, T_START, a, p, ipha, dec, *model[1:])
+        _check(got[t], want, (ipha, dec, ocean, t))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ipha,p,dec,ocean", COMMON_CASES)
+def test_hip_single_fwd_mode_matches_reflectivity_solution(ipha, p, dec, ocean):
+    """The same through the C ABI: the split spectra -> trace launch plan (the only one for common rays)."""
+    from rf_inv_amd import RFEngine
+
+    model = _common_model(ocean)
+    nlay = len(model[1])
+    with RFEngine(nfft=NFFT, delta=DELTA, t_start=T_START, deconv_mode=dec, sdep=float(model[4][0]) if ocean else 0.0,
+                  rayps=np.full(3, p), a_gus=np.array(COMMON_A), ipha=np.full(3, ipha, dtype=np.int32),
+                  obs=np.zeros((3, 101)), nsmp=101, max_walkers=1, nlay_max=nlay + 2) as eng:
+        assert not eng.launch_plan["fused"]
+        got = eng.calc_rf(nlay, *model[1:])
+    for t, a in enumerate(COMMON_A):
+        want = al.receiver_function(NFFT, DELTA, T_START, a, p, ipha, dec, *model[1:])
+        _check(got[:, t], want, (ipha, dec, ocean, t))
+
+
 def test_s_trace_is_offset_by_one_sample_like_the_reference(oracle):
     """forward.f90:188: j = mod(nfft + npre - i + 1, nfft) puts lag t_start + i * delta into the 1-based sample i
     -- the lag that nominally belongs to sample i + 1 (the P map of :179 has no such offset).  The physical
