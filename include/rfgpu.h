@@ -41,7 +41,7 @@ typedef struct rf_ctx rf_ctx;
  * (reference src/params.f90:34-96) plus capacity hints. */
 typedef struct rf_config {
     int32_t nfft;        /* params nfft >= 8.  Powers of two: in-LDS FFT (any size up to 8192).  Any other
-                            length (FFTW plans any n, src/fftw.f90:44): direct DFT, up to ~3300 samples */
+                            length (FFTW plans any n, src/fftw.f90:44): direct DFT, up to ~9000 samples */
     int32_t ntrc;        /* params ntrc                                         */
     int32_t nsmp;        /* params nsmp (src/params.f90:449-451)                */
     int32_t deconv_mode; /* params deconv_mode: 0 = normalise by vertical, 1 = water-level decon */

@@ -43,6 +43,7 @@ struct rf_ctx {
     // owned device allocations
     std::vector<void *> owned;
     double2 *spec = nullptr; // [nslots][nfwd][2][nh]
+    double2 *anyn_scratch = nullptr; // long non-power-of-two nfft only: [nslots * ntrc][trace_anyn_scratch_entries]
     int *slow_list = nullptr, *slow_count = nullptr; // walkers deferred to the generic-sincos kernel
     // staging for host-buffer calls
     int *d_ids = nullptr, *d_fwd = nullptr, *d_nlay = nullptr, *d_acc = nullptr;
@@ -434,10 +435,17 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     c->slow_list = (int *)p + 1;   // [nslots * nfwd]
     (void)hipMemset(p, 0, sizeof(int));
 
-    if (!pow2 && trace_anyn_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024)
-        return cleanup(fail("rf_ctx_create: an nfft that is not a power of two is transformed by a direct DFT whose tables "
-                            "must fit the 160 KiB LDS of a CU (nfft up to ~3300); use a power of two for longer series"));
-    if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || trace_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024 ||
+    if (!pow2 && trace_anyn_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024) {
+        // longer series: only the filtered spectra stay in LDS, the time series goes through a scratch row per block
+        if (trace_anyn_big_lds_bytes(n, nsmp) > 160 * 1024)
+            return cleanup(fail("rf_ctx_create: an nfft that is not a power of two is transformed by a direct DFT whose "
+                                "spectra must fit the 160 KiB LDS of a CU (nfft up to ~9000); use a power of two for "
+                                "longer series"));
+        if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * ntrc * trace_anyn_scratch_entries(n, nsmp)))
+            return cleanup(1);
+        c->anyn_scratch = (double2 *)p;
+    }
+    if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || (pow2 && trace_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024) ||
         sizeof(double) * (size_t)(5 * ((nsmp + 1) & ~1) + 8) > 160 * 1024)   // phi_kernel (host-owned traces)
         return cleanup(fail("rf_ctx_create: nfft / nsmp / nlay_max exceed the 160 KiB LDS of a gfx950 CU"));
     c->fused_allowed = pow2 && (c->nfwd == ntrc) && fused_lds_bytes(n, nsmp, cfg->nlay_max) <= 160 * 1024;
@@ -613,7 +621,7 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
                        c->slow_count, c->ws, s);
         if (e) (void)hipEventRecord(e, s);
         e = prof_begin(c, 1, s);
-        launch_trace(c->tab, b, c->spec, c->ws, c->slow_count, s);   // also forms logL
+        launch_trace(c->tab, b, c->spec, c->ws, c->slow_count, c->anyn_scratch, s);   // also forms logL
         if (e) (void)hipEventRecord(e, s);
     }
     if (c->prof_this) c->prof_n[0] += 1;

@@ -55,8 +55,9 @@ struct WalkerState {
 void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, int nsplit, int chain,
                     int waves_per_block, int *slow_list, int *slow_count, const WalkerState &w, hipStream_t s);
 // K2: decon / filter / c2r / shift / normalise / write trace / quadratic form
+// (xbuf: nullptr, or the scratch of the long non-power-of-two variant, trace_anyn_scratch_entries per block)
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec,
-                  const WalkerState &w, int *slow_count, hipStream_t s);
+                  const WalkerState &w, int *slow_count, double2 *xbuf, hipStream_t s);
 // log-likelihood from cached quadratic forms (used for host-owned traces; the batched path
 // forms logL inside trace_kernel)
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
@@ -133,6 +134,8 @@ void launch_post_mark_unused(const PostConfig &c, const PostState &st, hipStream
 
 size_t spectra_lds_bytes(int nlay_pad);
 size_t trace_anyn_lds_bytes(int nfft, int nsmp, int nlay_pad);
+size_t trace_anyn_big_lds_bytes(int nfft, int nsmp);
+__host__ __device__ size_t trace_anyn_scratch_entries(int nfft, int nsmp);
 size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad);
 
 } // namespace rfgpu

@@ -1547,6 +1547,7 @@ struct TraceParams {
     int defer_logl;    // misfits to HBM; quadratic form + logL by phi_deferred_kernel (+ logl_deferred_kernel) after this launch
     double *extra_out; // nullptr, or [ntrc][nfft] (device-mapped host memory): second copy of the proposed trace of
                        // batch item 0 -- the per-call drop-in gets prop_rft without a gather kernel
+    double2 *xbuf;     // nullptr, or [nslots * ntrc][fft_pad(nfft)]: the time series of trace_anyn_kernel<true>
 };
 
 // FFT with the last pass in registers, vertical maximum, shift / normalise / store and misfit for
@@ -1809,9 +1810,13 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
 // trace_anyn_kernel: K2 for an nfft that is NOT a power of two (FFTW plans any length, src/fftw.f90:44;
 // the reference accepts any nfft, src/params.f90:179).  Same steps as trace_kernel; the c2r step is the
 // DEFINITION of the unnormalised inverse real DFT (Hermitian extension of bins 0 .. n/2, imaginary parts
-// of the DC and -- for even n -- Nyquist bins ignored) summed directly from an LDS twiddle table:
+// of the DC and -- for even n -- Nyquist bins ignored) summed directly from a twiddle table:
 // O(n^2) per trace instead of O(n log n), which is fine for the rare sizes that need it (n = 1000:
 // ~2e6 FMA per trace) and keeps every other stage shared.  Split launch plan only.
+// BIG = false: time series, filtered spectra and twiddle table in LDS (nfft up to ~3300).
+// BIG = true (longer series, up to ~9000): only the filtered spectra stay in LDS; the twiddles are read from the
+// (L2-resident) global table and the time series goes through a global scratch row per block -- same sums in the
+// same order, so both variants and every other stage produce the same values.
 // ---------------------------------------------------------------------------
 __host__ __device__ inline size_t anyn_spec_offset(int nfft, int nsmp, int nlay_pad)
 {
@@ -1824,17 +1829,39 @@ size_t trace_anyn_lds_bytes(int nfft, int nsmp, int nlay_pad)
     return sizeof(double) * anyn_spec_offset(nfft, nsmp, nlay_pad) + sizeof(double2) * (2 * nh + (size_t)nfft);
 }
 
+size_t trace_anyn_big_lds_bytes(int nfft, int nsmp)
+{
+    const size_t nh = (size_t)nfft / 2 + 1;
+    return sizeof(double) * (size_t)(((nsmp + 1) & ~1) + 8) + sizeof(double2) * 2 * nh;   // mis | red | zr | zv
+}
+
+__host__ __device__ size_t trace_anyn_scratch_entries(int nfft, int nsmp)   // double2 per block: the padded time series, or the quadratic form's [4][nsmp]
+{
+    const size_t e = (size_t)fft_pad(nfft) + 1;
+    return e > (size_t)2 * nsmp ? e : (size_t)2 * nsmp;
+}
+
+template <bool BIG>
 __global__ __launch_bounds__(TRACE_THREADS) void trace_anyn_kernel(TraceParams P)
 {
     extern __shared__ double2 lds2[];
     const DeviceTables &t = P.t;
     const int n = t.nfft, nh = t.nh, nsmp = t.nsmp;
-    double2 *a = lds2;
-    double *mis = reinterpret_cast<double *>(a) + trace_work_doubles(n, nsmp, P.b.nlay_pad);
+    double2 *a, *zr;
+    double *mis;
+    if (BIG) {
+        a = P.xbuf + (size_t)blockIdx.x * trace_anyn_scratch_entries(n, nsmp);
+        mis = reinterpret_cast<double *>(lds2);
+        zr = reinterpret_cast<double2 *>(mis + ((nsmp + 1) & ~1) + 8);
+    } else {
+        a = lds2;
+        mis = reinterpret_cast<double *>(a) + trace_work_doubles(n, nsmp, P.b.nlay_pad);
+        zr = reinterpret_cast<double2 *>(reinterpret_cast<double *>(a) + anyn_spec_offset(n, nsmp, P.b.nlay_pad));
+    }
     double *red = mis + ((nsmp + 1) & ~1);
-    double2 *zr = reinterpret_cast<double2 *>(reinterpret_cast<double *>(a) + anyn_spec_offset(n, nsmp, P.b.nlay_pad));
     double2 *zv = zr + nh;                               // filtered RF and vertical spectra, bins 0 .. nh-1
-    double2 *tw = zv + nh;                               // exp(+2 pi i k / n), k = 0 .. n-1
+    double2 *tw_lds = zv + nh;                           // (!BIG) exp(+2 pi i k / n), k = 0 .. n-1
+    const double2 *tw = BIG ? t.twiddle_any : tw_lds;
 
     const int tid = threadIdx.x;
     const int itrc = blockIdx.x % t.ntrc;
@@ -1872,7 +1899,8 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_anyn_kernel(TraceParams P
     }
     const double tp = decon ? 0.0 : P.w.gtail[(size_t)(ib * t.nfwd + f) * GTAIL + 17];
     const int slot = 1 - P.w.cur_slot[walker];
-    for (int k = tid; k < n; k += TRACE_THREADS) tw[k] = t.twiddle_any[k];
+    if (!BIG)
+        for (int k = tid; k < n; k += TRACE_THREADS) tw_lds[k] = t.twiddle_any[k];
     for (int k = tid; k < nh; k += TRACE_THREADS) {
         double2 r = num[k];
         const double fk = flt[k];
@@ -2521,14 +2549,21 @@ size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad)
 }
 
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec, const WalkerState &w,
-                  int *slow_count, hipStream_t s)
+                  int *slow_count, double2 *xbuf, hipStream_t s)
 {
-    TraceParams P{t, b, spec, w, 0, {}, slow_count, 0, 0, nullptr};
-    if (t.twiddle_any) {   // nfft is not a power of two: direct-DFT variant
-        static LdsOptIn opt_any;
-        opt_any(reinterpret_cast<const void *>(trace_anyn_kernel));
-        hipLaunchKernelGGL(trace_anyn_kernel, dim3((unsigned)(b.nb * t.ntrc)), dim3(TRACE_THREADS),
-                           trace_anyn_lds_bytes(t.nfft, t.nsmp, b.nlay_pad), s, P);
+    TraceParams P{t, b, spec, w, 0, {}, slow_count, 0, 0, nullptr, xbuf};
+    if (t.twiddle_any) {   // nfft is not a power of two: direct-DFT variants
+        if (xbuf) {
+            static LdsOptIn opt_big;
+            opt_big(reinterpret_cast<const void *>(trace_anyn_kernel<true>));
+            hipLaunchKernelGGL(trace_anyn_kernel<true>, dim3((unsigned)(b.nb * t.ntrc)), dim3(TRACE_THREADS),
+                               trace_anyn_big_lds_bytes(t.nfft, t.nsmp), s, P);
+        } else {
+            static LdsOptIn opt_any;
+            opt_any(reinterpret_cast<const void *>(trace_anyn_kernel<false>));
+            hipLaunchKernelGGL(trace_anyn_kernel<false>, dim3((unsigned)(b.nb * t.ntrc)), dim3(TRACE_THREADS),
+                               trace_anyn_lds_bytes(t.nfft, t.nsmp, b.nlay_pad), s, P);
+        }
         return;
     }
     while ((1 << P.log2n) < t.nfft) ++P.log2n;

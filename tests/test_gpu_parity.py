@@ -393,11 +393,13 @@ def test_fft_sizes(oracle, nfft):
     assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (nfft, np.abs(ll - ref_ll).max())
 
 
-@pytest.mark.parametrize("nfft,deconv", [(1000, 0), (250, 1), (375, 0), (384, 1), (1500, 0)])
+@pytest.mark.parametrize("nfft,deconv", [(1000, 0), (250, 1), (375, 0), (384, 1), (1500, 0), (3400, 0), (5000, 1), (6001, 0)])
 def test_any_length_nfft(oracle, nfft, deconv):
     """nfft need not be a power of two: FFTW plans any length (src/fftw.f90:44) and the reference accepts any nfft.
     Even (with a Nyquist bin), odd (without), and a multiple of 128 (the Nyquist bin alone in its 64-bin iteration);
-    P and S traces; the oracle's c2r is then the O(n^2) long-double sum of the definition."""
+    series whose tables fit LDS (up to ~3300) and longer ones (spectra in LDS, twiddles from L2, the time series
+    through a scratch row per block); P and S traces; the oracle's c2r is then the O(n^2) long-double sum of the
+    definition."""
     rng = np.random.default_rng(nfft)
     nsmp = 101
     cfg = make_cfg(nfft=nfft, deconv_mode=deconv, rayps=[0.06, 0.10], ipha=[1, -1], t_start=-1.0, a_gus=[4.0, 2.5])
@@ -419,6 +421,16 @@ def test_any_length_nfft(oracle, nfft, deconv):
         one, rft1 = eng.calc_likelihood(0, True, int(nlay[1]), *[layers[1, r, :nlay[1]] for r in range(4)], sig[1])
         assert abs(one - ref_ll[1]) <= logl_tol(ref_ll[1]) and rft1.shape == (nfft, 2)
     assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (nfft, np.abs(ll - ref_ll).max())
+
+
+def test_non_power_of_two_nfft_beyond_the_direct_dft_is_refused():
+    from rf_inv_amd import RFEngine
+    from rf_inv_amd.engine import RFGPUError
+
+    with pytest.raises(RFGPUError, match="power of two"):
+        RFEngine(nfft=12000, delta=DELTA, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=np.array([0.06]),
+                 a_gus=np.array([4.0]), ipha=np.array([1], dtype=np.int32), obs=np.zeros((1, 101)), nsmp=101,
+                 max_walkers=1, nlay_max=8)
 
 
 def test_edge_shapes(oracle):
