@@ -145,6 +145,36 @@ def test_builtin_r_inv_agrees_with_lapack_in_rank_and_values(oracle, a_gus, nsmp
     assert gap > 1e-3
 
 
+@pytest.mark.parametrize("a_gus,nsmp", [(4.0, 101), (2.5, 161), (8.0, 61)])
+def test_r_inv_against_a_symmetric_eigendecomposition(oracle, a_gus, nsmp):
+    """An independent route to the reference's truncated pseudo-inverse (src/likelihood.f90:180-222: dgesvd of the
+    noise correlation matrix, 1/s for s > 1e-3, V diag U^T): the matrix is symmetric, so its eigen-decomposition
+    gives R+ = Q diag(1/lambda | lambda > 1e-3) Q^T and the quadratic form as sum (q_k . m)^2 / lambda_k -- no SVD,
+    no matrix product of factors.  Both builders (the oracle's LAPACK route and librfgpu's Jacobi SVD) and the
+    quadratic form of the log-likelihood agree with it."""
+    from rf_inv_amd.engine import compute_r_inv
+
+    delta = float(np.float32(0.05))
+    idx = np.arange(nsmp)
+    r = np.exp(-a_gus ** 2 * delta ** 2)
+    R = r ** ((idx[:, None] - idx[None, :]) ** 2.0)
+    lam, Q = np.linalg.eigh(R)
+    keep = lam > 1.0e-3
+    want = (Q[:, keep] / lam[keep]) @ Q[:, keep].T
+    ref, ranks = oracle.build_r_inv(nsmp, [a_gus], delta, return_rank=True)
+    own, rank = compute_r_inv(nsmp, a_gus, delta)
+    assert ranks[0] == rank == int(keep.sum())
+    scale = np.abs(want).max()
+    assert np.abs(ref[0].T - want).max() <= 1e-9 * scale          # conditioning 1e3: ~1e-13 * 1e3 of slack
+    assert np.abs(own.T - want).max() <= 1e-9 * scale
+    rng = np.random.default_rng(nsmp)
+    m = rng.standard_normal(nsmp)
+    phi = float(np.sum((Q[:, keep].T @ m) ** 2 / lam[keep]))
+    sig = np.array([0.37])
+    ll = oracle.log_likelihood(np.concatenate([m, np.zeros(7)])[None, :], np.zeros((1, nsmp)), ref, sig, nsmp)
+    assert abs(ll - (-0.5 * phi / sig[0] ** 2 - nsmp * np.log(sig[0]))) <= 1e-9 * abs(ll)
+
+
 def _a_gus_with_singular_value_on_the_cut(nsmp, delta):
     """Bisect the filter width until a singular value of the noise matrix sits on the 1e-3 cut-off."""
     from rf_inv_amd.engine import compute_r_inv
