@@ -1054,6 +1054,7 @@ struct StageParams {
     BatchArgs b;
     double *gcoef, *gtail;
     int *gflag;
+    int spread;   // G = 16 only: the four 16-lane groups of a wave share ONE item, one part each (small batches)
 };
 
 template <int G>
@@ -1064,12 +1065,17 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
     const int pad = S.b.nlay_pad;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane / G, sl = lane % G;
-    const int bf = (blockIdx.x * (blockDim.x >> 6) + wave) * NG + grp;
+    // Small batches (spread, G = 16): latency counts, not throughput -- the wave's four groups take the four parts
+    // of ONE item side by side (q = the group's part; the interface code runs once, the phase code once) instead
+    // of four items with the parts one after the other.  The arithmetic per (layer, part) is the same code either
+    // way: `part` is a run-time value in both modes, so the results are bit-identical.
+    const int q = (G == 16 && S.spread) ? grp : -1;
+    const int bf = q >= 0 ? blockIdx.x * (blockDim.x >> 6) + wave : (blockIdx.x * (blockDim.x >> 6) + wave) * NG + grp;
     const bool live = bf < S.b.nb * S.t.nfwd;
     const int ib = live ? bf / S.t.nfwd : 0, f = live ? bf % S.t.nfwd : 0;
     const bool run = live && (!S.b.fwd_flag || S.b.fwd_flag[ib] == 1);
     const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)) << (grp * G);
-    double *terms = lds + (size_t)(wave * NG + grp) * pad;
+    double *terms = lds + (size_t)(q >= 0 ? wave : wave * NG + grp) * pad;
     // The lanes store their pieces straight into the global image.  (Assembling the image in LDS and writing whole
     // rows was measured: no faster -- the kernel is bound by its divisions and square roots, not by its stores.)
     bool big = false;
@@ -1095,8 +1101,10 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
             const double a1 = L[l + 1], b1 = L[pad + l + 1], r1 = L[2 * pad + l + 1];
             double *c = coef + (size_t)l * NCOEF;
             if (l >= ilay0) {
-#pragma unroll
-                for (int part = 0; part < 2; ++part) {
+                const int part_lo = q < 0 ? 0 : (q < 2 ? q : 2), part_hi = q < 0 ? 2 : (q < 2 ? q + 1 : 2);
+                const int sph_lo = q < 0 ? 0 : (q >= 2 ? q - 2 : 2), sph_hi = q < 0 ? 2 : (q >= 2 ? q - 1 : 2);
+#pragma unroll 1
+                for (int part = part_lo; part < part_hi; ++part) {
                     // part 0: beta (eta), part 1: alpha (xi)
                     const LayerHalf u = layer_half(part ? a0 : b0, b0, r0, p);
                     if (l + 1 < nl - 1) {
@@ -1106,8 +1114,8 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
                         stage_interface(c + 3 + 4 * part, part, u, nullptr, unit);
                     }
                 }
-#pragma unroll
-                for (int sph = 0; sph < 2; ++sph) {
+#pragma unroll 1
+                for (int sph = sph_lo; sph < sph_hi; ++sph) {
                     // sph 0: the P phase (part 2), 1: the S phase (part 3)
                     const double slow = vertical_slowness(sph ? b0 : a0, p);
                     // phases of the Nyquist bin, argument formed like the reference (forward.f90:397-400)
@@ -1121,19 +1129,19 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
                     big |= fabs(omg_max * slow * h0) >= SINCOS_CW_LIMIT || !(fabs(S.t.omg_dc * slow * h0) < DC_PHASE_LIMIT);
                 }
             }
-            // walker constants, by the lanes that already hold the layers involved
-            if (l == nl - 2) {
+            // walker constants, by the lanes that already hold the layers involved (spread: of the lighter groups)
+            if (l == nl - 2 && (q < 0 || q == 2)) {
                 // half-space = layer l + 1; the last solid layer (if any) = layer l
                 LayerBasis last;
                 if (solid) last = layer_basis(a0, b0, r0, p);
                 stage_halfspace(tail, a1, b1, r1, p, solid ? &last : nullptr, gauge);
             }
-            if (l == (solid ? ilay0 : 0)) {
+            if (l == (solid ? ilay0 : 0) && (q < 0 || q == 3)) {
                 LayerBasis top;
                 if (solid) top = layer_basis(a0, b0, r0, p);
                 stage_start(tail + 11, solid ? &top : nullptr);
             }
-            if (l == 0 && sea) {
+            if (l == 0 && sea && (q < 0 || q == 3)) {
                 const double xiw = vertical_slowness(a0, p);   // forward.f90:431
                 tail[8] = xiw;
                 tail[9] = h0;
@@ -1145,11 +1153,12 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
         // strictly in layer order below (it feeds nint(): bit-exact bookkeeping)
         const double *vel = (S.t.ipha[f] == 1) ? L : L + pad;   // alpha for P, beta for S (:157,161)
         const int i0 = S.t.sdep > 0.0 ? 1 : 0;                  // keyed on sdep (:484)
-        for (int i = i0 + sl; i < nl - 1; i += G) terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], p);
+        if (q <= 0)
+            for (int i = i0 + sl; i < nl - 1; i += G) terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], p);
     }
-    const bool any_big = (__ballot(big) & group_mask) != 0;
+    const bool any_big = (__ballot(big) & (q >= 0 ? ~0ull : group_mask)) != 0;
     __syncthreads();
-    if (run && sl == 0) {
+    if (run && sl == 0 && q <= 0) {
         const double *L = S.b.layers + (size_t)ib * 4 * pad;
         const int i0 = S.t.sdep > 0.0 ? 1 : 0;
         S.gtail[(size_t)bf * GTAIL + 17] = arrival_sum(nl - 1 - i0, terms);
@@ -1161,16 +1170,20 @@ template <int G>
 static void launch_stage_g(const StageParams &S, unsigned nbf, int nlay_pad, hipStream_t s)
 {
     constexpr unsigned NG = 64 / G;
-    const unsigned nwave = (nbf + NG - 1) / NG;
+    StageParams P = S;
+    // tiny batches of shallow contexts (the per-call drop-in, a handful of chains): a wave per item, its four groups
+    // one part each -- half the latency; from ~1000 items on the packed layout is faster again (C2: 2 %)
+    P.spread = (G == 16 && nbf <= 256) ? 1 : 0;
+    const unsigned nwave = P.spread ? nbf : (nbf + NG - 1) / NG;
     // small batches: one wave per block, so that the few waves spread over the CUs
     const unsigned wpb = nwave <= 2048 ? 1 : 4;
     hipLaunchKernelGGL(stage_kernel<G>, dim3((nwave + wpb - 1) / wpb), dim3(64 * wpb),
-                       sizeof(double) * wpb * NG * (size_t)nlay_pad, s, S);
+                       sizeof(double) * wpb * NG * (size_t)nlay_pad, s, P);
 }
 
 void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
 {
-    StageParams S{t, b, w.gcoef, w.gtail, w.gflag};
+    StageParams S{t, b, w.gcoef, w.gtail, w.gflag, 0};
     const unsigned nbf = (unsigned)(b.nb * t.nfwd);
     // lanes per (item, trace): the layers above the half-space of the deepest walker the context allows
     const int nsolid_max = b.nlay_pad - 1;
