@@ -75,7 +75,8 @@ struct rf_ctx {
     int fused_override = -1;  // "fused": -1 = by shape
     int defer_logl = -1;      // "defer_logl": -1 = by batch size, 0 / 1 = never / always
     int block_threads = 0;    // "block_threads": 0 = by batch size, 256 / 512 = fused_kernel / fused8_kernel
-    int fused8_max_rounds = 4;   // batches of up to this many rounds of blocks (2 blocks per CU) take fused8_kernel
+    int fused8_max_rounds = 2;   // batches of up to this many rounds of blocks (2 blocks per CU) take fused8_kernel
+                                 // (measured: C2, two rounds, +1.6 %, with deconvolution +3.5 %; three and four rounds -2 %)
     double bin_cutoff = 0.0;  // "bin_cutoff": opt-in filter-support cut-off (0 = off: every bin like the reference)
     int n_overrides = 0;      // options set away from their defaults (echoed by rf_get_launch_plan)
     int ablate = 0;           // RFGPU_DIAGNOSTICS builds only ("ablate"): stops the kernel early, results invalid
@@ -552,12 +553,13 @@ static int pick_nsplit(const rf_ctx *c, int nb)
 }
 
 // 512-thread blocks (fused8_kernel: nfft 4096, land, default phase chains) or 256-thread blocks (fused_kernel).
-// The 8-wave block executes ~13 % more instructions per bin and layer (4-bin phase chains: twice the anchors of
-// 8-bin chains) but keeps four waves per SIMD and halves a block's latency-bound tail.  Measured A/B on MI355X
-// (tools/ab_opt.sh block_threads 256 512): C2 (2 rounds of blocks) -3 % kernel time, C3 (16 rounds) +-0, C4 (48
-// rounds) +5 %: it takes the launches of up to four rounds -- which includes the one-chain-per-call drop-in, whose
-// single block is pure latency -- and the 4-wave block the saturated ones.  The two factorise the FFT differently
-// (8^4 / 16^3): a chain's trace differs in the last bits between the two plans, never within one.
+// The 8-wave block has 4-bin phase chains started from a block-shared anchor table, keeps four waves per SIMD and
+// halves a block's latency-bound tail.  Measured A/B on MI355X at the end of round 2 (tools/ab_opt.sh block_threads
+// 256 512, and bench.py --walkers): two rounds of blocks (C2) +1.6 % throughput, with deconvolution +3.5 %;
+// three and four rounds -2 %; C3 (16 rounds) and C4 (48 rounds) level to -2 %: it takes the launches of up to two
+// rounds -- which includes the one-chain-per-call drop-in, whose single block is pure latency -- and the 4-wave
+// block the rest.  The two factorise the FFT differently (8^4 / 16^3): a chain's trace differs in the last bits
+// between the two plans, never within one.
 static bool use_fused8(const rf_ctx *c, long long blocks)
 {
     const bool can = c->fused && c->cfg.nfft == 4096 && c->cfg.sdep <= 0.0 && c->chain_override < 0 && c->ablate == 0 &&
