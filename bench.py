@@ -13,12 +13,21 @@ Workloads (BASELINE.json configs):
                  (2049 bins), <= 30 layers, PT swap
   c2             1024 walkers/GPU, 1 P trace (p 0.06), nfft 4096, <= 15 layers
   c3             8192 walkers/GPU (1024 x 8 temperatures), 1 P trace, PT swap on the device
-  c5             8192 walkers/GPU, 4 traces (2 P + 2 S), ocean layer, <= 31 layers, PT swap
+  c5             32768 walkers/GPU (BASELINE configs[4] / 8 GPUs), 4 traces (2 P + 2 S), ocean layer, <= 31 layers,
+                 PT swap
   c4common       c4 with ONE ray for all three traces (common-ray / "single FWD" mode,
                  src/forward.f90:59-91,141): spectra_kernel -> trace_kernel split path
   c1, c2d        sample_syn shape (nfft 256) / c2 with water-level deconvolution
 
-At N = 1 the default run also measures c2, c3, c5 and c4common briefly into "also".
+At N = 1 the default run also measures c2, c3, c5 (BASELINE's 32768 walkers/GPU) and c4common briefly into
+"also", plus the c4 shape with walker depths that change every step (`--perturb-nlay`: the dispatch order the
+previous launch prepared is then one proposal stale, as in a real chain).
+
+`--gpus N` without a launcher (WORLD_SIZE unset) starts N rank processes itself -- before anything touches a GPU,
+one per device, rendezvous on 127.0.0.1 -- relays rank 0's JSON line and exits non-zero if any rank fails or
+fewer than N devices are visible.  Under torchrun (WORLD_SIZE set) it must equal --gpus.  With N > 1 the swap
+step runs through librfgpu's own RCCL communicator (rf_comm_init / rf_pt_swap_allgather_device, include/rfgpu.h);
+torch.distributed is only the launcher's process group (rendezvous, barrier, max-over-ranks of the time).
 Prints ONE JSON line on rank 0.  Refuses to run with RFGPU_* variables in the environment
 (the library reads none; a stray one must not be mistaken for a setting) -- non-default
 launch plans are explicit `--opt name=value` flags and are echoed in `config`.
@@ -59,11 +68,12 @@ WORKLOADS = {
                      desc="c4common (single-FWD / common-ray mode, forward.f90:59-91,141): 8192 walkers/GPU x 3 P traces "
                           "of ONE ray (p .06; Gaussian a 4.0, 2.5, 1.5) x nfft 4096 x <=30 layers, PT swap; one "
                           "propagator pass feeds three traces: spectra_kernel -> trace_kernel"),
-    "c5": dict(walkers=8192, nfft=4096, rayps=[0.06, 0.08, 0.10, 0.12], ipha=[1, 1, -1, -1], k_max=30, sdep=2.0,
+    "c5": dict(walkers=32768, nfft=4096, rayps=[0.06, 0.08, 0.10, 0.12], ipha=[1, 1, -1, -1], k_max=30, sdep=2.0,
                deconv=0, temps=16,
-               desc="c5-shape: 8192 walkers/GPU x 4 traces (P .06, P .08, S .10, S .12) x nfft 4096 x ocean layer "
-                    "(sdep 2 km) x <=31 layers, PT swap (BASELINE's 'buried station' has no reference behaviour: "
-                    "the borehole branch of forward.f90:289-338 is commented out)"),
+               desc="c5 (one GPU's shard of BASELINE configs[4]: 16384 chains x 16 temperatures / 8 GPUs): 32768 "
+                    "walkers/GPU x 4 traces (P .06, P .08, S .10, S .12) x nfft 4096 x ocean layer (sdep 2 km) x <=31 "
+                    "layers, PT swap (BASELINE's 'buried station' has no reference behaviour: the borehole branch of "
+                    "forward.f90:289-338 is commented out)"),
     "c1": dict(walkers=1024, nfft=256, rayps=[0.06, 0.08], ipha=[1, 1], k_max=10, sdep=2.0, deconv=0, temps=1,
                desc="c1-shape: 1024 walkers/GPU x 2 P traces x nfft 256 x ocean x <=11 layers"),
 }
@@ -257,6 +267,80 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
     return base, ll_all[:nuse], nuse
 
 
+def spawn_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: start N rank processes, one per GPU, and relay rank 0's JSON line.
+    This parent never touches a GPU (torch.cuda.device_count() does not initialise one on this image) and never
+    exec()s: the ranks are ordinary children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
+    exactly what `python -m torch.distributed.run --nproc-per-node N` would give them.  Returns the exit code:
+    non-zero if any rank failed."""
+    import signal
+    import socket
+    import subprocess
+
+    import torch
+
+    have = torch.cuda.device_count()
+    shared = os.environ.get("RFGPU_BENCH_BACKEND", "nccl") != "nccl"   # functional test: ranks may share a GPU
+    if have < n and not shared:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have}: refusing to report a {n}-GPU "
+              "number from fewer devices (RCCL needs one GPU per rank)", file=sys.stderr)
+        return 2
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for q in procs[1:]:
+        try:
+            q.wait(timeout=120 if rc == 0 else 5)
+        except subprocess.TimeoutExpired:
+            q.send_signal(signal.SIGTERM)
+            q.wait()
+        rc = rc or q.returncode
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    if rc:
+        print(f"bench.py: a rank exited with code {rc}", file=sys.stderr)
+    return rc or 0
+
+
+KAPPA_MIN, KAPPA_SCALE = 100.0, 10.0      # the conditioning rule of tests/test_gpu_configs.py
+
+
+def parity_report(orc, cfg, obs, r_inv, nlay, layers, sig, nsmp, ll_gpu, ll_cpu, nthreads=1):
+    """GPU vs oracle logL over the compared walkers, with the conditioning accounted for.  Tolerance:
+    |dlogL| <= max(1e-9, 1e-12 |logL|).  Without deconvolution a trace is divided by the SIGNED maximum of the
+    filtered vertical trace (forward.f90:201-202); kappa = max|rx| / |maxval(rx)| says how much of that trace's
+    scale cancels in the divisor -- its rounding, in any double evaluation including the reference's, is amplified
+    kappa-fold in every sample and 2 kappa-fold in logL.  An item may exceed the plain tolerance only if its kappa
+    (from the oracle's own vertical trace) is >= 100, and must then stay within tolerance * kappa / 10."""
+    d = np.abs(ll_gpu - ll_cpu)
+    tol = np.maximum(1e-9, 1e-12 * np.abs(ll_cpu))
+    rel = d / np.abs(ll_cpu)
+    over = np.nonzero(~(d <= tol))[0]
+    worst = int(np.argmax(d / tol))
+    look = np.unique(np.concatenate([over[:256], [worst]])).astype(np.int64)
+    _, kap = orc.eval_batch(cfg, obs, r_inv, nlay[look], layers[look], sig[look], nsmp, nthreads=nthreads,
+                            want_kappa=True)
+    kappa = dict(zip(look.tolist(), kap.tolist()))
+    rule_ok = all(kappa[i] >= KAPPA_MIN and d[i] <= tol[i] * kappa[i] / KAPPA_SCALE for i in over[:256].tolist())
+    return {"n": int(len(d)), "max_abs_dlogl": float(d.max()), "max_rel_dlogl": float(rel.max()),
+            "n_over_1e-13": int(np.sum(rel > 1e-13)),
+            "within_tolerance": bool(len(over) == 0),
+            "n_used_kappa_allowance": int(len(over)),
+            "within_kappa_rule": bool(rule_ok and len(over) <= 256),
+            "worst": {"walker": worst, "nlay": int(nlay[worst]), "logl": float(ll_cpu[worst]),
+                      "abs": float(d[worst]), "rel": float(rel[worst]), "tolerance_used": float(d[worst] / tol[worst]),
+                      "kappa": float(kappa[worst])}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -281,7 +365,20 @@ def main():
     ap.add_argument("--copy-logl", action="store_true", help="always read logL back with an async copy")
     ap.add_argument("--dump-state", default=None, metavar="PATH.npz",
                     help="rank 0 writes every rank's final temperatures and logL (tests replay the swap schedule)")
+    ap.add_argument("--perturb-nlay", type=float, default=0.0, metavar="FRAC",
+                    help="every step a fresh FRAC of the walkers evaluates its model one layer shallower (a birth / "
+                         "death proposal changes nlay by one, pt_mcmc.f90:88-160): the dispatch order the previous "
+                         "launch prepared is then one proposal stale, as in a real chain")
     args = ap.parse_args()
+
+    # ---- N ranks asked for, no launcher around us: become the launcher (before torch / HIP are touched)
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: the launcher's "
+                         "rank count and --gpus must agree (a line saying n_gpus = N must come from N ranks)")
 
     stray = sorted(k for k in os.environ if k.startswith("RFGPU_") and k not in ENV_ALLOWED)
     if stray:
@@ -313,6 +410,8 @@ def main():
             dist.init_process_group(backend)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s): one GPU per rank")
     if backend != "nccl":
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
@@ -326,7 +425,7 @@ def main():
     def run(workload, steps, warmup, with_cpu, parity_n=64):
         from rf_inv_amd import RFEngine, format_model, read_ref_model
         from rf_inv_amd.likelihood import init_r_inv
-        from rf_inv_amd.pt import PTSwap
+        from rf_inv_amd.pt import PTSwap, open_exchange
 
         w = dict(WORKLOADS[workload])
         if args.walkers:
@@ -356,7 +455,21 @@ def main():
         d_sig = torch.from_numpy(sig).to(dev)
         d_logl = torch.empty(nb, dtype=torch.float64, device=dev)
         h_logl = torch.empty(nb, dtype=torch.float64).pin_memory()
-        swap = PTSwap(eng, nb, w["temps"], dev, seed=1234, t_high=15.0, mode=args.swap) if w["temps"] > 1 else None
+        # N > 1: the temperature exchange runs over librfgpu's own RCCL communicator (one GPU per rank); ranks
+        # that share a GPU (functional test) keep the launcher's process group as the transport
+        over_rccl = open_exchange(eng, dist) if world > 1 else False
+        swap = (PTSwap(eng, nb, w["temps"], dev, seed=1234, t_high=15.0, mode=args.swap, rccl=over_rccl)
+                if w["temps"] > 1 else None)
+        # --perturb-nlay: NV pre-built depth vectors cycled through, so that the timed loop does nothing extra
+        nlay_var = None
+        if args.perturb_nlay > 0.0:
+            g = np.random.Generator(np.random.Philox(key=4242 + rank))
+            nv = []
+            for _ in range(16):
+                pick = (g.random(nb) < args.perturb_nlay) & (nlay >= 3 + (1 if p.sdep > 0 else 0))
+                nv.append(torch.from_numpy((nlay - pick.astype(np.int32)).astype(np.int32)).to(dev))
+            nlay_var = nv
+        step_no = [0]
 
         # logL read-back: without a swap step the kernel writes logL straight into the pinned
         # (device-mapped) host buffer -- no copy kernel after the evaluation; with a swap step logL
@@ -364,11 +477,15 @@ def main():
         zero_copy = swap is None and not args.copy_logl
 
         def step():
+            nl_now = d_nlay
+            if nlay_var is not None:
+                nl_now = nlay_var[step_no[0] % len(nlay_var)]
+                step_no[0] += 1
             with torch.cuda.stream(stream):
                 if zero_copy:
-                    eng.eval_batch_device(d_ids, d_nlay, d_layers, d_sig, h_logl, stream=stream)
+                    eng.eval_batch_device(d_ids, nl_now, d_layers, d_sig, h_logl, stream=stream)
                 else:
-                    eng.eval_batch_device(d_ids, d_nlay, d_layers, d_sig, d_logl, stream=stream)
+                    eng.eval_batch_device(d_ids, nl_now, d_layers, d_sig, d_logl, stream=stream)
                     if swap is not None:
                         swap.step(d_logl, stream)
                     h_logl.copy_(d_logl, non_blocking=True)
@@ -460,13 +577,15 @@ def main():
         assert plan["build"] == "production" or overrides or args.lib, plan
         assert np.all(np.isfinite(ll_gpu)), "non-finite logL in the benchmark batch"
 
-        f_spec, f_tot, b_alg = alg_work(p, nlay.astype(np.float64), eng.is_ray_common)
+        # the depths the LAST step evaluated (they are what h_logl holds and what the checker must be given)
+        nlay_eval = nlay if nlay_var is None else nlay_var[(step_no[0] - 1) % len(nlay_var)].cpu().numpy()
+        f_spec, f_tot, b_alg = alg_work(p, nlay_eval.astype(np.float64), eng.is_ray_common)
         n_l = max(prof["launches"], 1)          # batches timed
         # dominant kernel: fused_kernel (propagator + trace + logL in one launch) where every trace has
         # its own forward computation, else spectra_kernel (then trace_kernel follows it)
         kernel_ms = prof["spectra_ms"] / n_l if prof["launches"] else None
         f_dom = f_tot if plan["fused"] else f_spec
-        bt = plan["block_threads_full_batch"]      # 512: fused8_kernel (launches of up to four rounds of blocks)
+        bt = plan["block_threads_full_batch"]      # 512: fused8_kernel (contexts of up to two rounds of blocks)
         kname = ("rfgpu::fused8_kernel" if bt == 512 else "rfgpu::fused_kernel") if plan["fused"] else "rfgpu::spectra_kernel"
         if plan["fused"]:
             grid_threads = bt * (nb * p.ntrc + (1 if (plan["lpt"] and plan["order_reuse"] and nb >= 512) else 0))
@@ -479,8 +598,11 @@ def main():
             "bound": "fp64_valu", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
             # EXECUTED fp64 flops of one launch (committed SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 counters of this
             # kernel at this launch shape) / live HIP-event kernel time: a hardware fraction, <= 1
-            "achieved": exe / t_k / 1e12 if exe and t_k else None,
-            "frac": exe / t_k / 1e12 / FP64_PEAK_TFLOPS if exe and t_k else None,
+            # (counters collected on ANOTHER build of the library say nothing about this one: no fraction then)
+            "achieved": exe / t_k / 1e12 if exe and t_k and ctr["_lib_sha256"] == lib_sha else None,
+            "frac": exe / t_k / 1e12 / FP64_PEAK_TFLOPS if exe and t_k and ctr["_lib_sha256"] == lib_sha else None,
+            "frac_with_stale_counters": (exe / t_k / 1e12 / FP64_PEAK_TFLOPS
+                                         if exe and t_k and ctr["_lib_sha256"] != lib_sha else None),
             "traffic": (2048.0 * ctr["FETCH_SIZE"] + 1024.0 * ctr["WRITE_SIZE"]) if ctr and "FETCH_SIZE" in ctr
                        and "WRITE_SIZE" in ctr else None,
             "kernel": kname, "kernel_ms": kernel_ms, "grid_threads": grid_threads,
@@ -509,6 +631,13 @@ def main():
                        "logl_readback": "kernel writes pinned host memory" if zero_copy else "device buffer + async copy",
                        "temperatures": w["temps"], "parallelism": f"walkers sharded x{world}",
                        "pt_swap": (f"{args.swap}, {swap.k} pair(s)/step" if swap is not None else "none"),
+                       "rccl": ({"ranks": eng.comm_info()["nranks"], "version": eng.comm_info()["rccl_version"],
+                                 "transport": "librfgpu RCCL group: 2 x ncclAllGather + 1 kernel per step "
+                                              "(rf_pt_swap_allgather_device)"} if over_rccl else
+                                {"ranks": 0, "version": eng.comm_info()["rccl_version"],
+                                 "transport": "none (one rank)" if world == 1 else
+                                              "launcher's process group (ranks share a GPU: functional mode)"}),
+                       "perturb_nlay": args.perturb_nlay,
                        "launch_plan": plan, "overrides": overrides,
                        "lib": {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "sha256": lib_sha,
                                "default_build": args.lib is None},
@@ -527,32 +656,43 @@ def main():
             "alg_gflop_per_step": float(f_tot.sum()) / 1e9,
         }
         if rank == 0 and (with_cpu or parity_n):
+            from oracle import rf_oracle as orc
+
+            cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep,
+                       rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha)
+            nthr = max(1, min(physical_cores(), orc.max_threads()))
             if with_cpu:
-                base, ll_cpu, n = cpu_baseline(p, obs, r_inv, nlay, layers, sig)
+                base, ll_cpu, n = cpu_baseline(p, obs, r_inv, nlay_eval, layers, sig)
                 res["cpu_baseline"] = base
             else:
-                from oracle import rf_oracle as orc
-
                 orc.build()
-                cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep,
-                           rayps=p.rayps, a_gus=p.a_gus, ipha=p.ipha)
                 n = min(nb, parity_n)
-                ll_cpu = orc.eval_batch(cfg, obs, r_inv, nlay[:n], layers[:n], sig[:n], p.nsmp,
-                                        nthreads=min(physical_cores(), orc.max_threads()))   # the checker build
-            d = np.abs(ll_gpu[:n] - ll_cpu)
-            res["parity_in_bench"] = {"n": int(n), "max_abs_dlogl": float(d.max()),
-                                      "max_rel_dlogl": float((d / np.abs(ll_cpu)).max()),
-                                      "within_tolerance": bool(np.all(d <= np.maximum(1e-9, 1e-12 * np.abs(ll_cpu))))}
+                ll_cpu = orc.eval_batch(cfg, obs, r_inv, nlay_eval[:n], layers[:n], sig[:n], p.nsmp, nthreads=nthr)   # the checker build
+            res["parity_in_bench"] = parity_report(orc, cfg, obs, r_inv, nlay_eval[:n], layers[:n], sig[:n], p.nsmp,
+                                                   ll_gpu[:n], ll_cpu, nthr)
         eng.close()
         return res
 
     main_res = run(args.workload, args.steps, args.warmup, not args.no_cpu_baseline and world == 1)
-    also_list = args.also if args.also is not None else ("c2,c3,c5,c4common" if world == 1 else "")
+    also_list = args.also if args.also is not None else ("c2,c3,c5,c4common,c4stale" if world == 1 else "")
     also = {}
+    keep = ("value", "ms_per_step", "ms_per_step_median", "config", "roofline", "kernel_ms", "parity_in_bench")
     for wl in [x for x in also_list.split(",") if x and x != args.workload]:
+        if wl == "c4stale":
+            # the c4 shape with 30 % of the walkers changing depth every step: the order the previous launch
+            # prepared is one proposal stale (order_reuse, the default), against a fresh order_kernel per launch
+            args.perturb_nlay, sv = 0.3, dict(overrides)
+            r = run("c4", max(30, min(200, args.steps)), max(5, min(20, args.warmup)), False)
+            overrides["order_reuse"] = 0.0
+            r2 = run("c4", max(30, min(200, args.steps)), max(5, min(20, args.warmup)), False, parity_n=0)
+            overrides.clear(); overrides.update(sv)
+            args.perturb_nlay = 0.0
+            also[wl] = {k: r[k] for k in keep if k in r}
+            also[wl]["fresh_order_every_launch"] = {"value": r2["value"], "ms_per_step": r2["ms_per_step"],
+                                                    "kernel_ms": r2["kernel_ms"]}
+            continue
         r = run(wl, max(30, min(200, args.steps)), max(5, min(20, args.warmup)), False)
-        also[wl] = {k: r[k] for k in ("value", "ms_per_step", "ms_per_step_median", "config", "roofline", "kernel_ms",
-                                      "parity_in_bench") if k in r}
+        also[wl] = {k: r[k] for k in keep if k in r}
     if rank == 0:
         out = {"metric": "forward+likelihood evals/sec (whole node)", "value": main_res["value"], "unit": "evals/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RFGPU_ABI_VERSION 3
+#define RFGPU_ABI_VERSION 4
 
 typedef struct rf_ctx rf_ctx;
 
@@ -212,13 +212,17 @@ int rf_pt_swap_device(rf_ctx *ctx, int32_t npairs, const int32_t *d_pairs, const
  * its own transport (the Fortran batched host: mpi_sendrecv). */
 #define RF_COMM_ID_BYTES 128
 /* 0 when this rank can join an RCCL communicator (librccl.so.1 loads); device_key = the physical GPU of the
- * context (PCI domain/bus/device).  ncclCommInitRank is collective: the host gathers (result, key) of all ranks
- * and calls rf_comm_init only if every rank returned 0 and all keys differ. */
+ * context (hash of the host name over PCI domain/bus/device, >= 0).  ncclCommInitRank is collective: the host
+ * gathers (result, key) of all ranks and calls rf_comm_init only if every rank returned 0 and all keys differ. */
 int rf_comm_probe(rf_ctx *ctx, int64_t *device_key);
 int rf_comm_get_unique_id(uint8_t *id /* [RF_COMM_ID_BYTES] */);
 int rf_comm_init(rf_ctx *ctx, const uint8_t *id, int32_t rank, int32_t nranks);
 int rf_comm_destroy(rf_ctx *ctx);
-/* mpi_bcast(ipack, 4, MPI_INTEGER4, 0, ...) of :518-519 (the pair rank 0 drew): buf[n] host, n <= 8 */
+/* rank / size of the context's communicator (0 of 1 without one) and the RCCL version in use (ncclGetVersion:
+ * major * 10000 + minor * 100 + patch; 0 when librccl.so.1 cannot be loaded); any pointer may be NULL */
+int rf_comm_info(rf_ctx *ctx, int32_t *rank, int32_t *nranks, int32_t *rccl_version);
+/* mpi_bcast(ipack, 4, MPI_INTEGER4, 0, ...) of :518-519 (the pair rank 0 drew): buf[n] host, n <= 8,
+ * 0 <= root < nranks */
 int rf_comm_bcast_i32(rf_ctx *ctx, int32_t *buf, int32_t n, int32_t root);
 /* the cross-rank branch :542-571 as ONE grouped ncclSend + ncclRecv with `peer`: both ranks exchange
  * (T, logL, log u) of their chain and form the same judge_pt decision (:580-595) from the uniform of the rank
@@ -227,11 +231,19 @@ int rf_comm_bcast_i32(rf_ctx *ctx, int32_t *buf, int32_t n, int32_t root);
  * new_temp: the temperature this rank's chain holds afterwards; accepted (may be NULL). */
 int rf_pt_swap_exchange(rf_ctx *ctx, int32_t peer, int32_t judge, double temp, double logl, double log_u,
                         double *new_temp, int32_t *accepted);
-/* throughput form: npairs DISJOINT pairs of GLOBAL walker ids per iteration: one ncclAllGather of every rank's
- * (T, logL) (16 B per walker), then rf_pt_swap_device's kernel on the gathered arrays; d_temps[nchains] of
- * this rank is updated in place.  d_pairs[npairs][2], d_log_u[npairs] replicated on every rank. */
+/* throughput form: npairs DISJOINT pairs of GLOBAL walker ids per iteration: ONE RCCL group (two all-gathers
+ * straight from d_temps / d_logl: 16 B per walker, no staging copies), then ONE kernel that judges every pair on
+ * the gathered snapshot and writes this rank's own temperatures, d_temps[nchains], in place.
+ * d_pairs[npairs][2], d_log_u[npairs] replicated on every rank. */
 int rf_pt_swap_allgather_device(rf_ctx *ctx, int32_t nchains, int32_t npairs, const int32_t *d_pairs,
                                 const double *d_log_u, double *d_temps, const double *d_logl, void *stream);
+/* the kernel of the form above on arrays some other transport gathered (the host's MPI / gloo when ranks share a
+ * GPU and RCCL cannot form a communicator): d_g_temps / d_g_logl [nranks * nchains] indexed by global id =
+ * rank * nchains + chain (:508-511), read only; d_temps[nchains] = this rank's temperatures, updated in place;
+ * d_accepted[npairs] may be NULL.  Needs no communicator. */
+int rf_pt_swap_gathered_device(rf_ctx *ctx, int32_t nchains, int32_t rank, int32_t nranks, int32_t npairs,
+                               const int32_t *d_pairs, const double *d_log_u, const double *d_g_temps,
+                               const double *d_g_logl, double *d_temps, int32_t *d_accepted, void *stream);
 
 /* ---- posterior accumulation ---------------------------- */
 /* The "record sampled model" block of subroutine mcmc (src/pt_mcmc.f90:204-286) with the
@@ -294,7 +306,8 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
 /* Launch-plan options.  librfgpu reads NO environment variables; a knob is set here, validated,
  * and reported by rf_get_launch_plan.  Every option re-partitions or re-orders the same work:
  * results do not depend on them (tests/test_gpu_parity.py), except "bin_cutoff", which is opt-in
- * and off by default.  Call between evaluations (the call synchronises the context's stream).
+ * and off by default, and "block_threads", whose two kernels factorise the FFT differently (last-bit differences
+ * between the two settings, never within one).  Call between evaluations (the call synchronises the device).
  *   "fused"            -1 by shape (default) | 0 split spectra -> trace kernels | 1 one fused kernel
  *   "chain"            -1 by shape (default) | 0, 2, 3, 4, 8 bins per phase chain
  *   "lpt"              1 (default) longest-first dispatch order | 0
@@ -302,7 +315,9 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
  *   "nsplit"           0 by batch size (default) | 1..64 bin-splits per walker (split spectra kernel)
  *   "waves_per_block"  1..4 (default 4) waves sharing a staged layer stack (split spectra kernel)
  *   "defer_logl"       -1 by batch size (default) | 0 quadratic form + logL inside the main kernel | 1 follow-up kernels
- *   "block_threads"    0 by batch size (default) | 256 fused_kernel | 512 fused8_kernel (nfft 4096 on land only)
+ *   "block_threads"    0 by the context's capacity (default: max_walkers * ntrc blocks within two rounds of the
+ *                      GPU -> 512; fixed per context, never per launch) | 256 fused_kernel | 512 fused8_kernel
+ *                      (nfft 4096 on land only)
  *   "bin_cutoff"       0 (default: every bin like the reference) | tol in (0, 1): bins whose Gaussian filter
  *                      weight is below tol * flt(1) are not propagated
  * A library built with -DRFGPU_DIAGNOSTICS (tools/ablate.sh; never the shipped one) also accepts
@@ -316,7 +331,7 @@ int rf_set_option(rf_ctx *ctx, const char *name, double value);
  *  [3] bin-splits per walker at a full batch     [4] lpt   [5] order_reuse   [6] defer_logl (-1 / 0 / 1)
  *  [7] 1 when a bin cut-off is active            [8] number of options away from their defaults
  *  [9] 0 production build | 1 RFGPU_DIAGNOSTICS build | 2 diagnostics build with "ablate" set (results invalid)
- *  [10] the "block_threads" option (0 = by batch size)   [11] threads per block of the fused kernel at a full batch */
+ *  [10] the "block_threads" option (0 = by capacity)   [11] threads per block of the context's fused kernel */
 int rf_get_launch_plan(const rf_ctx *ctx, int32_t *plan);
 
 /* HIP-event timing (on the streams the kernels are launched on) of the three kernels

@@ -455,9 +455,10 @@ static void scratch_free(rfo_scratch *w)
 static void calc_rf_impl(const rfo_cfg *c, const fft_plan *pl, const double *flt,
                          int nlay, const double *alpha, const double *beta,
                          const double *rho, const double *h, double *rft,
-                         int *npre_out, cplx *spec_out, rfo_scratch *w)
+                         int *npre_out, cplx *spec_out, rfo_scratch *w, double *kappa_out)
 {
     int n = c->nfft, nh = n / 2 + 1;
+    if (kappa_out) *kappa_out = 1.0;
     cplx *freq_r = w->freq_r, *freq_v = w->freq_v, *rff = w->rff, *cx = w->cx, *work = w->work;
     double *rx = w->rx;
     int common = rays_common(c);
@@ -518,6 +519,14 @@ static void calc_rf_impl(const rfo_cfg *c, const fft_plan *pl, const double *flt
             c2r_exec(pl, cx, rx, work);
             double fac_norm = rx[0];
             for (int i = 1; i < n; ++i) fac_norm = rx[i] > fac_norm ? rx[i] : fac_norm; /* maxval :201 */
+            if (kappa_out) {
+                /* diagnostic of the tests' conditioning rule (not part of the reference): how much of the
+                 * vertical trace's scale cancels in the SIGNED maximum it is divided by */
+                double amax = 0.0;
+                for (int i = 0; i < n; ++i) amax = fabs(rx[i]) > amax ? fabs(rx[i]) : amax;
+                double kap = fac_norm == 0.0 ? HUGE_VAL : amax / fabs(fac_norm);
+                if (kap > *kappa_out || kap != kap) *kappa_out = kap;
+            }
             for (int i = 0; i < n; ++i) out[i] = out[i] / fac_norm;        /* :202 */
         }
     }
@@ -543,7 +552,7 @@ void rfo_calc_rf(int nfft, int ntrc, int deconv_mode, double delta, double t_sta
     fft_plan_init(&pl, nfft);
     rfo_scratch w;
     scratch_init(&w, nfft, 0, 0);
-    calc_rf_impl(&c, &pl, flt, nlay, alpha, beta, rho, h, rft, npre_out, spec_out, &w);
+    calc_rf_impl(&c, &pl, flt, nlay, alpha, beta, rho, h, rft, npre_out, spec_out, &w, NULL);
     scratch_free(&w);
     fft_plan_free(&pl);
     free(flt);
@@ -693,12 +702,15 @@ int rfo_format_model(const rfo_model_cfg *m, int prop_k, const double *prop_z,
  * (src/likelihood.f90:56-101 with the layer stack already formatted).
  * layers is [nb][4][nlay_pad] (alpha, beta, rho, h rows), sig [nb][ntrc].
  * rft_out (may be NULL) is [nb][ntrc][nfft].  nthreads <= 1 -> scalar. */
-void rfo_eval_batch(int nfft, int ntrc, int nsmp, int deconv_mode, double delta,
-                    double t_start, double sdep, const double *rayps,
-                    const double *a_gus, const int *ipha, const double *obs,
-                    int ldobs, const double *r_inv, int nb, const int *nlay,
-                    int nlay_pad, const double *layers, const double *sig,
-                    double *logl_out, double *rft_out, int nthreads)
+/* kappa_out (may be NULL) [nb]: max over traces of max|rx| / |maxval(rx)| of the filtered vertical trace the
+ * item is normalised by (src/forward.f90:197-202) -- the conditioning number of the tests' kappa rule; 1 with
+ * deconvolution. */
+void rfo_eval_batch_kappa(int nfft, int ntrc, int nsmp, int deconv_mode, double delta,
+                          double t_start, double sdep, const double *rayps,
+                          const double *a_gus, const int *ipha, const double *obs,
+                          int ldobs, const double *r_inv, int nb, const int *nlay,
+                          int nlay_pad, const double *layers, const double *sig,
+                          double *logl_out, double *rft_out, int nthreads, double *kappa_out)
 {
     rfo_cfg c = {nfft, ntrc, nsmp, deconv_mode, delta, t_start, sdep, rayps, a_gus, ipha};
     int nh = nfft / 2 + 1;
@@ -720,7 +732,7 @@ void rfo_eval_batch(int nfft, int ntrc, int nsmp, int deconv_mode, double delta,
         for (int b = 0; b < nb; ++b) {
             const double *L = layers + (size_t)b * 4 * nlay_pad;
             calc_rf_impl(&c, &pl, flt, nlay[b], L, L + nlay_pad, L + 2 * nlay_pad,
-                         L + 3 * nlay_pad, w.rft, NULL, NULL, &w);
+                         L + 3 * nlay_pad, w.rft, NULL, NULL, &w, kappa_out ? kappa_out + b : NULL);
             logl_out[b] = log_likelihood_impl(nfft, ntrc, nsmp, w.rft, obs, ldobs, r_inv,
                                               sig + (size_t)b * ntrc, w.misfits, w.phi1);
             if (rft_out)
@@ -731,6 +743,17 @@ void rfo_eval_batch(int nfft, int ntrc, int nsmp, int deconv_mode, double delta,
     fft_plan_free(&pl);
     free(flt);
     (void)nthreads;
+}
+
+void rfo_eval_batch(int nfft, int ntrc, int nsmp, int deconv_mode, double delta,
+                    double t_start, double sdep, const double *rayps,
+                    const double *a_gus, const int *ipha, const double *obs,
+                    int ldobs, const double *r_inv, int nb, const int *nlay,
+                    int nlay_pad, const double *layers, const double *sig,
+                    double *logl_out, double *rft_out, int nthreads)
+{
+    rfo_eval_batch_kappa(nfft, ntrc, nsmp, deconv_mode, delta, t_start, sdep, rayps, a_gus, ipha, obs, ldobs, r_inv,
+                         nb, nlay, nlay_pad, layers, sig, logl_out, rft_out, nthreads, NULL);
 }
 
 int rfo_max_threads(void)

@@ -156,11 +156,13 @@ def log_likelihood(rft, obs, r_inv, sig, nsmp):
                                     C.c_int(obs.shape[1]), pri, ps)
 
 
-def eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=False, nthreads=1, fast=False):
+def eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=False, nthreads=1, fast=False, want_kappa=False):
     """nb x calc_likelihood(fwd_flag=.true.)  (src/likelihood.f90:56-101).
 
     layers[nb, 4, nlay_pad] rows = alpha, beta, rho, h;  sig[nb, ntrc].
-    Returns logL[nb] (and rft[nb, ntrc, nfft]).  fast: the speed build (lib_fast), same values."""
+    Returns logL[nb] (and rft[nb, ntrc, nfft]).  fast: the speed build (lib_fast), same values.
+    want_kappa: also kappa[nb] = max over traces of max|rx| / |maxval(rx)| of the filtered vertical trace each
+    item is normalised by (the conditioning number of the tests' kappa rule; 1 with deconvolution)."""
     rayps, prp = _d(cfg["rayps"]); a_gus, pag = _d(cfg["a_gus"]); ipha, pip = _i(cfg["ipha"])
     obs, po = _d(obs); r_inv, pri = _d(r_inv); layers, pl = _d(layers); sig, ps = _d(sig)
     nlay, pn = _i(nlay)
@@ -168,13 +170,16 @@ def eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=False, nthread
     ntrc, nfft = rayps.size, int(cfg["nfft"])
     logl = np.empty(nb)
     rft = np.empty((nb, ntrc, nfft)) if want_rft else None
-    (lib_fast() if fast else lib()).rfo_eval_batch(C.c_int(nfft), C.c_int(ntrc), C.c_int(nsmp),
+    kappa = np.ones(nb) if want_kappa else None
+    (lib_fast() if fast else lib()).rfo_eval_batch_kappa(C.c_int(nfft), C.c_int(ntrc), C.c_int(nsmp),
                          C.c_int(int(cfg["deconv_mode"])), C.c_double(cfg["delta"]),
                          C.c_double(cfg["t_start"]), C.c_double(cfg["sdep"]), prp, pag, pip,
                          po, C.c_int(obs.shape[1]), pri, C.c_int(nb), pn, C.c_int(nlay_pad),
                          pl, ps, logl.ctypes.data_as(_dp),
-                         rft.ctypes.data_as(_dp) if want_rft else None, C.c_int(nthreads))
-    return (logl, rft) if want_rft else logl
+                         rft.ctypes.data_as(_dp) if want_rft else None, C.c_int(nthreads),
+                         kappa.ctypes.data_as(_dp) if want_kappa else None)
+    out = (logl,) + ((rft,) if want_rft else ()) + ((kappa,) if want_kappa else ())
+    return out if len(out) > 1 else logl
 
 
 def max_threads():

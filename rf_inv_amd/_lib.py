@@ -87,9 +87,11 @@ SYMBOLS = {
     "rf_comm_get_unique_id": (C.c_int, [C.c_char_p]),
     "rf_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int32]),
     "rf_comm_destroy": (C.c_int, [_vp]),
+    "rf_comm_info": (C.c_int, [_vp, ip, ip, ip]),
     "rf_comm_bcast_i32": (C.c_int, [_vp, ip, C.c_int32, C.c_int32]),
     "rf_pt_swap_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, dp, ip]),
     "rf_pt_swap_allgather_device": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
+    "rf_pt_swap_gathered_device": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_post_create": (C.c_int, [_vp, C.POINTER(RFPostConfig)]),
     "rf_post_reset": (C.c_int, [_vp]),
     "rf_post_record": (C.c_int, [_vp, C.c_int32, ip, ip, dp, dp, dp, dp, dp, dp]),

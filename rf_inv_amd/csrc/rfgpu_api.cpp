@@ -55,6 +55,7 @@ struct rf_ctx {
     int fm_pad = 0;
     int *d_fm_nlay = nullptr, *d_fm_flag = nullptr;
     double *d_fm_layers = nullptr, *d_fm_scratch = nullptr;
+    int *d_nh_active = nullptr;   // [ntrc] "bin_cutoff": bins with a non-negligible filter weight
     int *d_order = nullptr;   // [nslots] LPT dispatch order of the current batch
     int *d_order_alt = nullptr;   // [nslots] the order the running launch computes for the next one
     int order_next_nb = 0;    // d_order_alt holds an order for a batch of this size (0: none)
@@ -429,8 +430,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->d_order_alt = (int *)p;
     c->ws.nslots = c->nslots;
-    if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * c->nfwd * 2 * nh)) return cleanup(1);
-    c->spec = (double2 *)p;
+    // (spec, the split launch plan's intermediate -- 8.6 GB at the C5 capacity -- is allocated by the first launch
+    // that takes that plan: run_batch)
     if (dev_alloc(c, &p, sizeof(int) * ((size_t)c->nslots * c->nfwd + 1))) return cleanup(1);
     c->slow_count = (int *)p;      // [1]
     c->slow_list = (int *)p + 1;   // [nslots * nfwd]
@@ -556,16 +557,18 @@ static int pick_nsplit(const rf_ctx *c, int nb)
 // The 8-wave block has 4-bin phase chains started from a block-shared anchor table, keeps four waves per SIMD and
 // halves a block's latency-bound tail.  Measured A/B on MI355X at the end of round 2 (tools/ab_opt.sh block_threads
 // 256 512, and bench.py --walkers): two rounds of blocks (C2) +1.6 % throughput, with deconvolution +3.5 %;
-// three and four rounds -2 %; C3 (16 rounds) and C4 (48 rounds) level to -2 %: it takes the launches of up to two
-// rounds -- which includes the one-chain-per-call drop-in, whose single block is pure latency -- and the 4-wave
-// block the rest.  The two factorise the FFT differently (8^4 / 16^3): a chain's trace differs in the last bits
-// between the two plans, never within one.
-static bool use_fused8(const rf_ctx *c, long long blocks)
+// three and four rounds -2 %; C3 (16 rounds) and C4 (48 rounds) level to -2 %.
+// The two factorise the FFT differently (8^4 / 16^3), so a chain's trace differs in the last bits between them.
+// The choice is therefore a property of the CONTEXT, made from its capacity (max_walkers * ntrc blocks at a full
+// batch: up to two rounds -> the 8-wave kernel), never of a launch's batch size: a chain evaluated alone, in a
+// partial batch or in a full one gets bit-identical results (tests/test_gpu_parity.py).
+static bool use_fused8(const rf_ctx *c)
 {
     const bool can = c->fused && c->cfg.nfft == 4096 && c->cfg.sdep <= 0.0 && c->chain_override < 0 && c->ablate == 0 &&
                      fused8_lds_bytes(c->cfg.nsmp, c->cfg.nlay_max) <= 80 * 1024;
     if (!can || c->block_threads == 256) return false;
     if (c->block_threads == 512) return true;
+    const long long blocks = (long long)c->cfg.max_walkers * c->cfg.ntrc;
     return blocks <= (long long)c->fused8_max_rounds * 2 * c->num_cu;
 }
 
@@ -611,13 +614,18 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl
                           : (c->cfg.ntrc > 1 ? blocks >= 2 * round : blocks >= 4 * round));
         hipEvent_t e = prof_begin(c, 0, s);
-        if (use_fused8(c, blocks))
+        if (use_fused8(c))
             launch_fused8(c->tab, b, c->ws, c->slow_count, defer, order_next, c->single_trace_out, s);
         else
             launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, c->single_trace_out, s);
         if (e) (void)hipEventRecord(e, s);
         if (defer) launch_logl_deferred(c->tab, b, c->ws, s);
     } else {
+        if (!c->spec) {
+            void *p = nullptr;
+            if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * c->nfwd * 2 * c->nh)) return 1;
+            c->spec = (double2 *)p;
+        }
         hipEvent_t e = prof_begin(c, 0, s);
         launch_spectra(c->tab, b, c->spec, pick_nsplit(c, b.nb), c->chain, c->waves_per_block, c->slow_list,
                        c->slow_count, c->ws, s);
@@ -928,6 +936,20 @@ extern "C" int rf_pt_swap_device(rf_ctx *c, int32_t npairs, const int32_t *d_pai
     return 0;
 }
 
+extern "C" int rf_pt_swap_gathered_device(rf_ctx *c, int32_t nchains, int32_t rank, int32_t nranks, int32_t npairs,
+                                          const int32_t *d_pairs, const double *d_log_u, const double *d_g_temps,
+                                          const double *d_g_logl, double *d_temps, int32_t *d_accepted, void *stream)
+{
+    if (!c || !d_pairs || !d_log_u || !d_g_temps || !d_g_logl || !d_temps)
+        return fail("rf_pt_swap_gathered_device: null argument");
+    if (nchains < 1 || nranks < 1 || rank < 0 || rank >= nranks) return fail("rf_pt_swap_gathered_device: bad rank / nranks / nchains");
+    if (npairs <= 0) return 0;
+    HIP_TRY(hipSetDevice(c->device));
+    launch_pt_swap_gathered(npairs, d_pairs, d_log_u, d_g_temps, d_g_logl, nchains, rank, d_temps, d_accepted,
+                            (hipStream_t)stream);
+    return 0;
+}
+
 // ---------------------------------------------------------------------------
 // posterior accumulation (src/pt_mcmc.f90:204-286 on the device; kernels in rfgpu_posterior.hip)
 // ---------------------------------------------------------------------------
@@ -1111,7 +1133,16 @@ static int upload_bin_cutoff(rf_ctx *c)
             if (c->flt[(size_t)k + (size_t)nh * t] >= c->bin_cutoff * c->flt[(size_t)nh * t]) last = k;
         act[t] = last + 1;
     }
-    return upload(c, act, &c->tab.nh_active);
+    // one ntrc-sized buffer for the life of the context, overwritten in place (rf_set_option has synchronised the
+    // device: nothing in flight reads it)
+    if (!c->d_nh_active) {
+        void *p = nullptr;
+        if (dev_alloc(c, &p, sizeof(int) * ntrc)) return 1;
+        c->d_nh_active = (int *)p;
+    }
+    HIP_TRY(hipMemcpy(c->d_nh_active, act.data(), sizeof(int) * ntrc, hipMemcpyHostToDevice));
+    c->tab.nh_active = c->d_nh_active;
+    return 0;
 }
 
 extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
@@ -1121,7 +1152,9 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     const int iv = (int)value;
     const bool integral = (double)iv == value;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    // the *_device entry points run on the caller's streams: an option must not change the launch plan or a table
+    // under a batch in flight on any of them
+    HIP_TRY(hipDeviceSynchronize());
     if (k == "fused") {
         if (!integral || iv < -1 || iv > 1) return fail("rf_set_option: fused must be -1 (by shape), 0 or 1");
         if (iv == 1 && !c->fused_allowed)
@@ -1187,7 +1220,7 @@ extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
     plan[9] = 0;
 #endif
     plan[10] = c->block_threads;
-    plan[11] = use_fused8(c, (long long)c->cfg.max_walkers * c->cfg.ntrc) ? 512 : 256;
+    plan[11] = use_fused8(c) ? 512 : 256;
     return 0;
 }
 

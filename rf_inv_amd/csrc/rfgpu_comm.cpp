@@ -10,6 +10,7 @@
 #include "../../include/rfgpu.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <cstring>
 #include <string>
@@ -31,6 +32,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) CommInitRank = nullptr;
     decltype(&ncclCommDestroy) CommDestroy = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclSend) Send = nullptr;
@@ -51,7 +53,7 @@ Rccl *rccl()
     }
     if (!r.h) return nullptr;
 #define RF_SYM(n) r.n = reinterpret_cast<decltype(r.n)>(dlsym(r.h, "nccl" #n))
-    RF_SYM(GetUniqueId); RF_SYM(CommInitRank); RF_SYM(CommDestroy); RF_SYM(GetErrorString); RF_SYM(Broadcast);
+    RF_SYM(GetUniqueId); RF_SYM(CommInitRank); RF_SYM(CommDestroy); RF_SYM(GetErrorString); RF_SYM(GetVersion); RF_SYM(Broadcast);
     RF_SYM(AllGather); RF_SYM(Send); RF_SYM(Recv); RF_SYM(GroupStart); RF_SYM(GroupEnd);
 #undef RF_SYM
     if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.AllGather || !r.Send || !r.Recv ||
@@ -69,7 +71,7 @@ struct rfgpu::CommState {
     int rank = 0, nranks = 1;
     double *d_buf = nullptr;     // [8] staging: [0..2] outgoing (T, logL, log u), [4..6] incoming
     double *h_buf = nullptr;     // pinned mirror
-    double *d_gather = nullptr;  // [nranks][2][nchains] for the all-gather exchange
+    double *d_gather = nullptr;  // [2][nranks * nchains]: every rank's T, then every rank's logL, by global walker id
     size_t gather_doubles = 0;
 };
 
@@ -86,15 +88,21 @@ struct rfgpu::CommState {
     } while (0)
 
 // Can this rank take part in an RCCL communicator?  Returns 0 when librccl.so.1 loads; device_key identifies
-// the context's physical GPU (PCI domain / bus / device): the host gathers the keys of all ranks and uses
-// RCCL only when every rank answered 0 and all keys differ -- ncclCommInitRank is collective, so the decision
-// has to be unanimous BEFORE anyone enters it.
+// the context's physical GPU -- a hash of the host name (ranks of different nodes with the same PCI address are
+// NOT the same GPU) over PCI domain / bus / device: the host gathers the keys of all ranks and uses RCCL only
+// when every rank answered 0 and all keys differ -- ncclCommInitRank is collective, so the decision has to be
+// unanimous BEFORE anyone enters it.
 extern "C" int rf_comm_probe(rf_ctx *c, int64_t *device_key)
 {
     if (!c || !device_key) return comm_fail("rf_comm_probe: null argument");
     hipDeviceProp_t prop;
     HIPC_TRY(hipGetDeviceProperties(&prop, ctx_device(c)));
-    *device_key = ((int64_t)prop.pciDomainID << 16) | ((int64_t)prop.pciBusID << 8) | (int64_t)prop.pciDeviceID;
+    char host[256] = {0};
+    (void)gethostname(host, sizeof host - 1);
+    uint32_t hh = 2166136261u;                         // FNV-1a
+    for (const char *q = host; *q; ++q) hh = (hh ^ (uint8_t)*q) * 16777619u;
+    *device_key = ((int64_t)(hh & 0x7fffffffu) << 32) | ((int64_t)(prop.pciDomainID & 0xffff) << 16) |
+                  ((int64_t)(prop.pciBusID & 0xff) << 8) | (int64_t)(prop.pciDeviceID & 0xff);
     if (!rccl()) return comm_fail("rf_comm_probe: librccl.so.1 cannot be loaded");
     return 0;
 }
@@ -164,6 +172,7 @@ extern "C" int rf_comm_bcast_i32(rf_ctx *c, int32_t *buf, int32_t n, int32_t roo
     CommState *s = ctx_comm(c);
     if (!s) return comm_fail("rf_comm_bcast_i32: rf_comm_init has not been called");
     if (n < 1 || n > 8) return comm_fail("rf_comm_bcast_i32: n must be 1 .. 8");
+    if (root < 0 || root >= s->nranks) return comm_fail("rf_comm_bcast_i32: root out of range");
     Rccl *R = rccl();
     hipStream_t st = ctx_stream(c);
     HIPC_TRY(hipSetDevice(ctx_device(c)));
@@ -216,9 +225,28 @@ extern "C" int rf_pt_swap_exchange(rf_ctx *c, int32_t peer, int32_t judge, doubl
     return 0;
 }
 
+// rank / size of the context's communicator and the RCCL version it runs on (major * 10000 + minor * 100 + patch,
+// ncclGetVersion); any pointer may be NULL.  Without a communicator: rank 0 of 1, version of the loadable library.
+extern "C" int rf_comm_info(rf_ctx *c, int32_t *rank, int32_t *nranks, int32_t *rccl_version)
+{
+    if (!c) return comm_fail("rf_comm_info: null context");
+    CommState *s = ctx_comm(c);
+    if (rank) *rank = s ? s->rank : 0;
+    if (nranks) *nranks = s ? s->nranks : 1;
+    if (rccl_version) {
+        *rccl_version = 0;
+        Rccl *R = rccl();
+        int v = 0;
+        if (R && R->GetVersion && R->GetVersion(&v) == ncclSuccess) *rccl_version = v;
+    }
+    return 0;
+}
+
 // Throughput form: K DISJOINT pairs per iteration over global walker ids (rank * nchains + chain,
-// src/pt_mcmc.f90:508-511).  One ncclAllGather of every rank's (T, logL) -- 16 bytes per walker -- then every
-// rank applies the same decisions with pt_swap_kernel and keeps its own slice of the temperatures.
+// src/pt_mcmc.f90:508-511).  ONE RCCL group -- two all-gathers straight from the caller's arrays, every rank's T
+// into g_t[nranks * nchains] and every rank's logL into g_l: rank blocks in rank order ARE the global-id order --
+// then ONE kernel that reads the gathered snapshot and writes this rank's own temperatures in place
+// (pt_swap_gathered_kernel).  No staging copies: 16 bytes per walker cross xGMI, nothing else moves.
 extern "C" int rf_pt_swap_allgather_device(rf_ctx *c, int32_t nchains, int32_t npairs, const int32_t *d_pairs,
                                            const double *d_log_u, double *d_temps, const double *d_logl, void *stream)
 {
@@ -230,27 +258,21 @@ extern "C" int rf_pt_swap_allgather_device(rf_ctx *c, int32_t nchains, int32_t n
     Rccl *R = rccl();
     hipStream_t st = (hipStream_t)stream;
     HIPC_TRY(hipSetDevice(ctx_device(c)));
-    const size_t per = 2 * (size_t)nchains, need = per * (size_t)(s->nranks + 1) + 2 * (size_t)s->nranks * nchains;
+    const size_t all = (size_t)s->nranks * (size_t)nchains, need = 2 * all;
     if (need > s->gather_doubles) {
+        // (growth only: the first call of a run; the old buffer may still be read by work in flight on `st`)
+        HIPC_TRY(hipStreamSynchronize(st));
         if (s->d_gather) (void)hipFree(s->d_gather);
         s->d_gather = nullptr;
+        s->gather_doubles = 0;
         HIPC_TRY(hipMalloc((void **)&s->d_gather, sizeof(double) * need));
         s->gather_doubles = need;
     }
-    double *local = s->d_gather;                      // [2][nchains]: T, logL of this rank
-    double *all = local + per;                        // [nranks][2][nchains]
-    double *g_t = all + per * s->nranks;              // [nranks * nchains] temperatures by global id
-    double *g_l = g_t + (size_t)s->nranks * nchains;  // [nranks * nchains] logL by global id
-    HIPC_TRY(hipMemcpyAsync(local, d_temps, sizeof(double) * nchains, hipMemcpyDeviceToDevice, st));
-    HIPC_TRY(hipMemcpyAsync(local + nchains, d_logl, sizeof(double) * nchains, hipMemcpyDeviceToDevice, st));
-    RCCL_TRY(R->AllGather(local, all, per, ncclDouble, s->comm, st));
-    for (int r = 0; r < s->nranks; ++r) {
-        HIPC_TRY(hipMemcpyAsync(g_t + (size_t)r * nchains, all + per * r, sizeof(double) * nchains, hipMemcpyDeviceToDevice, st));
-        HIPC_TRY(hipMemcpyAsync(g_l + (size_t)r * nchains, all + per * r + nchains, sizeof(double) * nchains,
-                                hipMemcpyDeviceToDevice, st));
-    }
-    launch_pt_swap(npairs, d_pairs, d_log_u, g_t, g_l, nullptr, st);
-    HIPC_TRY(hipGetLastError());
-    HIPC_TRY(hipMemcpyAsync(d_temps, g_t + (size_t)s->rank * nchains, sizeof(double) * nchains, hipMemcpyDeviceToDevice, st));
+    double *g_t = s->d_gather, *g_l = s->d_gather + all;
+    RCCL_TRY(R->GroupStart());
+    RCCL_TRY(R->AllGather(d_temps, g_t, (size_t)nchains, ncclDouble, s->comm, st));
+    RCCL_TRY(R->AllGather(d_logl, g_l, (size_t)nchains, ncclDouble, s->comm, st));
+    RCCL_TRY(R->GroupEnd());
+    launch_pt_swap_gathered(npairs, d_pairs, d_log_u, g_t, g_l, nchains, s->rank, d_temps, nullptr, st);
     return 0;
 }

@@ -2991,4 +2991,34 @@ void launch_pt_swap(int npairs, const int *pairs, const double *log_u, double *t
                        log_u, temps, logl, accepted);
 }
 
+// The same decisions on the GATHERED ensemble of a multi-rank run (pt_mcmc.f90:508-511: global id = rank * nchains +
+// chain): g_temps / g_logl [nranks * nchains] are every rank's (T, logL) as the all-gather delivered them -- rank
+// blocks in rank order, i.e. already indexed by global id -- and are only read; a swap writes the temperature this
+// rank's own chain holds afterwards straight into `temps` [nchains] (temperatures move, states stay: :532-535).
+// Pairs are disjoint, so every decision sees the pre-swap snapshot exactly as the in-place kernel does.
+__global__ void pt_swap_gathered_kernel(int npairs, const int *pairs, const double *log_u, const double *g_temps,
+                                        const double *g_logl, int nchains, int rank, double *temps, int *accepted)
+{
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npairs) return;
+    const int c1 = pairs[2 * i], c2 = pairs[2 * i + 1];
+    const double t1 = g_temps[c1], t2 = g_temps[c2];
+    const double del_s = (g_logl[c2] - g_logl[c1]) * (1.0 / t1 - 1.0 / t2);
+    const int yn = log_u[i] <= del_s;
+    if (yn) {
+        const int lo = rank * nchains;
+        if (c2 >= lo && c2 < lo + nchains) temps[c2 - lo] = t1;
+        if (c1 >= lo && c1 < lo + nchains) temps[c1 - lo] = t2;
+    }
+    if (accepted) accepted[i] = yn;
+}
+
+void launch_pt_swap_gathered(int npairs, const int *pairs, const double *log_u, const double *g_temps,
+                             const double *g_logl, int nchains, int rank, double *temps, int *accepted, hipStream_t s)
+{
+    hipLaunchKernelGGL(pt_swap_gathered_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, npairs, pairs,
+                       log_u, g_temps, g_logl, nchains, rank, temps, accepted);
+}
+
 } // namespace rfgpu

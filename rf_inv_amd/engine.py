@@ -275,6 +275,14 @@ class RFEngine:
     def comm_init(self, unique_id: bytes, rank: int, nranks: int):
         self._chk(self._lib.rf_comm_init(self._ctx, unique_id, int(rank), int(nranks)))
 
+    def comm_info(self):
+        """{rank, nranks} of the context's communicator (0 of 1 without one) and the RCCL version in use."""
+        r, n, v = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self._lib.rf_comm_info(self._ctx, C.byref(r), C.byref(n), C.byref(v)))
+        ver = v.value
+        return {"rank": r.value, "nranks": n.value,
+                "rccl_version": f"{ver // 10000}.{ver // 100 % 100}.{ver % 100}" if ver else None}
+
     def comm_destroy(self):
         self._chk(self._lib.rf_comm_destroy(self._ctx))
 
@@ -301,6 +309,17 @@ class RFEngine:
         self._chk(self._lib.rf_pt_swap_allgather_device(self._ctx, temps.numel(), pairs.shape[0], pairs.data_ptr(),
                                                         log_u.data_ptr(), temps.data_ptr(), logl.data_ptr(),
                                                         st.cuda_stream))
+
+    def pt_swap_gathered_device(self, pairs, log_u, g_temps, g_logl, temps, rank, nranks, accepted=None, stream=None):
+        """The same judgement on arrays another transport gathered: g_temps / g_logl [nranks * nchains] by global
+        walker id (read only), temps[nchains] = this rank's, updated in place."""
+        import torch
+
+        st = stream if stream is not None else torch.cuda.current_stream(temps.device)
+        self._chk(self._lib.rf_pt_swap_gathered_device(
+            self._ctx, temps.numel(), int(rank), int(nranks), pairs.shape[0], pairs.data_ptr(), log_u.data_ptr(),
+            g_temps.data_ptr(), g_logl.data_ptr(), temps.data_ptr(),
+            accepted.data_ptr() if accepted is not None else None, st.cuda_stream))
 
     # ---- instrumentation -----------------------------------------------------
     @property

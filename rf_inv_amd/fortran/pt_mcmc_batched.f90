@@ -301,11 +301,14 @@ contains
          call rfgpu_check(rf_comm_init(rf_ctx, token, int(rank, c_int32_t), int(nproc, c_int32_t)), "rf_comm_init")
          over_rccl = .true.
       end if
-      if (verb) then
+      ! (always said, on rank 0's error unit: a silent fall-back to MPI on a multi-GPU node would be a performance bug
+      ! nobody sees; the GPU identities compared above carry the host name, so ranks of different nodes never
+      ! count as sharing a device)
+      if (rank == 0) then
          if (over_rccl) then
-            write(*,*) "Temperature exchange: RCCL"
+            write(0,'(A,I0,A)') " Temperature exchange: RCCL (", nproc, " ranks, one GPU each)"
          else
-            write(*,*) "Temperature exchange: MPI (ranks share a GPU, or RCCL is not available)"
+            write(0,'(A)') " Temperature exchange: MPI (ranks share a GPU, or RCCL is not available)"
          end if
       end if
     end subroutine open_temperature_exchange

@@ -63,11 +63,42 @@ class PairSchedule:
         return pairs, np.log(u)
 
 
+def open_exchange(engine, dist):
+    """Decide once, unanimously, how this run's ranks exchange temperatures -- the Python host's
+    `open_temperature_exchange` (rf_inv_amd/fortran/pt_mcmc_batched.f90): every rank probes RCCL and names its
+    physical GPU (rf_comm_probe); if all can and all GPUs differ, rank 0 draws the RCCL id (rf_comm_get_unique_id),
+    the process group that launched the run carries its 128 bytes to everybody, and every rank joins
+    (rf_comm_init) -- from then on the swap step is librfgpu's own RCCL group over xGMI
+    (rf_pt_swap_allgather_device).  Ranks that share a GPU (functional tests on a one-GPU box) return False and keep
+    the process group as the transport.  Collective: every rank must call it."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    usable, key = engine.comm_probe()
+    seen = [None] * world
+    dist.all_gather_object(seen, (bool(usable), int(key)))
+    ok = all(u for u, _ in seen) and len({k for _, k in seen}) == world
+    token = [None]
+    if ok and rank == 0:
+        from .engine import RFEngine, RFGPUError
+
+        try:
+            token[0] = RFEngine.comm_unique_id()
+        except RFGPUError:
+            pass
+    dist.broadcast_object_list(token, src=0)
+    if token[0] is None:
+        return False
+    engine.comm_init(token[0], rank, world)
+    return True
+
+
 class PTSwap:
     """Temperature state of this rank's walkers + the exchange step."""
 
     def __init__(self, engine, nchains, ntemps, device, seed=0, t_high=15.0, pairs_per_step=None,
-                 mode="allgather", cache_steps=256):
+                 mode="allgather", cache_steps=256, rccl=None):
+        """rccl: True -- the engine holds an RCCL communicator (open_exchange): the device step is
+        rf_pt_swap_allgather_device; False -- gather through torch.distributed, judge with the same kernel
+        (rf_pt_swap_gathered_device); None -- whatever the engine reports (rf_comm_info)."""
         import torch
         import torch.distributed as dist
 
@@ -78,6 +109,9 @@ class PTSwap:
         self.rank = dist.get_rank() if self.world > 1 else 0
         self.device = torch.device(device)
         self.mode = mode
+        if rccl is None:
+            rccl = engine is not None and self.world > 1 and engine.comm_info()["nranks"] == self.world
+        self.rccl = bool(rccl) and self.world > 1
         n_all = self.world * self.nchains
         ncool = max(1, self.nchains // max(1, int(ntemps)))
         trng = np.random.Generator(np.random.Philox(key=seed + 7919 * (self.rank + 1)))
@@ -92,10 +126,10 @@ class PTSwap:
         self._cursor = 0
         if self.device.type == "cuda" and mode != "p2p":
             self._fill_cache()
-        # all_gather buffers: (T, logL) of every rank, concatenated along dim 0 (the layout both
-        # RCCL and gloo accept for all_gather_into_tensor)
-        self._gather = torch.empty((self.world * 2, self.nchains), dtype=torch.float64, device=self.device)
-        self._local = torch.empty((2, self.nchains), dtype=torch.float64, device=self.device)
+        # gathered (T, logL) of every rank, rank blocks in rank order = indexed by global walker id
+        # (only the transport-by-process-group modes use them; the RCCL step gathers inside librfgpu)
+        self._g_t = torch.empty(n_all, dtype=torch.float64, device=self.device)
+        self._g_l = torch.empty(n_all, dtype=torch.float64, device=self.device)
 
     def _fill_cache(self):
         torch = self.torch
@@ -107,7 +141,6 @@ class PTSwap:
     # -- device, throughput mode ------------------------------------------------
     def step(self, logl, stream=None):
         """One exchange step on device tensors (logl[nchains] float64 on self.device)."""
-        torch, dist = self.torch, self.dist
         if self.device.type != "cuda":
             return self.step_host(logl)
         if self.mode == "p2p":
@@ -119,26 +152,34 @@ class PTSwap:
         self._cursor += 1
         if self.world == 1:
             self.engine.pt_swap_device(pairs, logu, self.temps, logl, None, stream)
-            return
-        g_t, g_l = self._gather_global(logl)
-        self.engine.pt_swap_device(pairs, logu, g_t, g_l, None, stream)
-        self.temps.copy_(g_t[self.rank * self.nchains:(self.rank + 1) * self.nchains])
-
-    def _gather_global(self, logl):
-        """One collective: every rank's (T, logL) -> global arrays indexed by
-        global id = rank * nchains + chain (src/pt_mcmc.f90:508-511)."""
-        self._local[0].copy_(self.temps)
-        self._local[1].copy_(logl)
-        if self.device.type == "cuda" and self.dist.get_backend() == "gloo":
-            # functional mode (several ranks on ONE GPU, where RCCL cannot form a communicator): gloo moves host
-            # tensors, so stage through the host; the RCCL path below never leaves the device
-            h_all = self.torch.empty(self._gather.shape, dtype=self.torch.float64)
-            self.dist.all_gather_into_tensor(h_all, self._local.cpu())
-            self._gather.copy_(h_all)
+        elif self.rccl:
+            # one RCCL group (two all-gathers straight from temps / logl) + one kernel, all inside librfgpu
+            self.engine.pt_swap_allgather_device(pairs, logu, self.temps, logl, stream)
         else:
-            self.dist.all_gather_into_tensor(self._gather, self._local)
-        g = self._gather.view(self.world, 2, self.nchains)
-        return g[:, 0, :].reshape(-1).contiguous(), g[:, 1, :].reshape(-1).contiguous()
+            # ranks share a GPU: the process group gathers, the same kernel judges
+            self._gather_global(self.temps, logl)
+            self.engine.pt_swap_gathered_device(pairs, logu, self._g_t, self._g_l, self.temps, self.rank, self.world,
+                                                stream=stream)
+
+    def _gather_global(self, temps, logl):
+        """Every rank's T and logL -> self._g_t / self._g_l, indexed by global id = rank * nchains + chain
+        (src/pt_mcmc.f90:508-511): all_gather_into_tensor concatenates the rank blocks in rank order, which IS
+        that order -- no repacking."""
+        dist = self.dist
+        if self.device.type == "cuda" and dist.get_backend() == "gloo":
+            # functional mode (several ranks on ONE GPU, where RCCL cannot form a communicator): gloo moves host
+            # tensors, so stage through the host
+            h_t = self.torch.empty(self._g_t.shape, dtype=self.torch.float64)
+            h_l = self.torch.empty(self._g_l.shape, dtype=self.torch.float64)
+            self.torch.cuda.current_stream(self.device).synchronize()
+            dist.all_gather_into_tensor(h_t, temps.cpu())
+            dist.all_gather_into_tensor(h_l, logl.cpu())
+            self._g_t.copy_(h_t)
+            self._g_l.copy_(h_l)
+        else:
+            dist.all_gather_into_tensor(self._g_t, temps)
+            dist.all_gather_into_tensor(self._g_l, logl)
+        return self._g_t, self._g_l
 
     # -- the reference's p2p protocol, device-agnostic (RCCL send/recv on the GPU box, gloo in
     #    the CPU tests): one pair per iteration ---------------------------------------------
@@ -183,8 +224,8 @@ class PTSwap:
         temps = self.temps.numpy()
         ll = logl.numpy() if hasattr(logl, "numpy") else np.asarray(logl)
         if self.world > 1:
-            gt, gl = self._gather_global(torch.as_tensor(ll))
-            g_t, g_l = gt.numpy(), gl.numpy()
+            gt, gl = self._gather_global(self.temps, torch.as_tensor(ll))
+            g_t, g_l = gt.numpy().copy(), gl.numpy()
         else:
             g_t, g_l = temps.copy(), ll
         for (i1, i2), lu in zip(pairs, logu):

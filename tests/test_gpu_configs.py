@@ -1,9 +1,11 @@
-"""BASELINE.json configs C3, C4, C5 through the library's DEFAULT launch plan at their full per-GPU batch,
-with the parallel-tempering swap in the loop, and a seeded randomised sweep over contexts.  -m gpu only.
+"""BASELINE.json configs C3, C4, C5 through the library's DEFAULT launch plan at their full per-GPU batch
+(C3 8192, C4 8192, C5 32768 walkers per GPU), with the parallel-tempering swap in the loop, and a seeded randomised
+sweep over contexts.  -m gpu only.
 
-Full-size checks are the size-independent properties of the domain (walkers are independent; the true model
+Full-size checks: the size-independent properties of the domain (walkers are independent; the true model
 maximises logL; phi does not depend on sigma; temperatures follow a serial replay of the replicated swap
-schedule) plus a sampled comparison with the CPU oracle on the same inputs."""
+schedule) AND the logL of every walker of the batch against the CPU oracle on the same inputs, under the
+conditioning (kappa) rule; traces of a sample of walkers incl. the highest walker ids."""
 import os
 import sys
 import zlib
@@ -18,6 +20,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 pytestmark = pytest.mark.gpu
+
+KAPPA_MIN, KAPPA_SCALE = 100.0, 10.0      # the conditioning rule (see above test_randomised_contexts_against_oracle)
 
 
 def _workload(name):
@@ -112,17 +116,47 @@ def _run_config(name, expect_defer, nsample, extra_check=None):
         ll2 = eng.eval_batch(np.arange(nb), nlay, layers, 2 * sig)
         q = -(ll + nsmp * np.log(sigv).sum())                                   # = 0.5 sum phi_t / sigma_t^2
         assert np.allclose(ll2, -q / 4 - nsmp * np.log(2 * sigv).sum(), rtol=1e-12, atol=1e-9)
-        # (4) sampled oracle parity, incl. the deepest walkers and the true model
+        # (4) EVERY walker of the batch against the oracle, conditioning accounted for (the rule above
+        # test_randomised_contexts_against_oracle): an item may exceed the plain tolerance only if kappa >= KAPPA_MIN
+        # and must then stay within tolerance * kappa / KAPPA_SCALE; items below KAPPA_MIN get no allowance
+        ref, kap = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads(),
+                                     want_kappa=True)
+        d = np.abs(ll - ref)
+        tol = logl_tol(ref)
+        over = np.nonzero(~(d <= tol))[0]
+        for i in over:
+            assert kap[i] >= KAPPA_MIN, (name, int(i), "well-conditioned walker off tolerance", ll[i], ref[i], kap[i])
+            assert d[i] <= tol[i] * kap[i] / KAPPA_SCALE, (name, int(i), ll[i], ref[i], kap[i])
+        assert len(over) <= max(2, nb // 100), (name, len(over))
+        worst = int(np.argmax(d / tol))
+        report = {"config": name, "walkers": int(nb), "compared": int(nb), "n_kappa_ge_100": int(np.sum(kap >= KAPPA_MIN)),
+                  "n_used_kappa_allowance": int(len(over)), "max_rel_dlogl": float((d / np.abs(ref)).max()),
+                  "max_abs_dlogl": float(d.max()),
+                  "worst": {"walker": worst, "nlay": int(nlay[worst]), "logl": float(ref[worst]), "abs": float(d[worst]),
+                            "rel": float(d[worst] / abs(ref[worst])), "tolerance_used": float(d[worst] / tol[worst]),
+                            "kappa": float(kap[worst])}}
+        print("full-batch parity:", report)
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out_dir):
+            import json
+
+            with open(os.path.join(out_dir, f"parity_full_batch_{name}.json"), "w") as fh:
+                json.dump(report, fh, indent=1)
+        # traces of sampled walkers (the deepest, the true model, the highest walker ids -- at C5 beyond the 4 GiB
+        # mark of the trace array -- and the worst-conditioned ones)
         deep = np.argsort(nlay)[-4:]
-        idx = np.unique(np.concatenate([rng.choice(nb, nsample, replace=False), deep, [nb - 1]]))
-        ref, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], nsmp, want_rft=True,
-                                         nthreads=oracle.max_threads())
-        d = np.abs(ll[idx] - ref)
-        assert np.all(d <= logl_tol(ref)), (name, d.max(), (d / np.abs(ref)).max())
-        eng.eval_batch(np.arange(nb), nlay, layers, sig)                        # proposals = the sampled batch again
-        for j in rng.choice(len(idx), 6, replace=False):
-            got = eng.get_rft(int(idx[j]), which=1).T
-            assert np.abs(got - ref_rft[j]).max() <= 1e-12 * np.abs(ref_rft[j]).max(), (name, int(idx[j]))
+        idx = np.unique(np.concatenate([rng.choice(nb, nsample, replace=False), deep, [nb - 1, nb - 2, nb - 3],
+                                        np.argsort(kap)[-2:], np.arange(nb - 1, nb // 2, -(nb // 16))]))
+        _, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], nsmp, want_rft=True,
+                                       nthreads=oracle.max_threads())
+        eng.eval_batch(np.arange(nb), nlay, layers, sig)                        # proposals = the compared batch again
+        got_all = eng.get_rft_batch(idx, which=1)                                # [len(idx), ntrc, nfft]
+        for j in range(len(idx)):
+            scale = np.abs(ref_rft[j]).max()
+            allow = 1e-12 * max(1.0, kap[idx[j]] / KAPPA_SCALE if kap[idx[j]] >= KAPPA_MIN else 1.0)
+            assert np.abs(got_all[j] - ref_rft[j]).max() <= allow * scale, (name, int(idx[j]), kap[idx[j]])
+        j = int(rng.integers(len(idx)))
+        assert np.array_equal(eng.get_rft(int(idx[j]), which=1).T, got_all[j])
         if extra_check:
             extra_check(eng, p, cfg, obs, r_inv, oracle)
 
@@ -139,8 +173,9 @@ def test_c4_default_plan_full_batch():
 
 
 def test_c5_default_plan_full_batch():
-    """C5 shape: sdep 2.0, traces P, P, S, S, nfft 4096, <= 31 layers (ocean kernel, 4-bin chains, 3 propagated
-    columns), plus -- in the same context -- walkers whose own beta(1) >= 0 (a land stack under sdep > 0:
+    """C5 at BASELINE's per-GPU batch (16384 chains x 16 temperatures / 8 GPUs = 32768 walkers: 8.6 GB of traces,
+    offsets beyond 4 GiB): sdep 2.0, traces P, P, S, S, nfft 4096, <= 31 layers (ocean kernel, 4-bin chains, 3
+    propagated columns), plus -- in the same context -- walkers whose own beta(1) >= 0 (a land stack under sdep > 0:
     calc_seis keys on beta(1), forward.f90:229; direct_arrival on sdep, :484)."""
 
     def land_in_ocean_context(eng, p, cfg, obs, r_inv, oracle):
@@ -155,7 +190,7 @@ def test_c5_default_plan_full_batch():
             got = eng.get_rft(i, which=1).T
             assert np.abs(got - ref_rft[i]).max() <= 1e-12 * np.abs(ref_rft[i]).max(), i
 
-    _run_config("c5", expect_defer=True, nsample=32, extra_check=land_in_ocean_context)
+    _run_config("c5", expect_defer=True, nsample=64, extra_check=land_in_ocean_context)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -170,9 +205,6 @@ def test_c5_default_plan_full_batch():
 # (computed from the ORACLE's own vertical spectrum, in the test) is >= KAPPA_MIN, and then it must stay
 # within the plain tolerance times kappa / KAPPA_SCALE.  Items with kappa below KAPPA_MIN get no allowance.
 # ---------------------------------------------------------------------------------------------------------
-KAPPA_MIN, KAPPA_SCALE = 100.0, 10.0
-
-
 def _kappa(oracle, cfg, stack):
     """max over traces of max|rx_v| / |maxval(rx_v)| for the filtered vertical trace of forward.f90:197-201."""
     nfft = int(cfg["nfft"])
@@ -248,16 +280,40 @@ def test_randomised_contexts_against_oracle(oracle, seed):
     assert n_allow <= max(2, n_items // 50), (n_allow, n_items)
 
 
-def test_bench_two_ranks_on_one_gpu_swap_matches_serial_replay(tmp_path):
-    """bench.py's N > 1 path end to end: launched as two ranks (torch.distributed.run) that share the one GPU, with
-    gloo as the process-group backend (RCCL cannot put two ranks on one device) -- sharding, barrier, max-over-ranks
-    timing, the all-gather temperature exchange and the JSON line.  The final temperatures of both ranks equal a
-    serial replay of the replicated swap schedule on the logL values the run produced."""
+def _replay_bench_state(dump, nb, ntemps, nranks):
+    """Final temperatures of a bench.py run == serial replay of the replicated swap schedule on the logL the run
+    produced; swaps across the rank boundary present."""
+    from rf_inv_amd.pt import PairSchedule, init_temps, judge_pt
+
+    st = np.load(dump)
+    temps, logl = st["temps"], st["logl"]
+    assert temps.shape == (nranks, nb)
+    ref = np.concatenate([init_temps(nb, max(1, nb // ntemps), 15.0,
+                                     np.random.Generator(np.random.Philox(key=1234 + 7919 * (rk + 1)))) for rk in range(nranks)])
+    start = ref.copy()
+    sched = PairSchedule(nranks * nb, 1234, int(st["pairs_per_step"]))
+    ll = logl.reshape(-1)                       # the same models every step: logL is the same every step
+    for _ in range(int(st["swap_steps"])):
+        pairs, logu = sched.draw()
+        for (i1, i2), lu in zip(pairs, logu):
+            if judge_pt(ref[i1], ref[i2], ll[i1], ll[i2], lu):
+                ref[i1], ref[i2] = ref[i2], ref[i1]
+    assert np.array_equal(temps.reshape(-1), ref)
+    assert np.sum(ref != start) > 0             # swaps did happen
+    cross = [(a, b) for a, b in np.argwhere(ref[:, None] == start[None, :]) if (a // nb) != (b // nb)]
+    assert len(cross) > 0                       # ... also across the ranks' blocks
+    return st
+
+
+@pytest.mark.parametrize("launcher", ["torchrun", "direct"])
+def test_bench_two_ranks_on_one_gpu_swap_matches_serial_replay(tmp_path, launcher):
+    """bench.py's N > 1 path end to end as two ranks that share the one GPU, with gloo as the process-group backend
+    (RCCL cannot put two ranks on one device) -- sharding, barrier, max-over-ranks timing, the gathered temperature
+    exchange (rf_pt_swap_gathered_device) and the JSON line.  launcher = torchrun: the driver's own command line;
+    direct: `python bench.py --gpus 2` with no launcher around it -- bench.py starts the two ranks itself."""
     import json
     import socket
     import subprocess
-
-    from rf_inv_amd.pt import PairSchedule, init_temps, judge_pt
 
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -266,10 +322,15 @@ def test_bench_two_ranks_on_one_gpu_swap_matches_serial_replay(tmp_path):
     dump = tmp_path / "state.npz"
     nb, ntemps, steps, warm = 256, 8, 5, 1
     env = dict(os.environ, RFGPU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c3",
-           "--walkers", str(nb), "--steps", str(steps), "--warmup", str(warm), "--prewarm-seconds", "0",
-           "--no-cpu-baseline", "--also", "", "--dump-state", str(dump)]
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c3", "--walkers", str(nb), "--steps", str(steps),
+            "--warmup", str(warm), "--prewarm-seconds", "0", "--no-cpu-baseline", "--also", "", "--dump-state", str(dump)]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", str(port)] + tail
+    else:
+        cmd = [sys.executable] + tail
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
@@ -277,20 +338,37 @@ def test_bench_two_ranks_on_one_gpu_swap_matches_serial_replay(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == steps
     assert abs(d["value"] - 2 * nb * steps / (d["ms_per_step"] * 1e-3 * steps)) < 1e-6 * d["value"]
     assert d["config"]["parallelism"] == "walkers sharded x2"
-    st = np.load(dump)
-    temps, logl = st["temps"], st["logl"]
-    assert temps.shape == (2, nb) and int(st["swap_steps"]) == 16 + warm + steps
-    ref = np.concatenate([init_temps(nb, max(1, nb // ntemps), 15.0,
-                                     np.random.Generator(np.random.Philox(key=1234 + 7919 * (rk + 1)))) for rk in range(2)])
-    start = ref.copy()
-    sched = PairSchedule(2 * nb, 1234, int(st["pairs_per_step"]))
-    ll = logl.reshape(-1)                       # the same models every step: logL is the same every step
-    for _ in range(int(st["swap_steps"])):
-        pairs, logu = sched.draw()
-        for (i1, i2), lu in zip(pairs, logu):
-            if judge_pt(ref[i1], ref[i2], ll[i1], ll[i2], lu):
-                ref[i1], ref[i2] = ref[i2], ref[i1]
-    assert np.array_equal(temps.reshape(-1), ref)
-    assert np.sum(ref != start) > 0             # swaps (also across the two ranks' blocks) did happen
-    cross = [(a, b) for a, b in np.argwhere(ref[:, None] == start[None, :]) if (a < nb) != (b < nb)]
-    assert len(cross) > 0
+    assert d["config"]["rccl"]["ranks"] == 0 and "share a GPU" in d["config"]["rccl"]["transport"]
+    st = _replay_bench_state(dump, nb, ntemps, 2)
+    assert int(st["swap_steps"]) == 16 + warm + steps
+
+
+def test_bench_gpus_flag_is_honoured_or_refused(tmp_path):
+    """`python bench.py --gpus 2` the way the driver's SCALE run may invoke it (no launcher, RCCL backend): on a node
+    with two GPUs it must run two ranks over librfgpu's RCCL communicator (n_gpus == 2, config.rccl.ranks == 2, final
+    temperatures == the serial replay); on a one-GPU box it must REFUSE with a non-zero exit code and a message --
+    never print a line that says n_gpus: 1.  And a launcher whose WORLD_SIZE disagrees with --gpus is refused too."""
+    import json
+    import subprocess
+
+    import torch
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                              "RFGPU_BENCH_BACKEND")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    dump = tmp_path / "state.npz"
+    nb, ntemps, steps, warm = 256, 8, 5, 1
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c3", "--walkers", str(nb), "--steps",
+           str(steps), "--warmup", str(warm), "--prewarm-seconds", "0", "--no-cpu-baseline", "--also", "", "--dump-state",
+           str(dump)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+        assert d["n_gpus"] == 2 and d["config"]["rccl"]["ranks"] == 2 and d["config"]["rccl"]["version"]
+        _replay_bench_state(dump, nb, ntemps, 2)
+    else:
+        assert r.returncode != 0
+        assert "needs 2 visible GPUs" in r.stderr and not any(x.startswith("{") for x in r.stdout.splitlines())
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="3", RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "must agree" in r.stderr

@@ -29,7 +29,7 @@ def test_library_is_the_hip_one():
     from rf_inv_amd import _lib
 
     lib = _lib.load()
-    assert lib.rf_abi_version() == 3
+    assert lib.rf_abi_version() == 4
     assert os.path.basename(_lib.LIB_PATH) == "librfgpu.so"
 
 
@@ -279,6 +279,38 @@ def test_eight_wave_fused_kernel(oracle, deconv):
     assert np.array_equal(res[(512, 0)][0], res[(512, 1)][0])        # same arithmetic in-kernel and deferred
     d = np.abs(res[(512, 0)][1] - res[(256, 0)][1]).max(axis=(1, 2)) / np.abs(res[(256, 0)][1]).max(axis=(1, 2))
     assert d.max() <= 1e-12
+
+
+@pytest.mark.parametrize("cap", [1024, 3000])
+def test_results_do_not_depend_on_how_many_items_share_a_launch(oracle, cap):
+    """The kernel plan is a property of the CONTEXT (its capacity), never of a launch's batch size: at nfft 4096 on
+    land a context of up to two rounds of blocks runs the 8-wave kernel (8^4 FFT), a larger one the 4-wave kernel
+    (16^3 FFT) -- and within a context a chain evaluated alone (the per-call drop-in), in a partial batch or in a
+    full one gets bit-identical logL and traces (in-kernel and deferred quadratic forms included: the partial and
+    full batches below straddle that threshold)."""
+    rng = np.random.default_rng(cap)
+    cfg = make_cfg(nfft=4096, rayps=[0.06])
+    nsmp = 101
+    obs = synth_obs(oracle, cfg, random_stack(rng, 4), nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, int(rng.integers(2, 16))) for _ in range(cap)]
+    nlay, layers = pack_layers(stacks, 16)
+    sig = rng.uniform(0.01, 0.03, (cap, 1))
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=cap, nlay_max=16) as eng:
+        assert eng.launch_plan["block_threads_full_batch"] == (512 if cap <= 1024 else 256)
+        full = eng.eval_batch(np.arange(cap), nlay, layers, sig)
+        pick = [0, 7, cap // 2, cap - 1]
+        rft_full = {i: eng.get_rft(i, which=1).copy() for i in pick}
+        part = eng.eval_batch(np.arange(600), nlay[:600], layers[:600], sig[:600])
+        assert np.array_equal(part, full[:600])
+        for i in pick:
+            one = eng.eval_batch(np.array([i]), nlay[i:i + 1], layers[i:i + 1], sig[i:i + 1])
+            assert one[0] == full[i], (i, one[0], full[i])
+            assert np.array_equal(eng.get_rft(i, which=1), rft_full[i]), i
+            ll, rft = eng.calc_likelihood(i, True, int(nlay[i]), *[layers[i, r, :nlay[i]] for r in range(4)], sig[i])
+            assert ll == full[i] and np.array_equal(rft, rft_full[i]), i
+    ref = oracle.eval_batch(cfg, obs, r_inv, nlay[pick], layers[pick], sig[pick], nsmp)
+    assert np.all(np.abs(full[pick] - ref) <= logl_tol(ref))
 
 
 def test_r_inv_builtin_matches_lapack(oracle):
@@ -563,13 +595,61 @@ def test_make_syn_reproduces_the_shipped_sample(oracle, golden_dir, tmp_path):
     stack = load_true_model(golden_dir)
     cfg = make_cfg(rayps=p.rayps)
     with _engine(cfg, p.obs[:, :p.nsmp], p.nsmp, None, max_walkers=1) as eng:
-        make_syn(p, eng, stack, str(tmp_path), seed=1)
+        out = make_syn(p, eng, stack, str(tmp_path), seed=1)
     for i in (1, 2):
         ref = np.fromfile(os.path.join(golden_dir, "sample_syn", "data", f"sample_{i}.trc"), dtype="<f4")
-        got = np.fromfile(tmp_path / f"test_trace.{i:02d}", dtype="<f4")
+        # (the reference's '(A10,I2.2)' keeps ten characters of "test_trace.": its files have no dot)
+        got = np.fromfile(tmp_path / f"test_trace{i:02d}", dtype="<f4")
         assert np.array_equal(ref[158:], got[158:]) and ref[0] == got[0]
-        noisy = np.fromfile(tmp_path / f"test_trace.{i:02d}wn", dtype="<f4")
-        assert 0.002 < np.std(noisy[158:] - got[158:]) < 0.02      # filtered noise of sigma 0.01
+        noisy = np.fromfile(tmp_path / f"test_trace{i:02d}wn", dtype="<f4")
+        want = (out["rft"][:p.nsmp, i - 1] + out["noise"][:p.nsmp, i - 1]).astype(np.float32)
+        assert np.array_equal(noisy[158:], want)
+        assert p.sig_min[i - 1] <= out["noise_sigma"][i - 1] <= p.sig_max[i - 1]
+
+
+def test_make_syn_program_follows_the_reference_stream(golden_dir, tmp_path):
+    """`program make_syn` end to end on the shipped params.in (ocean, 2 traces): the MT19937 stream is consumed in
+    the reference's order -- init_model, init_sig, then per trace one grnd() for sigma and 2 * nfft for the white
+    series (src/make_syn.f90:100-106) -- chain 1's model is the "true" model, its device-resident trace is what
+    the noise-free files hold, and test_vel lists its layers."""
+    from rf_inv_amd import RFEngine, format_model, get_params, read_obs, read_ref_model
+    from rf_inv_amd.make_syn import make_syn_program
+    from rf_inv_amd.mcmc import EngineEvaluator, RJMCMC, gauss
+    from rf_inv_amd.mt19937 import MT19937
+
+    g = os.path.join(golden_dir, "sample_syn")
+    p = get_params(os.path.join(g, "params.in"))
+    read_obs(p)
+    p.nchains = 3
+    ref = read_ref_model(os.path.join(g, "model", "sample.velmod"))
+    with RFEngine.from_params(p, max_walkers=p.nchains) as eng:
+        out = make_syn_program(p, ref, eng, str(tmp_path))
+        assert not eng.is_ray_common
+        # replay: the same initialisation on a second stream, then the noise draws by hand
+        rng = MT19937(p.iseed)
+        s = RJMCMC(p, ref, EngineEvaluator(eng, p.k_max + 2), rng)
+        s.init_model()
+        s.init_likelihood()
+        flt = eng.flt
+        for t in range(p.ntrc):
+            sigma = rng.grnd() * (p.sig_max[t] - p.sig_min[t]) + p.sig_min[t]
+            assert sigma == out["noise_sigma"][t]
+            white = np.array([gauss(rng) * sigma for _ in range(p.nfft)])
+            assert np.array_equal(white, out["white"][:, t])
+            spec = np.fft.rfft(out["noise"][:, t])
+            assert np.allclose(spec, np.fft.rfft(white) * flt[:, t] * p.nfft, rtol=1e-9, atol=1e-12 * np.abs(spec).max())
+        assert rng.grnd() == out["rng"].grnd()                       # both streams stand at the same position
+        nl, a, b, r, h, ok = format_model(p, ref, int(s.k[0]), s.z[0], s.dvp[0], s.dvs[0])
+        assert ok and out["k"] == int(s.k[0]) and np.array_equal(out["stack"][1], b)
+        vel = np.loadtxt(tmp_path / "test_vel")
+        assert vel.shape == (nl, 4) and np.array_equal(vel[:, 0], a) and np.array_equal(vel[:, 3], h)
+        clean = eng.calc_rf(nl, a, b, r, h)
+    for t in range(p.ntrc):
+        got = np.fromfile(tmp_path / f"test_trace{t + 1:02d}", dtype="<f4")
+        assert got.size == 158 + p.nsmp and got.view("<i4")[79] == p.nsmp
+        assert np.array_equal(got[158:], clean[:p.nsmp, t].astype(np.float32))
+        noisy = np.fromfile(tmp_path / f"test_trace{t + 1:02d}wn", dtype="<f4")
+        assert np.array_equal(noisy[158:], (clean[:p.nsmp, t] + out["noise"][:p.nsmp, t]).astype(np.float32))
 
 
 def test_get_rft_batch_equals_single_gets(oracle):

@@ -129,3 +129,83 @@ def test_sac_window_edge_half_a_sample_off_grid(golden_dir, oracle):
         d, _, n = reader(src, 0.025, 4.975)
         # it1 = nint(0.49999999) + 1 = 1, it2 = nint(99.4999985) + 1 = 100
         assert n == 100 and np.array_equal(d, full[0:100]), reader
+
+
+def _noise_params(ntrc, rays_common, nfft=128):
+    from rf_inv_amd.params import Params
+
+    p = Params()
+    p.nfft, p.ntrc, p.nsmp = nfft, ntrc, 41
+    p.sig_min = np.array([0.01, 0.02, 0.005][:ntrc])
+    p.sig_max = np.array([0.05, 0.02, 0.02][:ntrc])
+    p.delta = float(np.float32(0.05))
+    p.a_gus = np.array([4.0, 2.5, 1.5][:ntrc])
+    return p
+
+
+def test_make_syn_noise_consumes_the_stream_like_the_reference(oracle):
+    """src/make_syn.f90:100-115 (rays not common): per trace ONE grnd() -> sigma = grnd() * (sig_max - sig_min) +
+    sig_min, then nfft gauss() values (two grnd() each) times sigma, in trace order; r2c -> flt -> c2r unnormalised.
+    Checked against a hand replay of the MT19937 stream; the stream position afterwards is
+    ntrc * (1 + 2 nfft) draws on."""
+    from rf_inv_amd.make_syn import reference_noise
+    from rf_inv_amd.mcmc import gauss
+    from rf_inv_amd.mt19937 import MT19937
+
+    p = _noise_params(3, False)
+    flt = oracle.init_filter(p.nfft, p.delta, p.a_gus).T                     # flt(nh, ntrc)
+    noise, sigma, white = reference_noise(MT19937(4321), p, flt, False)
+    g = MT19937(4321)
+    for t in range(3):
+        s = g.grnd() * (p.sig_max[t] - p.sig_min[t]) + p.sig_min[t]
+        assert s == sigma[t] and p.sig_min[t] <= s <= p.sig_max[t]
+        w = np.array([gauss(g) * s for _ in range(p.nfft)])
+        assert np.array_equal(w, white[:, t])
+        # the filtered series by the DEFINITIONS of FFTW's r2c / c2r (unnormalised), summed directly
+        j = np.arange(p.nfft)
+        spec = np.array([np.sum(w * np.exp(-2j * np.pi * j * k / p.nfft)) for k in range(p.nfft // 2 + 1)]) * flt[:, t]
+        full = np.concatenate([spec, np.conj(spec[-2:0:-1])])
+        full[0], full[p.nfft // 2] = full[0].real, full[p.nfft // 2].real
+        direct = np.array([np.sum(full * np.exp(2j * np.pi * j * m / p.nfft)) for m in range(p.nfft)]).real
+        assert np.abs(noise[:, t] - direct).max() <= 1e-12 * np.abs(direct).max()
+    g2 = MT19937(4321)
+    for _ in range(3 * (1 + 2 * p.nfft)):
+        g2.grnd()
+    assert g.grnd() == g2.grnd()
+    assert sigma[1] == 0.02                                                  # sig_min == sig_max: the draw is still consumed
+
+
+def test_make_syn_noise_common_rays_share_one_white_series(oracle):
+    """src/make_syn.f90:84-98: with a common ray geometry ONE sigma and ONE white series are drawn (1 + 2 nfft draws
+    in all) and every trace gets that series through its own filter: the noise spectra of two traces differ only by
+    flt(:, itrc)."""
+    from rf_inv_amd.make_syn import reference_noise
+    from rf_inv_amd.mt19937 import MT19937
+
+    p = _noise_params(3, True)
+    flt = oracle.init_filter(p.nfft, p.delta, p.a_gus).T
+    rng = MT19937(99)
+    noise, sigma, white = reference_noise(rng, p, flt, True)
+    assert white.shape == (p.nfft, 1) and np.all(sigma == sigma[0])
+    g2 = MT19937(99)
+    s = g2.grnd() * (p.sig_max[0] - p.sig_min[0]) + p.sig_min[0]
+    assert s == sigma[0]
+    for _ in range(2 * p.nfft):
+        g2.grnd()
+    assert rng.grnd() == g2.grnd()                                           # nothing else was drawn
+    w_spec = np.fft.rfft(white[:, 0])
+    for t in range(3):
+        spec = np.fft.rfft(noise[:, t]) / p.nfft
+        assert np.allclose(spec, w_spec * flt[:, t], rtol=1e-10, atol=1e-13 * np.abs(w_spec * flt[:, t]).max())
+    k = slice(1, 12)   # where all three filters are far from underflow
+    ratio = np.fft.rfft(noise[:, 1])[k] / np.fft.rfft(noise[:, 0])[k]
+    assert np.allclose(ratio, flt[k, 1] / flt[k, 0], rtol=1e-9)
+
+
+def test_make_syn_file_names_are_the_ones_the_reference_creates(tmp_path):
+    """'(A10,I2.2,A2)' applied to the 11-character literal "test_trace." keeps ten characters
+    (src/make_syn.f90:120,140): the reference's files are test_traceNNwn / test_traceNN."""
+    from rf_inv_amd.make_syn import _names
+
+    assert _names(3, False) == ("test_trace03", "test_trace03wn")
+    assert _names(3, True) == ("test_trace.03", "test_trace.03wn")

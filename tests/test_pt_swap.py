@@ -105,8 +105,12 @@ def test_rccl_exchange_entry_points_on_one_rank():
                   max_walkers=nch) as eng:
         ok, key = eng.comm_probe()
         assert ok and key >= 0
+        assert eng.comm_info()["nranks"] == 1 and eng.comm_info()["rank"] == 0 and eng.comm_info()["rccl_version"]
         eng.comm_init(RFEngine.comm_unique_id(), 0, 1)
+        assert eng.comm_info() == {"rank": 0, "nranks": 1, "rccl_version": eng.comm_info()["rccl_version"]}
         assert list(eng.comm_bcast_i32([7, 11, 13, 17])) == [7, 11, 13, 17]
+        with pytest.raises(Exception, match="root out of range"):
+            eng.comm_bcast_i32([1, 2], root=1)
         # self-exchange: both "sides" are this rank's chain; the rule is judge_pt with chain 1 = chain 2
         t_new, acc = eng.pt_swap_exchange(0, True, 2.5, -10.0, np.log(0.3))
         assert t_new == 2.5 and acc == judge_pt(2.5, 2.5, -10.0, -10.0, np.log(0.3))
@@ -129,3 +133,99 @@ def test_rccl_exchange_entry_points_on_one_rank():
             torch.cuda.synchronize()
             assert np.array_equal(d_t.cpu().numpy(), temps) and np.array_equal(d_t2.cpu().numpy(), temps)
         eng.comm_destroy()
+
+
+@pytest.mark.gpu
+def test_gathered_swap_kernel_as_three_ranks_on_one_gpu():
+    """rf_pt_swap_gathered_device -- the ONE kernel of the multi-rank swap step -- driven as three ranks in turn on
+    the one GPU: every "rank" reads the same gathered snapshot [3 * nchains] (global id = rank * nchains + chain,
+    src/pt_mcmc.f90:508-511) and writes only its own temperatures; together they equal the serial replay, pairs that
+    straddle ranks included, and the snapshot is left untouched."""
+    from rf_inv_amd import RFEngine
+
+    nch, world, K = 40, 3, 25
+    delta = float(np.float32(0.05))
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(12)
+    with RFEngine(nfft=256, delta=delta, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=np.array([0.06]),
+                  a_gus=np.array([4.0]), ipha=np.array([1], dtype=np.int32), obs=np.zeros((1, 101)), nsmp=101,
+                  max_walkers=nch) as eng:
+        temps = np.exp(rng.random(world * nch) * np.log(15.0))
+        sched = PairSchedule(world * nch, 7, K)
+        n_cross = 0
+        for step in range(6):
+            ll = -100.0 * rng.random(world * nch)
+            pairs, logu = sched.draw()
+            d_p, d_u = torch.from_numpy(pairs).to(dev), torch.from_numpy(logu).to(dev)
+            g_t, g_l = torch.from_numpy(temps.copy()).to(dev), torch.from_numpy(ll).to(dev)
+            new = []
+            acc = torch.zeros(K, dtype=torch.int32, device=dev)
+            for r in range(world):
+                mine = torch.from_numpy(temps[r * nch:(r + 1) * nch].copy()).to(dev)
+                eng.pt_swap_gathered_device(d_p, d_u, g_t, g_l, mine, r, world, accepted=acc)
+                torch.cuda.synchronize()
+                new.append(mine.cpu().numpy())
+            assert np.array_equal(g_t.cpu().numpy(), temps)             # the snapshot is read only
+            want = []
+            for (i1, i2), lu in zip(pairs, logu):
+                yes = judge_pt(temps[i1], temps[i2], ll[i1], ll[i2], lu)
+                want.append(int(yes))
+                if yes:
+                    temps[i1], temps[i2] = temps[i2], temps[i1]
+                    n_cross += (i1 // nch) != (i2 // nch)
+            assert np.array_equal(np.concatenate(new), temps), step
+            assert acc.cpu().numpy().tolist() == want
+        assert n_cross > 0
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_between_two_gpus(tmp_path):
+    """The cross-rank RCCL traffic for real: two FRESH processes, one per GPU, bootstrap the communicator from
+    rank 0's id and run both exchange forms (tests/tools/rccl_two_rank_worker.py); the temperature history of the
+    ensemble must equal the single-process replay step by step.  Needs two GPUs: skipped on a one-GPU box (where
+    the one-rank communicator test above and the gathered-kernel test are all that can run)."""
+    import subprocess
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
+    import rccl_two_rank_worker as wk
+
+    world = 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "rccl_two_rank_worker.py"), str(r),
+                               str(world), str(tmp_path)], env=env, cwd=ROOT) for r in range(world)]
+    for q in procs:
+        assert q.wait(timeout=600) == 0
+    keys = [open(tmp_path / f"key_{r}").read() for r in range(world)]
+    assert len(set(keys)) == world                                   # distinct physical GPUs
+    n_all = world * wk.NCHAINS
+    # p2p: rank 0's stream names the pair, then the uniform
+    temps = np.concatenate([wk.start_temps(r) for r in range(world)])
+    got = [np.load(tmp_path / f"p2p_{r}.npy") for r in range(world)]
+    rng = np.random.Generator(np.random.Philox(key=wk.SEED))
+    n_cross = 0
+    for s in range(wk.STEPS):
+        ll = np.concatenate([wk.logl_of(r, s) for r in range(world)])
+        i1 = int(rng.random() * n_all)
+        while True:
+            i2 = int(rng.random() * n_all)
+            if i2 != i1:
+                break
+        lu = float(np.log(max(rng.random(), np.finfo(float).tiny)))
+        if judge_pt(temps[i1], temps[i2], ll[i1], ll[i2], lu):
+            temps[i1], temps[i2] = temps[i2], temps[i1]
+            n_cross += (i1 // wk.NCHAINS) != (i2 // wk.NCHAINS)
+        assert np.array_equal(np.concatenate([g[s + 1] for g in got]), temps), ("p2p", s)
+    assert n_cross > 0
+    # all-gather form
+    temps = np.concatenate([wk.start_temps(r) for r in range(world)])
+    got = [np.load(tmp_path / f"allgather_{r}.npy") for r in range(world)]
+    sched = PairSchedule(n_all, wk.SEED, wk.K)
+    for s in range(wk.STEPS):
+        ll = np.concatenate([wk.logl_of(r, s) for r in range(world)])
+        pairs, logu = sched.draw()
+        for (i1, i2), lu in zip(pairs, logu):
+            if judge_pt(temps[i1], temps[i2], ll[i1], ll[i2], lu):
+                temps[i1], temps[i2] = temps[i2], temps[i1]
+        assert np.array_equal(np.concatenate([g[s + 1] for g in got]), temps), ("allgather", s)
