@@ -16,7 +16,7 @@ Workloads (BASELINE.json configs):
   c5             32768 walkers/GPU (BASELINE configs[4] / 8 GPUs), 4 traces (2 P + 2 S), ocean layer, <= 31 layers,
                  PT swap
   c4common       c4 with ONE ray for all three traces (common-ray / "single FWD" mode,
-                 src/forward.f90:59-91,141): spectra_kernel -> trace_kernel split path
+                 src/forward.f90:59-91,141): fusedc_kernel, one block per walker
   c1, c2d        sample_syn shape (nfft 256) / c2 with water-level deconvolution
 
 At N = 1 the default run also measures c2, c3, c5 (BASELINE's 32768 walkers/GPU) and c4common briefly into
@@ -67,7 +67,7 @@ WORKLOADS = {
                      k_max=30, sdep=0.0, deconv=0, temps=8,
                      desc="c4common (single-FWD / common-ray mode, forward.f90:59-91,141): 8192 walkers/GPU x 3 P traces "
                           "of ONE ray (p .06; Gaussian a 4.0, 2.5, 1.5) x nfft 4096 x <=30 layers, PT swap; one "
-                          "propagator pass feeds three traces: spectra_kernel -> trace_kernel"),
+                          "propagator pass per walker feeds three trace tails inside one fusedc_kernel block"),
     "c5": dict(walkers=32768, nfft=4096, rayps=[0.06, 0.08, 0.10, 0.12], ipha=[1, 1, -1, -1], k_max=30, sdep=2.0,
                deconv=0, temps=16,
                desc="c5 (one GPU's shard of BASELINE configs[4]: 16384 chains x 16 temperatures / 8 GPUs): 32768 "
@@ -586,9 +586,11 @@ def main():
         kernel_ms = prof["spectra_ms"] / n_l if prof["launches"] else None
         f_dom = f_tot if plan["fused"] else f_spec
         bt = plan["block_threads_full_batch"]      # 512: fused8_kernel (contexts of up to two rounds of blocks)
-        kname = ("rfgpu::fused8_kernel" if bt == 512 else "rfgpu::fused_kernel") if plan["fused"] else "rfgpu::spectra_kernel"
+        kname = ("rfgpu::fusedc_kernel" if plan["common_ray_fused"] else
+                 "rfgpu::fused8_kernel" if bt == 512 else "rfgpu::fused_kernel") if plan["fused"] else "rfgpu::spectra_kernel"
         if plan["fused"]:
-            grid_threads = bt * (nb * p.ntrc + (1 if (plan["lpt"] and plan["order_reuse"] and nb >= 512) else 0))
+            nblk = nb if plan["common_ray_fused"] else nb * p.ntrc       # common rays: one block per walker
+            grid_threads = bt * (nblk + (1 if (plan["lpt"] and plan["order_reuse"] and nb >= 512) else 0))
         else:
             grid_threads = None   # split path: matched by name only (nsplit decides the grid)
         ctr = committed_counters(kname, grid_threads) if grid_threads else None

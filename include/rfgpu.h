@@ -308,7 +308,8 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
  * results do not depend on them (tests/test_gpu_parity.py), except "bin_cutoff", which is opt-in
  * and off by default, and "block_threads", whose two kernels factorise the FFT differently (last-bit differences
  * between the two settings, never within one).  Call between evaluations (the call synchronises the device).
- *   "fused"            -1 by shape (default) | 0 split spectra -> trace kernels | 1 one fused kernel
+ *   "fused"            -1 by shape (default) | 0 split spectra -> trace kernels | 1 one fused kernel (per (walker,
+ *                      trace), or per walker when the rays are common: plan[0])
  *   "chain"            -1 by shape (default) | 0, 2, 3, 4, 8 bins per phase chain
  *   "lpt"              1 (default) longest-first dispatch order | 0
  *   "order_reuse"      1 (default) a launch prepares the next launch's order | 0 order kernel every time
@@ -325,8 +326,9 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
 int rf_set_option(rf_ctx *ctx, const char *name, double value);
 
 /* how rf_eval_batch* will launch, plan[12]:
- *  [0] 1 when spectra + trace run as ONE fused kernel (contexts with one forward computation per trace;
- *      then ms[0] of rf_profile_read is the fused kernel and ms[1] stays 0)
+ *  [0] 1 when spectra + trace run as ONE fused kernel (contexts with one forward computation per trace), 2 when
+ *      they run as the common-ray fused kernel (several traces of one ray, nfft 4096 on land: one block per walker,
+ *      one propagator pass, ntrc trace tails); then ms[0] of rf_profile_read is that kernel and ms[1] stays 0
  *  [1] bins per phase chain (0: direct sincos)   [2] waves per block of the split spectra kernel
  *  [3] bin-splits per walker at a full batch     [4] lpt   [5] order_reuse   [6] defer_logl (-1 / 0 / 1)
  *  [7] 1 when a bin cut-off is active            [8] number of options away from their defaults

@@ -73,6 +73,8 @@ struct rf_ctx {
     int nsplit_override = 0;  // "nsplit"
     int chain_override = -1;  // "chain": -1 = by shape
     bool fused_allowed = false;   // the context's shape admits the fused kernel
+    bool fusedc_allowed = false;  // ... the common-ray fused kernel (several traces of one ray: nfft 4096, land)
+    bool fusedc = false;          // one launch per batch: a block per walker, one propagator pass, ntrc trace tails
     int fused_override = -1;  // "fused": -1 = by shape
     int defer_logl = -1;      // "defer_logl": -1 = by batch size, 0 / 1 = never / always
     int block_threads = 0;    // "block_threads": 0 = by batch size, 256 / 512 = fused_kernel / fused8_kernel
@@ -266,6 +268,11 @@ static void default_plan(rf_ctx *c)
     const int niter = (c->nh + 63) / 64;
     c->chain = niter >= 16 ? 4 : 0;
     c->fused = c->fused_allowed && c->fused_override != 0;
+    // common rays ("single FWD mode", forward.f90:59-91,141): ONE propagator pass feeds ntrc traces.  nfft 4096 on
+    // land: fusedc_kernel keeps the spectra in registers (measured at the C4 shape: one launch instead of
+    // spectra_kernel -> 537 MB of spectra in HBM -> trace_kernel); other shapes, or an explicit phase-chain
+    // length, keep the split plan
+    c->fusedc = c->fusedc_allowed && c->fused_override != 0 && c->chain_override < 0 && c->ablate == 0;
     // fused kernel, land: chains of 8 when that gives each of the block's four waves whole chunks
     // (nfft 4096: 4 chunks of 8 iterations + the Nyquist iteration); measured C4 +7 %, C2 +2 % over 4.
     // Ocean (3 propagated columns): chains of 4 (239 VGPRs; 8 would not fit two waves per SIMD).
@@ -451,6 +458,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
         sizeof(double) * (size_t)(5 * ((nsmp + 1) & ~1) + 8) > 160 * 1024)   // phi_kernel (host-owned traces)
         return cleanup(fail("rf_ctx_create: nfft / nsmp / nlay_max exceed the 160 KiB LDS of a gfx950 CU"));
     c->fused_allowed = pow2 && (c->nfwd == ntrc) && fused_lds_bytes(n, nsmp, cfg->nlay_max) <= 160 * 1024;
+    c->fusedc_allowed = n == 4096 && c->ray_common && ntrc > 1 && cfg->sdep <= 0.0 &&
+                        fused8_lds_bytes(nsmp, cfg->nlay_max) <= 80 * 1024;
     default_plan(c);
     *ctx_out = c;
     return 0;
@@ -581,25 +590,36 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
     BatchArgs b = b_in;
     c->prof_this = c->prof && (c->prof_batch++ % c->prof_every) == 0;
     int *order_next = nullptr;
+    const bool one_launch = c->fused || c->fusedc;   // spectra + traces + (small batches) logL in one kernel
     if (c->lpt && !b.order && b.nb >= 2 * c->num_cu) {
         // deepest walkers first (worth it once blocks outnumber the CUs).  Fused path: the previous
         // launch of a batch of this size left the order in d_order_alt (sorted by its own depths -- one
         // proposal step stale for this launch, which costs a little balance, never correctness), and
         // this launch does the same for the next; otherwise a ~4 us order_kernel in front.
-        if (c->fused && c->order_reuse && c->order_next_nb == b.nb) {
+        if (one_launch && c->order_reuse && c->order_next_nb == b.nb) {
             std::swap(c->d_order, c->d_order_alt);
         } else {
             launch_order(b.nb, b.nlay, b.fwd_flag, c->d_order, s);
         }
         b.order = c->d_order;
-        if (c->fused && c->order_reuse) order_next = c->d_order_alt;
+        if (one_launch && c->order_reuse) order_next = c->d_order_alt;
         c->order_next_nb = order_next ? b.nb : 0;
     } else {
         c->order_next_nb = 0;
     }
     // the per-(item, forward-trace) constants of the propagator, once per batch item, for whichever plan follows
     launch_stage(c->tab, b, c->ws, s);
-    if (c->fused) {
+    if (c->fusedc) {
+        // one block per walker carries all its traces: the same "misfits to HBM, quadratic forms by the follow-up
+        // kernels" rule as below, counted in (walker, trace) units of work
+        const int defer_ok = phi_deferred_lds_bytes(c->cfg.nsmp) <= 60 * 1024;
+        const long long units = (long long)b.nb * c->cfg.ntrc, round = 2LL * c->num_cu;
+        const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl : units >= 2 * round);
+        hipEvent_t e = prof_begin(c, 0, s);
+        launch_fusedc(c->tab, b, c->ws, c->slow_count, defer, order_next, c->single_trace_out, s);
+        if (e) (void)hipEventRecord(e, s);
+        if (defer) launch_logl_deferred(c->tab, b, c->ws, s);
+    } else if (c->fused) {
         // several traces per walker and at least two rounds of blocks: the block ends with the trace store;
         // misfits go to HBM (808 B per trace) and two small follow-up kernels form the quadratic forms -- the
         // rows of R^-1 fetched once per 8 walkers instead of once per block, same arithmetic -- and logL.  That removes from
@@ -776,7 +796,7 @@ extern "C" int rf_calc_likelihood(rf_ctx *c, int32_t walker, int32_t fwd_flag, i
     BatchArgs b{1, pad, di, di + 1, di + 2, dl, dl + 4 * (size_t)pad, c->d_single_out, nullptr};
     // fused path with a forward evaluation: the kernel itself writes the proposed trace to the mapped
     // buffer; otherwise (split kernels, or the stored trace of a sigma-only call) a gather kernel does
-    const bool direct = prop_rft && fwd_flag && c->fused;
+    const bool direct = prop_rft && fwd_flag && (c->fused || c->fusedc);
     c->single_trace_out = direct ? c->d_single_out + 1 : nullptr;
     const int rc = run_batch(c, b, s);
     c->single_trace_out = nullptr;
@@ -1157,7 +1177,7 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     HIP_TRY(hipDeviceSynchronize());
     if (k == "fused") {
         if (!integral || iv < -1 || iv > 1) return fail("rf_set_option: fused must be -1 (by shape), 0 or 1");
-        if (iv == 1 && !c->fused_allowed)
+        if (iv == 1 && !c->fused_allowed && !c->fusedc_allowed)
             return fail("rf_set_option: this context cannot use the fused kernel (common rays or LDS footprint)");
         c->fused_override = iv;
     } else if (k == "chain") {
@@ -1205,7 +1225,7 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
 extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
 {
     if (!c || !plan) return fail("rf_get_launch_plan: null argument");
-    plan[0] = c->fused ? 1 : 0;
+    plan[0] = c->fusedc ? 2 : (c->fused ? 1 : 0);
     plan[1] = c->chain;
     plan[2] = c->waves_per_block;
     plan[3] = pick_nsplit(c, c->cfg.max_walkers);
@@ -1220,7 +1240,7 @@ extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
     plan[9] = 0;
 #endif
     plan[10] = c->block_threads;
-    plan[11] = use_fused8(c) ? 512 : 256;
+    plan[11] = (c->fusedc || use_fused8(c)) ? 512 : 256;
     return 0;
 }
 

@@ -68,6 +68,10 @@ void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &
 void launch_fused8(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int defer_logl,
                    int *order_next, double *extra_out, hipStream_t s);
 size_t fused8_lds_bytes(int nsmp, int nlay_pad);
+// "single FWD mode" (common rays, several traces) in one launch: one 512-thread block per walker, one propagator
+// pass, ntrc trace tails from registers (nfft 4096, land): see fusedc_kernel
+void launch_fusedc(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int defer_logl,
+                   int *order_next, double *extra_out, hipStream_t s);
 // K0: per-(item, forward-trace) constants of the propagator, once per batch item, in front of K1 / the fused kernel
 void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 // logL of a batch launched with defer_logl (one thread per batch item, after the fused kernel)

@@ -614,7 +614,8 @@ struct GlobalSink {
     int nh;
     // (the sinks that apply the Gaussian filter hand out its weight ahead of the bin: see LdsSink)
     __device__ __forceinline__ double weight(int) const { return 1.0; }
-    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz, double) const
+    // (last argument: the bin's slot within the lane's chain, -1 for a leftover iteration; only RegSink uses it)
+    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz, double, int = 0) const
     {
         store_bin(out_r, out_v, k, nh, ur, uz);
     }
@@ -634,7 +635,7 @@ __device__ __forceinline__ void spectra_iter_direct(const SpectraParams &P, CP c
     for (int l = ilay0; l < nl - 1; ++l) apply_layer<NCOL, FAST>(st, coef + l * NCOEF, omg);
     double2 ur, uz;
     finish_bin<NCOL, FAST>(st, tail, omg, ipha, ur, uz);
-    sink(k, ur, uz, wgt);
+    sink(k, ur, uz, wgt, -1);
 }
 
 // The iteration that holds the Nyquist bin has one active lane (nfft / 2 is a multiple of 64): a whole
@@ -655,7 +656,7 @@ __device__ __forceinline__ void spectra_iter_nyquist(const SpectraParams &P, CP 
     }
     double2 ur, uz;
     finish_bin<NCOL, true>(st, tail, omg, ipha, ur, uz);
-    sink(k, ur, uz, wgt);
+    sink(k, ur, uz, wgt, -1);
 }
 
 // eps = arg - k * phi, phi = (hi, lo): the rounding perturbation of the reference's argument (omega*xi)*z
@@ -758,7 +759,8 @@ __device__ __forceinline__ void sincos_small(double x, double &sn, double &cs)
 template <int BK, int NCOL, class Sink, class CP = const double *, bool TIGHT = false, bool TABLE = false>
 __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP coef, CP tail,
                                                     int nl, int ilay0, int ipha, const Sink &sink, int it0, int lane,
-                                                    const double2 *tab = nullptr)
+                                                    const double2 *tab = nullptr, double2 *keep_ur = nullptr,
+                                                    double2 *keep_uz = nullptr)
 {
     // Register budget (two waves per SIMD: 256 VGPRs; TIGHT: the 128 of fused8_kernel).  Short 2-column chains hold
     // k and omega of every bin; the 8-bin land kernel and the 3-column ocean kernels hold the omegas and rebuild k
@@ -889,7 +891,13 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
         const double omgm = km == 0 ? P.t.omg_dc : (double)km * P.t.domg;
         double2 ur, uz;
         finish_bin<NCOL, true>(st[m], tail, omgm, ipha, ur, uz);
-        sink(km, ur, uz, wgt[m]);
+        if (keep_ur) {
+            // fusedc_kernel: the lane keeps its bins (the caller's register arrays; constant indices after unrolling)
+            keep_ur[m] = ur;
+            keep_uz[m] = uz;
+        } else {
+            sink(km, ur, uz, wgt[m], m);
+        }
     }
 }
 
@@ -899,7 +907,8 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
 template <int BK, int NCOL, bool FAST, class Sink, class CP = const double *, bool TIGHT = false, bool TABLE = false>
 __device__ __forceinline__ void spectra_body(const SpectraParams &P, CP coef, CP tail,
                                              int nl, int ilay0, int ipha, const Sink &sink, int split, int lane,
-                                             const double2 *tab = nullptr)
+                                             const double2 *tab = nullptr, double2 *keep_ur = nullptr,
+                                             double2 *keep_uz = nullptr)
 {
     const int niter = (P.t.nh + 63) / 64;
     int it_direct0 = 0;
@@ -907,10 +916,13 @@ __device__ __forceinline__ void spectra_body(const SpectraParams &P, CP coef, CP
         const int nchunk = niter / BK;
         if constexpr (TABLE) {
             // (the caller checked nchunk == P.nsplit: one chunk per wave, see spectra_chunk_chain)
-            spectra_chunk_chain<BK, NCOL, Sink, CP, TIGHT, true>(P, coef, tail, nl, ilay0, ipha, sink, split * BK, lane, tab);
+            spectra_chunk_chain<BK, NCOL, Sink, CP, TIGHT, true>(P, coef, tail, nl, ilay0, ipha, sink, split * BK, lane, tab,
+                                                                 keep_ur, keep_uz);
         } else {
+            // (keep_ur: the caller runs exactly one chunk per wave, nchunk == P.nsplit)
             for (int ch = split; ch < nchunk; ch += P.nsplit)
-                spectra_chunk_chain<(BK > 1 ? BK : 2), NCOL, Sink, CP, TIGHT>(P, coef, tail, nl, ilay0, ipha, sink, ch * BK, lane);
+                spectra_chunk_chain<(BK > 1 ? BK : 2), NCOL, Sink, CP, TIGHT>(P, coef, tail, nl, ilay0, ipha, sink, ch * BK, lane,
+                                                                              nullptr, keep_ur, keep_uz);
         }
         it_direct0 = nchunk * BK;
     }
@@ -1991,7 +2003,7 @@ struct LdsSink {
     // Gaussian filter weight of bin k (forward.f90:168,198), fetched by the caller before the bin's boundary
     // condition is evaluated; deconvolution applies the filter after the water level (no weight here)
     __device__ __forceinline__ double weight(int k) const { return (!decon && k < nh) ? flt[k] : 0.0; }
-    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz, double fk) const
+    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz, double fk, int = 0) const
     {
         if (k >= nh) return;
         const double2 fr = make_double2(ur.x, -ur.y);    // freq_r = conjg(ur)   forward.f90:145
@@ -2215,7 +2227,7 @@ struct W8Sink {
     // Gaussian filter weight of bin k (forward.f90:168,198), fetched by the caller before the bin's boundary
     // condition is evaluated; deconvolution applies the filter after the water level (no weight here)
     __device__ __forceinline__ double weight(int k) const { return (!decon && k < nh) ? flt[k] : 0.0; }
-    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz, double fk) const
+    __device__ __forceinline__ void operator()(int k, double2 ur, double2 uz, double fk, int = 0) const
     {
         if (k >= nh) return;
         const double2 fr = make_double2(ur.x, -ur.y);    // freq_r = conjg(ur)   forward.f90:145
@@ -2266,11 +2278,123 @@ __device__ __forceinline__ void w8_pass(double2 *a, const double2 *__restrict__ 
     for (int k = 0; k < 8; ++k) a[w8_pad(base + (bitrev_small<3>(k) << SL))] = v[k];
 }
 
+// water_level_decon (forward.f90:447-470) on the deposited array of the 8-wave kernels, in place: slot(k) holds the
+// numerator, slot(n - k) the denominator of bin k (side[0..1]: the denominators of the DC and Nyquist bins); leaves
+// Z = (num conj(den) / max(|den|^2, wlvl)) flt, Hermitian-extended.  Ends with a barrier.
+__device__ __forceinline__ void w8_water_level(const DeviceTables &t, double2 *a, const double2 *side, double *red, int itrc,
+                                               int tid)
+{
+    constexpr int n = 4096, nh = 2049;
+    const int wave = tid >> 6, lane = tid & 63;
+    double m = -HUGE_VAL;
+    for (int k = tid; k < nh; k += W8_THREADS) {
+        const bool self = (k == 0 || k == 2048);
+        const double2 x = self ? side[k == 0 ? 0 : 1] : a[w8_pad(w8_pos(n - k))];
+        m = fmax(m, x.x * x.x + x.y * x.y);                   // forward.f90:458
+    }
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    double mm = red[0];
+#pragma unroll
+    for (int w = 1; w < W8_THREADS / 64; ++w) mm = fmax(mm, red[w]);
+    const double wlvl = 0.001 * mm;                           // forward.f90:460, pcnt = 0.001 (:149)
+    const double *__restrict__ flt = t.flt + (size_t)itrc * nh;
+    for (int k = tid; k < nh; k += W8_THREADS) {
+        const bool self = (k == 0 || k == 2048);
+        const int pk = w8_pad(w8_pos(k));
+        const int pnk = self ? pk : w8_pad(w8_pos(n - k));
+        const double2 y = a[pk];
+        const double2 x = self ? side[k == 0 ? 0 : 1] : a[pnk];
+        const double amp = x.x * x.x + x.y * x.y;
+        const double dd = fmax(amp, wlvl);                    // forward.f90:464
+        const double2 yx = cmul(y, make_double2(x.x, -x.y));
+        const double fk = flt[k];
+        const double2 R = make_double2(yx.x / dd * fk, yx.y / dd * fk);
+        if (self) {
+            a[pk] = make_double2(R.x, 0.0);
+        } else {
+            a[pk] = R;
+            a[pnk] = make_double2(R.x, -R.y);
+        }
+    }
+    __syncthreads();
+}
+
+// Inverse FFT (radix-8 passes of stride 1, 8, 64 through LDS, the last -- stride 512 -- in registers), vertical
+// maximum, shift / normalise / store and misfit of one trace whose Z sits in `a`: the tail of the 8-wave kernels.
+__device__ __forceinline__ void w8_fft_store(const TraceParams &P, double2 *a, double *mis, double *red, int ib, int itrc,
+                                             int walker, int ipha, bool decon, double tp, int slot, int tid)
+{
+    const DeviceTables &t = P.t;
+    constexpr int n = 4096;
+    const int nsmp = t.nsmp;
+    const int wave = tid >> 6, lane = tid & 63;
+    // ---- inverse FFT: radix-8 passes of stride 1, 8, 64 through LDS, the last (stride 512) in registers -------
+    const double2 *__restrict__ tw = t.twiddle;
+    w8_pass<0>(a, tw, tid);
+    __syncthreads();
+    w8_pass<3>(a, tw, tid);
+    __syncthreads();
+    w8_pass<6>(a, tw, tid);
+    __syncthreads();
+    double2 v[8];
+    {
+        double2 w[8];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) w[k] = tw[(unsigned)(tid * k)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(tid + (k << 9))];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
+        dft_regs<3>(v);                    // v[k] = sample tid + (bitrev3(k) << 9): .x RF trace, .y vertical trace
+    }
+    double fac = 1.0;
+    if (!decon) {
+        double m = -HUGE_VAL;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) m = fmax(m, v[k].y);
+        m = wave_max(m);
+        __syncthreads();
+        if (lane == 0) red[wave] = m;
+        __syncthreads();
+        fac = red[0];                                                // maxval(rx) forward.f90:201
+#pragma unroll
+        for (int w = 1; w < W8_THREADS / 64; ++w) fac = fmax(fac, red[w]);
+    }
+    double *__restrict__ dst = P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
+    const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
+    double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
+    double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
+    const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
+    // (the same store loop as tail_in_registers: one signed reciprocal per thread, 0-based masked sample index)
+    const double rfac = (ipha == 1 ? 1.0 : -1.0) / fac;
+    const int at0 = ipha == 1 ? tid + npre : npre - tid - 1;        // sample j = tid + 1
+    const int step = ipha == 1 ? 512 : -512;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const unsigned i0 = (unsigned)(at0 + step * bitrev_small<3>(k)) & 4095u;      // 0-based sample of rft
+        const double val = v[k].x * rfac;                            // forward.f90:202 (see rfac)
+        __builtin_nontemporal_store(val, &dst[i0]);
+        if (xout) xout[i0] = val;
+        if (i0 < (unsigned)nsmp) {
+            const double m = val - obs[i0];                          // likelihood.f90:88
+            // (both stores, not an either / or: hipcc turns `defer ? mis_g : mis` into ONE store through a select of a
+            // global and an LDS pointer -- a flat store -- and its backend then fails on the common-ray kernel
+            // ("Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base", ROCm 7.2); the LDS copy is one
+            // ds_write for the first nsmp samples)
+            mis[i0] = m;
+            if (P.defer_logl) mis_g[i0] = m;
+        }
+    }
+}
+
 size_t fused8_lds_bytes(int nsmp, int nlay_pad)
 {
     // FFT array | misfits | reductions | side | (generic path only) layer constants
+    // (side: [0..1] decon denominators of the DC / Nyquist bins, [2..3] fusedc_kernel's Nyquist pair)
     return sizeof(double2) * (size_t)(w8_pad(4095) + 2) + sizeof(double) * (size_t)(((nsmp + 1) & ~1) + 8) +
-           sizeof(double2) * 2 + spectra_lds_bytes(nlay_pad);
+           sizeof(double2) * 4 + spectra_lds_bytes(nlay_pad);
 }
 
 template <int NCOL>
@@ -2285,7 +2409,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
     double *mis = reinterpret_cast<double *>(a + ((w8_pad(4095) + 2) & ~1));
     double *red = mis + ((nsmp + 1) & ~1);
     double2 *side = reinterpret_cast<double2 *>(red + 8);
-    double *coef = reinterpret_cast<double *>(side + 2);          // generic path only
+    double *coef = reinterpret_cast<double *>(side + 4);          // generic path only
     double *tail = coef + (size_t)P.b.nlay_pad * NCOEF;
 
     const int tid = threadIdx.x;
@@ -2363,98 +2487,8 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
     __syncthreads();
     const double tp = decon ? 0.0 : gtail[17];
 
-    if (decon) {
-        // water_level_decon (forward.f90:447-470) in place: slot(k) holds the numerator, slot(n-k) the denominator
-        double m = -HUGE_VAL;
-        for (int k = tid; k < nh; k += W8_THREADS) {
-            const bool self = (k == 0 || k == 2048);
-            const double2 x = self ? side[k == 0 ? 0 : 1] : a[w8_pad(w8_pos(n - k))];
-            m = fmax(m, x.x * x.x + x.y * x.y);                   // forward.f90:458
-        }
-        m = wave_max(m);
-        if (lane == 0) red[wave] = m;
-        __syncthreads();
-        double mm = red[0];
-#pragma unroll
-        for (int w = 1; w < W8_THREADS / 64; ++w) mm = fmax(mm, red[w]);
-        const double wlvl = 0.001 * mm;                           // forward.f90:460, pcnt = 0.001 (:149)
-        const double *__restrict__ flt = t.flt + (size_t)itrc * nh;
-        for (int k = tid; k < nh; k += W8_THREADS) {
-            const bool self = (k == 0 || k == 2048);
-            const int pk = w8_pad(w8_pos(k));
-            const int pnk = self ? pk : w8_pad(w8_pos(n - k));
-            const double2 y = a[pk];
-            const double2 x = self ? side[k == 0 ? 0 : 1] : a[pnk];
-            const double amp = x.x * x.x + x.y * x.y;
-            const double dd = fmax(amp, wlvl);                    // forward.f90:464
-            const double2 yx = cmul(y, make_double2(x.x, -x.y));
-            const double fk = flt[k];
-            const double2 R = make_double2(yx.x / dd * fk, yx.y / dd * fk);
-            if (self) {
-                a[pk] = make_double2(R.x, 0.0);
-            } else {
-                a[pk] = R;
-                a[pnk] = make_double2(R.x, -R.y);
-            }
-        }
-        __syncthreads();
-    }
-
-    // ---- inverse FFT: radix-8 passes of stride 1, 8, 64 through LDS, the last (stride 512) in registers -------
-    const double2 *__restrict__ tw = t.twiddle;
-    w8_pass<0>(a, tw, tid);
-    __syncthreads();
-    w8_pass<3>(a, tw, tid);
-    __syncthreads();
-    w8_pass<6>(a, tw, tid);
-    __syncthreads();
-    double2 v[8];
-    {
-        double2 w[8];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) w[k] = tw[(unsigned)(tid * k)];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(tid + (k << 9))];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
-        dft_regs<3>(v);                    // v[k] = sample tid + (bitrev3(k) << 9): .x RF trace, .y vertical trace
-    }
-    double fac = 1.0;
-    if (!decon) {
-        double m = -HUGE_VAL;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) m = fmax(m, v[k].y);
-        m = wave_max(m);
-        __syncthreads();
-        if (lane == 0) red[wave] = m;
-        __syncthreads();
-        fac = red[0];                                                // maxval(rx) forward.f90:201
-#pragma unroll
-        for (int w = 1; w < W8_THREADS / 64; ++w) fac = fmax(fac, red[w]);
-    }
-    double *__restrict__ dst = P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
-    const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
-    double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
-    double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
-    const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
-    // (the same store loop as tail_in_registers: one signed reciprocal per thread, 0-based masked sample index)
-    const double rfac = (ipha == 1 ? 1.0 : -1.0) / fac;
-    const int at0 = ipha == 1 ? tid + npre : npre - tid - 1;        // sample j = tid + 1
-    const int step = ipha == 1 ? 512 : -512;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const unsigned i0 = (unsigned)(at0 + step * bitrev_small<3>(k)) & 4095u;      // 0-based sample of rft
-        const double val = v[k].x * rfac;                            // forward.f90:202 (see rfac)
-        __builtin_nontemporal_store(val, &dst[i0]);
-        if (xout) xout[i0] = val;
-        if (i0 < (unsigned)nsmp) {
-            const double m = val - obs[i0];                          // likelihood.f90:88
-            if (P.defer_logl)
-                mis_g[i0] = m;
-            else
-                mis[i0] = m;
-        }
-    }
+    if (decon) w8_water_level(t, a, side, red, itrc, tid);
+    w8_fft_store(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
     if (P.defer_logl) return;   // quadratic form and logL: phi_deferred_kernel (+ logl_deferred_kernel)
     __syncthreads();
     // ---- phi = (misfit . R^-1) . misfit (likelihood.f90:92-93) and logL, as in trace_tail ------------------
@@ -2475,6 +2509,184 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
             P.w.prop_fwd[walker] = 1;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// fusedc_kernel: "single FWD mode" (common ray geometry, forward.f90:59-91,141) in ONE launch for nfft = 4096 on land:
+// every trace has the same ray parameter and phase, so ONE propagator pass per walker feeds all ntrc traces, which
+// differ only by their Gaussian filter flt(:, itrc) (:168,198).  One 512-thread block per WALKER:
+//   1. the propagator phase of fused8_kernel (8 waves x one 4-bin chain from the block's anchor table), but the
+//      finished bins stay where they are -- each lane keeps the (ur, uz) pairs of its four bins in REGISTERS (32
+//      VGPRs; the Nyquist bin's pair, one lane of the block, in LDS: NyqSink) -- instead of going to the FFT array;
+//   2. for itrc = 1 .. ntrc: deposit Z = RF flt_t + i V flt_t from those registers (the very code of fused8_kernel's
+//      sink: a common-ray trace is bit-identical to the single-trace answer of its own filter), water level if
+//      deconv_mode = 1, inverse FFT, vertical maximum, shift / normalise / store, misfit (w8_fft_store), quadratic form;
+//   3. logL by the block itself (all traces of a walker are its own: no cross-block hand-off).
+// The spectra never travel through HBM: the split plan (spectra_kernel -> spec[nb][2][nh] complex128 -> trace_kernel,
+// re-read once per trace) moved 3.9x the algorithmic bytes at the C4 shape and ran its trace kernel at 8 % of the
+// FP64 peak.  LDS: the FFT array only (70.7 KB) -> two blocks per CU, four waves per SIMD: one block's latency-bound
+// tails overlap the other's propagator phase.  Walkers on the generic path (rare) lay their spectra out as a plain
+// table in the FFT array's space first and pick their bins up from there.
+// ---------------------------------------------------------------------------
+struct NyqSink {
+    double2 *nyq;                      // LDS [2]: (ur, uz) of the Nyquist bin, the one bin outside the waves' chains
+    __device__ __forceinline__ double weight(int) const { return 1.0; }
+    __device__ __forceinline__ void operator()(int k, double2 r, double2 z, double, int) const
+    {
+        if (k == 2048) {
+            nyq[0] = r;
+            nyq[1] = z;
+        }
+    }
+};
+
+struct TableSink {
+    double2 *tab;         // [2][2049]: ur, then uz, by bin
+    __device__ __forceinline__ double weight(int) const { return 1.0; }
+    __device__ __forceinline__ void operator()(int k, double2 r, double2 z, double, int) const
+    {
+        if (k < 2049) {
+            tab[k] = r;
+            tab[2049 + k] = z;
+        }
+    }
+};
+
+template <int NCOL>
+__global__ __launch_bounds__(W8_THREADS, 4) void fusedc_kernel(FusedParams F)
+{
+    extern __shared__ double2 lds2[];
+    const TraceParams &P = F.tp;
+    const DeviceTables &t = P.t;
+    constexpr int nh = 2049;
+    const int nsmp = t.nsmp, ntrc = t.ntrc;
+    double2 *a = lds2;
+    double *mis = reinterpret_cast<double *>(a + ((w8_pad(4095) + 2) & ~1));
+    double *red = mis + ((nsmp + 1) & ~1);
+    double2 *side = reinterpret_cast<double2 *>(red + 8);
+    double *coef = reinterpret_cast<double *>(side + 4);          // generic path only
+    double *tail = coef + (size_t)P.b.nlay_pad * NCOEF;
+
+    const int tid = threadIdx.x;
+    const int bid = blockIdx.x;
+    if (F.order_next && bid == P.b.nb) {
+        // the dispatch order of the next launch (see fused_kernel)
+        int *w = reinterpret_cast<int *>(lds2);
+        order_block(P.b.nb, P.b.nlay, P.b.fwd_flag, F.order_next, w, w + 256, w + 512);
+        return;
+    }
+    const int ib = P.b.order ? P.b.order[bid] : bid;
+    if (bid == 0 && tid == 0) *P.slow_count = 0;
+    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
+        // 0: sigma-only proposal (likelihood.f90:81); < 0: no evaluation at all (see fused_kernel)
+        if (tid == 0 && P.b.fwd_flag[ib] < 0) {
+            P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
+            P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
+        } else if (tid == 0) {
+            const int wk = P.b.walker_ids[ib];
+            const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * ntrc;
+            P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * ntrc, ntrc, nsmp, false);
+            P.w.prop_fwd[wk] = 0;
+        }
+        return;
+    }
+    const int walker = P.b.walker_ids[ib];
+    const int ipha = t.ipha[0];                   // common to every trace (check_ray, forward.f90:59-91)
+    const bool decon = t.deconv_mode == 1;
+
+    const int bfi = ib;                           // one forward computation per walker (nfwd = 1)
+    const int nl = P.b.nlay[ib];
+    const int stage_flags = P.w.gflag[bfi];
+    const bool sea = stage_flags & 1;             // beta(1) < 0  (forward.f90:229)
+    const int ilay0 = sea ? 1 : 0;
+    const bool generic = (stage_flags & 2) != 0 || sea != (NCOL == 3);
+    const KPtr gcoef = as_scalar_ptr(P.w.gcoef + (size_t)bfi * P.b.nlay_pad * NCOEF);
+    const KPtr gtail = as_scalar_ptr(P.w.gtail + (size_t)bfi * GTAIL);
+    const int slot = 1 - P.w.cur_slot[walker];
+
+    // ---- 1. propagator phase: the lane's four bins 64 (4 wave + m) + lane end up in ur / uz ---------------------
+    SpectraParams sp = F.sp;
+    sp.nsplit = W8_THREADS / 64;
+    const int wave = tid >> 6, lane = tid & 63;
+    double2 ur[4], uz[4];
+    if (generic) {
+        int nl2, il2;
+        bool sea2;
+        (void)load_staged(P.w, P.b, 1, ib, 0, coef, tail, nl2, il2, sea2);
+        const TableSink ts{a};
+        if (sea)
+            spectra_body<0, 3, false>(sp, (const double *)coef, (const double *)tail, nl, ilay0, ipha, ts, wave, lane);
+        else
+            spectra_body<0, 2, false>(sp, (const double *)coef, (const double *)tail, nl, ilay0, ipha, ts, wave, lane);
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const int k = 64 * (4 * wave + m) + lane;
+            ur[m] = a[k];
+            uz[m] = a[nh + k];
+        }
+        if (tid == 0) {
+            side[2] = a[2048];
+            side[3] = a[nh + 2048];
+        }
+    } else {
+        const NyqSink rs{side + 2};
+        const int nsolid = nl - 1 - ilay0;
+        const int cap = ((w8_pad(4095) + 2) & ~1) / (2 * ANCHOR_ROW);
+        if (nsolid >= 1 && nsolid <= cap) {
+            build_anchor_table<W8_THREADS>(a, P.w.gcoef + (size_t)bfi * P.b.nlay_pad * NCOEF, nsolid, ilay0, W8_THREADS / 64,
+                                           64 * 4, tid);
+            __syncthreads();
+            spectra_body<4, NCOL, true, NyqSink, KPtr, true, true>(sp, gcoef, gtail, nl, ilay0, ipha, rs, wave, lane, a, ur, uz);
+        } else {
+            spectra_body<4, NCOL, true, NyqSink, KPtr, true>(sp, gcoef, gtail, nl, ilay0, ipha, rs, wave, lane, nullptr, ur, uz);
+        }
+    }
+    // (tp, the direct-arrival time, is common to the traces too: forward.f90:141 skips its recomputation)
+    const double tp = decon ? 0.0 : gtail[17];
+    const int lane_m = (64 - lane) & 63;
+    const int lane_pos = ((lane & 7) << 9) + ((lane >> 3) << 6), lane_pos_m = ((lane_m & 7) << 9) + ((lane_m >> 3) << 6);
+    double *phis = P.w.phi + ((size_t)slot * P.w.nslots + walker) * ntrc;
+
+    // ---- 2. one trace after the other from the same spectra ---------------------------------------------------------
+    for (int itrc = 0; itrc < ntrc; ++itrc) {
+        __syncthreads();   // the array is free: table / anchor reads, the previous trace's last FFT pass and quadratic form are done
+        const W8Sink sink{a, side, t.flt + (size_t)itrc * nh, nh, ipha, decon, lane_pos, lane_pos_m};
+        double wgt[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wgt[m] = sink.weight(64 * (4 * wave + m) + lane);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) sink(64 * (4 * wave + m) + lane, ur[m], uz[m], wgt[m]);
+        if (tid == 0) sink(2048, side[2], side[3], sink.weight(2048));
+        __syncthreads();
+        if (decon) w8_water_level(t, a, side, red, itrc, tid);
+        w8_fft_store(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
+        if (!P.defer_logl) {
+            // phi = (misfit . R^-1) . misfit (likelihood.f90:92-93); the array doubles as quad_form's scratch
+            __syncthreads();
+            const double phi = quad_form(t, itrc, mis, reinterpret_cast<double *>(a), red, tid);
+            if (tid == 0) phis[itrc] = phi;
+        }
+    }
+    if (P.defer_logl) return;   // quadratic forms and logL: phi_deferred_kernel + logl_deferred_kernel
+    if (tid == 0) {
+        P.b.logl[ib] = logl_from_phi(phis, P.b.sig + (size_t)ib * ntrc, ntrc, nsmp, false);
+        P.w.prop_fwd[walker] = 1;
+    }
+}
+
+void launch_fusedc(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int defer_logl,
+                   int *order_next, double *extra_out, hipStream_t s)
+{
+    FusedParams F{};
+    F.order_next = order_next;
+    F.sp = SpectraParams{t, b, nullptr, W8_THREADS / 64, nullptr, slow_count, w};
+    F.tp = TraceParams{t, b, nullptr, w, 12, {}, slow_count, 0, defer_logl, extra_out};
+    const size_t lds = fused8_lds_bytes(t.nsmp, b.nlay_pad);
+    const dim3 grid((unsigned)b.nb + (order_next ? 1u : 0u));
+    static LdsOptIn opt;
+    opt(reinterpret_cast<const void *>(fusedc_kernel<2>));
+    hipLaunchKernelGGL((fusedc_kernel<2>), grid, dim3(W8_THREADS), lds, s, F);
 }
 
 void launch_fused8(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int defer_logl,

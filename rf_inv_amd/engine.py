@@ -326,7 +326,7 @@ class RFEngine:
     def launch_plan(self):
         plan = (C.c_int32 * 12)()
         self._chk(self._lib.rf_get_launch_plan(self._ctx, plan))
-        return {"fused": bool(plan[0]), "chain": plan[1], "waves_per_block": plan[2], "nsplit": plan[3],
+        return {"fused": bool(plan[0]), "common_ray_fused": plan[0] == 2, "chain": plan[1], "waves_per_block": plan[2], "nsplit": plan[3],
                 "lpt": bool(plan[4]), "order_reuse": bool(plan[5]), "defer_logl": plan[6],
                 "bin_cutoff": bool(plan[7]), "overrides": plan[8],
                 "build": ("production", "diagnostics", "diagnostics+ablate")[plan[9]],

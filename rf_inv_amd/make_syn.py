@@ -118,7 +118,7 @@ def make_syn_program(p: Params, ref, engine, out_dir: str, dotted: bool = False)
     os.makedirs(out_dir, exist_ok=True)
     with open(os.path.join(out_dir, "test_vel"), "w") as fh:                # :69-77 (list-directed reals)
         for i in range(nlay):
-            fh.write(f" {alpha[i]!r} {beta[i]!r} {rho[i]!r} {h[i]!r}\n")
+            fh.write(f" {float(alpha[i])!r} {float(beta[i])!r} {float(rho[i])!r} {float(h[i])!r}\n")
     rft = engine.get_rft(0, which=0)                                        # rft(:, :, 1)
     noise, sigma, white = reference_noise(rng, p, engine.flt, engine.is_ray_common)
     _write_pair(p, out_dir, rft, noise, dotted)
