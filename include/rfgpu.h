@@ -40,8 +40,9 @@ typedef struct rf_ctx rf_ctx;
 /* Everything `init_forward` / `init_likelihood` read from `module params`
  * (reference src/params.f90:34-96) plus capacity hints. */
 typedef struct rf_config {
-    int32_t nfft;        /* params nfft >= 8.  Powers of two: in-LDS FFT (any size up to 8192).  Any other
-                            length (FFTW plans any n, src/fftw.f90:44): direct DFT, up to ~9000 samples */
+    int32_t nfft;        /* params nfft >= 8 (FFTW plans any n, src/fftw.f90:44).  Powers of two: in-LDS FFT up to
+                            8192, four-step transform through HBM up to 65536.  Any other length: direct DFT up
+                            to 2048, Bluestein's algorithm (two power-of-two transforms) up to 32768 */
     int32_t ntrc;        /* params ntrc                                         */
     int32_t nsmp;        /* params nsmp (src/params.f90:449-451)                */
     int32_t deconv_mode; /* params deconv_mode: 0 = normalise by vertical, 1 = water-level decon */
@@ -315,7 +316,7 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
  *   "order_reuse"      1 (default) a launch prepares the next launch's order | 0 order kernel every time
  *   "nsplit"           0 by batch size (default) | 1..64 bin-splits per walker (split spectra kernel)
  *   "waves_per_block"  1..4 (default 4) waves sharing a staged layer stack (split spectra kernel)
- *   "defer_logl"       -1 by batch size (default) | 0 quadratic form + logL inside the main kernel | 1 follow-up kernels
+ *   "defer_logl"       -1 by batch size (default) | 0 quadratic form + logL inside the main kernel | 1 follow-up kernel
  *   "block_threads"    0 by the context's capacity (default: max_walkers * ntrc blocks within two rounds of the
  *                      GPU -> 512; fixed per context, never per launch) | 256 fused_kernel | 512 fused8_kernel
  *                      (nfft 4096 on land only)

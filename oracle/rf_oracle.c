@@ -330,11 +330,22 @@ void rfo_c2r_naive(int n, const cplx *cx, double *rx)
     }
 }
 
-typedef struct { int n; cplx *tw; int *rev; } fft_plan;
+typedef struct { int n; cplx *tw; int *rev; long double *ct, *st; } fft_plan;
+
+static int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
 
 static void fft_plan_init(fft_plan *pl, int n)
 {
     pl->n = n;
+    pl->ct = pl->st = NULL;
+    if (!is_pow2(n)) {
+        /* any other length: the table cos / sin(2 pi m / n), m = 0 .. n-1, in long double, for the direct sum of the
+         * definition (c2r_direct) -- the same values rfo_c2r_naive evaluates inside its loops */
+        const long double w = 2.0L * 3.14159265358979323846264338327950288L / n;
+        pl->ct = (long double *)malloc(sizeof(long double) * (size_t)n);
+        pl->st = (long double *)malloc(sizeof(long double) * (size_t)n);
+        for (int m = 0; m < n; ++m) { pl->ct[m] = cosl(w * m); pl->st[m] = sinl(w * m); }
+    }
     pl->tw = (cplx *)malloc(sizeof(cplx) * (size_t)(n / 2 > 0 ? n / 2 : 1));
     pl->rev = (int *)malloc(sizeof(int) * (size_t)n);
     for (int k = 0; k < n / 2; ++k) {
@@ -351,7 +362,26 @@ static void fft_plan_init(fft_plan *pl, int n)
         pl->rev[i] = r;
     }
 }
-static void fft_plan_free(fft_plan *pl) { free(pl->tw); free(pl->rev); }
+static void fft_plan_free(fft_plan *pl) { free(pl->tw); free(pl->rev); free(pl->ct); free(pl->st); }
+
+/* rfo_c2r_naive with the plan's table: the O(n^2) long-double sum of the definition of FFTW's c2r */
+static void c2r_direct(const fft_plan *pl, const cplx *cx, double *rx)
+{
+    int n = pl->n, nh = n / 2 + 1;
+    for (int j = 0; j < n; ++j) {
+        long double s = cx[0].re;
+        int m = 0;
+        for (int k = 1; k < nh; ++k) {
+            m += j;
+            if (m >= n) m -= n;                    /* (j * k) mod n */
+            if (2 * k == n)
+                s += (long double)cx[k].re * pl->ct[m];
+            else
+                s += 2.0L * ((long double)cx[k].re * pl->ct[m] - (long double)cx[k].im * pl->st[m]);
+        }
+        rx[j] = (double)s;
+    }
+}
 
 /* in-place radix-2 DIT, sign +, unnormalised; n must be a power of two */
 static void fft_pow2_inverse(const fft_plan *pl, cplx *a)
@@ -373,13 +403,11 @@ static void fft_pow2_inverse(const fft_plan *pl, cplx *a)
     }
 }
 
-static int is_pow2(int n) { return n > 0 && (n & (n - 1)) == 0; }
-
 /* c2r through the full Hermitian-extended complex transform */
 static void c2r_exec(const fft_plan *pl, const cplx *cx, double *rx, cplx *work)
 {
     int n = pl->n, nh = n / 2 + 1;
-    if (!is_pow2(n)) { rfo_c2r_naive(n, cx, rx); return; }
+    if (!is_pow2(n)) { c2r_direct(pl, cx, rx); return; }
     work[0] = c_make(cx[0].re, 0.0);
     for (int k = 1; k < nh; ++k) {
         if (2 * k == n) { work[k] = c_make(cx[k].re, 0.0); continue; }

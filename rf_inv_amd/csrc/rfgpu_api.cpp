@@ -44,6 +44,9 @@ struct rf_ctx {
     std::vector<void *> owned;
     double2 *spec = nullptr; // [nslots][nfwd][2][nh]
     double2 *anyn_scratch = nullptr; // long non-power-of-two nfft only: [nslots * ntrc][trace_anyn_scratch_entries]
+    bool long_series = false;        // trace_long_kernel: 2^n beyond 8192 (four-step transform) or Bluestein
+    LongTables longt{};
+    int long_rows = 0;               // resident blocks of trace_long_kernel = scratch rows
     int *slow_list = nullptr, *slow_count = nullptr; // walkers deferred to the generic-sincos kernel
     // staging for host-buffer calls
     int *d_ids = nullptr, *d_fwd = nullptr, *d_nlay = nullptr, *d_acc = nullptr;
@@ -272,7 +275,7 @@ static void default_plan(rf_ctx *c)
     // land: fusedc_kernel keeps the spectra in registers (measured at the C4 shape: one launch instead of
     // spectra_kernel -> 537 MB of spectra in HBM -> trace_kernel); other shapes, or an explicit phase-chain
     // length, keep the split plan
-    c->fusedc = c->fusedc_allowed && c->fused_override != 0 && c->chain_override < 0 && c->ablate == 0;
+    c->fusedc = c->fusedc_allowed && c->fused_override != 0 && c->chain_override < 0;
     // fused kernel, land: chains of 8 when that gives each of the block's four waves whole chunks
     // (nfft 4096: 4 chunks of 8 iterations + the Nyquist iteration); measured C4 +7 %, C2 +2 % over 4.
     // Ocean (3 propagated columns): chains of 4 (239 VGPRs; 8 would not fit two waves per SIMD).
@@ -444,7 +447,80 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     c->slow_list = (int *)p + 1;   // [nslots * nfwd]
     (void)hipMemset(p, 0, sizeof(int));
 
-    if (!pow2 && trace_anyn_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024) {
+    // Long series: a power of two beyond 8192 runs the four-step transform (4096-point in-LDS transforms + a radix
+    // n / 4096 stage through a scratch row per resident block); any other nfft beyond 2048 runs Bluestein's algorithm
+    // on top of it (two power-of-two transforms of length M >= 2 nfft - 1) instead of the O(n^2) direct DFT
+    c->long_series = (pow2 && n > 8192) || (!pow2 && n > 2048);
+    if (c->long_series) {
+        int m = n;
+        if (!pow2) {
+            m = 8192;
+            while (m < 2 * n - 1) m <<= 1;
+        }
+        if (m > 65536)
+            return cleanup(fail("rf_ctx_create: nfft beyond 65536 (power of two) / 32768 (any other length) is not supported"));
+        LongTables &L = c->longt;
+        L.m = m;
+        L.log2n2 = 0;
+        while ((4096 << L.log2n2) < m) ++L.log2n2;
+        L.bluestein = pow2 ? 0 : 1;
+        const long double PI_L = 3.14159265358979323846264338327950288L;
+        std::vector<double2> twm((size_t)m);
+        for (int k = 0; k < m / 2; ++k) {
+            const long double a = 2.0L * PI_L * k / m;
+            twm[k] = make_double2((double)cosl(a), (double)sinl(a));
+            twm[(size_t)k + m / 2] = make_double2(-twm[k].x, -twm[k].y);
+        }
+        if (upload(c, twm, &L.tw_m)) return cleanup(1);
+        if (L.bluestein) {
+            // chirp c[j] = exp(+i pi j^2 / n): the argument reduced exactly, j^2 mod 2n in integers
+            std::vector<double2> ch((size_t)n), bh((size_t)m);
+            std::vector<long double> br((size_t)m, 0.0L), bi((size_t)m, 0.0L);
+            for (int j = 0; j < n; ++j) {
+                const long long q = ((long long)j * j) % (2LL * n);
+                const long double a = PI_L * (long double)q / (long double)n;
+                const long double cr = cosl(a), ci = sinl(a);
+                ch[j] = make_double2((double)cr, (double)ci);
+                // b[j] = conj(c[|j|]) wrapped onto 0 .. M-1
+                br[j] = cr; bi[j] = -ci;
+                if (j) { br[(size_t)m - j] = cr; bi[(size_t)m - j] = -ci; }
+            }
+            // Bhat = DFT_M(b) (sign -), radix-2 in long double on the host
+            {
+                int lg = 0;
+                while ((1 << lg) < m) ++lg;
+                for (int i = 0; i < m; ++i) {
+                    int r = 0;
+                    for (int bb = 0; bb < lg; ++bb)
+                        if (i & (1 << bb)) r |= 1 << (lg - 1 - bb);
+                    if (r > i) { std::swap(br[i], br[r]); std::swap(bi[i], bi[r]); }
+                }
+                for (int len = 2; len <= m; len <<= 1) {
+                    const int half = len >> 1;
+                    for (int k = 0; k < half; ++k) {
+                        const long double a = -2.0L * PI_L * k / len;
+                        const long double wr = cosl(a), wi = sinl(a);
+                        for (int s0 = 0; s0 < m; s0 += len) {
+                            const long double xr = br[s0 + k + half] * wr - bi[s0 + k + half] * wi;
+                            const long double xi = br[s0 + k + half] * wi + bi[s0 + k + half] * wr;
+                            br[s0 + k + half] = br[s0 + k] - xr; bi[s0 + k + half] = bi[s0 + k] - xi;
+                            br[s0 + k] += xr; bi[s0 + k] += xi;
+                        }
+                    }
+                }
+                for (int k = 0; k < m; ++k) bh[k] = make_double2((double)br[k], (double)bi[k]);
+            }
+            if (upload(c, ch, &L.chirp) || upload(c, bh, &L.bhat)) return cleanup(1);
+        }
+        L.row_entries = long_row_entries(n, m, nsmp);
+        c->long_rows = 2 * c->num_cu;
+        const long long units = (long long)c->nslots * ntrc;
+        if (units < c->long_rows) c->long_rows = (int)units;
+        void *q = nullptr;
+        if (dev_alloc(c, &q, sizeof(double2) * 2 * L.row_entries * (size_t)c->long_rows)) return cleanup(1);
+        L.scratch = (double2 *)q;
+    }
+    if (!c->long_series && !pow2 && trace_anyn_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024) {
         // longer series: only the filtered spectra stay in LDS, the time series goes through a scratch row per block
         if (trace_anyn_big_lds_bytes(n, nsmp) > 160 * 1024)
             return cleanup(fail("rf_ctx_create: an nfft that is not a power of two is transformed by a direct DFT whose "
@@ -454,7 +530,9 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
             return cleanup(1);
         c->anyn_scratch = (double2 *)p;
     }
-    if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 || (pow2 && trace_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024) ||
+    if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 ||
+        (pow2 && !c->long_series && trace_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024) ||
+        (c->long_series && trace_long_lds_bytes(nsmp) > 160 * 1024) ||
         sizeof(double) * (size_t)(5 * ((nsmp + 1) & ~1) + 8) > 160 * 1024)   // phi_kernel (host-owned traces)
         return cleanup(fail("rf_ctx_create: nfft / nsmp / nlay_max exceed the 160 KiB LDS of a gfx950 CU"));
     c->fused_allowed = pow2 && (c->nfwd == ntrc) && fused_lds_bytes(n, nsmp, cfg->nlay_max) <= 160 * 1024;
@@ -573,7 +651,7 @@ static int pick_nsplit(const rf_ctx *c, int nb)
 // partial batch or in a full one gets bit-identical results (tests/test_gpu_parity.py).
 static bool use_fused8(const rf_ctx *c)
 {
-    const bool can = c->fused && c->cfg.nfft == 4096 && c->cfg.sdep <= 0.0 && c->chain_override < 0 && c->ablate == 0 &&
+    const bool can = c->fused && c->cfg.nfft == 4096 && c->cfg.sdep <= 0.0 && c->chain_override < 0 &&
                      fused8_lds_bytes(c->cfg.nsmp, c->cfg.nlay_max) <= 80 * 1024;
     if (!can || c->block_threads == 256) return false;
     if (c->block_threads == 512) return true;
@@ -616,26 +694,26 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         const long long units = (long long)b.nb * c->cfg.ntrc, round = 2LL * c->num_cu;
         const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl : units >= 2 * round);
         hipEvent_t e = prof_begin(c, 0, s);
-        launch_fusedc(c->tab, b, c->ws, c->slow_count, defer, order_next, c->single_trace_out, s);
+        launch_fusedc(c->tab, b, c->ws, c->slow_count, c->ablate, defer, order_next, c->single_trace_out, s);
         if (e) (void)hipEventRecord(e, s);
         if (defer) launch_logl_deferred(c->tab, b, c->ws, s);
     } else if (c->fused) {
         // several traces per walker and at least two rounds of blocks: the block ends with the trace store;
-        // misfits go to HBM (808 B per trace) and two small follow-up kernels form the quadratic forms -- the
+        // misfits go to HBM (808 B per trace) and ONE small follow-up kernel forms the quadratic forms -- the
         // rows of R^-1 fetched once per 8 walkers instead of once per block, same arithmetic -- and logL.  That removes from
         // every block the R^-1 read (80 KB from L2), the cross-block hand-off of phi and ~5 us of holding
         // its CU slot (measured C4 +5 %, C5 +6 %, C1 shape +13 %).  Smaller batches (the per-call drop-in), single-trace
         // contexts and long windows (misfits of 8 walkers must fit the follow-up kernel's LDS) keep the
         // single launch.
         const int defer_ok = phi_deferred_lds_bytes(c->cfg.nsmp) <= 60 * 1024;
-        // (single trace: one follow-up kernel; it pays from four rounds of blocks on -- measured C3 +6 %,
+        // (single trace: it pays from four rounds of blocks on -- measured C3 +6 %,
         // C2, two rounds, -2 %)
         const long long blocks = (long long)b.nb * c->cfg.ntrc, round = 2LL * c->num_cu;
         const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl
                           : (c->cfg.ntrc > 1 ? blocks >= 2 * round : blocks >= 4 * round));
         hipEvent_t e = prof_begin(c, 0, s);
         if (use_fused8(c))
-            launch_fused8(c->tab, b, c->ws, c->slow_count, defer, order_next, c->single_trace_out, s);
+            launch_fused8(c->tab, b, c->ws, c->slow_count, c->ablate, defer, order_next, c->single_trace_out, s);
         else
             launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, c->single_trace_out, s);
         if (e) (void)hipEventRecord(e, s);
@@ -651,7 +729,10 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
                        c->slow_count, c->ws, s);
         if (e) (void)hipEventRecord(e, s);
         e = prof_begin(c, 1, s);
-        launch_trace(c->tab, b, c->spec, c->ws, c->slow_count, c->anyn_scratch, s);   // also forms logL
+        if (c->long_series)
+            launch_trace_long(c->tab, b, c->spec, c->ws, c->slow_count, c->longt, c->long_rows, s);
+        else
+            launch_trace(c->tab, b, c->spec, c->ws, c->slow_count, c->anyn_scratch, s);   // also forms logL
         if (e) (void)hipEventRecord(e, s);
     }
     if (c->prof_this) c->prof_n[0] += 1;

@@ -65,13 +65,13 @@ void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w
 void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int chain, int *slow_count,
                   int ablate, int defer_logl, int *order_next, double *extra_out, hipStream_t s);
 // the fused kernel with 512-thread blocks (nfft 4096, land): see fused8_kernel
-void launch_fused8(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int defer_logl,
-                   int *order_next, double *extra_out, hipStream_t s);
+void launch_fused8(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int ablate,
+                   int defer_logl, int *order_next, double *extra_out, hipStream_t s);
 size_t fused8_lds_bytes(int nsmp, int nlay_pad);
 // "single FWD mode" (common rays, several traces) in one launch: one 512-thread block per walker, one propagator
 // pass, ntrc trace tails from registers (nfft 4096, land): see fusedc_kernel
-void launch_fusedc(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int defer_logl,
-                   int *order_next, double *extra_out, hipStream_t s);
+void launch_fusedc(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int ablate,
+                   int defer_logl, int *order_next, double *extra_out, hipStream_t s);
 // K0: per-(item, forward-trace) constants of the propagator, once per batch item, in front of K1 / the fused kernel
 void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 // logL of a batch launched with defer_logl (one thread per batch item, after the fused kernel)
@@ -137,6 +137,21 @@ struct PostBatch {
 void launch_post_record(const PostConfig &c, const PostState &st, const PostBatch &b, const WalkerState &w,
                         hipStream_t s);
 void launch_post_mark_unused(const PostConfig &c, const PostState &st, hipStream_t s);
+
+// ---- long series (trace_long_kernel): a power of two beyond 8192, or Bluestein for any other long nfft --------
+struct LongTables {
+    int m, log2n2;               // M = 4096 << log2n2; log2n2 = 1 .. 4
+    int bluestein;               // 0: nfft == M (four-step transform only); 1: Bluestein on top
+    const double2 *tw_m;         // [M] exp(+2 pi i k / M), second half the exact negative of the first
+    const double2 *chirp;        // [nfft] exp(+i pi m^2 / nfft)            (Bluestein)
+    const double2 *bhat;         // [M] DFT_M of the wrapped conj chirp       (Bluestein)
+    double2 *scratch;            // [rows][2][row_entries]
+    size_t row_entries;          // >= max(M, fft_pad(nfft) + 1, 2 nsmp)
+};
+size_t long_row_entries(int nfft, int m, int nsmp);
+size_t trace_long_lds_bytes(int nsmp);
+void launch_trace_long(const DeviceTables &t, const BatchArgs &b, const double2 *spec, const WalkerState &w, int *slow_count,
+                       const LongTables &L, int rows, hipStream_t s);
 
 size_t spectra_lds_bytes(int nlay_pad);
 size_t trace_anyn_lds_bytes(int nfft, int nsmp, int nlay_pad);

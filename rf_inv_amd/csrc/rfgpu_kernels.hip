@@ -1378,9 +1378,11 @@ __device__ __forceinline__ void dft_regs(double2 (&v)[1 << LOG2R])
     }
 }
 
+// (tw_sh: the table holds exp(+2 pi i k / (n << tw_sh)) -- a longer transform's table read with a stride; 0 in the
+// in-LDS transforms of the trace kernels)
 template <int LOG2R, int THREADS>
 __device__ __forceinline__ void fft_pass(double2 *a, int log2n, int stride_log2, const double2 *__restrict__ tw,
-                                         int tid)
+                                         int tid, int tw_sh = 0)
 {
     constexpr int R = 1 << LOG2R;
     const int n = 1 << log2n;
@@ -1394,7 +1396,7 @@ __device__ __forceinline__ void fft_pass(double2 *a, int log2n, int stride_log2,
         // whole pass pays one global round trip, not R-1 of them
         if (stride_log2 > 0) {
 #pragma unroll
-            for (int k = 1; k < R; ++k) w[k] = tw[(unsigned)((jp * k) << tw_mul_log2)];   // (< n: the table holds the full turn)
+            for (int k = 1; k < R; ++k) w[k] = tw[(unsigned)(((jp * k) << tw_mul_log2) << tw_sh)];   // (< n: the table holds the full turn)
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) v[k] = a[fft_pad(base + (k << stride_log2))];
@@ -1412,14 +1414,15 @@ __device__ __forceinline__ void fft_pass(double2 *a, int log2n, int stride_log2,
 // passes 2 and 3 depend only on the thread index, so their 30 loads (L2-resident table) are issued
 // before pass 1 and land while it runs; the last pass leaves its 16 outputs in registers:
 // v[k] is sample tid + (bitrev4(k) << 8).  Same operations as fft_pass, pass by pass.
-__device__ __forceinline__ void fft4096_regs(double2 *a, const double2 *__restrict__ tw, int tid, double2 (&v)[16])
+__device__ __forceinline__ void fft4096_regs(double2 *a, const double2 *__restrict__ tw, int tid, double2 (&v)[16],
+                                             int tw_sh = 0)
 {
     double2 w2[16], w3[16];
     const int jp = tid & 15;
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w2[k] = tw[(unsigned)((jp * k) << 4)];
+    for (int k = 1; k < 16; ++k) w2[k] = tw[(unsigned)(((jp * k) << 4) << tw_sh)];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w3[k] = tw[(unsigned)(tid * k)];
+    for (int k = 1; k < 16; ++k) w3[k] = tw[(unsigned)((tid * k) << tw_sh)];
     fft_pass<4, TRACE_THREADS>(a, 12, 0, tw, tid);          // pass 1: stride 1, no twiddles
     __syncthreads();
     {                                                       // pass 2: stride 16
@@ -1569,7 +1572,7 @@ struct TraceParams {
     FftPlan plan;
     int *slow_count;   // re-armed here for the next batch (the slow kernel ran earlier on the stream)
     int ablate;        // RFGPU_DIAGNOSTICS builds only: stop the tail after phase N (timing split, results invalid)
-    int defer_logl;    // misfits to HBM; quadratic form + logL by phi_deferred_kernel (+ logl_deferred_kernel) after this launch
+    int defer_logl;    // misfits to HBM; quadratic form + logL by phi_deferred_kernel after this launch
     double *extra_out; // nullptr, or [ntrc][nfft] (device-mapped host memory): second copy of the proposed trace of
                        // batch item 0 -- the per-call drop-in gets prop_rft without a gather kernel
     double2 *xbuf;     // nullptr, or [nslots * ntrc][fft_pad(nfft)]: the time series of trace_anyn_kernel<true>
@@ -1625,7 +1628,7 @@ __device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 
                 mis[i0] = m;
         }
     }
-    return P.defer_logl != 0;   // quadratic form and logL: phi_deferred_kernel (+ logl_deferred_kernel), after this launch
+    return P.defer_logl != 0;   // quadratic form and logL: phi_deferred_kernel, after this launch
 }
 
 // Everything after Z is in LDS: inverse FFT, vertical max, shift / normalise / store,
@@ -1965,6 +1968,207 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_anyn_kernel(TraceParams P
     }
     __syncthreads();
     trace_tail(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid, true);
+}
+
+// ---------------------------------------------------------------------------
+// trace_long_kernel: K2 for the series the in-LDS transforms do not reach -- a power of two beyond 8192 (up to
+// 65536), and any other length beyond the direct DFT's sensible range (2048 < nfft <= 32768; FFTW plans any length,
+// src/fftw.f90:44).  Same steps as trace_kernel; only the c2r step differs.  Split launch plan.
+//
+// (a) M = 4096 n2 a power of two, n2 = 2 .. 16: the four-step transform.  With k = n2 k1 + r and j = j1 + 4096 j2,
+//       x[j1 + 4096 j2] = sum_r w_n2^(j2 r) [ w_M^(j1 r) Y_r[j1] ],     Y_r = IDFT_4096( Z[n2 k1 + r] over k1 ):
+//     stage 1: n2 in-LDS 4096-point transforms (the trace kernels' radix-16 passes, last pass in registers), each
+//     output times its twiddle w_M^(j1 r), to a global scratch row Y[r][j1] (coalesced both ways);
+//     stage 2: one radix-n2 butterfly per j1 in registers.
+// (b) any other nfft = n: Bluestein.  jk = (j^2 + k^2 - (j - k)^2) / 2, so with the chirp c[m] = exp(+i pi m^2 / n)
+//       x[j] = c[j] sum_k (Z[k] c[k]) conj(c[j - k]):
+//     a linear convolution, done as a circular one of length M >= 2n - 1 (M a power of two: (a) twice):
+//     U = DFT_M(Z c, zero-padded), V = U Bhat (Bhat = DFT_M of the wrapped conj chirp: a host table, long double),
+//     x[j] = c[j] IDFT_M(V)[j] / M.  The forward transform is conj(IDFT(conj .)).  The chirp's argument is reduced
+//     exactly (m^2 mod 2n in integers) on the host.
+// The time series (RF trace in .x, vertical trace in .y: both real transforms ride one complex one, as everywhere)
+// ends up in the block's scratch row and trace_tail does the rest (vertical maximum, shift / normalise / store,
+// misfit, quadratic form, logL).  Blocks are persistent: a grid of at most 2 per CU walks the (item, trace) units,
+// so the scratch is two rows of M (+ padding) per resident block, not per trace.  (LongTables: rfgpu_internal.h)
+// ---------------------------------------------------------------------------
+size_t long_row_entries(int nfft, int m, int nsmp)
+{
+    size_t e = (size_t)m;
+    if ((size_t)fft_pad(nfft) + 1 > e) e = (size_t)fft_pad(nfft) + 1;
+    if ((size_t)2 * nsmp > e) e = (size_t)2 * nsmp;
+    return (e + 1) & ~(size_t)1;
+}
+
+// radix-2^LOG2R inverse butterfly over the n2 sub-transforms of one j1: y[r] -> x[j1 + 4096 j2] for j2 = 0 .. n2 - 1,
+// handed to out(j, value)
+template <int LOG2R, class Out>
+__device__ __forceinline__ void long_stage2(const double2 *__restrict__ Y, int tid, const Out &out)
+{
+    constexpr int R = 1 << LOG2R;
+    for (int j1 = tid; j1 < 4096; j1 += TRACE_THREADS) {
+        double2 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = Y[(size_t)r * 4096 + j1];
+        dft_regs<LOG2R>(v);                       // output j2 sits in v[bitrev(j2)]
+#pragma unroll
+        for (int k = 0; k < R; ++k) out(j1 + 4096 * bitrev_small<LOG2R>(k), v[k]);
+    }
+}
+
+// unnormalised inverse DFT of length M = 4096 << log2n2 of the sequence in(k), k = 0 .. M-1; out(j, x[j]).
+// a: the block's padded 4096-point LDS array; Y: a global scratch row of M entries.
+template <class In, class Out>
+__device__ __forceinline__ void long_idft(const LongTables &L, double2 *a, double2 *__restrict__ Y, const FftPlan &plan,
+                                          int tid, const In &in, const Out &out)
+{
+    const int n2 = 1 << L.log2n2;
+    for (int r = 0; r < n2; ++r) {
+        __syncthreads();                          // the previous sub-transform's last pass has read the array
+#pragma unroll 4
+        for (int k1 = tid; k1 < 4096; k1 += TRACE_THREADS) a[fft_pad(fft_input_pos(plan, 12, k1))] = in((k1 << L.log2n2) + r);
+        __syncthreads();
+        double2 v[16];
+        fft4096_regs(a, L.tw_m, tid, v, L.log2n2);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int j1 = tid + (bitrev_small<4>(k) << 8);
+            const double2 w = L.tw_m[(unsigned)(j1 * r) & (unsigned)(L.m - 1)];     // w_M^(j1 r)
+            Y[(size_t)r * 4096 + j1] = cmul(v[k], w);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();                              // every Y[r][j1] is written (and visible) before stage 2 gathers them
+    switch (L.log2n2) {
+    case 1: long_stage2<1>(Y, tid, out); break;
+    case 2: long_stage2<2>(Y, tid, out); break;
+    case 3: long_stage2<3>(Y, tid, out); break;
+    default: long_stage2<4>(Y, tid, out); break;
+    }
+}
+
+struct LongParams {
+    TraceParams tp;
+    LongTables L;
+};
+
+__global__ __launch_bounds__(TRACE_THREADS) void trace_long_kernel(LongParams Q)
+{
+    extern __shared__ double2 lds2[];
+    const TraceParams &P = Q.tp;
+    const LongTables &L = Q.L;
+    const DeviceTables &t = P.t;
+    const int n = t.nfft, nh = t.nh, nsmp = t.nsmp;
+    double2 *a = lds2;                                                   // [fft_pad(4096)] the 4096-point work array
+    double *mis = reinterpret_cast<double *>(a + ((fft_pad(4095) + 2) & ~1));   // [nsmp] misfits
+    double *red = mis + ((nsmp + 1) & ~1);                               // [8] reductions
+    const int tid = threadIdx.x;
+    double2 *Y = L.scratch + (size_t)blockIdx.x * 2 * L.row_entries;      // stage-1 outputs
+    double2 *W = Y + L.row_entries;                                       // Bluestein: V = U Bhat; finally the time series
+    if (blockIdx.x == 0 && tid == 0) *P.slow_count = 0;
+    const bool decon = t.deconv_mode == 1;
+    const int units = P.b.nb * t.ntrc;
+    for (int u = blockIdx.x; u < units; u += gridDim.x) {
+        __syncthreads();                                                  // the previous unit is finished with LDS and its rows
+        const int itrc = u % t.ntrc;
+        const int ib = P.b.order ? P.b.order[u / t.ntrc] : u / t.ntrc;
+        if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
+            // 0: sigma-only proposal (likelihood.f90:81); < 0: no evaluation at all (see trace_kernel)
+            if (itrc == 0 && tid == 0 && P.b.fwd_flag[ib] < 0) {
+                P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
+                P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
+            } else if (itrc == 0 && tid == 0) {
+                const int wk = P.b.walker_ids[ib];
+                const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * t.ntrc;
+                P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
+                P.w.prop_fwd[wk] = 0;
+            }
+            continue;
+        }
+        const int walker = P.b.walker_ids[ib];
+        const int f = t.ray_common ? 0 : itrc;
+        const int ipha = t.ipha[itrc];
+        const double2 *__restrict__ sr = P.spec + ((size_t)(ib * t.nfwd + f) * 2) * nh;   // freq_r
+        const double2 *__restrict__ sv = sr + nh;                                          // freq_v
+        const double *__restrict__ flt = t.flt + (size_t)itrc * nh;
+        const double2 *num = (ipha == 1) ? sr : sv;      // forward.f90:148-163
+        const double2 *den = (ipha == 1) ? sv : sr;      // decon only
+        double wlvl = 0.0;
+        if (decon) {
+            double m = -HUGE_VAL;
+            for (int k = tid; k < nh; k += TRACE_THREADS) {
+                const double2 x = den[k];
+                m = fmax(m, x.x * x.x + x.y * x.y);      // forward.f90:458
+            }
+            wlvl = 0.001 * block_max(m, red);            // forward.f90:460, pcnt = 0.001 (:149)
+        }
+        const double tp = decon ? 0.0 : P.w.gtail[(size_t)(ib * t.nfwd + f) * GTAIL + 17];
+        const int slot = 1 - P.w.cur_slot[walker];
+        // Z[k], k = 0 .. n-1: RF flt + i V flt with its Hermitian extension (trace_kernel's fill, bin by bin)
+        auto zfull = [&](int k) -> double2 {
+            const int kk = 2 * k <= n ? k : n - k;
+            double2 r = num[kk];
+            double2 V = make_double2(0.0, 0.0);
+            const double fk = flt[kk];
+            if (decon) {
+                const double2 x = den[kk];
+                const double amp = x.x * x.x + x.y * x.y;
+                const double dd = fmax(amp, wlvl);                       // forward.f90:464
+                const double2 yx = cmul(r, make_double2(x.x, -x.y));
+                r = make_double2(yx.x / dd, yx.y / dd);
+            } else {
+                const double2 v = sv[kk];
+                V = make_double2(v.x * fk, v.y * fk);                    // forward.f90:198
+            }
+            const double2 R = make_double2(r.x * fk, r.y * fk);          // forward.f90:168
+            if (k == 0 || 2 * k == n) return make_double2(R.x, V.x);     // c2r ignores Im of the DC and Nyquist bins
+            return 2 * k < n ? make_double2(R.x - V.y, R.y + V.x) : make_double2(R.x + V.y, V.x - R.y);
+        };
+        if (!L.bluestein) {
+            long_idft(L, a, Y, P.plan, tid, zfull, [&](int j, double2 x) { W[fft_pad(j)] = x; });
+        } else {
+            // U = DFT_M(Z c) = conj(IDFT_M(conj(Z c)));  V = U Bhat
+            long_idft(L, a, Y, P.plan, tid,
+                      [&](int k) -> double2 {
+                          if (k >= n) return make_double2(0.0, 0.0);
+                          const double2 zc = cmul(zfull(k), L.chirp[k]);
+                          return make_double2(zc.x, -zc.y);
+                      },
+                      [&](int j, double2 uc) { W[j] = cmul(make_double2(uc.x, -uc.y), L.bhat[j]); });
+            __threadfence_block();
+            __syncthreads();
+            // x[j] = c[j] IDFT_M(V)[j] / M for j < n.  The time series overwrites W, which the stage-1 fills of this
+            // transform have finished reading before its stage 2 writes anything (the barrier inside long_idft)
+            const double inv_m = 1.0 / (double)L.m;
+            long_idft(L, a, Y, P.plan, tid, [&](int k) -> double2 { return W[k]; },
+                      [&](int j, double2 y) {
+                          if (j < n) {
+                              const double2 x = cmul(y, L.chirp[j]);
+                              W[fft_pad(j)] = make_double2(x.x * inv_m, x.y * inv_m);
+                          }
+                      });
+        }
+        __threadfence_block();
+        __syncthreads();
+        trace_tail(P, W, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid, true);
+    }
+}
+
+size_t trace_long_lds_bytes(int nsmp)
+{
+    return sizeof(double2) * (size_t)((fft_pad(4095) + 2) & ~1) + sizeof(double) * (size_t)(((nsmp + 1) & ~1) + 8);
+}
+
+void launch_trace_long(const DeviceTables &t, const BatchArgs &b, const double2 *spec, const WalkerState &w, int *slow_count,
+                       const LongTables &L, int rows, hipStream_t s)
+{
+    LongParams Q{};
+    Q.tp = TraceParams{t, b, spec, w, 12, make_fft_plan(12), slow_count, 0, 0, nullptr, nullptr};
+    Q.L = L;
+    const int units = b.nb * t.ntrc;
+    static LdsOptIn opt;
+    opt(reinterpret_cast<const void *>(trace_long_kernel));
+    hipLaunchKernelGGL(trace_long_kernel, dim3((unsigned)(units < rows ? units : rows)), dim3(TRACE_THREADS),
+                       trace_long_lds_bytes(t.nsmp), s, Q);
 }
 
 // ---------------------------------------------------------------------------
@@ -2349,6 +2553,7 @@ __device__ __forceinline__ void w8_fft_store(const TraceParams &P, double2 *a, d
         for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
         dft_regs<3>(v);                    // v[k] = sample tid + (bitrev3(k) << 9): .x RF trace, .y vertical trace
     }
+    RFGPU_ABLATE_AT(2, );
     double fac = 1.0;
     if (!decon) {
         double m = -HUGE_VAL;
@@ -2485,11 +2690,14 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
         }
     }
     __syncthreads();
+    RFGPU_ABLATE_AT(1, );
     const double tp = decon ? 0.0 : gtail[17];
 
     if (decon) w8_water_level(t, a, side, red, itrc, tid);
     w8_fft_store(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
-    if (P.defer_logl) return;   // quadratic form and logL: phi_deferred_kernel (+ logl_deferred_kernel)
+    RFGPU_ABLATE_AT(2, );
+    RFGPU_ABLATE_AT(3, );
+    if (P.defer_logl) return;   // quadratic form and logL: phi_deferred_kernel
     __syncthreads();
     // ---- phi = (misfit . R^-1) . misfit (likelihood.f90:92-93) and logL, as in trace_tail ------------------
     const double phi = quad_form(t, itrc, mis, reinterpret_cast<double *>(a), red, tid);
@@ -2642,25 +2850,37 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fusedc_kernel(FusedParams F)
             spectra_body<4, NCOL, true, NyqSink, KPtr, true>(sp, gcoef, gtail, nl, ilay0, ipha, rs, wave, lane, nullptr, ur, uz);
         }
     }
+    RFGPU_ABLATE_AT(1, );
     // (tp, the direct-arrival time, is common to the traces too: forward.f90:141 skips its recomputation)
     const double tp = decon ? 0.0 : gtail[17];
-    const int lane_m = (64 - lane) & 63;
-    const int lane_pos = ((lane & 7) << 9) + ((lane >> 3) << 6), lane_pos_m = ((lane_m & 7) << 9) + ((lane_m >> 3) << 6);
     double *phis = P.w.phi + ((size_t)slot * P.w.nslots + walker) * ntrc;
 
     // ---- 2. one trace after the other from the same spectra ---------------------------------------------------------
     for (int itrc = 0; itrc < ntrc; ++itrc) {
         __syncthreads();   // the array is free: table / anchor reads, the previous trace's last FFT pass and quadratic form are done
-        const W8Sink sink{a, side, t.flt + (size_t)itrc * nh, nh, ipha, decon, lane_pos, lane_pos_m};
+        // The thread index goes through an empty asm in every iteration: everything derived from it below -- the ~70 LDS
+        // and global addresses of the deposits, the four FFT passes and the stores -- is then recomputed per trace
+        // (a few integer instructions each) instead of being hoisted out of the loop and kept alive across it, which
+        // at the kernel's 128-VGPR budget pushed the spectra and half of those addresses into scratch (242 spilled
+        // VGPRs, 6.4 GB of scratch traffic per C4-shaped launch)
+        int tix = tid;
+        asm volatile("" : "+v"(tix));
+        const int wv = tix >> 6, ln = tix & 63, ln_m = (64 - ln) & 63;
+        const W8Sink sink{a, side, t.flt + (size_t)itrc * nh, nh, ipha, decon, ((ln & 7) << 9) + ((ln >> 3) << 6),
+                          ((ln_m & 7) << 9) + ((ln_m >> 3) << 6)};
         double wgt[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) wgt[m] = sink.weight(64 * (4 * wave + m) + lane);
+        for (int m = 0; m < 4; ++m) wgt[m] = sink.weight(64 * (4 * wv + m) + ln);
 #pragma unroll
-        for (int m = 0; m < 4; ++m) sink(64 * (4 * wave + m) + lane, ur[m], uz[m], wgt[m]);
-        if (tid == 0) sink(2048, side[2], side[3], sink.weight(2048));
+        for (int m = 0; m < 4; ++m) sink(64 * (4 * wv + m) + ln, ur[m], uz[m], wgt[m]);
+        if (tix == 0) sink(2048, side[2], side[3], sink.weight(2048));
         __syncthreads();
-        if (decon) w8_water_level(t, a, side, red, itrc, tid);
-        w8_fft_store(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
+        if (decon) w8_water_level(t, a, side, red, itrc, tix);
+        w8_fft_store(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tix);
+#ifdef RFGPU_DIAGNOSTICS
+        if (P.ablate == 2 || P.ablate == 3) continue;     // timing split: no quadratic form
+        if (P.ablate == 6) return;                        // ... one trace only
+#endif
         if (!P.defer_logl) {
             // phi = (misfit . R^-1) . misfit (likelihood.f90:92-93); the array doubles as quad_form's scratch
             __syncthreads();
@@ -2668,20 +2888,20 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fusedc_kernel(FusedParams F)
             if (tid == 0) phis[itrc] = phi;
         }
     }
-    if (P.defer_logl) return;   // quadratic forms and logL: phi_deferred_kernel + logl_deferred_kernel
+    if (P.defer_logl) return;   // quadratic forms and logL: phi_deferred_kernel
     if (tid == 0) {
         P.b.logl[ib] = logl_from_phi(phis, P.b.sig + (size_t)ib * ntrc, ntrc, nsmp, false);
         P.w.prop_fwd[walker] = 1;
     }
 }
 
-void launch_fusedc(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int defer_logl,
-                   int *order_next, double *extra_out, hipStream_t s)
+void launch_fusedc(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int ablate,
+                   int defer_logl, int *order_next, double *extra_out, hipStream_t s)
 {
     FusedParams F{};
     F.order_next = order_next;
     F.sp = SpectraParams{t, b, nullptr, W8_THREADS / 64, nullptr, slow_count, w};
-    F.tp = TraceParams{t, b, nullptr, w, 12, {}, slow_count, 0, defer_logl, extra_out};
+    F.tp = TraceParams{t, b, nullptr, w, 12, {}, slow_count, ablate, defer_logl, extra_out};
     const size_t lds = fused8_lds_bytes(t.nsmp, b.nlay_pad);
     const dim3 grid((unsigned)b.nb + (order_next ? 1u : 0u));
     static LdsOptIn opt;
@@ -2689,13 +2909,13 @@ void launch_fusedc(const DeviceTables &t, const BatchArgs &b, const WalkerState 
     hipLaunchKernelGGL((fusedc_kernel<2>), grid, dim3(W8_THREADS), lds, s, F);
 }
 
-void launch_fused8(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int defer_logl,
-                   int *order_next, double *extra_out, hipStream_t s)
+void launch_fused8(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, int *slow_count, int ablate,
+                   int defer_logl, int *order_next, double *extra_out, hipStream_t s)
 {
     FusedParams F{};
     F.order_next = order_next;
     F.sp = SpectraParams{t, b, nullptr, W8_THREADS / 64, nullptr, slow_count, w};
-    F.tp = TraceParams{t, b, nullptr, w, 12, {}, slow_count, 0, defer_logl, extra_out};
+    F.tp = TraceParams{t, b, nullptr, w, 12, {}, slow_count, ablate, defer_logl, extra_out};
     const size_t lds = fused8_lds_bytes(t.nsmp, b.nlay_pad);
     const dim3 grid((unsigned)(b.nb * t.ntrc) + (order_next ? 1u : 0u));
     static LdsOptIn opt;
@@ -2832,13 +3052,16 @@ __global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
     P.w.prop_fwd[walker] = fwd;
 }
 
-// Follow-up kernels of a batch whose fused kernel ran with defer_logl (likelihood.f90:87-98).
+// Follow-up kernel of a batch whose fused kernel ran with defer_logl (likelihood.f90:87-98): the quadratic forms of
+// every trace and logL, ONE launch.
 //
-// (1) phi_deferred_kernel: the quadratic forms.  One 256-thread block per (PHI_W batch items, trace);
-// the arithmetic is quad_form's, operation for operation (lanes own columns j of R^-1, the four waves
-// own contiguous row quarters, quarter sums combined in wave order, the final dot product by a wave
-// reduction) -- so the values are bit-identical to the in-kernel path -- but a row of R^-1 is fetched once
-// for PHI_W items instead of once per block.
+// phi_deferred_kernel: one 256-thread block per PHI_W batch items; it walks the items' traces one after the other.
+// Per trace the arithmetic is quad_form's, operation for operation (lanes own columns j of R^-1, the four waves own
+// contiguous row quarters, quarter sums combined in wave order, the final dot product by a wave reduction) -- so the
+// values are bit-identical to the in-kernel path -- but a row of R^-1 is fetched once for PHI_W items instead of once
+// per block.  The thread that stored an item's quadratic forms then forms its logL (likelihood.f90:94-96, same
+// operation order, no FMA contraction).  (Until round 3 a block handled one trace and a second kernel, one thread
+// per item, formed logL: one launch and its ~5 us of stream time more per batch.)
 constexpr int PHI_W = 8;
 
 __global__ __launch_bounds__(256) void phi_deferred_kernel(LoglParams P)
@@ -2849,85 +3072,73 @@ __global__ __launch_bounds__(256) void phi_deferred_kernel(LoglParams P)
     double *part = mis + (size_t)PHI_W * nsmp;            // [4][PHI_W][nsmp]
     double *red = part + (size_t)4 * PHI_W * nsmp;        // [4][PHI_W]
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int it = blockIdx.x % ntrc, ib0 = (blockIdx.x / ntrc) * PHI_W;
-    for (int e = tid; e < PHI_W * nsmp; e += 256) {
-        const int w = e / nsmp, i = e - w * nsmp, ib = ib0 + w;
-        const bool live = ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1);
-        mis[e] = live ? P.w.misfit[((size_t)ib * ntrc + it) * nsmp + i] : 0.0;
-    }
-    __syncthreads();
-    const double *__restrict__ RT = P.t.r_inv_t + (size_t)it * nsmp * nsmp;
+    const int ib0 = blockIdx.x * PHI_W;
     const int rows = (nsmp + 3) >> 2;
     const int r0 = wv * rows, r1 = min(nsmp, r0 + rows);
-    // two columns per lane and pass (j, j + 64): twice the loads in flight per row
-    for (int j = lane; j < nsmp; j += 128) {
-        const int j2 = j + 64;
-        const bool two = j2 < nsmp;
-        double acc0[PHI_W], acc1[PHI_W];
+    // the item this thread finishes (tid < PHI_W)
+    const int my_ib = ib0 + tid;
+    const bool mine = tid < PHI_W && my_ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[my_ib] == 1);
+    const int my_walker = mine ? P.b.walker_ids[my_ib] : 0;
+    double *my_phis = mine ? P.w.phi + ((size_t)(1 - P.w.cur_slot[my_walker]) * P.w.nslots + my_walker) * ntrc : nullptr;
+    for (int it = 0; it < ntrc; ++it) {
+        if (it) __syncthreads();                          // the previous trace's mis / part / red are done with
+        for (int e = tid; e < PHI_W * nsmp; e += 256) {
+            const int w = e / nsmp, i = e - w * nsmp, ib = ib0 + w;
+            const bool live = ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1);
+            mis[e] = live ? P.w.misfit[((size_t)ib * ntrc + it) * nsmp + i] : 0.0;
+        }
+        __syncthreads();
+        const double *__restrict__ RT = P.t.r_inv_t + (size_t)it * nsmp * nsmp;
+        // two columns per lane and pass (j, j + 64): twice the loads in flight per row
+        for (int j = lane; j < nsmp; j += 128) {
+            const int j2 = j + 64;
+            const bool two = j2 < nsmp;
+            double acc0[PHI_W], acc1[PHI_W];
 #pragma unroll
-        for (int w = 0; w < PHI_W; ++w) acc0[w] = acc1[w] = 0.0;
+            for (int w = 0; w < PHI_W; ++w) acc0[w] = acc1[w] = 0.0;
 #pragma unroll 4
-        for (int i = r0; i < r1; ++i) {
-            const double xa = RT[(size_t)i * nsmp + j];
-            const double xb = two ? RT[(size_t)i * nsmp + j2] : 0.0;
+            for (int i = r0; i < r1; ++i) {
+                const double xa = RT[(size_t)i * nsmp + j];
+                const double xb = two ? RT[(size_t)i * nsmp + j2] : 0.0;
+#pragma unroll
+                for (int w = 0; w < PHI_W; ++w) {
+                    const double m = mis[w * nsmp + i];
+                    acc0[w] = fma(m, xa, acc0[w]);
+                    acc1[w] = fma(m, xb, acc1[w]);
+                }
+            }
 #pragma unroll
             for (int w = 0; w < PHI_W; ++w) {
-                const double m = mis[w * nsmp + i];
-                acc0[w] = fma(m, xa, acc0[w]);
-                acc1[w] = fma(m, xb, acc1[w]);
+                part[((size_t)wv * PHI_W + w) * nsmp + j] = acc0[w];
+                if (two) part[((size_t)wv * PHI_W + w) * nsmp + j2] = acc1[w];
+            }
+        }
+        __syncthreads();
+        double acc[PHI_W];
+#pragma unroll
+        for (int w = 0; w < PHI_W; ++w) acc[w] = 0.0;
+        for (int j = tid; j < nsmp; j += 256) {
+#pragma unroll
+            for (int w = 0; w < PHI_W; ++w) {
+                const double *pw = part + (size_t)w * nsmp + j;
+                const size_t q = (size_t)PHI_W * nsmp;
+                const double phi1 = ((pw[0] + pw[q]) + pw[2 * q]) + pw[3 * q];
+                acc[w] = fma(phi1, mis[w * nsmp + j], acc[w]);
             }
         }
 #pragma unroll
         for (int w = 0; w < PHI_W; ++w) {
-            part[((size_t)wv * PHI_W + w) * nsmp + j] = acc0[w];
-            if (two) part[((size_t)wv * PHI_W + w) * nsmp + j2] = acc1[w];
+            const double v = wave_sum(acc[w]);
+            if (lane == 0) red[wv * PHI_W + w] = v;
         }
+        __syncthreads();
+        if (mine) my_phis[it] = (red[tid] + red[PHI_W + tid]) + (red[2 * PHI_W + tid] + red[3 * PHI_W + tid]);
     }
-    __syncthreads();
-    double acc[PHI_W];
-#pragma unroll
-    for (int w = 0; w < PHI_W; ++w) acc[w] = 0.0;
-    for (int j = tid; j < nsmp; j += 256) {
-#pragma unroll
-        for (int w = 0; w < PHI_W; ++w) {
-            const double *pw = part + (size_t)w * nsmp + j;
-            const size_t q = (size_t)PHI_W * nsmp;
-            const double phi1 = ((pw[0] + pw[q]) + pw[2 * q]) + pw[3 * q];
-            acc[w] = fma(phi1, mis[w * nsmp + j], acc[w]);
-        }
+    if (mine) {
+        // (this thread's own stores: program order makes them visible to its loads)
+        P.b.logl[my_ib] = logl_from_phi(my_phis, P.b.sig + (size_t)my_ib * ntrc, ntrc, nsmp, false);
+        P.w.prop_fwd[my_walker] = 1;
     }
-#pragma unroll
-    for (int w = 0; w < PHI_W; ++w) {
-        const double v = wave_sum(acc[w]);
-        if (lane == 0) red[wv * PHI_W + w] = v;
-    }
-    __syncthreads();
-    if (tid < PHI_W) {
-        const int ib = ib0 + tid;
-        if (ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1)) {
-            const int walker = P.b.walker_ids[ib];
-            const int slot = 1 - P.w.cur_slot[walker];
-            const double phi = (red[tid] + red[PHI_W + tid]) + (red[2 * PHI_W + tid] + red[3 * PHI_W + tid]);
-            P.w.phi[((size_t)slot * P.w.nslots + walker) * ntrc + it] = phi;
-            if (ntrc == 1) {   // nothing to wait for: logL right here, no second follow-up kernel
-                P.b.logl[ib] = logl_from_phi(&phi, P.b.sig + ib, 1, nsmp, false);
-                P.w.prop_fwd[walker] = 1;
-            }
-        }
-    }
-}
-
-// (2) logl_deferred_kernel: logL from the quadratic forms of all traces, one thread per batch item.
-__global__ __launch_bounds__(256) void logl_deferred_kernel(LoglParams P)
-{
-    const int ib = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ib >= P.b.nb) return;
-    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) return;   // sigma-only / skipped items were finished in the main kernel
-    const int walker = P.b.walker_ids[ib];
-    const int slot = 1 - P.w.cur_slot[walker];
-    const double *phi = P.w.phi + ((size_t)slot * P.w.nslots + walker) * P.t.ntrc;
-    P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * P.t.ntrc, P.t.ntrc, P.t.nsmp, false);
-    P.w.prop_fwd[walker] = 1;
 }
 
 size_t phi_deferred_lds_bytes(int nsmp) { return sizeof(double) * ((size_t)5 * PHI_W * nsmp + 4 * PHI_W); }
@@ -2936,10 +3147,7 @@ void launch_logl_deferred(const DeviceTables &t, const BatchArgs &b, const Walke
 {
     LoglParams P{t, b, w};
     const unsigned groups = (unsigned)((b.nb + PHI_W - 1) / PHI_W);
-    hipLaunchKernelGGL(phi_deferred_kernel, dim3(groups * (unsigned)t.ntrc), dim3(256), phi_deferred_lds_bytes(t.nsmp), s,
-                       P);
-    if (t.ntrc > 1)
-        hipLaunchKernelGGL(logl_deferred_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P);
+    hipLaunchKernelGGL(phi_deferred_kernel, dim3(groups), dim3(256), phi_deferred_lds_bytes(t.nsmp), s, P);
 }
 
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)

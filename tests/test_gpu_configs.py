@@ -168,7 +168,7 @@ def test_c3_default_plan_full_batch():
 
 def test_c4_default_plan_full_batch():
     """C4 per-GPU shard: 8192 walkers x (P, P, S) x <= 30 layers: 8-bin chains, misfits to HBM,
-    phi_deferred_kernel + logl_deferred_kernel."""
+    phi_deferred_kernel."""
     _run_config("c4", expect_defer=True, nsample=36)
 
 

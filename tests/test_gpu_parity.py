@@ -425,13 +425,17 @@ def test_fft_sizes(oracle, nfft):
     assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (nfft, np.abs(ll - ref_ll).max())
 
 
-@pytest.mark.parametrize("nfft,deconv", [(1000, 0), (250, 1), (375, 0), (384, 1), (1500, 0), (3400, 0), (5000, 1), (6001, 0)])
+@pytest.mark.parametrize("nfft,deconv", [(1000, 0), (250, 1), (375, 0), (384, 1), (1500, 0), (2048 + 2, 0), (3400, 0),
+                                         (5000, 1), (6001, 0), (10007, 0), (12000, 1), (20000, 0), (32768 - 1, 1),
+                                         (16384, 0), (32768, 1), (65536, 0)])
 def test_any_length_nfft(oracle, nfft, deconv):
-    """nfft need not be a power of two: FFTW plans any length (src/fftw.f90:44) and the reference accepts any nfft.
-    Even (with a Nyquist bin), odd (without), and a multiple of 128 (the Nyquist bin alone in its 64-bin iteration);
-    series whose tables fit LDS (up to ~3300) and longer ones (spectra in LDS, twiddles from L2, the time series
-    through a scratch row per block); P and S traces; the oracle's c2r is then the O(n^2) long-double sum of the
-    definition."""
+    """nfft need not be a power of two, nor short: FFTW plans any length (src/fftw.f90:44) and the reference accepts
+    any nfft.  Up to 2048: the direct DFT (even lengths with a Nyquist bin, odd ones without, a multiple of 128 --
+    the Nyquist bin alone in its 64-bin iteration).  Beyond: Bluestein's algorithm on two power-of-two transforms of
+    length M >= 2 nfft - 1 (2050 -> M 8192; the prime 10007 -> 32768; 20000 and 32767 -> 65536), and for powers
+    of two beyond 8192 the four-step transform itself (16384 = 4096 x 4 ... 65536 = 4096 x 16), all through
+    trace_long_kernel.  P and S traces, with and without deconvolution; for lengths that are not a power of two the
+    oracle's c2r is the O(n^2) long-double sum of the definition."""
     rng = np.random.default_rng(nfft)
     nsmp = 101
     cfg = make_cfg(nfft=nfft, deconv_mode=deconv, rayps=[0.06, 0.10], ipha=[1, -1], t_start=-1.0, a_gus=[4.0, 2.5])
@@ -441,26 +445,35 @@ def test_any_length_nfft(oracle, nfft, deconv):
     stacks = [random_stack(rng, 2), random_stack(rng, 6), random_stack(rng, 19), true]
     nlay, layers = pack_layers(stacks, 21)
     sig = np.full((4, 2), 0.02)
-    ref_ll, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True, nthreads=4)
+    ref_ll, ref_rft, kap = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True, nthreads=4,
+                                             want_kappa=True)
+    # the conditioning rule of tests/test_gpu_configs.py: a trace normalised by a nearly cancelling signed maximum
+    # (kappa >= 100; the 2-layer stack resonates) carries kappa times the transform's rounding, in any evaluation
+    allow = np.where(kap >= 100.0, kap / 10.0, 1.0)
     with _engine(cfg, obs, nsmp, r_inv, max_walkers=4) as eng:
-        assert not eng.launch_plan["fused"]                         # split plan: spectra_kernel -> trace_anyn_kernel
+        assert not eng.launch_plan["fused"]                         # split plan: spectra_kernel -> trace_anyn_kernel / trace_long_kernel
         ll = eng.eval_batch(np.arange(4), nlay, layers, sig)
         for i in range(4):
             got = eng.get_rft(i, which=1).T
             assert got.shape == (2, nfft)
-            assert np.abs(got - ref_rft[i]).max() <= 1e-12 * np.abs(ref_rft[i]).max(), (nfft, i)
+            err = np.abs(got - ref_rft[i]).max() / np.abs(ref_rft[i]).max()
+            assert err <= 1e-12 * allow[i], (nfft, i, err, kap[i])
         # the per-call drop-in on the same context
         one, rft1 = eng.calc_likelihood(0, True, int(nlay[1]), *[layers[1, r, :nlay[1]] for r in range(4)], sig[1])
-        assert abs(one - ref_ll[1]) <= logl_tol(ref_ll[1]) and rft1.shape == (nfft, 2)
-    assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll)), (nfft, np.abs(ll - ref_ll).max())
+        assert abs(one - ref_ll[1]) <= logl_tol(ref_ll[1]) * allow[1] and rft1.shape == (nfft, 2)
+    assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll) * allow), (nfft, np.abs(ll - ref_ll) / logl_tol(ref_ll), kap)
+    assert np.sum(kap >= 100.0) <= 2
 
 
-def test_non_power_of_two_nfft_beyond_the_direct_dft_is_refused():
+@pytest.mark.parametrize("nfft", [32769, 40000, 131072])
+def test_nfft_beyond_the_long_series_transforms_is_refused(nfft):
+    """The limits are stated, not silently exceeded: 65536 for a power of two, 32768 for any other length (Bluestein
+    needs a power-of-two transform of 2 nfft - 1 points or more)."""
     from rf_inv_amd import RFEngine
     from rf_inv_amd.engine import RFGPUError
 
-    with pytest.raises(RFGPUError, match="power of two"):
-        RFEngine(nfft=12000, delta=DELTA, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=np.array([0.06]),
+    with pytest.raises(RFGPUError, match="not supported"):
+        RFEngine(nfft=nfft, delta=DELTA, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=np.array([0.06]),
                  a_gus=np.array([4.0]), ipha=np.array([1], dtype=np.int32), obs=np.zeros((1, 101)), nsmp=101,
                  max_walkers=1, nlay_max=8)
 
