@@ -1590,6 +1590,10 @@ __device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 
     constexpr int R = 1 << LOG2R;
     const DeviceTables &t = P.t;
     const int n = t.nfft, nsmp = t.nsmp;
+    // (the integer shift -- a call with a division -- and the maximum's LDS cell are prepared ahead of the transform:
+    // the tail is a chain of latencies, see w8_fft_store)
+    const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
+    if (tid == 0) red[0] = -HUGE_VAL;
     double2 v[R];
     if constexpr (LOG2R == 4)
         fft4096_regs(a, t.twiddle, tid, v);
@@ -1601,9 +1605,13 @@ __device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 
         double m = -HUGE_VAL;
 #pragma unroll
         for (int k = 0; k < R; ++k) m = fmax(m, v[k].y);
-        fac = block_max(m, red);                                     // maxval(rx) forward.f90:201
+        // maxval(rx) forward.f90:201 across the block: one LDS atomic per wave and ONE barrier (the transform's
+        // barriers separate the cell's initialisation from these updates)
+        m = wave_max(m);
+        if ((tid & 63) == 0) (void)__hip_atomic_fetch_max(&red[0], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        fac = red[0];
     }
-    const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
     // one reciprocal per thread instead of a division per sample (each sample within 1 ulp of the quotient); it
     // carries the sign of the S map (decon: fac = 1, the product is exact)
     const double rfac = (ipha == 1 ? 1.0 : -1.0) / fac;
@@ -2459,29 +2467,6 @@ struct W8Sink {
     }
 };
 
-// one in-place radix-8 DIT pass of the 4096-point inverse transform, one butterfly per thread
-template <int SL>   // log2 of the stride: 0, 3, 6
-__device__ __forceinline__ void w8_pass(double2 *a, const double2 *__restrict__ tw, int tid)
-{
-    constexpr int STRIDE = 1 << SL;
-    const int jp = tid & (STRIDE - 1);
-    const int base = ((tid >> SL) << (SL + 3)) + jp;
-    double2 v[8], w[8];
-    if (SL > 0) {
-#pragma unroll
-        for (int k = 1; k < 8; ++k) w[k] = tw[(unsigned)((jp * k) << (9 - SL))];   // (< 4096: the table holds the full turn)
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(base + (k << SL))];
-    if (SL > 0) {
-#pragma unroll
-        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
-    }
-    dft_regs<3>(v);
-#pragma unroll
-    for (int k = 0; k < 8; ++k) a[w8_pad(base + (bitrev_small<3>(k) << SL))] = v[k];
-}
-
 // water_level_decon (forward.f90:447-470) on the deposited array of the 8-wave kernels, in place: slot(k) holds the
 // numerator, slot(n - k) the denominator of bin k (side[0..1]: the denominators of the DC and Nyquist bins); leaves
 // Z = (num conj(den) / max(|den|^2, wlvl)) flt, Hermitian-extended.  Ends with a barrier.
@@ -2527,32 +2512,70 @@ __device__ __forceinline__ void w8_water_level(const DeviceTables &t, double2 *a
 
 // Inverse FFT (radix-8 passes of stride 1, 8, 64 through LDS, the last -- stride 512 -- in registers), vertical
 // maximum, shift / normalise / store and misfit of one trace whose Z sits in `a`: the tail of the 8-wave kernels.
+// The tail is a chain of latencies (nothing else of the block runs meanwhile, and in the common-ray kernel nothing of
+// the CU either), so: the twiddles of a pass (L2-resident table) are requested while the PREVIOUS pass still does its
+// butterflies and LDS writes and waits at its barrier -- they have arrived when the pass starts; the vertical maximum
+// crosses the waves by one LDS atomic (ds_max_f64) and ONE barrier instead of a store / barrier / load round with two;
+// the integer shift (a call with a division) is formed before the transform, not between the maximum and the stores.
+template <int SL>   // the twiddles of the pass of stride 2^SL (SL = 3, 6, 9): w[k] = exp(+2 pi i jp k 2^(9 - SL) / 4096)
+__device__ __forceinline__ void w8_twiddles(double2 (&w)[8], const double2 *__restrict__ tw, int tid)
+{
+    const int jp = tid & ((1 << SL) - 1);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) w[k] = tw[(unsigned)((jp * k) << (9 - SL))];   // (< 4096: the table holds the full turn)
+}
+
+// one in-place radix-8 pass with this pass's twiddles already in w; afterwards w holds the NEXT pass's (NEXT = 0: none)
+template <int SL, int NEXT>
+__device__ __forceinline__ void w8_pass_pf(double2 *a, const double2 *__restrict__ tw, int tid, double2 (&w)[8])
+{
+    constexpr int STRIDE = 1 << SL;
+    const int jp = tid & (STRIDE - 1);
+    const int base = ((tid >> SL) << (SL + 3)) + jp;
+    double2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(base + (k << SL))];
+    if (SL > 0) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
+    }
+    if (NEXT > 0) w8_twiddles<NEXT>(w, tw, tid);
+    dft_regs<3>(v);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[w8_pad(base + (bitrev_small<3>(k) << SL))] = v[k];
+}
+
+// AHEAD: request a pass's twiddles one pass ahead (fused8_kernel).  The common-ray kernel, which keeps a walker's
+// spectra in 32 VGPRs across this function, loads them inside the pass instead: the 28 registers of twiddles in
+// flight across a barrier do not fit its 128-register budget (measured: the spills cost what the prefetch saves).
+template <bool AHEAD>
 __device__ __forceinline__ void w8_fft_store(const TraceParams &P, double2 *a, double *mis, double *red, int ib, int itrc,
                                              int walker, int ipha, bool decon, double tp, int slot, int tid)
 {
     const DeviceTables &t = P.t;
     constexpr int n = 4096;
     const int nsmp = t.nsmp;
-    const int wave = tid >> 6, lane = tid & 63;
-    // ---- inverse FFT: radix-8 passes of stride 1, 8, 64 through LDS, the last (stride 512) in registers -------
+    const int lane = tid & 63;
     const double2 *__restrict__ tw = t.twiddle;
-    w8_pass<0>(a, tw, tid);
+    const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
+    if (tid == 0) red[0] = -HUGE_VAL;      // the vertical maximum's cell (three barriers ahead of its first use)
+    double2 w[8];
+    if (AHEAD) w8_twiddles<3>(w, tw, tid);
+    w8_pass_pf<0, 0>(a, tw, tid, w);
     __syncthreads();
-    w8_pass<3>(a, tw, tid);
+    if (!AHEAD) w8_twiddles<3>(w, tw, tid);
+    w8_pass_pf<3, AHEAD ? 6 : 0>(a, tw, tid, w);
     __syncthreads();
-    w8_pass<6>(a, tw, tid);
+    if (!AHEAD) w8_twiddles<6>(w, tw, tid);
+    w8_pass_pf<6, AHEAD ? 9 : 0>(a, tw, tid, w);
     __syncthreads();
+    if (!AHEAD) w8_twiddles<9>(w, tw, tid);
     double2 v[8];
-    {
-        double2 w[8];
 #pragma unroll
-        for (int k = 1; k < 8; ++k) w[k] = tw[(unsigned)(tid * k)];
+    for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(tid + (k << 9))];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(tid + (k << 9))];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
-        dft_regs<3>(v);                    // v[k] = sample tid + (bitrev3(k) << 9): .x RF trace, .y vertical trace
-    }
+    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
+    dft_regs<3>(v);                        // v[k] = sample tid + (bitrev3(k) << 9): .x RF trace, .y vertical trace
     RFGPU_ABLATE_AT(2, );
     double fac = 1.0;
     if (!decon) {
@@ -2560,18 +2583,15 @@ __device__ __forceinline__ void w8_fft_store(const TraceParams &P, double2 *a, d
 #pragma unroll
         for (int k = 0; k < 8; ++k) m = fmax(m, v[k].y);
         m = wave_max(m);
-        __syncthreads();
-        if (lane == 0) red[wave] = m;
+        // (NaN: ds_max_f64 and fmax both return the other operand, like the store / load round this replaces)
+        if (lane == 0) (void)__hip_atomic_fetch_max(&red[0], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __syncthreads();
         fac = red[0];                                                // maxval(rx) forward.f90:201
-#pragma unroll
-        for (int w = 1; w < W8_THREADS / 64; ++w) fac = fmax(fac, red[w]);
     }
     double *__restrict__ dst = P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
     double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
     double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
-    const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
     // (the same store loop as tail_in_registers: one signed reciprocal per thread, 0-based masked sample index)
     const double rfac = (ipha == 1 ? 1.0 : -1.0) / fac;
     const int at0 = ipha == 1 ? tid + npre : npre - tid - 1;        // sample j = tid + 1
@@ -2694,7 +2714,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
     const double tp = decon ? 0.0 : gtail[17];
 
     if (decon) w8_water_level(t, a, side, red, itrc, tid);
-    w8_fft_store(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
+    w8_fft_store<true>(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
     RFGPU_ABLATE_AT(2, );
     RFGPU_ABLATE_AT(3, );
     if (P.defer_logl) return;   // quadratic form and logL: phi_deferred_kernel
@@ -2876,7 +2896,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fusedc_kernel(FusedParams F)
         if (tix == 0) sink(2048, side[2], side[3], sink.weight(2048));
         __syncthreads();
         if (decon) w8_water_level(t, a, side, red, itrc, tix);
-        w8_fft_store(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tix);
+        w8_fft_store<false>(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tix);
 #ifdef RFGPU_DIAGNOSTICS
         if (P.ablate == 2 || P.ablate == 3) continue;     // timing split: no quadratic form
         if (P.ablate == 6) return;                        // ... one trace only
