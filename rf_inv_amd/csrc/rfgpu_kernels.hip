@@ -26,8 +26,10 @@
 // to split the kernel time; the production library has no such exits.
 #ifdef RFGPU_DIAGNOSTICS
 #define RFGPU_ABLATE_AT(n, ret) do { if (P.ablate == (n)) return ret; } while (0)
+#define RFGPU_ABLATE_DO(n, stmt) if (P.ablate == (n)) stmt
 #else
 #define RFGPU_ABLATE_AT(n, ret) do { } while (0)
+#define RFGPU_ABLATE_DO(n, stmt)
 #endif
 
 namespace rfgpu {
@@ -2897,10 +2899,9 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fusedc_kernel(FusedParams F)
         __syncthreads();
         if (decon) w8_water_level(t, a, side, red, itrc, tix);
         w8_fft_store<false>(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tix);
-#ifdef RFGPU_DIAGNOSTICS
-        if (P.ablate == 2 || P.ablate == 3) continue;     // timing split: no quadratic form
-        if (P.ablate == 6) return;                        // ... one trace only
-#endif
+        RFGPU_ABLATE_DO(2, continue);     // timing split: no quadratic form
+        RFGPU_ABLATE_DO(3, continue);
+        RFGPU_ABLATE_AT(6, );             // ... one trace only
         if (!P.defer_logl) {
             // phi = (misfit . R^-1) . misfit (likelihood.f90:92-93); the array doubles as quad_form's scratch
             __syncthreads();
