@@ -43,7 +43,7 @@ struct WalkerState {
     int *cur_slot;    // [nslots] 0/1: which half holds the current trace
     int *prop_fwd;    // [nslots] last proposal ran the forward model
     int *done;        // [nslots] per batch item: traces finished (last one forms logL), self-resetting
-    double *misfit;   // [nslots][ntrc][nsmp] per batch item: misfits handed to the deferred phi / logL kernel
+    double *misfit;   // [nslots][ntrc][nsmp] per batch item: misfits handed to phi_deferred_kernel
     double *gcoef;    // [nslots * nfwd][nlay_max][NCOEF] per batch item: stage_kernel's per-layer constants
     double *gtail;    // [nslots * nfwd][GTAIL]           ... walker constants + direct-arrival time
     int *gflag;       // [nslots * nfwd]                  ... bit 0 sea, bit 1 phases beyond the fast sincos range

@@ -1084,9 +1084,12 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
     // of four items with the parts one after the other.  The arithmetic per (layer, part) is the same code either
     // way: `part` is a run-time value in both modes, so the results are bit-identical.
     const int q = (G == 16 && S.spread) ? grp : -1;
-    const int bf = q >= 0 ? blockIdx.x * (blockDim.x >> 6) + wave : (blockIdx.x * (blockDim.x >> 6) + wave) * NG + grp;
-    const bool live = bf < S.b.nb * S.t.nfwd;
-    const int ib = live ? bf / S.t.nfwd : 0, f = live ? bf % S.t.nfwd : 0;
+    // position in DISPATCH order (deepest walkers first, when the batch has one): the groups of a wave then hold
+    // walkers of similar depth, so a wave of shallow walkers makes one pass over its lanes where a deep one makes two
+    const int pos = q >= 0 ? blockIdx.x * (blockDim.x >> 6) + wave : (blockIdx.x * (blockDim.x >> 6) + wave) * NG + grp;
+    const bool live = pos < S.b.nb * S.t.nfwd;
+    const int ib = live ? (S.b.order ? S.b.order[pos / S.t.nfwd] : pos / S.t.nfwd) : 0, f = live ? pos % S.t.nfwd : 0;
+    const int bf = ib * S.t.nfwd + f;                  // index of the (item, forward-trace) images, batch order
     const bool run = live && (!S.b.fwd_flag || S.b.fwd_flag[ib] == 1);
     const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)) << (grp * G);
     double *terms = lds + (size_t)(q >= 0 ? wave : wave * NG + grp) * pad;
@@ -1199,11 +1202,13 @@ void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &
 {
     StageParams S{t, b, w.gcoef, w.gtail, w.gflag, 0};
     const unsigned nbf = (unsigned)(b.nb * t.nfwd);
-    // lanes per (item, trace): the layers above the half-space of the deepest walker the context allows
+    // lanes per (item, trace): 16 up to 32 layers (a walker of more than 16 makes two passes over its lanes; with the
+    // batch in depth order a wave's four walkers are alike, and the mean walker is half as deep as the deepest the
+    // context allows), 32 or 64 beyond
     const int nsolid_max = b.nlay_pad - 1;
-    if (nsolid_max <= 16)
+    if (nsolid_max <= 32)
         launch_stage_g<16>(S, nbf, b.nlay_pad, s);
-    else if (nsolid_max <= 32)
+    else if (nsolid_max <= 64)
         launch_stage_g<32>(S, nbf, b.nlay_pad, s);
     else
         launch_stage_g<64>(S, nbf, b.nlay_pad, s);
@@ -1508,21 +1513,23 @@ static FftPlan make_fft_plan(int log2n)
 __device__ __forceinline__ double quad_form(const DeviceTables &t, int itrc, const double *mis, double *part,
                                             double *red, int tid)
 {
-    // (blocks of more than four waves -- fused8_kernel -- leave the arithmetic to waves 0..3: the same partition
-    // of the rows and the same summation order as in a 256-thread block and in phi_deferred_kernel)
+    // The partition of the rows into four quarters and the summation order are the same in every block shape and in
+    // phi_deferred_kernel (bit-identical values).  Eight-wave blocks (fused8_kernel, fusedc_kernel) spread the COLUMNS
+    // of a quarter over two waves -- wave q takes columns lane, lane + 128, ..., wave q + 4 columns lane + 64, ... --
+    // so the usual 101-sample window is one pass per wave instead of two.  The step is a chain of L2 round trips
+    // (80 KB of R^-1 per trace, nothing else of the block runs meanwhile): 16 rows' loads are in flight per trip.
     const int nsmp = t.nsmp;
     const double *__restrict__ RT = t.r_inv_t + (size_t)itrc * nsmp * nsmp;
     const int wv = tid >> 6, lane = tid & 63;
+    const int quarter = wv & 3, cpass = wv >> 2, ncpass = (int)(blockDim.x >> 8);   // 1 (256 threads) or 2 (512)
     const int rows = (nsmp + 3) >> 2;
-    const int r0 = wv * rows, r1 = min(nsmp, r0 + rows);
+    const int r0 = quarter * rows, r1 = min(nsmp, r0 + rows);
     __syncthreads();                                          // `part` may alias a buffer still being read
-    if (wv < 4) {
-        for (int j = lane; j < nsmp; j += 64) {
-            double acc = 0.0;
-#pragma unroll 8
-            for (int i = r0; i < r1; ++i) acc = fma(mis[i], RT[(size_t)i * nsmp + j], acc);
-            part[wv * nsmp + j] = acc;
-        }
+    for (int j = lane + 64 * cpass; j < nsmp; j += 64 * ncpass) {
+        double acc = 0.0;
+#pragma unroll 16
+        for (int i = r0; i < r1; ++i) acc = fma(mis[i], RT[(size_t)i * nsmp + j], acc);
+        part[quarter * nsmp + j] = acc;
     }
     __syncthreads();
     double acc = 0.0;
@@ -1579,6 +1586,8 @@ struct TraceParams {
                        // batch item 0 -- the per-call drop-in gets prop_rft without a gather kernel
     double2 *xbuf;     // nullptr, or [nslots * ntrc][fft_pad(nfft)]: the time series of trace_anyn_kernel<true>
 };
+
+constexpr int PHI_W = 8;   // batch items per block of phi_deferred_kernel
 
 // FFT with the last pass in registers, vertical maximum, shift / normalise / store and misfit for
 // nfft = 256 * 2^LOG2R (trace_tail).  Returns true when the block is finished (ablation, or the misfits
@@ -3076,15 +3085,16 @@ __global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
 // Follow-up kernel of a batch whose fused kernel ran with defer_logl (likelihood.f90:87-98): the quadratic forms of
 // every trace and logL, ONE launch.
 //
-// phi_deferred_kernel: one 256-thread block per PHI_W batch items; it walks the items' traces one after the other.
-// Per trace the arithmetic is quad_form's, operation for operation (lanes own columns j of R^-1, the four waves own
-// contiguous row quarters, quarter sums combined in wave order, the final dot product by a wave reduction) -- so the
-// values are bit-identical to the in-kernel path -- but a row of R^-1 is fetched once for PHI_W items instead of once
-// per block.  The thread that stored an item's quadratic forms then forms its logL (likelihood.f90:94-96, same
-// operation order, no FMA contraction).  (Until round 3 a block handled one trace and a second kernel, one thread
-// per item, formed logL: one launch and its ~5 us of stream time more per batch.)
-constexpr int PHI_W = 8;
-
+// phi_deferred_kernel: one 256-thread block per (PHI_W batch items, trace).  The arithmetic is quad_form's, operation
+// for operation (lanes own columns j of R^-1, the four waves own contiguous row quarters, quarter sums combined in
+// wave order, the final dot product by a wave reduction) -- so the values are bit-identical to the in-kernel path --
+// but a row of R^-1 is fetched once for PHI_W items instead of once per block.  The block that finishes a group's
+// LAST trace forms the group's logL (likelihood.f90:94-96, same operation order, no FMA contraction): the quadratic
+// forms cross blocks by agent-scope stores, a drained write and a counter, like the in-kernel multi-trace hand-off.
+// (Until round 3 a second kernel, one thread per item, formed logL: one launch and ~5 us of stream time more per
+// batch.  Measured alternatives, all slower than this 45 us at the C4 shape: one block walking a group's traces in
+// turn, 56 us; that with 512 threads, one column per lane and 32 row loads in flight, 60 us; the misfits as scalar
+// operands from an item-interleaved layout instead of LDS, 78 us.)
 __global__ __launch_bounds__(256) void phi_deferred_kernel(LoglParams P)
 {
     extern __shared__ double lds[];
@@ -3092,83 +3102,101 @@ __global__ __launch_bounds__(256) void phi_deferred_kernel(LoglParams P)
     double *mis = lds;                                    // [PHI_W][nsmp]
     double *part = mis + (size_t)PHI_W * nsmp;            // [4][PHI_W][nsmp]
     double *red = part + (size_t)4 * PHI_W * nsmp;        // [4][PHI_W]
+    int *flag = reinterpret_cast<int *>(red + 4 * PHI_W); // [1] "this block finishes the group"
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int ib0 = blockIdx.x * PHI_W;
+    const int it = blockIdx.x % ntrc, grp = blockIdx.x / ntrc, ib0 = grp * PHI_W;
+    for (int e = tid; e < PHI_W * nsmp; e += 256) {
+        const int w = e / nsmp, i = e - w * nsmp, ib = ib0 + w;
+        const bool live = ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1);
+        mis[e] = live ? P.w.misfit[((size_t)ib * ntrc + it) * nsmp + i] : 0.0;
+    }
+    __syncthreads();
+    const double *__restrict__ RT = P.t.r_inv_t + (size_t)it * nsmp * nsmp;
     const int rows = (nsmp + 3) >> 2;
     const int r0 = wv * rows, r1 = min(nsmp, r0 + rows);
-    // the item this thread finishes (tid < PHI_W)
-    const int my_ib = ib0 + tid;
-    const bool mine = tid < PHI_W && my_ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[my_ib] == 1);
-    const int my_walker = mine ? P.b.walker_ids[my_ib] : 0;
-    double *my_phis = mine ? P.w.phi + ((size_t)(1 - P.w.cur_slot[my_walker]) * P.w.nslots + my_walker) * ntrc : nullptr;
-    for (int it = 0; it < ntrc; ++it) {
-        if (it) __syncthreads();                          // the previous trace's mis / part / red are done with
-        for (int e = tid; e < PHI_W * nsmp; e += 256) {
-            const int w = e / nsmp, i = e - w * nsmp, ib = ib0 + w;
-            const bool live = ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1);
-            mis[e] = live ? P.w.misfit[((size_t)ib * ntrc + it) * nsmp + i] : 0.0;
-        }
-        __syncthreads();
-        const double *__restrict__ RT = P.t.r_inv_t + (size_t)it * nsmp * nsmp;
-        // two columns per lane and pass (j, j + 64): twice the loads in flight per row
-        for (int j = lane; j < nsmp; j += 128) {
-            const int j2 = j + 64;
-            const bool two = j2 < nsmp;
-            double acc0[PHI_W], acc1[PHI_W];
+    // two columns per lane and pass (j, j + 64): twice the loads in flight per row
+    for (int j = lane; j < nsmp; j += 128) {
+        const int j2 = j + 64;
+        const bool two = j2 < nsmp;
+        double acc0[PHI_W], acc1[PHI_W];
 #pragma unroll
-            for (int w = 0; w < PHI_W; ++w) acc0[w] = acc1[w] = 0.0;
+        for (int w = 0; w < PHI_W; ++w) acc0[w] = acc1[w] = 0.0;
 #pragma unroll 4
-            for (int i = r0; i < r1; ++i) {
-                const double xa = RT[(size_t)i * nsmp + j];
-                const double xb = two ? RT[(size_t)i * nsmp + j2] : 0.0;
-#pragma unroll
-                for (int w = 0; w < PHI_W; ++w) {
-                    const double m = mis[w * nsmp + i];
-                    acc0[w] = fma(m, xa, acc0[w]);
-                    acc1[w] = fma(m, xb, acc1[w]);
-                }
-            }
+        for (int i = r0; i < r1; ++i) {
+            const double xa = RT[(size_t)i * nsmp + j];
+            const double xb = two ? RT[(size_t)i * nsmp + j2] : 0.0;
 #pragma unroll
             for (int w = 0; w < PHI_W; ++w) {
-                part[((size_t)wv * PHI_W + w) * nsmp + j] = acc0[w];
-                if (two) part[((size_t)wv * PHI_W + w) * nsmp + j2] = acc1[w];
-            }
-        }
-        __syncthreads();
-        double acc[PHI_W];
-#pragma unroll
-        for (int w = 0; w < PHI_W; ++w) acc[w] = 0.0;
-        for (int j = tid; j < nsmp; j += 256) {
-#pragma unroll
-            for (int w = 0; w < PHI_W; ++w) {
-                const double *pw = part + (size_t)w * nsmp + j;
-                const size_t q = (size_t)PHI_W * nsmp;
-                const double phi1 = ((pw[0] + pw[q]) + pw[2 * q]) + pw[3 * q];
-                acc[w] = fma(phi1, mis[w * nsmp + j], acc[w]);
+                const double m = mis[w * nsmp + i];
+                acc0[w] = fma(m, xa, acc0[w]);
+                acc1[w] = fma(m, xb, acc1[w]);
             }
         }
 #pragma unroll
         for (int w = 0; w < PHI_W; ++w) {
-            const double v = wave_sum(acc[w]);
-            if (lane == 0) red[wv * PHI_W + w] = v;
+            part[((size_t)wv * PHI_W + w) * nsmp + j] = acc0[w];
+            if (two) part[((size_t)wv * PHI_W + w) * nsmp + j2] = acc1[w];
         }
-        __syncthreads();
-        if (mine) my_phis[it] = (red[tid] + red[PHI_W + tid]) + (red[2 * PHI_W + tid] + red[3 * PHI_W + tid]);
     }
-    if (mine) {
-        // (this thread's own stores: program order makes them visible to its loads)
-        P.b.logl[my_ib] = logl_from_phi(my_phis, P.b.sig + (size_t)my_ib * ntrc, ntrc, nsmp, false);
-        P.w.prop_fwd[my_walker] = 1;
+    __syncthreads();
+    double acc[PHI_W];
+#pragma unroll
+    for (int w = 0; w < PHI_W; ++w) acc[w] = 0.0;
+    for (int j = tid; j < nsmp; j += 256) {
+#pragma unroll
+        for (int w = 0; w < PHI_W; ++w) {
+            const double *pw = part + (size_t)w * nsmp + j;
+            const size_t q = (size_t)PHI_W * nsmp;
+            const double phi1 = ((pw[0] + pw[q]) + pw[2 * q]) + pw[3 * q];
+            acc[w] = fma(phi1, mis[w * nsmp + j], acc[w]);
+        }
+    }
+#pragma unroll
+    for (int w = 0; w < PHI_W; ++w) {
+        const double v = wave_sum(acc[w]);
+        if (lane == 0) red[wv * PHI_W + w] = v;
+    }
+    __syncthreads();
+    const int ib = ib0 + tid;
+    const bool mine = tid < PHI_W && ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1);
+    const int walker = mine ? P.b.walker_ids[ib] : 0;
+    double *phis = P.w.phi + ((size_t)(mine ? 1 - P.w.cur_slot[walker] : 0) * P.w.nslots + walker) * ntrc;
+    const double phi = (red[tid & (PHI_W - 1)] + red[PHI_W + (tid & (PHI_W - 1))]) +
+                       (red[2 * PHI_W + (tid & (PHI_W - 1))] + red[3 * PHI_W + (tid & (PHI_W - 1))]);
+    if (ntrc == 1) {
+        // nothing to wait for: logL right here
+        if (mine) {
+            phis[0] = phi;
+            P.b.logl[ib] = logl_from_phi(&phi, P.b.sig + ib, 1, nsmp, false);
+            P.w.prop_fwd[walker] = 1;
+        }
+        return;
+    }
+    // hand-off between the ntrc blocks of a group (see trace_tail): write-through stores of the quadratic forms,
+    // drained, then the group's counter (done[] of the group's first item; self-resetting); the last arriver reads
+    // every trace's value with agent-scope loads
+    if (mine) __hip_atomic_store(phis + it, phi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const bool last = atomicAdd(P.w.done + ib0, 1) == ntrc - 1;
+        if (last) P.w.done[ib0] = 0;
+        *flag = last ? 1 : 0;
+    }
+    __syncthreads();
+    if (*flag && mine) {
+        P.b.logl[ib] = logl_from_phi(phis, P.b.sig + (size_t)ib * ntrc, ntrc, nsmp, true);
+        P.w.prop_fwd[walker] = 1;
     }
 }
 
-size_t phi_deferred_lds_bytes(int nsmp) { return sizeof(double) * ((size_t)5 * PHI_W * nsmp + 4 * PHI_W); }
+size_t phi_deferred_lds_bytes(int nsmp) { return sizeof(double) * ((size_t)5 * PHI_W * nsmp + 4 * PHI_W + 2); }
 
 void launch_logl_deferred(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
 {
     LoglParams P{t, b, w};
     const unsigned groups = (unsigned)((b.nb + PHI_W - 1) / PHI_W);
-    hipLaunchKernelGGL(phi_deferred_kernel, dim3(groups), dim3(256), phi_deferred_lds_bytes(t.nsmp), s, P);
+    hipLaunchKernelGGL(phi_deferred_kernel, dim3(groups * (unsigned)t.ntrc), dim3(256), phi_deferred_lds_bytes(t.nsmp), s, P);
 }
 
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
