@@ -147,6 +147,8 @@ __device__ __noinline__ double arrival_sum(int n, const double *terms)
 //   tail[8..10]  water layer: xi_w, h_w, rho_w / xi_w
 //   tail[11..16] unit columns 1, 2, 4 in the top solid layer's eigen-coordinates (stage_start)
 //   tail[17]     direct-arrival time of the forward trace (forward.f90:474-519)
+//   tail[18..21] (ur, uz) of the Nyquist bin when that bin sits alone in its 64-bin iteration (nfft a multiple of
+//                128) and the walker is on the fast paths: stage_kernel runs that one bin's chain itself (stage_nyquist)
 __device__ __forceinline__ void sincos_cw(double x, double &sn, double &cs);
 
 // vertical slowness sqrt(1/v^2 - p^2) exactly as the reference's double arithmetic forms it
@@ -640,25 +642,34 @@ __device__ __forceinline__ void spectra_iter_direct(const SpectraParams &P, CP c
     sink(k, ur, uz, wgt, -1);
 }
 
-// The iteration that holds the Nyquist bin has one active lane (nfft / 2 is a multiple of 64): a whole
-// wave walks the layer stack for it, so its sines and cosines come from the staged constants
-// (same function, same argument as spectra_iter_direct would use: identical values).
-template <int NCOL, class Sink, class CP = const double *>
-__device__ __forceinline__ void spectra_iter_nyquist(const SpectraParams &P, CP coef, CP tail,
-                                                     int nl, int ilay0, int ipha, const Sink &sink, int it, int lane)
+// The iteration that holds the Nyquist bin has one active lane (nfft / 2 is a multiple of 64).  A whole wave used to
+// walk the layer stack for it after its own chunk -- ~30 instructions per layer on ONE wave's critical path while
+// the block's other waves waited at the barrier (+6 % of the 8-bin chain, +15 % of the 4-bin chain of the 8-wave
+// kernels).  Now stage_kernel, which forms the sines and cosines of that bin's phases anyway, runs the bin's chain
+// too (stage_nyquist: the same functions, the same arguments as spectra_iter_direct would use) and the kernels only
+// deposit the result.
+template <int NCOL>
+__device__ __forceinline__ void stage_nyquist(const double *nyq, const double *tail, int nl, int ilay0, int ipha,
+                                              double omg_nyq, double2 &ur, double2 &uz)
 {
-    const int k = it * 64 + lane;
-    const double omg = (double)k * P.t.domg;
-    const double wgt = sink.weight(k);
+    // nyq[l][0..5] = c[4..9] of layer l, [6..9] = c[19..22] (stage_kernel's LDS row); tail: the walker constants
     ColState<NCOL> st;
     init_cols<NCOL>(st, tail);
     for (int l = ilay0; l < nl - 1; ++l) {
-        const CP c = coef + l * NCOEF;
-        apply_layer_trig_unit<NCOL>(st, c, c[19], c[20], c[21], c[22]);
+        const double *r = nyq + (size_t)l * 10;
+        LayerK k;
+        k.g1 = r[0]; k.g2 = r[1]; k.g3 = r[2]; k.g4 = r[3]; k.g5 = r[4]; k.g6 = r[5];
+        apply_layer_trig_unit<NCOL>(st, k, r[6], r[7], r[8], r[9]);
     }
-    double2 ur, uz;
-    finish_bin<NCOL, true>(st, tail, omg, ipha, ur, uz);
-    sink(k, ur, uz, wgt, -1);
+    finish_bin<NCOL, true>(st, tail, omg_nyq, ipha, ur, uz);
+}
+
+template <class Sink, class CP = const double *>
+__device__ __forceinline__ void spectra_iter_nyquist(CP tail, const Sink &sink, int it, int lane)
+{
+    const int k = it * 64 + lane;                // lane 0: the Nyquist bin; the sinks drop the bins beyond it
+    const double wgt = sink.weight(k);
+    sink(k, make_double2(tail[18], tail[19]), make_double2(tail[20], tail[21]), wgt, -1);
 }
 
 // eps = arg - k * phi, phi = (hi, lo): the rounding perturbation of the reference's argument (omega*xi)*z
@@ -932,7 +943,7 @@ __device__ __forceinline__ void spectra_body(const SpectraParams &P, CP coef, CP
     // the low splits first)
     for (int it = it_direct0 + (P.nsplit - 1 - split); it < niter; it += P.nsplit) {
         if (FAST && it > 0 && it * 128 == P.t.nfft)
-            spectra_iter_nyquist<NCOL>(P, coef, tail, nl, ilay0, ipha, sink, it, lane);
+            spectra_iter_nyquist(tail, sink, it, lane);
         else
             spectra_iter_direct<NCOL, FAST>(P, coef, tail, nl, ilay0, ipha, sink, it, lane);
     }
@@ -1071,10 +1082,16 @@ struct StageParams {
     int spread;   // G = 16 only: the four 16-lane groups of a wave share ONE item, one part each (small batches)
 };
 
+// LDS of stage_kernel per (item, forward-trace) group: the direct-arrival terms [pad], the constants the Nyquist
+// bin's chain reads [pad][STAGE_NYQ] (per layer: c[4..9] = G in the unit gauge, c[19..22] = that bin's sines and
+// cosines) and the walker constants tail[0..GTAIL) before they go to the global image in one coalesced write
+constexpr int STAGE_NYQ = 10;
+__host__ __device__ inline size_t stage_row_doubles(int pad) { return (size_t)pad * (1 + STAGE_NYQ) + GTAIL; }
+
 template <int G>
 __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
 {
-    extern __shared__ double lds[];                 // [waves][64 / G][nlay_pad] direct-arrival terms, one row per group
+    extern __shared__ double lds[];                 // [waves][64 / G] rows of stage_row_doubles(nlay_pad), one per group
     constexpr int NG = 64 / G;                      // groups per wave
     const int pad = S.b.nlay_pad;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1092,22 +1109,24 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
     const int bf = ib * S.t.nfwd + f;                  // index of the (item, forward-trace) images, batch order
     const bool run = live && (!S.b.fwd_flag || S.b.fwd_flag[ib] == 1);
     const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)) << (grp * G);
-    double *terms = lds + (size_t)(q >= 0 ? wave : wave * NG + grp) * pad;
-    // The lanes store their pieces straight into the global image.  (Assembling the image in LDS and writing whole
-    // rows was measured: no faster -- the kernel is bound by its divisions and square roots, not by its stores.)
+    double *terms = lds + (size_t)(q >= 0 ? wave : wave * NG + grp) * stage_row_doubles(pad);
+    double *nyq = terms + pad;                      // [pad][STAGE_NYQ]
+    double *tl = nyq + (size_t)pad * STAGE_NYQ;     // [GTAIL] the walker constants, assembled here
+    // The lanes store their per-layer pieces straight into the global image.  (Assembling that image in LDS and
+    // writing whole rows was measured: no faster -- the kernel is bound by its divisions and square roots.)
     bool big = false;
     int nl = 2;
+    bool sea = false;
     if (run) {
         const double *L = S.b.layers + (size_t)ib * 4 * pad;
         nl = S.b.nlay[ib];
         const double p = S.t.rayps[f];
-        const bool sea = L[pad] < 0.0;              // beta(1) < 0  (forward.f90:229)
+        sea = L[pad] < 0.0;                         // beta(1) < 0  (forward.f90:229)
         const int ilay0 = sea ? 1 : 0;
         const bool solid = nl - 1 > ilay0;          // at least one solid layer above the half-space
         const double omg_max = (double)(S.t.nh - 1) * S.t.domg;
         const double omg_nyq = (double)(S.t.nfft / 2) * S.t.domg;
         double *coef = S.gcoef + (size_t)bf * pad * NCOEF;
-        double *tail = S.gtail + (size_t)bf * GTAIL;
         bool unit;
         const double gauge = walker_gauge<G>(L, pad, nl, ilay0, p, sl, group_mask, unit);
         big = !unit;
@@ -1117,6 +1136,7 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
             const double a0 = L[l], b0 = L[pad + l], r0 = L[2 * pad + l], h0 = L[3 * pad + l];
             const double a1 = L[l + 1], b1 = L[pad + l + 1], r1 = L[2 * pad + l + 1];
             double *c = coef + (size_t)l * NCOEF;
+            double *ny = nyq + (size_t)l * STAGE_NYQ;
             if (l >= ilay0) {
                 const int part_lo = q < 0 ? 0 : (q < 2 ? q : 2), part_hi = q < 0 ? 2 : (q < 2 ? q + 1 : 2);
                 const int sph_lo = q < 0 ? 0 : (q >= 2 ? q - 2 : 2), sph_hi = q < 0 ? 2 : (q >= 2 ? q - 1 : 2);
@@ -1124,12 +1144,16 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
                 for (int part = part_lo; part < part_hi; ++part) {
                     // part 0: beta (eta), part 1: alpha (xi)
                     const LayerHalf u = layer_half(part ? a0 : b0, b0, r0, p);
+                    double g4[4];
                     if (l + 1 < nl - 1) {
                         const LayerHalf w = layer_half(part ? a1 : b1, b1, r1, p);
-                        stage_interface(c + 3 + 4 * part, part, u, &w, unit);
+                        stage_interface(g4, part, u, &w, unit);
                     } else {
-                        stage_interface(c + 3 + 4 * part, part, u, nullptr, unit);
+                        stage_interface(g4, part, u, nullptr, unit);
                     }
+                    c[3 + 4 * part] = g4[0]; c[4 + 4 * part] = g4[1]; c[5 + 4 * part] = g4[2]; c[6 + 4 * part] = g4[3];
+                    // (the unit-gauge chain reads c[4..9]: part 0 supplies c[4..6], part 1 c[7..9])
+                    ny[3 * part] = g4[1 - part]; ny[3 * part + 1] = g4[2 - part]; ny[3 * part + 2] = g4[3 - part];
                 }
 #pragma unroll 1
                 for (int sph = sph_lo; sph < sph_hi; ++sph) {
@@ -1143,6 +1167,8 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
                     stage_phase(c + 11 + 2 * sph, c + 15 + 2 * sph, S.t.domg, slow, h0);
                     c[19 + 2 * sph] = sn;
                     c[20 + 2 * sph] = cn;
+                    ny[6 + 2 * sph] = sn;
+                    ny[7 + 2 * sph] = cn;
                     big |= fabs(omg_max * slow * h0) >= SINCOS_CW_LIMIT || !(fabs(S.t.omg_dc * slow * h0) < DC_PHASE_LIMIT);
                 }
             }
@@ -1151,18 +1177,18 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
                 // half-space = layer l + 1; the last solid layer (if any) = layer l
                 LayerBasis last;
                 if (solid) last = layer_basis(a0, b0, r0, p);
-                stage_halfspace(tail, a1, b1, r1, p, solid ? &last : nullptr, gauge);
+                stage_halfspace(tl, a1, b1, r1, p, solid ? &last : nullptr, gauge);
             }
             if (l == (solid ? ilay0 : 0) && (q < 0 || q == 3)) {
                 LayerBasis top;
                 if (solid) top = layer_basis(a0, b0, r0, p);
-                stage_start(tail + 11, solid ? &top : nullptr);
+                stage_start(tl + 11, solid ? &top : nullptr);
             }
             if (l == 0 && sea && (q < 0 || q == 3)) {
                 const double xiw = vertical_slowness(a0, p);   // forward.f90:431
-                tail[8] = xiw;
-                tail[9] = h0;
-                tail[10] = r0 / xiw;
+                tl[8] = xiw;
+                tl[9] = h0;
+                tl[10] = r0 / xiw;
                 big |= fabs(omg_max * xiw * h0) >= SINCOS_CW_LIMIT;
             }
         }
@@ -1174,12 +1200,31 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
             for (int i = i0 + sl; i < nl - 1; i += G) terms[i - i0] = arrival_term(L[3 * pad + i], vel[i], p);
     }
     const bool any_big = (__ballot(big) & (q >= 0 ? ~0ull : group_mask)) != 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the row is complete: every lane of the group may read it
+    // The Nyquist bin, when it sits alone in its 64-bin iteration (nfft a multiple of 128): its chain over the walker's
+    // layers, here, from the LDS row the group's lanes have just filled -- every lane runs it (same values; no lane
+    // would do anything else meanwhile).  Walkers on the generic path evaluate the bin with every other one.
+    if (run && !any_big && S.t.nfft % 128 == 0) {
+        const int ilay0 = sea ? 1 : 0;
+        const double omg_nyq = (double)(S.t.nfft / 2) * S.t.domg;
+        double2 ur, uz;
+        if (sea)
+            stage_nyquist<3>(nyq, tl, nl, ilay0, S.t.ipha[f], omg_nyq, ur, uz);
+        else
+            stage_nyquist<2>(nyq, tl, nl, ilay0, S.t.ipha[f], omg_nyq, ur, uz);
+        if (sl == 0 && q <= 0) {
+            tl[18] = ur.x; tl[19] = ur.y; tl[20] = uz.x; tl[21] = uz.y;
+        }
+    }
     __syncthreads();
-    if (run && sl == 0 && q <= 0) {
-        const double *L = S.b.layers + (size_t)ib * 4 * pad;
+    if (run && q <= 0) {
+        // the walker constants to the global image: one coalesced write per group ([17]: the direct-arrival time)
+        double *tail = S.gtail + (size_t)bf * GTAIL;
         const int i0 = S.t.sdep > 0.0 ? 1 : 0;
-        S.gtail[(size_t)bf * GTAIL + 17] = arrival_sum(nl - 1 - i0, terms);
-        S.gflag[bf] = (L[pad] < 0.0 ? 1 : 0) | (any_big ? 2 : 0);
+        if (sl == 0) tl[17] = arrival_sum(nl - 1 - i0, terms);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        for (int i = sl; i < 22; i += G) tail[i] = tl[i];
+        if (sl == 0) S.gflag[bf] = (sea ? 1 : 0) | (any_big ? 2 : 0);
     }
 }
 
@@ -1192,10 +1237,14 @@ static void launch_stage_g(const StageParams &S, unsigned nbf, int nlay_pad, hip
     // one part each -- half the latency; from ~1000 items on the packed layout is faster again (C2: 2 %)
     P.spread = (G == 16 && nbf <= 256) ? 1 : 0;
     const unsigned nwave = P.spread ? nbf : (nbf + NG - 1) / NG;
-    // small batches: one wave per block, so that the few waves spread over the CUs
-    const unsigned wpb = nwave <= 2048 ? 1 : 4;
-    hipLaunchKernelGGL(stage_kernel<G>, dim3((nwave + wpb - 1) / wpb), dim3(64 * wpb),
-                       sizeof(double) * wpb * NG * (size_t)nlay_pad, s, P);
+    // small batches: one wave per block, so that the few waves spread over the CUs; deep contexts: as many waves as
+    // 60 KB of LDS rows allow
+    const size_t wave_bytes = sizeof(double) * NG * stage_row_doubles(nlay_pad);
+    unsigned wpb = nwave <= 2048 ? 1 : 4;
+    while (wpb > 1 && wpb * wave_bytes > 60 * 1024) wpb >>= 1;
+    static LdsOptIn opt;     // one wave of a 200-layer context needs 18 KB per group
+    opt(reinterpret_cast<const void *>(stage_kernel<G>));
+    hipLaunchKernelGGL(stage_kernel<G>, dim3((nwave + wpb - 1) / wpb), dim3(64 * wpb), wpb * wave_bytes, s, P);
 }
 
 void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)

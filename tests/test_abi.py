@@ -218,3 +218,25 @@ def test_ctx_create_refuses_to_build_an_ill_defined_r_inv():
     with RFEngine(a_gus=np.array([a]), r_inv=np.zeros((1, 61, 61)), **kw) as eng:   # the host's own r_inv is taken as is
         rank, g = eng.r_inv_info
         assert rank[0] == -1 and np.isnan(g[0])
+
+
+def test_bench_refuses_a_rank_count_it_cannot_honour():
+    """`bench.py --gpus N` must never report fewer GPUs than it was asked for (the flag was parsed and
+    ignored).  Without a launcher it starts the ranks itself -- and refuses, before anything touches a GPU, when the
+    node shows fewer than N devices (this container shows none); under a launcher WORLD_SIZE must equal --gpus."""
+    import subprocess
+    import sys
+
+    import torch
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "RFGPU_BENCH_BACKEND")}
+    bench = os.path.join(ROOT, "bench.py")
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300,
+                           env=env, cwd=ROOT)
+        assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300,
+                       env=dict(env, WORLD_SIZE="3", RANK="0"), cwd=ROOT)
+    assert r.returncode != 0 and "must agree" in r.stderr and "{" not in r.stdout
+    r = subprocess.run([sys.executable, bench, "--gpus", "0"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0
