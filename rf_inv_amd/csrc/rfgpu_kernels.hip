@@ -2577,16 +2577,20 @@ __device__ __forceinline__ void w8_water_level(const DeviceTables &t, double2 *a
 // butterflies and LDS writes and waits at its barrier -- they have arrived when the pass starts; the vertical maximum
 // crosses the waves by one LDS atomic (ds_max_f64) and ONE barrier instead of a store / barrier / load round with two;
 // the integer shift (a call with a division) is formed before the transform, not between the maximum and the stores.
-template <int SL>   // the twiddles of the pass of stride 2^SL (SL = 3, 6, 9): w[k] = exp(+2 pi i jp k 2^(9 - SL) / 4096)
+template <int SL, bool LEAN = false>   // the twiddles of the pass of stride 2^SL (SL = 3, 6, 9): w[k] = exp(+2 pi i jp k 2^(9 - SL) / 4096)
 __device__ __forceinline__ void w8_twiddles(double2 (&w)[8], const double2 *__restrict__ tw, int tid)
 {
     const int jp = tid & ((1 << SL) - 1);
 #pragma unroll
-    for (int k = 1; k < 8; ++k) w[k] = tw[(unsigned)((jp * k) << (9 - SL))];   // (< 4096: the table holds the full turn)
+    for (int k = 1; k < 8; ++k)
+        if (!LEAN || k == 1 || k == 2 || k == 4) w[k] = tw[(unsigned)((jp * k) << (9 - SL))];   // (< 4096: the table holds the full turn)
 }
 
 // one in-place radix-8 pass with this pass's twiddles already in w; afterwards w holds the NEXT pass's (NEXT = 0: none)
-template <int SL, int NEXT>
+// LEAN (the common-ray kernel, which keeps 32 VGPRs of spectra alive across the transform): only w[1], w[2], w[4]
+// are loaded; w3 = w1 w2, w5 = w4 w1, w6 = w4 w2, w7 = w4 w3 are formed as they are used (each within 2 ulp of the
+// table's value) -- 12 instead of 28 registers of twiddles next to the 32 of the butterfly.
+template <int SL, int NEXT, bool LEAN = false>
 __device__ __forceinline__ void w8_pass_pf(double2 *a, const double2 *__restrict__ tw, int tid, double2 (&w)[8])
 {
     constexpr int STRIDE = 1 << SL;
@@ -2595,7 +2599,16 @@ __device__ __forceinline__ void w8_pass_pf(double2 *a, const double2 *__restrict
     double2 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(base + (k << SL))];
-    if (SL > 0) {
+    if (SL > 0 && LEAN) {
+        const double2 w3 = cmul(w[1], w[2]);
+        v[1] = cmul(v[1], w[1]);
+        v[2] = cmul(v[2], w[2]);
+        v[3] = cmul(v[3], w3);
+        v[7] = cmul(v[7], cmul(w[4], w3));
+        v[5] = cmul(v[5], cmul(w[4], w[1]));
+        v[6] = cmul(v[6], cmul(w[4], w[2]));
+        v[4] = cmul(v[4], w[4]);
+    } else if (SL > 0) {
 #pragma unroll
         for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
     }
@@ -2623,18 +2636,29 @@ __device__ __forceinline__ void w8_fft_store(const TraceParams &P, double2 *a, d
     if (AHEAD) w8_twiddles<3>(w, tw, tid);
     w8_pass_pf<0, 0>(a, tw, tid, w);
     __syncthreads();
-    if (!AHEAD) w8_twiddles<3>(w, tw, tid);
-    w8_pass_pf<3, AHEAD ? 6 : 0>(a, tw, tid, w);
+    if (!AHEAD) w8_twiddles<3, true>(w, tw, tid);
+    w8_pass_pf<3, AHEAD ? 6 : 0, !AHEAD>(a, tw, tid, w);
     __syncthreads();
-    if (!AHEAD) w8_twiddles<6>(w, tw, tid);
-    w8_pass_pf<6, AHEAD ? 9 : 0>(a, tw, tid, w);
+    if (!AHEAD) w8_twiddles<6, true>(w, tw, tid);
+    w8_pass_pf<6, AHEAD ? 9 : 0, !AHEAD>(a, tw, tid, w);
     __syncthreads();
-    if (!AHEAD) w8_twiddles<9>(w, tw, tid);
+    if (!AHEAD) w8_twiddles<9, true>(w, tw, tid);
     double2 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(tid + (k << 9))];
+    if (!AHEAD) {
+        const double2 w3 = cmul(w[1], w[2]);
+        v[1] = cmul(v[1], w[1]);
+        v[2] = cmul(v[2], w[2]);
+        v[3] = cmul(v[3], w3);
+        v[7] = cmul(v[7], cmul(w[4], w3));
+        v[5] = cmul(v[5], cmul(w[4], w[1]));
+        v[6] = cmul(v[6], cmul(w[4], w[2]));
+        v[4] = cmul(v[4], w[4]);
+    } else {
 #pragma unroll
-    for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
+        for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
+    }
     dft_regs<3>(v);                        // v[k] = sample tid + (bitrev3(k) << 9): .x RF trace, .y vertical trace
     RFGPU_ABLATE_AT(2, );
     double fac = 1.0;
