@@ -1,6 +1,6 @@
 """Latency of the per-call drop-in (rf_calc_likelihood, one chain per call: src/pt_mcmc.f90:178-180) on the shipped
 sample_syn shape and on a C2-shaped context: microseconds per call, with and without the trace copied back.
-usage: python tests/tools/percall_latency.py [ncalls]"""
+usage: python tests/tools/percall_latency.py [ncalls] [path of another librfgpu.so build]"""
 import os
 import sys
 import time
@@ -12,7 +12,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from helpers import DELTA, random_stack  # noqa: E402
-from rf_inv_amd import RFEngine  # noqa: E402
+from rf_inv_amd import RFEngine, _lib  # noqa: E402
+
+if len(sys.argv) > 2:
+    _lib.load(sys.argv[2])
+    print("library:", sys.argv[2])
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 rng = np.random.default_rng(1)
