@@ -133,21 +133,25 @@ def test_oracle_single_fwd_mode_matches_reflectivity_solution(oracle, ipha, p, d
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nfft", [NFFT, 4096])
 @pytest.mark.parametrize("ipha,p,dec,ocean", COMMON_CASES)
-def test_hip_single_fwd_mode_matches_reflectivity_solution(ipha, p, dec, ocean):
-    """The same through the C ABI: the split spectra -> trace launch plan (the only one for common rays)."""
+def test_hip_single_fwd_mode_matches_reflectivity_solution(ipha, p, dec, ocean, nfft):
+    """The same through the C ABI, on both launch plans of common rays: the split spectra -> trace kernels (nfft 2048,
+    and every ocean context) and, at nfft 4096 on land, fusedc_kernel -- one block per walker, one propagator pass,
+    the three traces' tails from the spectra it keeps in registers."""
     from rf_inv_amd import RFEngine
 
     model = _common_model(ocean)
     nlay = len(model[1])
-    with RFEngine(nfft=NFFT, delta=DELTA, t_start=T_START, deconv_mode=dec, sdep=float(model[4][0]) if ocean else 0.0,
+    with RFEngine(nfft=nfft, delta=DELTA, t_start=T_START, deconv_mode=dec, sdep=float(model[4][0]) if ocean else 0.0,
                   rayps=np.full(3, p), a_gus=np.array(COMMON_A), ipha=np.full(3, ipha, dtype=np.int32),
                   obs=np.zeros((3, 101)), nsmp=101, max_walkers=1, nlay_max=nlay + 2) as eng:
-        assert not eng.launch_plan["fused"]
+        assert eng.launch_plan["common_ray_fused"] == (nfft == 4096 and not ocean)
+        assert eng.launch_plan["fused"] == eng.launch_plan["common_ray_fused"]
         got = eng.calc_rf(nlay, *model[1:])
     for t, a in enumerate(COMMON_A):
-        want = al.receiver_function(NFFT, DELTA, T_START, a, p, ipha, dec, *model[1:])
-        _check(got[:, t], want, (ipha, dec, ocean, t))
+        want = al.receiver_function(nfft, DELTA, T_START, a, p, ipha, dec, *model[1:])
+        _check(got[:, t], want, (ipha, dec, ocean, t, nfft))
 
 
 def test_s_trace_is_offset_by_one_sample_like_the_reference(oracle):

@@ -313,6 +313,62 @@ def test_results_do_not_depend_on_how_many_items_share_a_launch(oracle, cap):
     assert np.all(np.abs(full[pick] - ref) <= logl_tol(ref))
 
 
+@pytest.mark.parametrize("ipha", [1, -1])
+@pytest.mark.parametrize("deconv", [0, 1])
+def test_common_ray_fused_kernel(oracle, deconv, ipha):
+    """fusedc_kernel (nfft 4096, land, several traces of ONE ray: single-FWD mode, forward.f90:59-91,141) on every
+    branch it carries: P and S, with and without water-level deconvolution, walkers on the generic path (out-of-range
+    phases; no unit gauge; a stack deeper than the anchor table holds), in-kernel and deferred quadratic forms,
+    sigma-only items after a commit, the per-call entry -- against the oracle, and against the split plan
+    (spectra_kernel -> trace_kernel) to rounding."""
+    rng = np.random.default_rng(300 + 2 * deconv + (ipha > 0))
+    p = 0.06 if ipha == 1 else 0.10
+    cfg = make_cfg(nfft=4096, deconv_mode=deconv, rayps=[p, p, p], ipha=[ipha] * 3, t_start=-2.0, a_gus=[4.0, 2.5, 1.5])
+    nsmp = 101
+    true = random_stack(rng, 5)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, int(n)) for n in (2, 3, 8, 17, 30, 12, 12, 40)] + [true]
+    stacks[5][3][3] = 2.5e5                        # out-of-range phases
+    stacks[6][2][4] = 40.0 * stacks[6][2][5]       # density contrast of 40 across an interface: no unit gauge
+    nlay, layers = pack_layers(stacks, 42)
+    nb = len(stacks)
+    sig = np.column_stack([np.full(nb, 0.01), np.full(nb, 0.03), np.full(nb, 0.02)])
+    ref_ll, ref_rft, kap = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, want_rft=True, nthreads=4,
+                                             want_kappa=True)
+    allow = np.where(kap >= 100.0, kap / 10.0, 1.0)
+    res = {}
+    for fused in (-1, 0):
+        for defer in (0, 1):
+            with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=42, options={"fused": fused, "defer_logl": defer}) as eng:
+                plan = eng.launch_plan
+                assert plan["common_ray_fused"] == (fused == -1) and plan["fused"] == (fused == -1)
+                ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+                rft = np.stack([eng.get_rft(i, which=1).T for i in range(nb)])
+                assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll) * allow), (fused, defer, np.abs(ll - ref_ll) / logl_tol(ref_ll))
+                for i in range(nb):
+                    err = np.abs(rft[i] - ref_rft[i]).max() / np.abs(ref_rft[i]).max()
+                    assert err <= 1e-11 * allow[i], (fused, i, err)
+                eng.commit(np.arange(nb), np.ones(nb, dtype=np.int32))
+                ff = (np.arange(nb) % 2).astype(np.int32)
+                ll2 = eng.eval_batch(np.arange(nb), nlay[::-1].copy(), layers[::-1].copy(), 2 * sig, fwd_flag=ff)
+                use_l = np.where(ff[:, None, None] == 1, layers[::-1], layers)
+                use_n = np.where(ff == 1, nlay[::-1], nlay)
+                ref2, kap2 = oracle.eval_batch(cfg, obs, r_inv, use_n, use_l, 2 * sig, nsmp, nthreads=4, want_kappa=True)
+                allow2 = np.where(kap2 >= 100.0, kap2 / 10.0, 1.0)
+                assert np.all(np.abs(ll2 - ref2) <= logl_tol(ref2) * allow2), (fused, defer, np.abs(ll2 - ref2).max())
+                one, rft1 = eng.calc_likelihood(0, True, int(nlay[3]), *[layers[3, r, :nlay[3]] for r in range(4)], sig[3])
+                assert abs(one - ref_ll[3]) <= logl_tol(ref_ll[3]) * allow[3]
+                assert np.abs(rft1.T - ref_rft[3]).max() <= 1e-12 * allow[3] * np.abs(ref_rft[3]).max()
+                if fused == -1:
+                    assert one == ll[3] and np.array_equal(rft1.T, rft[3])     # alone or in a batch: the same bits
+                res[(fused, defer)] = (ll, rft)
+    assert np.array_equal(res[(-1, 0)][0], res[(-1, 1)][0])          # same arithmetic in-kernel and deferred
+    assert np.array_equal(res[(-1, 0)][1], res[(-1, 1)][1])
+    d = np.abs(res[(-1, 0)][1] - res[(0, 0)][1]).max(axis=(1, 2)) / np.abs(res[(0, 0)][1]).max(axis=(1, 2))
+    assert np.all(d <= 1e-12 * allow), d
+
+
 def test_r_inv_builtin_matches_lapack(oracle):
     from rf_inv_amd.engine import compute_r_inv
 
