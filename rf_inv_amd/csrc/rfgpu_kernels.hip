@@ -1470,21 +1470,36 @@ __device__ __forceinline__ void fft_pass(double2 *a, int log2n, int stride_log2,
 // passes 2 and 3 depend only on the thread index, so their 30 loads (L2-resident table) are issued
 // before pass 1 and land while it runs; the last pass leaves its 16 outputs in registers:
 // v[k] is sample tid + (bitrev4(k) << 8).  Same operations as fft_pass, pass by pass.
+// the fifteen twiddles w^1 .. w^15 of a radix-16 butterfly from w^1, w^2, w^4, w^8 (each product within ~4 ulp of the
+// table's value): four loads per pass and thread instead of fifteen -- the table is L2-resident, but at the C4 shape
+// the fifteen-load version moved 3 GB per launch through the vector memory path for twiddles alone
+__device__ __forceinline__ void tw16_expand(double2 (&w)[16])
+{
+    w[3] = cmul(w[2], w[1]);
+    w[5] = cmul(w[4], w[1]);
+    w[6] = cmul(w[4], w[2]);
+    w[7] = cmul(w[4], w[3]);
+#pragma unroll
+    for (int k = 1; k < 8; ++k) w[8 + k] = cmul(w[8], w[k]);
+}
+
 __device__ __forceinline__ void fft4096_regs(double2 *a, const double2 *__restrict__ tw, int tid, double2 (&v)[16],
                                              int tw_sh = 0)
 {
     double2 w2[16], w3[16];
     const int jp = tid & 15;
+    // (requested before pass 1, which needs none: they land while it runs)
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w2[k] = tw[(unsigned)(((jp * k) << 4) << tw_sh)];
+    for (int k = 1; k < 16; k <<= 1) w2[k] = tw[(unsigned)(((jp * k) << 4) << tw_sh)];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) w3[k] = tw[(unsigned)((tid * k) << tw_sh)];
+    for (int k = 1; k < 16; k <<= 1) w3[k] = tw[(unsigned)((tid * k) << tw_sh)];
     fft_pass<4, TRACE_THREADS>(a, 12, 0, tw, tid);          // pass 1: stride 1, no twiddles
     __syncthreads();
     {                                                       // pass 2: stride 16
         const int base = ((tid >> 4) << 8) + jp;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = a[fft_pad(base + (k << 4))];
+        tw16_expand(w2);
 #pragma unroll
         for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], w2[k]);
         dft_regs<4>(v);
@@ -1494,6 +1509,7 @@ __device__ __forceinline__ void fft4096_regs(double2 *a, const double2 *__restri
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = a[fft_pad(tid + (k << 8))];   // pass 3: stride 256
+    tw16_expand(w3);
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], w3[k]);
     dft_regs<4>(v);
@@ -2612,7 +2628,7 @@ __device__ __forceinline__ void w8_pass_pf(double2 *a, const double2 *__restrict
 #pragma unroll
         for (int k = 1; k < 8; ++k) v[k] = cmul(v[k], w[k]);
     }
-    if (NEXT > 0) w8_twiddles<NEXT>(w, tw, tid);
+    if (NEXT > 0) w8_twiddles<NEXT, LEAN>(w, tw, tid);
     dft_regs<3>(v);
 #pragma unroll
     for (int k = 0; k < 8; ++k) a[w8_pad(base + (bitrev_small<3>(k) << SL))] = v[k];
@@ -2621,7 +2637,7 @@ __device__ __forceinline__ void w8_pass_pf(double2 *a, const double2 *__restrict
 // AHEAD: request a pass's twiddles one pass ahead (fused8_kernel).  The common-ray kernel, which keeps a walker's
 // spectra in 32 VGPRs across this function, loads them inside the pass instead: the 28 registers of twiddles in
 // flight across a barrier do not fit its 128-register budget (measured: the spills cost what the prefetch saves).
-template <bool AHEAD>
+template <bool AHEAD, bool LEAN = !AHEAD>
 __device__ __forceinline__ void w8_fft_store(const TraceParams &P, double2 *a, double *mis, double *red, int ib, int itrc,
                                              int walker, int ipha, bool decon, double tp, int slot, int tid)
 {
@@ -2633,20 +2649,20 @@ __device__ __forceinline__ void w8_fft_store(const TraceParams &P, double2 *a, d
     const int npre = calc_npre(t.t_start, tp, t.delta, ipha);
     if (tid == 0) red[0] = -HUGE_VAL;      // the vertical maximum's cell (three barriers ahead of its first use)
     double2 w[8];
-    if (AHEAD) w8_twiddles<3>(w, tw, tid);
+    if (AHEAD) w8_twiddles<3, LEAN>(w, tw, tid);
     w8_pass_pf<0, 0>(a, tw, tid, w);
     __syncthreads();
-    if (!AHEAD) w8_twiddles<3, true>(w, tw, tid);
-    w8_pass_pf<3, AHEAD ? 6 : 0, !AHEAD>(a, tw, tid, w);
+    if (!AHEAD) w8_twiddles<3, LEAN>(w, tw, tid);
+    w8_pass_pf<3, AHEAD ? 6 : 0, LEAN>(a, tw, tid, w);
     __syncthreads();
-    if (!AHEAD) w8_twiddles<6, true>(w, tw, tid);
-    w8_pass_pf<6, AHEAD ? 9 : 0, !AHEAD>(a, tw, tid, w);
+    if (!AHEAD) w8_twiddles<6, LEAN>(w, tw, tid);
+    w8_pass_pf<6, AHEAD ? 9 : 0, LEAN>(a, tw, tid, w);
     __syncthreads();
-    if (!AHEAD) w8_twiddles<9, true>(w, tw, tid);
+    if (!AHEAD) w8_twiddles<9, LEAN>(w, tw, tid);
     double2 v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) v[k] = a[w8_pad(tid + (k << 9))];
-    if (!AHEAD) {
+    if (LEAN) {
         const double2 w3 = cmul(w[1], w[2]);
         v[1] = cmul(v[1], w[1]);
         v[2] = cmul(v[2], w[2]);
@@ -2798,7 +2814,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
     const double tp = decon ? 0.0 : gtail[17];
 
     if (decon) w8_water_level(t, a, side, red, itrc, tid);
-    w8_fft_store<true>(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
+    w8_fft_store<true, true>(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
     RFGPU_ABLATE_AT(2, );
     RFGPU_ABLATE_AT(3, );
     if (P.defer_logl) return;   // quadratic form and logL: phi_deferred_kernel
