@@ -276,10 +276,12 @@ static void default_plan(rf_ctx *c)
     // spectra_kernel -> 537 MB of spectra in HBM -> trace_kernel); other shapes, or an explicit phase-chain
     // length, keep the split plan
     c->fusedc = c->fusedc_allowed && c->fused_override != 0 && c->chain_override < 0;
-    // fused kernel, land: chains of 8 when that gives each of the block's four waves whole chunks
-    // (nfft 4096: 4 chunks of 8 iterations + the Nyquist iteration); measured C4 +7 %, C2 +2 % over 4.
-    // Ocean (3 propagated columns): chains of 4 (239 VGPRs; 8 would not fit two waves per SIMD).
-    if (c->fused && c->chain == 4 && c->cfg.sdep <= 0.0 && (niter / 8) >= 4 && (niter / 8) % 4 == 0) c->chain = 8;
+    // fused kernel: chains of 8 when that gives each of the block's four waves whole chunks (nfft 4096: 4 chunks of 8
+    // iterations; the Nyquist bin comes from stage_kernel); measured C4 +7 %, C2 +2 % over 4.  Ocean (3 propagated
+    // columns) too since round 3: the 8-bin loop fits 256 VGPRs without a spill inside it once the tail's twiddles
+    // are formed as products (33 VGPRs spilled around it, block start and finish only) -- measured C5 shape +3.5 % over
+    // chains of 4 (two per wave, each paying its own sincos).
+    if (c->fused && c->chain == 4 && (niter / 8) >= 4 && (niter / 8) % 4 == 0) c->chain = 8;
     if (c->chain_override >= 0) c->chain = c->chain_override;
 }
 

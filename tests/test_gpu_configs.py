@@ -73,7 +73,7 @@ def _run_config(name, expect_defer, nsample, extra_check=None):
         plan = eng.launch_plan
         # the DEFAULT plan is the subject: no option set, production build
         assert plan["overrides"] == 0 and plan["build"] == "production" and plan["fused"] and plan["defer_logl"] == -1
-        assert plan["chain"] == (4 if p.sdep > 0 else 8)
+        assert plan["chain"] == 8        # land and ocean: one 8-bin chain per wave
         # by batch size the library defers the quadratic form + logL to the follow-up kernel(s) here
         # (rfgpu_api.cpp run_batch: >= 2 rounds of blocks with several traces, >= 4 rounds with one)
         blocks, rnd = nb * ntrc, 2 * 256
@@ -174,7 +174,7 @@ def test_c4_default_plan_full_batch():
 
 def test_c5_default_plan_full_batch():
     """C5 at BASELINE's per-GPU batch (16384 chains x 16 temperatures / 8 GPUs = 32768 walkers: 8.6 GB of traces,
-    offsets beyond 4 GiB): sdep 2.0, traces P, P, S, S, nfft 4096, <= 31 layers (ocean kernel, 4-bin chains, 3
+    offsets beyond 4 GiB): sdep 2.0, traces P, P, S, S, nfft 4096, <= 31 layers (ocean kernel, 8-bin chains, 3
     propagated columns), plus -- in the same context -- walkers whose own beta(1) >= 0 (a land stack under sdep > 0:
     calc_seis keys on beta(1), forward.f90:229; direct_arrival on sdep, :484)."""
 
