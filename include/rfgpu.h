@@ -317,7 +317,7 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
  *   "nsplit"           0 by batch size (default) | 1..64 bin-splits per walker (split spectra kernel)
  *   "waves_per_block"  1..4 (default 4) waves sharing a staged layer stack (split spectra kernel)
  *   "defer_logl"       -1 by batch size (default) | 0 quadratic form + logL inside the main kernel | 1 follow-up kernel
- *   "block_threads"    0 by the context's capacity (default: max_walkers * ntrc blocks within two rounds of the
+ *   "block_threads"    0 by the context's capacity (default: max_walkers * ntrc blocks within three rounds of the
  *                      GPU -> 512; fixed per context, never per launch) | 256 fused_kernel | 512 fused8_kernel
  *                      (nfft 4096 on land only)
  *   "bin_cutoff"       0 (default: every bin like the reference) | tol in (0, 1): bins whose Gaussian filter

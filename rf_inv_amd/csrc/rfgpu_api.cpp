@@ -81,8 +81,9 @@ struct rf_ctx {
     int fused_override = -1;  // "fused": -1 = by shape
     int defer_logl = -1;      // "defer_logl": -1 = by batch size, 0 / 1 = never / always
     int block_threads = 0;    // "block_threads": 0 = by batch size, 256 / 512 = fused_kernel / fused8_kernel
-    int fused8_max_rounds = 2;   // batches of up to this many rounds of blocks (2 blocks per CU) take fused8_kernel
-                                 // (measured: C2, two rounds, +1.6 %, with deconvolution +3.5 %; three and four rounds -2 %)
+    int fused8_max_rounds = 3;   // contexts of up to this many rounds of blocks (2 blocks per CU) take fused8_kernel
+                                 // (measured at the end of round 3, 8-wave vs 4-wave: two rounds +2.7 %, three +1.5 %,
+                                 // four -3.8 %, six -4 %, C3's sixteen and C4's forty-eight -3..4 %)
     double bin_cutoff = 0.0;  // "bin_cutoff": opt-in filter-support cut-off (0 = off: every bin like the reference)
     int n_overrides = 0;      // options set away from their defaults (echoed by rf_get_launch_plan)
     int ablate = 0;           // RFGPU_DIAGNOSTICS builds only ("ablate"): stops the kernel early, results invalid
@@ -649,7 +650,7 @@ static int pick_nsplit(const rf_ctx *c, int nb)
 // three and four rounds -2 %; C3 (16 rounds) and C4 (48 rounds) level to -2 %.
 // The two factorise the FFT differently (8^4 / 16^3), so a chain's trace differs in the last bits between them.
 // The choice is therefore a property of the CONTEXT, made from its capacity (max_walkers * ntrc blocks at a full
-// batch: up to two rounds -> the 8-wave kernel), never of a launch's batch size: a chain evaluated alone, in a
+// batch: up to three rounds -> the 8-wave kernel), never of a launch's batch size: a chain evaluated alone, in a
 // partial batch or in a full one gets bit-identical results (tests/test_gpu_parity.py).
 static bool use_fused8(const rf_ctx *c)
 {
