@@ -638,7 +638,8 @@ def main():
                                               "(rf_pt_swap_allgather_device)"} if over_rccl else
                                 {"ranks": 0, "version": eng.comm_info()["rccl_version"],
                                  "transport": "none (one rank)" if world == 1 else
-                                              "launcher's process group (ranks share a GPU: functional mode)"}),
+                                              "launcher's process group + rf_pt_swap_gathered_device (librfgpu's own RCCL "
+                                              "communicator not formed: ranks share a GPU, or its bootstrap failed)"}),
                        "perturb_nlay": args.perturb_nlay,
                        "launch_plan": plan, "overrides": overrides,
                        "lib": {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "sha256": lib_sha,

@@ -321,7 +321,9 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
  *                      GPU -> 512; fixed per context, never per launch) | 256 fused_kernel | 512 fused8_kernel
  *                      (nfft 4096 on land only)
  *   "bin_cutoff"       0 (default: every bin like the reference) | tol in (0, 1): bins whose Gaussian filter
- *                      weight is below tol * flt(1) are not propagated
+ *                      weight is below tol * flt(1) are not propagated (contexts with one
+ *                      forward computation per trace only: common-ray contexts share one pass between filters
+ *                      of different width and ignore it)
  * A library built with -DRFGPU_DIAGNOSTICS (tools/ablate.sh; never the shipped one) also accepts
  * "ablate" = N: blocks stop after phase N, results are invalid. */
 int rf_set_option(rf_ctx *ctx, const char *name, double value);

@@ -87,7 +87,24 @@ def open_exchange(engine, dist):
     dist.broadcast_object_list(token, src=0)
     if token[0] is None:
         return False
-    engine.comm_init(token[0], rank, world)
+    # ncclCommInitRank is collective; if it fails anywhere (it fails everywhere or nowhere in practice) every rank
+    # must know, drop what it has and keep the process group as the transport -- a benchmark that dies in its
+    # bootstrap measures nothing
+    from .engine import RFGPUError
+
+    try:
+        engine.comm_init(token[0], rank, world)
+        mine = True
+    except RFGPUError as e:
+        print(f"rank {rank}: librfgpu's RCCL communicator could not be formed ({e}); the launcher's process group "
+              "carries the temperature exchange instead", flush=True)
+        mine = False
+    oks = [None] * world
+    dist.all_gather_object(oks, mine)
+    if not all(oks):
+        if mine:
+            engine.comm_destroy()
+        return False
     return True
 
 
