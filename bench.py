@@ -47,6 +47,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector == matrix peak (datasheet)
+SPEC_CLOCK_GHZ = 2.4      # the engine clock 78.6 TF is quoted at (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4e9)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 ENV_ALLOWED = {"RFGPU_BENCH_BACKEND"}   # "gloo": functional test of the N > 1 path on one GPU
 
@@ -168,6 +169,7 @@ def committed_counters(kernel, grid_threads):
                 out = dict(e["counters"])
                 out["_file"] = os.path.relpath(f, ROOT)
                 out["_lib_sha256"] = d.get("lib_sha256")
+                out["_clock_ghz"] = e.get("clock_ghz")
                 return out
     return None
 
@@ -609,6 +611,13 @@ def main():
                        and "WRITE_SIZE" in ctr else None,
             "kernel": kname, "kernel_ms": kernel_ms, "grid_threads": grid_threads,
             "executed_gflop_per_launch": exe / 1e9 if exe else None,
+            # shader clock this kernel ran at in the counter pass (GRBM_GUI_ACTIVE / 8 XCDs / its duration,
+            # tools/summarize_counters.py): the part lowers it below the 2.4 GHz `peak` is quoted at when the fp64
+            # vector ALUs are the load (HBM-bound kernels of the same pass run at 2.4).  `frac_at_clock` = frac
+            # priced at that clock -- `frac` stays the spec-clock figure.
+            "clock_ghz": ctr.get("_clock_ghz") if ctr else None,
+            "frac_at_clock": (exe / t_k / 1e12 / (FP64_PEAK_TFLOPS * ctr["_clock_ghz"] / SPEC_CLOCK_GHZ)
+                              if exe and t_k and ctr.get("_clock_ghz") and ctr["_lib_sha256"] == lib_sha else None),
             "counters": ({"file": ctr["_file"], "lib_sha256_matches_this_build": ctr["_lib_sha256"] == lib_sha}
                          if ctr else None),
             # SURVEY.md 8d's ALGORITHMIC figure (reference arithmetic: 570 flop/(bin*layer) + 580/bin, + FFT /

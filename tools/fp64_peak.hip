@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -o fp64_peak tools/fp64_peak.hip && ./fp64_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 
 template <int CHAINS>
 __global__ __launch_bounds__(256) void fma_kernel(double *out, double a, double b, int iters)
@@ -46,8 +47,38 @@ static void run(int blocks_per_cu)
     hipFree(out);
 }
 
-int main()
+// `fp64_peak sustain SECONDS`: the 8-chain, 4-waves/SIMD kernel back to back, rate per second of wall time -- does the
+// rate hold once the part has been at full FP64 load for a while (tools/clock_under_load.sh samples clock + power beside it)?
+static void sustain(double seconds)
 {
+    hipDeviceProp_t p;
+    hipGetDeviceProperties(&p, 0);
+    const int blocks = p.multiProcessorCount * 4, iters = 20000;
+    double *out;
+    hipMalloc(&out, sizeof(double) * blocks * 256);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    const double flops = 2.0 * 8 * (double)iters * blocks * 256;
+    double total_ms = 0;
+    for (int window = 0; total_ms < seconds * 1e3; ++window) {
+        int n = 0;
+        float ms = 0;
+        hipEventRecord(e0);
+        for (; n < 200; ++n) hipLaunchKernelGGL(fma_kernel<8>, dim3(blocks), dim3(256), 0, 0, out, 0.999999, 1e-9, iters);
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        hipEventElapsedTime(&ms, e0, e1);
+        total_ms += ms;
+        printf("t=%6.2f s  %.1f TFLOP/s fp64\n", total_ms / 1e3, flops * n / ms / 1e9);
+        fflush(stdout);
+    }
+    hipFree(out);
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 2 && argv[1][0] == 's') { sustain(atof(argv[2])); return 0; }
     run<1>(1); run<2>(1); run<4>(1); run<8>(1);
     run<1>(2); run<4>(2); run<8>(2);
     run<4>(4); run<8>(4); run<8>(8);

@@ -14,14 +14,18 @@ from collections import defaultdict
 out, root = sys.argv[1], sys.argv[2]
 agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
 meta = {}
+gui = defaultdict(list)      # (kernel, grid, wg) -> [(GRBM_GUI_ACTIVE summed over the 8 XCDs, duration in ns)], every kernel
+XCDS = 8
 for f in glob.glob(os.path.join(out, "p*/**/*counter_collection.csv"), recursive=True):
     with open(f) as fh:
         for r in csv.DictReader(fh):
             k = r["Kernel_Name"]
-            if "rfgpu" not in k:
-                continue
             k = k.split("(")[0].replace("void ", "").strip()
             key = (k, int(r["Grid_Size"]), int(r["Workgroup_Size"]))
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp"):
+                gui[key].append((float(r["Counter_Value"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+            if "rfgpu" not in k:
+                continue
             a = agg[key][r["Counter_Name"]]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
@@ -34,9 +38,29 @@ doc = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.pa
                  "means per launch over the launches of that (kernel, grid) shape; FETCH_SIZE / WRITE_SIZE in KiB as "
                  "rocprofv3 reports them (HBM bytes = 2048 * FETCH_SIZE + 1024 * WRITE_SIZE: gfx950 read correction)",
        "kernels": []}
+# Shader clock a kernel actually ran at = busy cycles per XCD / its duration in the same pass.  Every dispatch of a
+# --pmc pass carries a constant bracket of busy cycles (the shortest dispatches are nothing else): subtracted.  Only
+# for shapes that run > 100 us, where that bracket is < 10 % of the count.  `clock_reference`: the longest
+# non-rfgpu dispatch of the pass (an HBM-bound fill) -- what the clock is when the vector ALUs are not the load.
+bracket = min((g / XCDS for v in gui.values() for g, _ in v), default=0.0)
+
+
+def clock_ghz(v):
+    d = sum(t for _, t in v) / len(v)
+    return round(sum(g / XCDS - bracket for g, _ in v) / sum(t for _, t in v), 3) if d > 1e5 else None
+
+
+other = [(sum(t for _, t in v) / len(v), k) for k, v in gui.items() if "rfgpu" not in k[0]]
+if other:
+    d, k = max(other)
+    doc["clock_reference"] = {"kernel": k[0], "grid_threads": k[1], "mean_us": round(d / 1e3, 1), "clock_ghz": clock_ghz(gui[k])}
+doc["clock_method"] = ("GRBM_GUI_ACTIVE (summed over the 8 XCDs by rocprofv3) / 8, minus the per-dispatch bracket "
+                       f"{bracket:.0f} cycles, / (End_Timestamp - Start_Timestamp) of the same dispatch")
 for (k, grid, wg), ctrs in sorted(agg.items()):
     e = {"kernel": k, "grid_threads": grid, "workgroup": wg, **meta[(k, grid, wg)],
          "launches": max(n for n, _ in ctrs.values()), "counters": {c: v / n for c, (n, v) in sorted(ctrs.items())}}
+    if gui.get((k, grid, wg)):
+        e["clock_ghz"] = clock_ghz(gui[(k, grid, wg)])
     doc["kernels"].append(e)
 json.dump(doc, open(os.path.join(out, "counters.json"), "w"), indent=1)
 
@@ -73,4 +97,8 @@ for e in doc["kernels"]:
         line += f" lds_conflict={c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:.2f}"
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         line += f" hbm_MB={(2048 * c['FETCH_SIZE'] + 1024 * c['WRITE_SIZE']) / 1e6:.1f}"
+    if e.get("clock_ghz"):
+        line += f" clock_ghz={e['clock_ghz']}"
     print(line)
+if doc.get("clock_reference"):
+    print(f"\nclock reference: {doc['clock_reference']}\n({doc['clock_method']})")
