@@ -895,13 +895,19 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
     if constexpr (TABLE) __syncthreads();   // every wave is done with the table: the deposits below overwrite it
     // the bins' filter weights: every load is in flight before the first boundary condition is evaluated (the
     // chain's registers are free by now); loaded where they are used, each bin waited for its own
+    // (the 8-bin ocean chain holds 192 state registers at this point: its weights are fetched one bin ahead instead)
+    // and its bin indices are rebuilt from the copy that went through the loop's asm, which nothing derived from can
+    // be hoisted above the loop into registers that would be spilled there)
+    constexpr bool ROLL = NCOL != 2 && BK >= 8;
+    const int kf = ROLL ? kk : k0;
     double wgt[BK];
 #pragma unroll
-    for (int m = 0; m < BK; ++m) wgt[m] = sink.weight(k0 + 64 * m);
+    for (int m = 0; m < (ROLL ? 1 : BK); ++m) wgt[m] = sink.weight(kf + 64 * m);
 #pragma unroll
     for (int m = 0; m < BK; ++m) {
-        const int km = k0 + 64 * m;
+        const int km = kf + 64 * m;
         const double omgm = km == 0 ? P.t.omg_dc : (double)km * P.t.domg;
+        if (ROLL && m + 1 < BK) wgt[m + 1] = sink.weight(km + 64);
         double2 ur, uz;
         finish_bin<NCOL, true>(st[m], tail, omgm, ipha, ur, uz);
         if (keep_ur) {
@@ -2464,7 +2470,11 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
         }
         __syncthreads();
     }
-    trace_tail(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid);
+    // (the 8-bin ocean chain leaves no register for what the compiler would compute ahead of the propagator phase from
+    // the thread index -- shift map, masks, addresses of the tail -- and then spill: its tail gets an opaque copy)
+    int tid_tail = tid;
+    if constexpr (NCOL != 2 && BK >= 8) asm volatile("" : "+v"(tid_tail));
+    trace_tail(P, a, mis, red, ib, itrc, walker, ipha, decon, tp, slot, tid_tail);
 }
 
 // ---------------------------------------------------------------------------
