@@ -47,9 +47,27 @@ static void run(int blocks_per_cu)
     hipFree(out);
 }
 
-// `fp64_peak sustain SECONDS`: the 8-chain, 4-waves/SIMD kernel back to back, rate per second of wall time -- does the
+// The chains above converge to a fixed point: their operands stop toggling, which flatters the power the FMA pipe
+// draws.  `chaos_kernel` iterates x <- x * x + c (c = -1.9: bounded, chaotic, every mantissa bit keeps changing) on 8
+// chains per lane seeded differently: the same instruction rate with operands that behave like data.
+__global__ __launch_bounds__(256) void chaos_kernel(double *out, double c, int iters)
+{
+    double x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = -1.0 + 1e-3 * (threadIdx.x + 1) + 0.11 * k + 1e-7 * blockIdx.x;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) x[k] = fma(x[k], x[k], c);
+    }
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s += x[k];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+// `fp64_peak sustain SECONDS [chaos]`: the 8-chain, 4-waves/SIMD kernel back to back, rate per second of wall time -- does the
 // rate hold once the part has been at full FP64 load for a while (tools/clock_under_load.sh samples clock + power beside it)?
-static void sustain(double seconds)
+static void sustain(double seconds, bool chaos)
 {
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
@@ -65,7 +83,12 @@ static void sustain(double seconds)
         int n = 0;
         float ms = 0;
         hipEventRecord(e0);
-        for (; n < 200; ++n) hipLaunchKernelGGL(fma_kernel<8>, dim3(blocks), dim3(256), 0, 0, out, 0.999999, 1e-9, iters);
+        for (; n < 200; ++n) {
+            if (chaos)
+                hipLaunchKernelGGL(chaos_kernel, dim3(blocks), dim3(256), 0, 0, out, -1.9, iters);
+            else
+                hipLaunchKernelGGL(fma_kernel<8>, dim3(blocks), dim3(256), 0, 0, out, 0.999999, 1e-9, iters);
+        }
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         hipEventElapsedTime(&ms, e0, e1);
@@ -78,7 +101,7 @@ static void sustain(double seconds)
 
 int main(int argc, char **argv)
 {
-    if (argc > 2 && argv[1][0] == 's') { sustain(atof(argv[2])); return 0; }
+    if (argc > 2 && argv[1][0] == 's') { sustain(atof(argv[2]), argc > 3); return 0; }
     run<1>(1); run<2>(1); run<4>(1); run<8>(1);
     run<1>(2); run<4>(2); run<8>(2);
     run<4>(4); run<8>(4); run<8>(8);
