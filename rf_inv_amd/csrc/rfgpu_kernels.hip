@@ -27,9 +27,13 @@
 #ifdef RFGPU_DIAGNOSTICS
 #define RFGPU_ABLATE_AT(n, ret) do { if (P.ablate == (n)) return ret; } while (0)
 #define RFGPU_ABLATE_DO(n, stmt) if (P.ablate == (n)) stmt
+#define RFGPU_ABLATE_IS(n) (P.ablate == (n))
+#define RFGPU_ABLATE_COPY(dst) (dst).ablate = P.ablate
 #else
 #define RFGPU_ABLATE_AT(n, ret) do { } while (0)
 #define RFGPU_ABLATE_DO(n, stmt)
+#define RFGPU_ABLATE_IS(n) false
+#define RFGPU_ABLATE_COPY(dst)
 #endif
 
 namespace rfgpu {
@@ -577,6 +581,7 @@ struct SpectraParams {
     int *slow_list;   // [nslots * nfwd] (walker, trace) pairs deferred to spectra_slow_kernel
     int *slow_count;  // [1] reset by logl_kernel
     WalkerState w;    // stage_kernel's constants (gcoef, gtail, gflag)
+    int ablate;       // RFGPU_DIAGNOSTICS builds only (7: the chained path skips boundary condition + deposit)
 };
 
 // One wave (64 lanes) per (walker, forward-trace, bin-split).  Lanes own frequency
@@ -893,6 +898,16 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
     }
     asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(touch0), "+s"(touch1), "+s"(touch2));
     if constexpr (TABLE) __syncthreads();   // every wave is done with the table: the deposits below overwrite it
+    if (RFGPU_ABLATE_IS(7)) {
+        // timing split (diagnostics builds): the layer loop alone (one store keeps the chain alive)
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < BK; ++m)
+#pragma unroll
+            for (int j = 0; j < NCOL; ++j) acc += st[m].v[j][0] + st[m].v[j][1] + st[m].v[j][2] + st[m].v[j][3];
+        if (acc == 1.2345e300) sink(k0, make_double2(acc, 0.0), make_double2(0.0, acc), 1.0, 0);
+        return;
+    }
     // the bins' filter weights: every load is in flight before the first boundary condition is evaluated (the
     // chain's registers are free by now); loaded where they are used, each bin waited for its own
     // (the 8-bin ocean chain holds 192 state registers at this point: its weights are fetched one bin ahead instead)
@@ -2418,6 +2433,7 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
     const int nh_eff = (t.nh_active && !decon) ? t.nh_active[itrc] : nh;
     SpectraParams sp = F.sp;
     sp.t.nh = nh_eff;
+    RFGPU_ABLATE_COPY(sp);
     for (int k = nh_eff + tid; k < nh; k += TRACE_THREADS) {
         a[fft_pad(fft_input_pos(P.plan, P.log2n, k))] = make_double2(0.0, 0.0);
         if (k != 0 && 2 * k != n) a[fft_pad(fft_input_pos(P.plan, P.log2n, n - k))] = make_double2(0.0, 0.0);

@@ -102,12 +102,18 @@ def test_scalar_prefetch_registers_stay_reserved(isa):
                     exits.append(hi + 1)
                 assert exits, name
                 for e in exits:
-                    k = e
+                    k, steps, hops = e, 0, 0
                     while not ("s_waitcnt lgkmcnt(0)" in body[k] and body[k - 1].strip().startswith(";;#ASMSTART")):
                         assert not touches(k), (name, "prefetch destination touched before the loads are retired", body[k].strip())
+                        jump = re.match(r"\s+s_branch\s+(\.LBB\d+_\d+)", body[k])
+                        if jump:
+                            k = labels[jump.group(1)]      # an unconditional jump is one path: follow it
+                            hops += 1
+                            continue
                         assert not re.search(r"\ts_c?branch|s_endpgm|s_setpc", body[k]), (name, "no retiring wait on a loop exit", body[k].strip())
                         k += 1
-                        assert k - e < 40, (name, "retiring wait not found after the loop")
+                        steps += 1
+                        assert steps < 60 and hops < 4, (name, "retiring wait not found after the loop")
                 checked += 1
                 i = j
             i += 1
@@ -118,8 +124,32 @@ def test_default_plan_kernels_do_not_spill(isa):
     text = "\n".join(isa)
     for kern in ("_ZN5rfgpu12fused_kernelILi8ELi2EEEvNS_11FusedParamsE", "_ZN5rfgpu12fused_kernelILi4ELi3EEEvNS_11FusedParamsE",
                  "_ZN5rfgpu13fused8_kernelILi2EEEvNS_11FusedParamsE", "_ZN5rfgpu14spectra_kernelILi4ELi2EEEvNS_13SpectraParamsE"):
+        # (fused_kernel<8, 3>, the ocean default since round 3, holds 192 state registers: see the next test)
         m = re.search(r"\.name:\s+" + kern + r"\n(?:.*\n){1,20}?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
         assert m, kern
         assert int(m.group(2)) == 0, (kern, "vgpr spills", m.group(2))
     m = re.search(r"\.name:\s+_ZN5rfgpu13fused8_kernelILi2EEEvNS_11FusedParamsE\n(?:.*\n){1,20}?\s+\.vgpr_count:\s+(\d+)", text)
     assert int(m.group(1)) <= 128, "fused8_kernel must fit four waves per SIMD"
+
+
+def test_ocean_eight_bin_chain_spills_only_outside_the_layer_loop(isa):
+    """fused_kernel<8, 3> (three propagated columns x eight bins = 192 state VGPRs) may park a few loop-invariant
+    values in scratch around the layer loop, never inside it."""
+    text = "\n".join(isa)
+    kern = "_ZN5rfgpu12fused_kernelILi8ELi3EEEvNS_11FusedParamsE"
+    m = re.search(r"\.name:\s+" + kern + r"\n(?:.*\n){1,20}?\s+\.vgpr_count:\s+(\d+)\n\s+\.vgpr_spill_count:\s+(\d+)", text)
+    assert m, kern
+    assert int(m.group(2)) <= 24, ("vgpr spills", m.group(2))
+    a, b = _functions(isa)[kern]
+    body = isa[a:b]
+    labels = {mm.group(1): i for i, l in enumerate(body) for mm in [re.match(r"^(\.LBB\d+_\d+):", l)] if mm}
+    loops = []
+    for i, l in enumerate(body):
+        mm = re.search(r"\ts_c?branch\w*\s+(\.LBB\d+_\d+)", l)
+        if mm and mm.group(1) in labels and labels[mm.group(1)] < i:
+            loops.append((labels[mm.group(1)], i))
+    pref = [i for i, l in enumerate(body) if "s_load_dword " in l and body[i - 1].strip().startswith(";;#ASMSTART")]
+    assert pref
+    for i in pref:
+        lo, hi = min((lp for lp in loops if lp[0] <= i <= lp[1]), key=lambda lp: lp[1] - lp[0])
+        assert not any("scratch_" in l for l in body[lo:hi + 1]), "scratch access inside the layer loop"

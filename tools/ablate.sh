@@ -2,7 +2,8 @@
 # where the fused kernel spends its time: a DIAGNOSTICS build (-DRFGPU_DIAGNOSTICS, tools/_ab/librfgpu_diag.so,
 # built here; never the shipped library) stops every block after phase N -- results invalid, timing only:
 #   5: launch + staging only, 1: + propagator phase (no tail), 2: + FFT, 3: + max/shift/store,
-#   4: + quadratic form, 0: full kernel   (8-wave kernels: 1, 2, 3, 0; fusedc_kernel also 6: one trace only)
+#   4: + quadratic form, 0: full kernel   (8-wave kernels: 1, 2, 3, 0; fusedc_kernel also 6: one trace only;
+#   4-wave kernel also 7: everything but the boundary condition + deposit of the bins)
 # ABL_ARGS: extra bench.py arguments (e.g. "--walkers 512": one round of blocks = pure block latency)
 # ABL_LIST: the phases to run (default "5 1 2 3 4 0")
 R=${GRAFT_REPO_ROOT:-$(pwd)}
