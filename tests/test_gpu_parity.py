@@ -868,3 +868,38 @@ def test_long_time_window(oracle):
     with _engine(cfg, obs, nsmp, r_inv, max_walkers=4, nlay_max=30) as eng:
         ll = eng.eval_batch(np.arange(4), nlay, layers, sig)
     assert np.all(np.abs(ll - ref) <= logl_tol(ref)), np.abs(ll - ref)
+
+
+@pytest.mark.parametrize("shape", ["land3", "ocean4", "common3", "decon2"])
+def test_repeated_launches_are_bit_stable(oracle, shape):
+    """Soak: the same batch evaluated 200 times in a row (proposal slots flipping through commits in between) returns
+    the same bits every time -- the hand-offs between blocks (last-arriving trace forms logL, deferred quadratic
+    forms, the order block that sorts for the next launch) have no run-to-run freedom -- and so do the stored traces."""
+    rng = np.random.default_rng(zlib.crc32(shape.encode()))
+    kw = {"land3": dict(rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1]),
+          "ocean4": dict(rayps=[0.06, 0.08, 0.10, 0.12], ipha=[1, 1, -1, -1], sdep=2.0),
+          "common3": dict(rayps=[0.06, 0.06, 0.06], ipha=[1, 1, 1], a_gus=[4.0, 2.5, 1.5]),
+          "decon2": dict(rayps=[0.06, 0.07], ipha=[1, 1], deconv_mode=1)}[shape]
+    cfg = make_cfg(nfft=4096, **kw)
+    ocean = cfg["sdep"] > 0
+    ntrc, nsmp, nb = len(cfg["rayps"]), 101, 1536
+    true = random_stack(rng, 6, ocean, cfg["sdep"])
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, int(rng.integers(3 if ocean else 2, 31)), ocean, cfg["sdep"]) for _ in range(nb)]
+    nlay, layers = pack_layers(stacks, 32)
+    sig = rng.uniform(0.01, 0.05, (nb, ntrc))
+    ids = np.arange(nb)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb) as eng:
+        first = eng.eval_batch(ids, nlay, layers, sig)
+        assert np.all(np.isfinite(first))
+        trace0 = eng.get_rft(7, which=1).copy()
+        for rep in range(200):
+            if rep % 3 == 0:
+                eng.commit(ids, (rng.integers(0, 2, nb)).astype(np.int32))      # some walkers flip their slot
+            ll = eng.eval_batch(ids, nlay, layers, sig)
+            assert np.array_equal(ll, first), (rep, int(np.argmax(ll != first)))
+        assert np.array_equal(eng.get_rft(7, which=1), trace0)
+    idx = rng.choice(nb, 6, replace=False)
+    ref = oracle.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], nsmp)
+    assert np.all(np.abs(first[idx] - ref) <= logl_tol(ref))
