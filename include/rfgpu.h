@@ -216,6 +216,9 @@ int rf_pt_swap_device(rf_ctx *ctx, int32_t npairs, const int32_t *d_pairs, const
  * context (hash of the host name over PCI domain/bus/device, >= 0).  ncclCommInitRank is collective: the host
  * gathers (result, key) of all ranks and calls rf_comm_init only if every rank returned 0 and all keys differ. */
 int rf_comm_probe(rf_ctx *ctx, int64_t *device_key);
+/* optional, process-wide, before anything else of this section: load RCCL from this file instead of the default search
+ * (librccl.so.1 by soname -- inside a PyTorch process the RCCL torch loaded -- then /opt/rocm/lib/librccl.so.1) */
+int rf_comm_set_library(const char *path);
 int rf_comm_get_unique_id(uint8_t *id /* [RF_COMM_ID_BYTES] */);
 int rf_comm_init(rf_ctx *ctx, const uint8_t *id, int32_t rank, int32_t nranks);
 int rf_comm_destroy(rf_ctx *ctx);

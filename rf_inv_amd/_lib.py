@@ -84,6 +84,7 @@ SYMBOLS = {
     "rf_eval_models_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_pt_swap_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_comm_probe": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
+    "rf_comm_set_library": (C.c_int, [C.c_char_p]),
     "rf_comm_get_unique_id": (C.c_int, [C.c_char_p]),
     "rf_comm_init": (C.c_int, [_vp, C.c_char_p, C.c_int32, C.c_int32]),
     "rf_comm_destroy": (C.c_int, [_vp]),

@@ -41,15 +41,21 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
 };
 
+std::string g_rccl_path;   // rf_comm_set_library: this file instead of the default search
+bool g_rccl_tried = false;
+
 Rccl *rccl()
 {
     static Rccl r;
-    static bool tried = false;
-    if (tried) return r.h ? &r : nullptr;
-    tried = true;
-    for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
-        r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-        if (r.h) break;
+    if (g_rccl_tried) return r.h ? &r : nullptr;
+    g_rccl_tried = true;
+    if (!g_rccl_path.empty()) {
+        r.h = dlopen(g_rccl_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    } else {
+        for (const char *name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (r.h) break;
+        }
     }
     if (!r.h) return nullptr;
 #define RF_SYM(n) r.n = reinterpret_cast<decltype(r.n)>(dlsym(r.h, "nccl" #n))
@@ -86,6 +92,17 @@ struct rfgpu::CommState {
         hipError_t e_ = (expr);                                                         \
         if (e_ != hipSuccess) return comm_fail(std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// Which RCCL to load: a file path instead of the default search (librccl.so.1 by soname, then /opt/rocm/lib).  For
+// sites with several RCCL builds -- and for the two-ranks-on-one-GPU test, which points it at a host-staged test
+// double (tests/c/rccl_double.cpp).  Process-wide; must come before the first call that needs RCCL.
+extern "C" int rf_comm_set_library(const char *path)
+{
+    if (!path || !*path) return comm_fail("rf_comm_set_library: empty path");
+    if (g_rccl_tried) return comm_fail("rf_comm_set_library: RCCL has already been loaded in this process");
+    g_rccl_path = path;
+    return 0;
+}
 
 // Can this rank take part in an RCCL communicator?  Returns 0 when librccl.so.1 loads; device_key identifies
 // the context's physical GPU -- a hash of the host name (ranks of different nodes with the same PCI address are

@@ -5,6 +5,8 @@ in the *_device entry points.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 
 import numpy as np
@@ -265,6 +267,13 @@ class RFEngine:
         if lib.rf_comm_get_unique_id(buf):
             raise RFGPUError(lib.rf_last_error().decode())
         return buf.raw
+
+    @staticmethod
+    def comm_set_library(path: str):
+        """Load RCCL from this file instead of the default search (process-wide; before any other comm_* call)."""
+        lib = _lib.load()
+        if lib.rf_comm_set_library(os.fsencode(path)):
+            raise RFGPUError(lib.rf_last_error().decode())
 
     def comm_probe(self):
         """(usable, device_key): can this rank join an RCCL communicator, and on which physical GPU it sits."""

@@ -172,6 +172,11 @@ module rfgpu_c
        integer(c_int64_t), intent(out) :: device_key
      end function rf_comm_probe
 
+     integer(c_int) function rf_comm_set_library(path) bind(C, name="rf_comm_set_library")
+       import :: c_int, c_char
+       character(kind=c_char), intent(in) :: path(*)     ! NUL-terminated
+     end function rf_comm_set_library
+
      integer(c_int) function rf_comm_get_unique_id(id) bind(C, name="rf_comm_get_unique_id")
        import :: c_int, c_int8_t
        integer(c_int8_t), intent(out) :: id(*)

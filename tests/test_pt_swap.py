@@ -178,27 +178,23 @@ def test_gathered_swap_kernel_as_three_ranks_on_one_gpu():
         assert n_cross > 0
 
 
-@pytest.mark.gpu
-def test_rccl_exchange_between_two_gpus(tmp_path):
-    """The cross-rank RCCL traffic for real: two FRESH processes, one per GPU, bootstrap the communicator from
-    rank 0's id and run both exchange forms (tests/tools/rccl_two_rank_worker.py); the temperature history of the
-    ensemble must equal the single-process replay step by step.  Needs two GPUs: skipped on a one-GPU box (where
-    the one-rank communicator test above and the gathered-kernel test are all that can run)."""
+def _run_two_rank_exchange(tmp_path, world, devices, rccl_library=None):
+    """Two FRESH processes drive librfgpu's RCCL entry points like the Fortran host does
+    (tests/tools/rccl_two_rank_worker.py); the temperature history of the ensemble must equal the single-process
+    replay step by step, in the reference's one-pair protocol and in the all-gather form."""
     import subprocess
 
-    if torch.cuda.device_count() < 2:
-        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
     sys.path.insert(0, os.path.join(ROOT, "tests", "tools"))
     import rccl_two_rank_worker as wk
 
-    world = 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "rccl_two_rank_worker.py"), str(r),
-                               str(world), str(tmp_path)], env=env, cwd=ROOT) for r in range(world)]
+                               str(world), str(tmp_path), str(devices[r])] + ([rccl_library] if rccl_library else []),
+                              env=env, cwd=ROOT) for r in range(world)]
     for q in procs:
         assert q.wait(timeout=600) == 0
     keys = [open(tmp_path / f"key_{r}").read() for r in range(world)]
-    assert len(set(keys)) == world                                   # distinct physical GPUs
+    assert len(set(keys)) == len(set(devices))                       # one key per physical GPU
     n_all = world * wk.NCHAINS
     # p2p: rank 0's stream names the pair, then the uniform
     temps = np.concatenate([wk.start_temps(r) for r in range(world)])
@@ -222,10 +218,42 @@ def test_rccl_exchange_between_two_gpus(tmp_path):
     temps = np.concatenate([wk.start_temps(r) for r in range(world)])
     got = [np.load(tmp_path / f"allgather_{r}.npy") for r in range(world)]
     sched = PairSchedule(n_all, wk.SEED, wk.K)
+    n_cross = 0
     for s in range(wk.STEPS):
         ll = np.concatenate([wk.logl_of(r, s) for r in range(world)])
         pairs, logu = sched.draw()
         for (i1, i2), lu in zip(pairs, logu):
             if judge_pt(temps[i1], temps[i2], ll[i1], ll[i2], lu):
                 temps[i1], temps[i2] = temps[i2], temps[i1]
+                n_cross += (i1 // wk.NCHAINS) != (i2 // wk.NCHAINS)
         assert np.array_equal(np.concatenate([g[s + 1] for g in got]), temps), ("allgather", s)
+    assert n_cross > 0
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_between_two_gpus(tmp_path):
+    """The cross-rank RCCL traffic for real: one process per GPU bootstraps the communicator from rank 0's id and
+    runs both exchange forms.  Needs two GPUs: skipped on a one-GPU box (where the next test runs the same ranks
+    over a test double of RCCL)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    _run_two_rank_exchange(tmp_path, 2, [0, 1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_cross_rank_entry_points_with_several_ranks_on_one_gpu(tmp_path, world):
+    """rf_comm_init, rf_comm_bcast_i32, rf_pt_swap_exchange and rf_pt_swap_allgather_device with nranks > 1 on a
+    ONE-GPU box: the ranks share device 0 and librfgpu is pointed (rf_comm_set_library) at tests/c/rccl_double.cpp,
+    a host-staged stand-in for the eleven nccl* calls -- real RCCL refuses two ranks on one device.  Everything
+    above those calls (rank -> walker block mapping, the grouped send/receive and the decision both ranks form from
+    it, the gathered layout the swap kernel indexes, the in-place temperature update) is the code a multi-GPU run
+    executes."""
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib = str(tmp_path / "librccl_double.so")
+    subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-o", lib, os.path.join(ROOT, "tests", "c", "rccl_double.cpp")],
+                   check=True, capture_output=True, timeout=300)
+    _run_two_rank_exchange(tmp_path, world, [0] * world, rccl_library=lib)

@@ -7,7 +7,10 @@ librfgpu's RCCL entry points exactly like the Fortran host does (rf_inv_amd/fort
               (rf_comm_bcast_i32); a cross-rank pair is ONE grouped send/receive (rf_pt_swap_exchange)
   allgather   K disjoint pairs per iteration: rf_pt_swap_allgather_device
 
-usage: rccl_two_rank_worker.py RANK WORLD OUT_DIR
+usage: rccl_two_rank_worker.py RANK WORLD OUT_DIR [DEVICE [RCCL_LIBRARY]]
+DEVICE: the GPU of this rank (default: RANK).  RCCL_LIBRARY: rf_comm_set_library -- the one-GPU variant of the test
+runs both ranks on device 0 over tests/c/rccl_double.cpp, a host-staged test double (real RCCL refuses two ranks on
+one device); everything of librfgpu above the eleven nccl* calls is the code a multi-GPU run executes.
 Writes OUT_DIR/p2p_RANK.npy and OUT_DIR/allgather_RANK.npy: the temperature history [steps + 1, nchains]."""
 import os
 import sys
@@ -34,15 +37,18 @@ def start_temps(rank):
 
 def main():
     rank, world, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    device = int(sys.argv[4]) if len(sys.argv) > 4 else rank
     import torch
 
     from rf_inv_amd import RFEngine
     from rf_inv_amd.pt import PairSchedule
 
+    if len(sys.argv) > 5:
+        RFEngine.comm_set_library(sys.argv[5])
     delta = float(np.float32(0.05))
     eng = RFEngine(nfft=256, delta=delta, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=np.array([0.06]),
                    a_gus=np.array([4.0]), ipha=np.array([1], dtype=np.int32), obs=np.zeros((1, 101)), nsmp=101,
-                   max_walkers=NCHAINS, device=rank)
+                   max_walkers=NCHAINS, device=device)
     ok, key = eng.comm_probe()
     assert ok
     open(os.path.join(out, f"key_{rank}"), "w").write(str(key))
@@ -92,7 +98,7 @@ def main():
     np.save(os.path.join(out, f"p2p_{rank}.npy"), np.stack(hist))
 
     # ---- all-gather form: K disjoint pairs per iteration, everything on the device --------------------------
-    dev = torch.device("cuda", rank)
+    dev = torch.device("cuda", device)
     torch.cuda.set_device(dev)
     d_t = torch.from_numpy(start_temps(rank)).to(dev)
     sched = PairSchedule(n_all, SEED, K)
