@@ -364,6 +364,9 @@ def main():
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="launch-plan option (rf_set_option); echoed in config.overrides")
     ap.add_argument("--lib", default=None, help="another build of librfgpu.so (A/B timing); echoed in config.lib")
+    ap.add_argument("--rccl-library", default=None, metavar="PATH",
+                    help="functional tests on a one-GPU box: librfgpu loads RCCL from this file (rf_comm_set_library; "
+                         "tests/c/rccl_double.cpp) and ranks that share a GPU join its communicator; echoed in config.rccl")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not time the dominant kernel with HIP events")
     ap.add_argument("--copy-logl", action="store_true", help="always read logL back with an async copy")
     ap.add_argument("--dump-state", default=None, metavar="PATH.npz",
@@ -398,6 +401,10 @@ def main():
 
     _lib.load(args.lib)
     lib_sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    if args.rccl_library:
+        from rf_inv_amd import RFEngine as _E
+
+        _E.comm_set_library(args.rccl_library)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -460,7 +467,7 @@ def main():
         h_logl = torch.empty(nb, dtype=torch.float64).pin_memory()
         # N > 1: the temperature exchange runs over librfgpu's own RCCL communicator (one GPU per rank); ranks
         # that share a GPU (functional test) keep the launcher's process group as the transport
-        over_rccl = open_exchange(eng, dist) if world > 1 else False
+        over_rccl = open_exchange(eng, dist, shared_gpu_ok=bool(args.rccl_library)) if world > 1 else False
         swap = (PTSwap(eng, nb, w["temps"], dev, seed=1234, t_high=15.0, mode=args.swap, rccl=over_rccl)
                 if w["temps"] > 1 else None)
         # --perturb-nlay: NV pre-built depth vectors cycled through, so that the timed loop does nothing extra
@@ -646,7 +653,8 @@ def main():
                        "pt_swap": (f"{args.swap}, {swap.k} pair(s)/step" if swap is not None else "none"),
                        "rccl": ({"ranks": eng.comm_info()["nranks"], "version": eng.comm_info()["rccl_version"],
                                  "transport": "librfgpu RCCL group: 2 x ncclAllGather + 1 kernel per step "
-                                              "(rf_pt_swap_allgather_device)"} if over_rccl else
+                                              "(rf_pt_swap_allgather_device)",
+                                 **({"library": args.rccl_library} if args.rccl_library else {})} if over_rccl else
                                 {"ranks": 0, "version": eng.comm_info()["rccl_version"],
                                  "transport": "none (one rank)" if world == 1 else
                                               "launcher's process group + rf_pt_swap_gathered_device (librfgpu's own RCCL "

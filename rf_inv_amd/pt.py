@@ -63,19 +63,21 @@ class PairSchedule:
         return pairs, np.log(u)
 
 
-def open_exchange(engine, dist):
+def open_exchange(engine, dist, shared_gpu_ok=False):
     """Decide once, unanimously, how this run's ranks exchange temperatures -- the Python host's
     `open_temperature_exchange` (rf_inv_amd/fortran/pt_mcmc_batched.f90): every rank probes RCCL and names its
     physical GPU (rf_comm_probe); if all can and all GPUs differ, rank 0 draws the RCCL id (rf_comm_get_unique_id),
     the process group that launched the run carries its 128 bytes to everybody, and every rank joins
     (rf_comm_init) -- from then on the swap step is librfgpu's own RCCL group over xGMI
     (rf_pt_swap_allgather_device).  Ranks that share a GPU (functional tests on a one-GPU box) return False and keep
-    the process group as the transport.  Collective: every rank must call it."""
+    the process group as the transport.  Collective: every rank must call it.
+    shared_gpu_ok: functional tests only -- ranks on one GPU join too (over a test double of RCCL selected with
+    RFEngine.comm_set_library; real RCCL refuses two ranks on one device)."""
     world, rank = dist.get_world_size(), dist.get_rank()
     usable, key = engine.comm_probe()
     seen = [None] * world
     dist.all_gather_object(seen, (bool(usable), int(key)))
-    ok = all(u for u, _ in seen) and len({k for _, k in seen}) == world
+    ok = all(u for u, _ in seen) and (shared_gpu_ok or len({k for _, k in seen}) == world)
     token = [None]
     if ok and rank == 0:
         from .engine import RFEngine, RFGPUError

@@ -343,6 +343,39 @@ def test_bench_two_ranks_on_one_gpu_swap_matches_serial_replay(tmp_path, launche
     assert int(st["swap_steps"]) == 16 + warm + steps
 
 
+def test_bench_rccl_route_with_two_ranks_on_one_gpu(tmp_path):
+    """bench.py's N > 1 path over librfgpu's own communicator -- the route a multi-GPU SCALE run takes:
+    open_exchange's bootstrap (rank 0's id through the process group, rf_comm_init on every rank, unanimous
+    agreement), then rf_pt_swap_allgather_device every step -- as two ranks on the one GPU, with librfgpu pointed at
+    the RCCL test double (tests/c/rccl_double.cpp; real RCCL refuses two ranks on one device).  The JSON line says
+    config.rccl.ranks == 2 and the final temperatures equal the serial replay, swaps across the rank boundary
+    included."""
+    import json
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib = str(tmp_path / "librccl_double.so")
+    subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-o", lib, os.path.join(ROOT, "tests", "c", "rccl_double.cpp")],
+                   check=True, capture_output=True, timeout=300)
+    dump = tmp_path / "state.npz"
+    nb, ntemps, steps, warm = 256, 8, 5, 1
+    env = dict(os.environ, RFGPU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c3", "--walkers", str(nb), "--steps",
+           str(steps), "--warmup", str(warm), "--prewarm-seconds", "0", "--no-cpu-baseline", "--also", "", "--dump-state",
+           str(dump), "--rccl-library", lib]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "walkers sharded x2"
+    assert d["config"]["rccl"]["ranks"] == 2 and d["config"]["rccl"]["library"] == lib
+    assert "rf_pt_swap_allgather_device" in d["config"]["rccl"]["transport"]
+    st = _replay_bench_state(dump, nb, ntemps, 2)
+    assert int(st["swap_steps"]) == 16 + warm + steps
+
+
 def test_bench_gpus_flag_is_honoured_or_refused(tmp_path):
     """`python bench.py --gpus 2` the way the driver's SCALE run may invoke it (no launcher, RCCL backend): on a node
     with two GPUs it must run two ranks over librfgpu's RCCL communicator (n_gpus == 2, config.rccl.ranks == 2, final
