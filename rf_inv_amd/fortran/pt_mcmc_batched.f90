@@ -30,6 +30,11 @@ module pt_mcmc_batched
   implicit none
   public pt_control_batched
   private
+  ! Which RCCL build librfgpu loads for the temperature exchange ("" = its default search: librccl.so.1), set before
+  ! pt_control_batched; and whether ranks that share a GPU may join its communicator -- functional tests only, over a
+  ! test double of RCCL (real RCCL refuses two ranks on one device).
+  character(len=1024), public :: rf_rccl_library = ""
+  logical, public :: rf_exchange_shared_gpu_ok = .false.
 
 contains
 
@@ -283,12 +288,15 @@ contains
       over_rccl = .false.
       if (nproc < 2) return
       usable = 0
+      if (len_trim(rf_rccl_library) > 0) then
+         call rfgpu_check(rf_comm_set_library(trim(rf_rccl_library) // c_null_char), "rf_comm_set_library")
+      end if
       if (rf_comm_probe(rf_ctx, my_key) == 0) usable = 1
       allocate(keys(nproc))
       call mpi_allgather(my_key, 1, MPI_INTEGER8, keys, 1, MPI_INTEGER8, MPI_COMM_WORLD, ierr)
       do ia = 1, nproc - 1
          do ib2 = ia + 1, nproc
-            if (keys(ia) == keys(ib2)) usable = 0      ! two ranks on one GPU
+            if (keys(ia) == keys(ib2) .and. .not. rf_exchange_shared_gpu_ok) usable = 0      ! two ranks on one GPU
          end do
       end do
       token = 0

@@ -5,7 +5,7 @@
 ! init_fftw, which the replaced modules no longer need, and dumps the
 ! per-iteration mean T=1 log-likelihood (what mcmc_out writes to
 ! rslt/likelihood, src/mcmc_out.f90:142) and the proposal counters.
-!   usage: drive_rfinv params.in n_burn n_iter mode [out]  (mode 0: the reference's
+!   usage: drive_rfinv params.in n_burn n_iter mode [out [rccl_library]]  (mode 0: the reference's
 !          pt_control, 1: our pt_control_batched; a fifth argument makes the reference's own
 !          output_results (src/mcmc_out.f90, compiled unmodified) write its result files
 !          into params.in's output directory)
@@ -40,6 +40,11 @@ program drive_rfinv
   if (command_argument_count() > 3) then
      call get_command_argument(4, arg)
      read(arg, *) mode
+  end if
+  if (command_argument_count() > 5) then
+     ! sixth argument: an RCCL library for the temperature exchange (the test double), ranks may share a GPU
+     call get_command_argument(6, rf_rccl_library)
+     rf_exchange_shared_gpu_ok = .true.
   end if
   call read_obs(.false.)
   iseed = iseed + rank * rank * 10000 + 23 * rank

@@ -189,6 +189,38 @@ def test_fortran_batched_sampler_two_mpi_ranks(golden_dir, tmp_path):
 
 
 @pytest.mark.gpu
+def test_fortran_batched_sampler_two_mpi_ranks_over_the_rccl_entry_points(golden_dir, tmp_path):
+    """The same two ranks with the exchange on librfgpu's communicator -- the branch a one-GPU-per-rank run takes
+    (open_temperature_exchange: rf_comm_probe / rf_comm_get_unique_id / mpi_bcast of the id / rf_comm_init;
+    propose_temperature_swap: rf_comm_bcast_i32 + rf_pt_swap_exchange) -- over the RCCL test double
+    (tests/c/rccl_double.cpp; real RCCL refuses two ranks on the one GPU of the box): rank by rank and file by file
+    equal to the reference's pt_control under `mpiexec -np 2`."""
+    mpiexec = "/opt/conda/bin/mpiexec"
+    if not os.path.exists(RFINV) or not os.path.exists(mpiexec):
+        pytest.skip("drive_rfinv or mpiexec not available")
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib = str(tmp_path / "librccl_double.so")
+    subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-o", lib, os.path.join(ROOT, "tests", "c", "rccl_double.cpp")],
+                   check=True, capture_output=True, timeout=300)
+    dumps = []
+    for mode in ("0", "1"):
+        work = tmp_path / f"mpi{mode}"
+        shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
+        os.makedirs(work / "rslt")
+        r = subprocess.run([mpiexec, "-np", "2", RFINV, "params.in", "40", "160", mode, "out"] + ([lib] if mode == "1" else []),
+                           cwd=work, env=dict(os.environ), capture_output=True, text=True, timeout=900)
+        if r.returncode != 0 and ("hydra" in r.stderr.lower() or "unable" in r.stderr.lower()):
+            pytest.skip("mpiexec cannot start processes here: " + r.stderr[-200:])
+        assert r.returncode == 0 and r.stdout.count("drive_rfinv: ok") == 2, r.stdout + r.stderr
+        if mode == "1":
+            assert "Temperature exchange: RCCL (2 ranks" in r.stderr, r.stderr[-500:]
+        dumps.append([open(work / f"rfinv_dump_{k}.txt").read() for k in (0, 1)])
+    assert dumps[0][0] == dumps[1][0] and dumps[0][1] == dumps[1][1]
+    for name in RESULT_FILES:
+        assert open(tmp_path / "mpi0" / "rslt" / name).read() == open(tmp_path / "mpi1" / "rslt" / name).read(), name
+
+
+@pytest.mark.gpu
 def test_fortran_batched_sampler_many_chains(golden_dir, tmp_path):
     """600 chains, 100 of them non-tempered: the batched sampler's evaluation goes through the large-batch
     launch plan (misfits to HBM, quadratic forms and logL by follow-up kernels) while the reference's
