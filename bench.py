@@ -170,6 +170,7 @@ def committed_counters(kernel, grid_threads):
                 out = dict(e["counters"])
                 out["_file"] = os.path.relpath(f, ROOT)
                 out["_lib_sha256"] = d.get("lib_sha256")
+                out["_kernels_sha256"] = d.get("kernels_sha256")
                 out["_clock_ghz"] = e.get("clock_ghz")
                 return out
     return None
@@ -401,6 +402,7 @@ def main():
 
     _lib.load(args.lib)
     lib_sha = hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()
+    kernels_sha = _lib.kernels_sha256(_lib.LIB_PATH)     # the gfx950 code objects alone (.hip_fatbin)
     if args.rccl_library:
         from rf_inv_amd import RFEngine as _E
 
@@ -606,15 +608,20 @@ def main():
         ctr = committed_counters(kname, grid_threads) if grid_threads else None
         exe = executed_fp64_flops(ctr) if ctr else None
         t_k = kernel_ms * 1e-3 if kernel_ms else None
+        # counters describe kernels: they are this build's if its gfx950 code objects (.hip_fatbin) are the ones they
+        # were collected on -- a host-only change of the library keeps them -- or, for files without that hash, if the
+        # whole library is the same file
+        counters_fresh = bool(ctr) and ((bool(ctr.get("_kernels_sha256")) and ctr["_kernels_sha256"] == kernels_sha)
+                                        or ctr["_lib_sha256"] == lib_sha)
         roof = {
             "bound": "fp64_valu", "unit": "TFLOP/s", "peak": FP64_PEAK_TFLOPS,
             # EXECUTED fp64 flops of one launch (committed SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 counters of this
             # kernel at this launch shape) / live HIP-event kernel time: a hardware fraction, <= 1
             # (counters collected on ANOTHER build of the library say nothing about this one: no fraction then)
-            "achieved": exe / t_k / 1e12 if exe and t_k and ctr["_lib_sha256"] == lib_sha else None,
-            "frac": exe / t_k / 1e12 / FP64_PEAK_TFLOPS if exe and t_k and ctr["_lib_sha256"] == lib_sha else None,
+            "achieved": exe / t_k / 1e12 if exe and t_k and counters_fresh else None,
+            "frac": exe / t_k / 1e12 / FP64_PEAK_TFLOPS if exe and t_k and counters_fresh else None,
             "frac_with_stale_counters": (exe / t_k / 1e12 / FP64_PEAK_TFLOPS
-                                         if exe and t_k and ctr["_lib_sha256"] != lib_sha else None),
+                                         if exe and t_k and not counters_fresh else None),
             "traffic": (2048.0 * ctr["FETCH_SIZE"] + 1024.0 * ctr["WRITE_SIZE"]) if ctr and "FETCH_SIZE" in ctr
                        and "WRITE_SIZE" in ctr else None,
             "kernel": kname, "kernel_ms": kernel_ms, "grid_threads": grid_threads,
@@ -625,8 +632,9 @@ def main():
             # priced at that clock -- `frac` stays the spec-clock figure.
             "clock_ghz": ctr.get("_clock_ghz") if ctr else None,
             "frac_at_clock": (exe / t_k / 1e12 / (FP64_PEAK_TFLOPS * ctr["_clock_ghz"] / SPEC_CLOCK_GHZ)
-                              if exe and t_k and ctr.get("_clock_ghz") and ctr["_lib_sha256"] == lib_sha else None),
-            "counters": ({"file": ctr["_file"], "lib_sha256_matches_this_build": ctr["_lib_sha256"] == lib_sha}
+                              if exe and t_k and ctr.get("_clock_ghz") and counters_fresh else None),
+            "counters": ({"file": ctr["_file"], "lib_sha256_matches_this_build": ctr["_lib_sha256"] == lib_sha,
+                          "kernels_sha256_matches_this_build": bool(ctr.get("_kernels_sha256")) and ctr["_kernels_sha256"] == kernels_sha}
                          if ctr else None),
             # SURVEY.md 8d's ALGORITHMIC figure (reference arithmetic: 570 flop/(bin*layer) + 580/bin, + FFT /
             # shift / quadratic form when fused) over the same kernel time.  The eigen-coordinate real-form
@@ -661,7 +669,7 @@ def main():
                                               "communicator not formed: ranks share a GPU, or its bootstrap failed)"}),
                        "perturb_nlay": args.perturb_nlay,
                        "launch_plan": plan, "overrides": overrides,
-                       "lib": {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "sha256": lib_sha,
+                       "lib": {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "sha256": lib_sha, "kernels_sha256": kernels_sha,
                                "default_build": args.lib is None},
                        "prewarm": {"seconds": args.prewarm_seconds, "steps": n_pre},
                        "events_every": every},

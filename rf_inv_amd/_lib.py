@@ -137,3 +137,30 @@ def load(path=None):
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def kernels_sha256(path=None):
+    """sha256 of the library's `.hip_fatbin` section -- the gfx950 code objects of every kernel, nothing of the host
+    side: what hardware counters of a kernel are a property of (bench.py's roofline matches committed counters on
+    it, so that a host-only change of the library does not orphan them).  None if the section cannot be found."""
+    import hashlib
+    import struct
+
+    path = path or LIB_PATH
+    try:
+        with open(path, "rb") as fh:
+            b = fh.read()
+        if b[:4] != b"\x7fELF" or b[4] != 2:
+            return None
+        shoff, = struct.unpack_from("<Q", b, 0x28)
+        shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+        sec = lambda i: struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize)   # name, type, flags, addr, off, size, ...
+        str_off = sec(shstrndx)[4]
+        for i in range(shnum):
+            name, _, _, _, off, size = sec(i)[:6]
+            end = b.index(b"\0", str_off + name)
+            if b[str_off + name:end] == b".hip_fatbin":
+                return hashlib.sha256(b[off:off + size]).hexdigest()
+    except (OSError, ValueError, struct.error):
+        pass
+    return None

@@ -32,7 +32,12 @@ for f in glob.glob(os.path.join(out, "p*/**/*counter_collection.csv"), recursive
             meta[key] = {"lds": int(r["LDS_Block_Size"]), "scratch": int(r["Scratch_Size"]), "vgpr": int(r["VGPR_Count"]),
                          "sgpr": int(r["SGPR_Count"])}
 lib = os.path.join(root, "rf_inv_amd", "lib", "librfgpu.so")
+sys.path.insert(0, root)
+from rf_inv_amd._lib import kernels_sha256  # noqa: E402  (ELF parsing only: loads nothing)
+
 doc = {"lib_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest() if os.path.exists(lib) else None,
+       # the library's .hip_fatbin section alone: counters are a property of the kernels, bench.py matches on this
+       "kernels_sha256": kernels_sha256(lib) if os.path.exists(lib) else None,
        "source": "tools/collect_counters.sh: rocprofv3 --pmc <set> (one set per run; FETCH_SIZE and WRITE_SIZE in separate "
                  "passes) over `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --prewarm-seconds 0`; values are "
                  "means per launch over the launches of that (kernel, grid) shape; FETCH_SIZE / WRITE_SIZE in KiB as "
