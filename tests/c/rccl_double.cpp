@@ -7,7 +7,7 @@
 // contribution device -> shared memory, waits for the other ranks, copies their contributions back to the device.
 // Same call semantics as RCCL at the level librfgpu relies on: results are in place for later work on the stream;
 // all-gather lays rank blocks out in rank order; sends and receives of one group do not deadlock.  Every wait gives
-// up after 30 s with an error instead of hanging a test.
+// up after 120 s with an error instead of hanging a test.
 //   hipcc -shared -fPIC -o librccl_double.so tests/c/rccl_double.cpp
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -78,7 +78,7 @@ bool wait_for(F ready)
 {
     const double t0 = now();
     while (!ready()) {
-        if (now() - t0 > 30.0) return false;
+        if (now() - t0 > 120.0) return false;
         sched_yield();
     }
     __sync_synchronize();
@@ -151,7 +151,7 @@ ncclResult_t ncclGetVersion(int *version)
 
 const char *ncclGetErrorString(ncclResult_t r)
 {
-    return r == ncclSuccess ? "no error" : r == ncclSystemError ? "rccl_double: a rank did not arrive within 30 s"
+    return r == ncclSuccess ? "no error" : r == ncclSystemError ? "rccl_double: a rank did not arrive within 120 s"
                                                                   : "rccl_double: error";
 }
 
