@@ -26,6 +26,9 @@ def main():
     worst, n_allow, n_items = 0.0, 0, 0
     for case in range(ncases):
         nfft = int(rng.choice([256, 512, 1024, 2048, 4096]))
+        long_series = rng.integers(0, 7) == 0       # now and then: the split plans (direct DFT, four-step, Bluestein)
+        if long_series:
+            nfft = int(rng.choice([1000, 1500, 3000, 6000, 8192, 16384]))
         ntrc = int(rng.integers(1, 5))
         ocean = bool(rng.integers(0, 2))
         sdep = 2.0 if ocean else 0.0
@@ -40,6 +43,8 @@ def main():
         nsmp = int(rng.choice([61, 101, 161]))
         kmax = int(rng.choice([6, 15, 30]))
         nb = int(rng.choice([1, 3, 17, 130, 300, 700]))
+        if long_series:
+            nb = int(rng.choice([1, 3, 17]))           # (the oracle's any-length transform is O(n^2))
         cfg = make_cfg(nfft=nfft, deconv_mode=deconv, t_start=t_start, sdep=sdep, rayps=rayps, a_gus=a_gus, ipha=ipha)
         true = random_stack(rng, int(rng.integers(3, 7)), ocean, sdep)
         obs = synth_obs(oracle, cfg, true, nsmp)
