@@ -1674,6 +1674,7 @@ struct TraceParams {
 };
 
 constexpr int PHI_W = 8;   // batch items per block of phi_deferred_kernel
+constexpr int PHI_ROWS = 13;   // rows of R^-1 whose loads are in flight together
 
 // FFT with the last pass in registers, vertical maximum, shift / normalise / store and misfit for
 // nfft = 256 * 2^LOG2R (trace_tail).  Returns true when the block is finished (ablation, or the misfits
@@ -3207,9 +3208,11 @@ __global__ __launch_bounds__(256) void logl_kernel(LoglParams P)
 // LAST trace forms the group's logL (likelihood.f90:94-96, same operation order, no FMA contraction): the quadratic
 // forms cross blocks by agent-scope stores, a drained write and a counter, like the in-kernel multi-trace hand-off.
 // (Until round 3 a second kernel, one thread per item, formed logL: one launch and ~5 us of stream time more per
-// batch.  Measured alternatives, all slower than this 45 us at the C4 shape: one block walking a group's traces in
+// batch.  Measured alternatives, all slower than its 55 us at the C4 shape: one block walking a group's traces in
 // turn, 56 us; that with 512 threads, one column per lane and 32 row loads in flight, 60 us; the misfits as scalar
-// operands from an item-interleaved layout instead of LDS, 78 us.)
+// operands from an item-interleaved layout instead of LDS, 78 us.  With the row loads grouped (PHI_ROWS): 51.5 us.
+// The block is a chain of latencies -- misfits in, rows of R^-1 from L2, partial sums across the waves, the
+// hand-off's drained store and counter -- with 4 blocks per CU to hide them behind.)
 __global__ __launch_bounds__(256) void phi_deferred_kernel(LoglParams P)
 {
     extern __shared__ double lds[];
@@ -3236,15 +3239,27 @@ __global__ __launch_bounds__(256) void phi_deferred_kernel(LoglParams P)
         double acc0[PHI_W], acc1[PHI_W];
 #pragma unroll
         for (int w = 0; w < PHI_W; ++w) acc0[w] = acc1[w] = 0.0;
-#pragma unroll 4
-        for (int i = r0; i < r1; ++i) {
-            const double xa = RT[(size_t)i * nsmp + j];
-            const double xb = two ? RT[(size_t)i * nsmp + j2] : 0.0;
+        // rows in groups of PHI_ROWS: every load of a group is in flight before its first use (the loop is a chain of
+        // L2 latencies otherwise: 7 of them for nsmp = 101 at four rows per trip); rows stay in ascending order
+        for (int g0 = r0; g0 < r1; g0 += PHI_ROWS) {
+            double xa[PHI_ROWS], xb[PHI_ROWS];
 #pragma unroll
-            for (int w = 0; w < PHI_W; ++w) {
-                const double m = mis[w * nsmp + i];
-                acc0[w] = fma(m, xa, acc0[w]);
-                acc1[w] = fma(m, xb, acc1[w]);
+            for (int u = 0; u < PHI_ROWS; ++u) {
+                const int i = g0 + u < r1 ? g0 + u : r1 - 1;
+                xa[u] = RT[(size_t)i * nsmp + j];
+                xb[u] = two ? RT[(size_t)i * nsmp + j2] : 0.0;
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int u = 0; u < PHI_ROWS; ++u) {
+                if (g0 + u < r1) {
+#pragma unroll
+                    for (int w = 0; w < PHI_W; ++w) {
+                        const double m = mis[w * nsmp + g0 + u];
+                        acc0[w] = fma(m, xa[u], acc0[w]);
+                        acc1[w] = fma(m, xb[u], acc1[w]);
+                    }
+                }
             }
         }
 #pragma unroll
