@@ -903,3 +903,41 @@ def test_repeated_launches_are_bit_stable(oracle, shape):
     idx = rng.choice(nb, 6, replace=False)
     ref = oracle.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], nsmp)
     assert np.all(np.abs(first[idx] - ref) <= logl_tol(ref))
+
+
+def test_contexts_give_their_memory_back(oracle):
+    """Create / use / destroy a context 60 times (every kind of plan: fused, common-ray, long series; posterior
+    accumulators; the per-call staging): the device's free memory ends where it started -- rf_ctx_destroy releases
+    everything a context allocated, lazily allocated buffers included."""
+    import torch
+
+    rng = np.random.default_rng(11)
+    shapes = [dict(nfft=4096, rayps=[0.06, 0.08], ipha=[1, -1]),
+              dict(nfft=4096, rayps=[0.06, 0.06, 0.06], ipha=[1, 1, 1], a_gus=[4.0, 2.5, 1.5]),
+              dict(nfft=512, rayps=[0.06], ipha=[1], sdep=2.0),
+              dict(nfft=3000, rayps=[0.06], ipha=[1]),
+              dict(nfft=16384, rayps=[0.07], ipha=[1])]
+    nsmp = 61
+
+    def cycle(kw):
+        cfg = make_cfg(**kw)
+        ocean = cfg["sdep"] > 0
+        stack = random_stack(rng, 5, ocean, cfg["sdep"])
+        obs = np.zeros((len(cfg["rayps"]), nsmp))
+        r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+        nlay, layers = pack_layers([stack] * 4, 8)
+        with _engine(cfg, obs, nsmp, r_inv, max_walkers=300, nlay_max=8) as eng:
+            ll = eng.eval_batch(np.arange(4), nlay, layers, np.full((4, len(cfg["rayps"])), 0.02))
+            eng.calc_rf(len(stack[0]), *stack)          # the per-call staging
+            assert np.all(np.isfinite(ll))
+
+    for kw in shapes:          # first use of every code path (kernel images, allocator pools) before the baseline
+        cycle(kw)
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for rep in range(12):
+        for kw in shapes:
+            cycle(kw)
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    assert free0 - free1 < 64 << 20, (free0, free1)      # (the allocator may keep a few pooled blocks: far below one context)
