@@ -819,12 +819,12 @@ def test_optional_filter_support_cutoff(oracle):
     assert np.abs(out["1e-20"][1] - out[""][1]).max() <= 1e-15 * np.abs(out[""][1]).max()
 
 
-@pytest.mark.parametrize("nsmp", [101, 161])
+@pytest.mark.parametrize("nsmp", [5, 101, 161])
 @pytest.mark.parametrize("defer", ["0", "1"])
 def test_deferred_loglikelihood_kernel(oracle, defer, nsmp):
     """Multi-trace batches can form logL in a follow-up kernel instead of the cross-block hand-off inside
     the fused kernel (option defer_logl; chosen by batch size by default): same values, including
-    sigma-only items (fwd_flag 0) and a second evaluation after a commit.  nsmp 101: R^-1 held in
+    sigma-only items (fwd_flag 0) and a second evaluation after a commit.  nsmp 5: waves without rows; 101: R^-1 held in
     registers by the follow-up kernel; 161: streamed."""
     rng = np.random.default_rng(321)
     cfg = make_cfg(nfft=512, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], t_start=-1.0)
