@@ -18,9 +18,11 @@ Workloads (BASELINE.json configs):
   c4common       c4 with ONE ray for all three traces (common-ray / "single FWD" mode,
                  src/forward.f90:59-91,141): fusedc_kernel, one block per walker
   c1, c2d        sample_syn shape (nfft 256) / c2 with water-level deconvolution
+  c4w20, c4w60   c4 with a 20 s / 60 s time window (nsmp 401 / 1201): the long-window likelihood plan, the batch's
+                 quadratic forms as one FP64-MFMA GEMM
 
-At N = 1 the default run also measures c2, c3, c5 (BASELINE's 32768 walkers/GPU) and c4common briefly into
-"also", plus the c4 shape with walker depths that change every step (`--perturb-nlay`: the dispatch order the
+At N = 1 the default run also measures c2, c2d, c3, c5 (BASELINE's 32768 walkers/GPU), c4common, c4w20 and c4w60
+briefly into "also", plus the c4 shape with walker depths that change every step (`--perturb-nlay`: the dispatch order the
 previous launch prepared is then one proposal stale, as in a real chain).
 
 `--gpus N` without a launcher (WORLD_SIZE unset) starts N rank processes itself -- before anything touches a GPU,
@@ -47,7 +49,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector == matrix peak (datasheet)
-ALSO_NOMINAL_MS = {"c1": 0.03, "c2": 0.075, "c2d": 0.08, "c3": 0.45, "c4": 1.9, "c4common": 0.95, "c5": 13.0}   # ms per step
+ALSO_NOMINAL_MS = {"c1": 0.03, "c2": 0.075, "c2d": 0.08, "c3": 0.45, "c4": 1.9, "c4common": 0.95, "c5": 13.0,
+                   "c4w20": 2.2, "c4w60": 4.0}   # ms per step
 SPEC_CLOCK_GHZ = 2.4      # the engine clock 78.6 TF is quoted at (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4e9)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 ENV_ALLOWED = {"RFGPU_BENCH_BACKEND"}   # "gloo": functional test of the N > 1 path on one GPU
@@ -76,6 +79,18 @@ WORKLOADS = {
                     "walkers/GPU x 4 traces (P .06, P .08, S .10, S .12) x nfft 4096 x ocean layer (sdep 2 km) x <=31 "
                     "layers, PT swap (BASELINE's 'buried station' has no reference behaviour: the borehole branch of "
                     "forward.f90:289-338 is commented out)"),
+    # real time windows: the reference takes any window up to npts_max = 2000 samples (src/params.f90:44) and its
+    # quadratic form grows with nsmp^2 (src/likelihood.f90:92-93): the long-window plan (one FP64-MFMA GEMM per batch)
+    "c4w20": dict(walkers=8192, nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], k_max=30, sdep=0.0, deconv=0,
+                  temps=8, t_end=20.0,
+                  desc="c4w20: the c4 shape with a 20 s time window (t_end 20 -> nsmp 401; R^-1 1.29 MB per trace): "
+                       "8192 walkers/GPU x 3 traces x nfft 4096 x <=30 layers, PT swap; quadratic forms as one "
+                       "FP64-MFMA GEMM per batch (phi_gemm_kernel)"),
+    "c4w60": dict(walkers=8192, nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], k_max=30, sdep=0.0, deconv=0,
+                  temps=8, t_end=60.0,
+                  desc="c4w60: the c4 shape with a 60 s time window (t_end 60 -> nsmp 1201; R^-1 11.5 MB per trace): "
+                       "8192 walkers/GPU x 3 traces x nfft 4096 x <=30 layers, PT swap; quadratic forms as one "
+                       "FP64-MFMA GEMM per batch (phi_gemm_kernel)"),
     "c1": dict(walkers=1024, nfft=256, rayps=[0.06, 0.08], ipha=[1, 1], k_max=10, sdep=2.0, deconv=0, temps=1,
                desc="c1-shape: 1024 walkers/GPU x 2 P traces x nfft 256 x ocean x <=11 layers"),
 }
@@ -95,7 +110,11 @@ def make_params(w):
     p.sig_min = np.full(n, 0.01); p.sig_max = np.full(n, 0.01); p.sig_mode = np.zeros(n, dtype=np.int32)
     p.k_min, p.k_max, p.sdep, p.deconv_mode = 1, w["k_max"], w["sdep"], w["deconv"]
     p.delta = float(np.float32(0.05))
-    p.t_start, p.t_end, p.nsmp = 0.0, 5.0, 101
+    # nsmp as read_obs forms it (src/params.f90:449-451) for a SAC file that starts at b = 0: 101 for the 5 s window
+    from rf_inv_amd.params import _nint
+
+    p.t_start, p.t_end = 0.0, float(w.get("t_end", 5.0))
+    p.nsmp = _nint(p.t_end / p.delta) - _nint(p.t_start / p.delta) + 1
     return p
 
 
@@ -359,7 +378,7 @@ def main():
                          "reference's one pair per iteration via send/recv")
     ap.add_argument("--also", default=None,
                     help="comma list of extra workloads measured briefly into 'also' (default at N = 1: "
-                         "c2,c3,c5,c4common; '' for none)")
+                         "c2,c2d,c3,c5,c4common,c4w20,c4w60,c4stale; '' for none)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
                     help="untimed steps run for at least this long before --warmup (clock ramp; independent of --warmup)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -681,10 +700,25 @@ def main():
                 "note": "algorithmic bytes/eval (layers+sigma in, prop_rft(nfft,ntrc)+logL out) x evals/s of this rank; "
                         "the path is FP64-ALU bound, not HBM bound",
             },
-            "kernel_ms": ({"fused": kernel_ms} if plan["fused"] else
-                          {"spectra": kernel_ms, "trace": prof["trace_ms"] / n_l}),
+            # HIP-event times per step of the kernels of the batch: the fused kernel (or spectra + trace), and the
+            # follow-up that forms the quadratic forms + logL when the trace kernel leaves its misfits in HBM
+            # (phi_deferred_kernel, or on the long-window plan phi_gemm_kernel + phi_gemm_finish_kernel)
+            "kernel_ms": dict(({"fused": kernel_ms} if plan["fused"] else
+                               {"spectra": kernel_ms, "trace": prof["trace_ms"] / n_l}),
+                              **({"quadratic_form_logl": prof["logl_ms"] / n_l} if prof["logl_launches"] else {})),
             "alg_gflop_per_step": float(f_tot.sum()) / 1e9,
         }
+        if plan["long_window_gemm"] and prof["logl_launches"]:
+            # the long-window plan's GEMM: Phi1 = M_t R^-1_t per trace on the FP64 matrix cores, 2 nb ntrc nsmp^2
+            # algorithmic flops (src/likelihood.f90:92: matmul(misfits, r_inv)); the time includes the logL kernel
+            gf = 2.0 * nb * p.ntrc * float(p.nsmp) ** 2
+            t_q = prof["logl_ms"] / n_l * 1e-3
+            res["quadratic_form_gemm"] = {
+                "kernel": "rfgpu::phi_gemm_kernel + phi_gemm_finish_kernel", "bound": "fp64_mfma", "unit": "TFLOP/s",
+                "peak": FP64_PEAK_TFLOPS, "gflop_per_launch": gf / 1e9, "ms": 1e3 * t_q,
+                "achieved": gf / t_q / 1e12, "frac": gf / t_q / 1e12 / FP64_PEAK_TFLOPS,
+                "note": "v_mfma_f64_16x16x4_f64 alone reaches 47 TF on this part (tools/mfma_overlap.hip, "
+                        "profiles/r03_mfma_overlap.txt); R^-1 streamed once per 128 walkers"}
         if rank == 0 and (with_cpu or parity_n):
             from oracle import rf_oracle as orc
 
@@ -704,9 +738,10 @@ def main():
         return res
 
     main_res = run(args.workload, args.steps, args.warmup, not args.no_cpu_baseline and world == 1)
-    also_list = args.also if args.also is not None else ("c2,c3,c5,c4common,c4stale" if world == 1 else "")
+    also_list = args.also if args.also is not None else ("c2,c2d,c3,c5,c4common,c4w20,c4w60,c4stale" if world == 1 else "")
     also = {}
-    keep = ("value", "ms_per_step", "ms_per_step_median", "steps", "config", "roofline", "kernel_ms", "parity_in_bench")
+    keep = ("value", "ms_per_step", "ms_per_step_median", "steps", "config", "roofline", "kernel_ms", "parity_in_bench",
+            "quadratic_form_gemm")
     for wl in [x for x in also_list.split(",") if x and x != args.workload]:
         if wl == "c4stale":
             # the c4 shape with 30 % of the walkers changing depth every step: the order the previous launch

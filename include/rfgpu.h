@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define RFGPU_ABI_VERSION 4
+#define RFGPU_ABI_VERSION 5
 
 typedef struct rf_ctx rf_ctx;
 
@@ -331,7 +331,7 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
  * "ablate" = N: blocks stop after phase N, results are invalid. */
 int rf_set_option(rf_ctx *ctx, const char *name, double value);
 
-/* how rf_eval_batch* will launch, plan[12]:
+/* how rf_eval_batch* will launch, plan[16] (entries beyond those listed are 0):
  *  [0] 1 when spectra + trace run as ONE fused kernel (contexts with one forward computation per trace), 2 when
  *      they run as the common-ray fused kernel (several traces of one ray, nfft 4096 on land: one block per walker,
  *      one propagator pass, ntrc trace tails); then ms[0] of rf_profile_read is that kernel and ms[1] stays 0
@@ -339,7 +339,11 @@ int rf_set_option(rf_ctx *ctx, const char *name, double value);
  *  [3] bin-splits per walker at a full batch     [4] lpt   [5] order_reuse   [6] defer_logl (-1 / 0 / 1)
  *  [7] 1 when a bin cut-off is active            [8] number of options away from their defaults
  *  [9] 0 production build | 1 RFGPU_DIAGNOSTICS build | 2 diagnostics build with "ablate" set (results invalid)
- *  [10] the "block_threads" option (0 = by capacity)   [11] threads per block of the context's fused kernel */
+ *  [10] the "block_threads" option (0 = by capacity)   [11] threads per block of the context's fused kernel
+ *  [12] 1 on the long-window plan (nsmp > 191; the reference allows npts_max = 2000, src/params.f90:44): every trace
+ *       kernel leaves its misfits in HBM and the quadratic forms misfit . R^-1 . misfit of the whole batch run as ONE
+ *       tiled GEMM on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) followed by logL; "defer_logl" is then ignored.
+ *       Fixed per context from nsmp; ms[2] of rf_profile_read is the GEMM + logL pair */
 int rf_get_launch_plan(const rf_ctx *ctx, int32_t *plan);
 
 /* HIP-event timing (on the streams the kernels are launched on) of the three kernels

@@ -38,6 +38,7 @@ struct rf_ctx {
     int device = 0;
     int nh = 0, nfwd = 1, ray_common = 1, nslots = 0;
     DeviceTables tab{};
+    PhiGemmTables pg{};       // long windows (tab.phi_gemm): the zero-padded R^-1 image and the partial sums of phi_gemm_kernel
     WalkerState ws{};
     hipStream_t stream = nullptr;
     // owned device allocations
@@ -238,6 +239,17 @@ static std::vector<double> transpose_r_inv(const std::vector<double> &r, int ntr
     return out;
 }
 
+// long windows: R^-1(i, j, t) at [(t * kp + i) * np + j], zero beyond nsmp (phi_gemm_kernel's B operand)
+static std::vector<double> pad_r_inv(const std::vector<double> &r, int ntrc, int nsmp, int kp, int np)
+{
+    std::vector<double> out((size_t)ntrc * kp * np, 0.0);
+    for (int t = 0; t < ntrc; ++t)
+        for (int j = 0; j < nsmp; ++j)
+            for (int i = 0; i < nsmp; ++i)
+                out[((size_t)t * kp + i) * np + j] = r[((size_t)t * nsmp + j) * nsmp + i];
+    return out;
+}
+
 static int ensure_stage(rf_ctx *c, int nb, int pad)
 {
     if (nb <= c->stage_nb && pad <= c->stage_pad) return 0;
@@ -402,6 +414,23 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     T.omg_dc = (double)1.0e-5f;             // forward.f90:247 single-precision literal
     std::vector<double> r_inv_t = transpose_r_inv(c->r_inv, ntrc, nsmp);
     T.nh_active = nullptr;   // rf_set_option("bin_cutoff"): opt-in, off by default
+    // Windows beyond what phi_deferred_kernel's LDS holds (nsmp > 191; the reference allows npts_max = 2000,
+    // src/params.f90:44): the quadratic forms of a batch run as one GEMM on the FP64 matrix cores (phi_gemm_kernel).
+    // Decided from nsmp alone, once: a chain evaluated alone, in a partial or in a full batch takes the same plan.
+    T.phi_gemm = phi_deferred_lds_bytes(nsmp) > 60 * 1024 ? 1 : 0;
+    T.lds_nsmp = T.phi_gemm ? 0 : nsmp;
+    T.mis_stride = T.phi_gemm ? (nsmp + 15) / 16 * 16 : nsmp;
+    if (T.phi_gemm) {
+        PhiGemmTables &g = c->pg;
+        g.kp = T.mis_stride;
+        g.np = (nsmp + 127) / 128 * 128;
+        g.nchunk = g.np / 64;
+        g.pstride = c->nslots;
+        const std::vector<double> rg = pad_r_inv(c->r_inv, ntrc, nsmp, g.kp, g.np);
+        void *q = nullptr;
+        if (upload(c, rg, &g.rg) || dev_alloc(c, &q, sizeof(double) * (size_t)ntrc * g.nchunk * g.pstride)) return cleanup(1);
+        g.part = (double *)q;
+    }
     if (upload(c, c->flt, &T.flt) || upload(c, obs, &T.obs) || upload(c, r_inv_t, &T.r_inv_t) ||
         upload(c, rayps, &T.rayps) || upload(c, ipha, &T.ipha) || upload(c, tw, &T.twiddle))
         return cleanup(1);
@@ -429,8 +458,10 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->ws.done = (int *)p;
     (void)hipMemset(p, 0, sizeof(int) * c->nslots);
-    if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * ntrc * nsmp)) return cleanup(1);
+    if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * ntrc * T.mis_stride)) return cleanup(1);
     c->ws.misfit = (double *)p;
+    // (long windows: the padding of a row is never written and must read as zero)
+    if (hipMemset(p, 0, sizeof(double) * (size_t)c->nslots * ntrc * T.mis_stride) != hipSuccess) return cleanup(fail("hipMemset failed"));
     // stage_kernel's output (fused path): nlay_max * NCOEF doubles per (walker, forward-trace)
     if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * c->nfwd * cfg->nlay_max * NCOEF)) return cleanup(1);
     c->ws.gcoef = (double *)p;
@@ -523,9 +554,10 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
         if (dev_alloc(c, &q, sizeof(double2) * 2 * L.row_entries * (size_t)c->long_rows)) return cleanup(1);
         L.scratch = (double2 *)q;
     }
-    if (!c->long_series && !pow2 && trace_anyn_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024) {
+    const int lnsmp = T.lds_nsmp;   // what the trace kernels keep of the window in LDS (nothing on the long-window plan)
+    if (!c->long_series && !pow2 && trace_anyn_lds_bytes(n, lnsmp, cfg->nlay_max) > 160 * 1024) {
         // longer series: only the filtered spectra stay in LDS, the time series goes through a scratch row per block
-        if (trace_anyn_big_lds_bytes(n, nsmp) > 160 * 1024)
+        if (trace_anyn_big_lds_bytes(n, lnsmp) > 160 * 1024)
             return cleanup(fail("rf_ctx_create: an nfft that is not a power of two is transformed by a direct DFT whose "
                                 "spectra must fit the 160 KiB LDS of a CU (nfft up to ~9000); use a power of two for "
                                 "longer series"));
@@ -534,13 +566,13 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
         c->anyn_scratch = (double2 *)p;
     }
     if (spectra_lds_bytes(cfg->nlay_max) > 160 * 1024 ||
-        (pow2 && !c->long_series && trace_lds_bytes(n, nsmp, cfg->nlay_max) > 160 * 1024) ||
-        (c->long_series && trace_long_lds_bytes(nsmp) > 160 * 1024) ||
-        sizeof(double) * (size_t)(5 * ((nsmp + 1) & ~1) + 8) > 160 * 1024)   // phi_kernel (host-owned traces)
+        (pow2 && !c->long_series && trace_lds_bytes(n, lnsmp, cfg->nlay_max) > 160 * 1024) ||
+        (c->long_series && trace_long_lds_bytes(lnsmp) > 160 * 1024) ||
+        (!T.phi_gemm && sizeof(double) * (size_t)(5 * ((nsmp + 1) & ~1) + 8) > 160 * 1024))   // phi_kernel (host-owned traces)
         return cleanup(fail("rf_ctx_create: nfft / nsmp / nlay_max exceed the 160 KiB LDS of a gfx950 CU"));
-    c->fused_allowed = pow2 && (c->nfwd == ntrc) && fused_lds_bytes(n, nsmp, cfg->nlay_max) <= 160 * 1024;
+    c->fused_allowed = pow2 && (c->nfwd == ntrc) && fused_lds_bytes(n, lnsmp, cfg->nlay_max) <= 160 * 1024;
     c->fusedc_allowed = n == 4096 && c->ray_common && ntrc > 1 && cfg->sdep <= 0.0 &&
-                        fused8_lds_bytes(nsmp, cfg->nlay_max) <= 80 * 1024;
+                        fused8_lds_bytes(lnsmp, cfg->nlay_max) <= 80 * 1024;
     default_plan(c);
     *ctx_out = c;
     return 0;
@@ -655,11 +687,25 @@ static int pick_nsplit(const rf_ctx *c, int nb)
 static bool use_fused8(const rf_ctx *c)
 {
     const bool can = c->fused && c->cfg.nfft == 4096 && c->cfg.sdep <= 0.0 && c->chain_override < 0 &&
-                     fused8_lds_bytes(c->cfg.nsmp, c->cfg.nlay_max) <= 80 * 1024;
+                     fused8_lds_bytes(c->tab.lds_nsmp, c->cfg.nlay_max) <= 80 * 1024;
     if (!can || c->block_threads == 256) return false;
     if (c->block_threads == 512) return true;
     const long long blocks = (long long)c->cfg.max_walkers * c->cfg.ntrc;
     return blocks <= (long long)c->fused8_max_rounds * 2 * c->num_cu;
+}
+
+// what follows a trace kernel that left its misfits in HBM: the quadratic forms and logL of the batch
+// (defer 1: phi_deferred_kernel, 8 items per block; defer 2, long windows: one GEMM on the FP64 matrix cores)
+static int finish_likelihood(rf_ctx *c, const BatchArgs &b, int defer, hipStream_t s)
+{
+    if (!defer) return 0;
+    hipEvent_t e = prof_begin(c, 2, s);
+    if (defer == 2)
+        launch_phi_gemm(c->tab, b, c->ws, c->pg, s);
+    else
+        launch_logl_deferred(c->tab, b, c->ws, s);
+    if (e) (void)hipEventRecord(e, s);
+    return 0;
 }
 
 static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
@@ -693,13 +739,12 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
     if (c->fusedc) {
         // one block per walker carries all its traces: the same "misfits to HBM, quadratic forms by the follow-up
         // kernels" rule as below, counted in (walker, trace) units of work
-        const int defer_ok = phi_deferred_lds_bytes(c->cfg.nsmp) <= 60 * 1024;
         const long long units = (long long)b.nb * c->cfg.ntrc, round = 2LL * c->num_cu;
-        const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl : units >= 2 * round);
+        const int defer = c->tab.phi_gemm ? 2 : (c->defer_logl >= 0 ? c->defer_logl : units >= 2 * round);
         hipEvent_t e = prof_begin(c, 0, s);
         launch_fusedc(c->tab, b, c->ws, c->slow_count, c->ablate, defer, order_next, c->single_trace_out, s);
         if (e) (void)hipEventRecord(e, s);
-        if (defer) launch_logl_deferred(c->tab, b, c->ws, s);
+        if (finish_likelihood(c, b, defer, s)) return 1;
     } else if (c->fused) {
         // several traces per walker and at least two rounds of blocks: the block ends with the trace store;
         // misfits go to HBM (808 B per trace) and ONE small follow-up kernel forms the quadratic forms -- the
@@ -708,11 +753,11 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         // its CU slot (measured C4 +5 %, C5 +6 %, C1 shape +13 %).  Smaller batches (the per-call drop-in), single-trace
         // contexts and long windows (misfits of 8 walkers must fit the follow-up kernel's LDS) keep the
         // single launch.
-        const int defer_ok = phi_deferred_lds_bytes(c->cfg.nsmp) <= 60 * 1024;
         // (single trace: it pays from four rounds of blocks on -- measured C3 +6 %,
         // C2, two rounds, -2 %)
+        // Long windows (phi_gemm): always the misfits to HBM, then the batch's quadratic forms as one MFMA GEMM.
         const long long blocks = (long long)b.nb * c->cfg.ntrc, round = 2LL * c->num_cu;
-        const int defer = defer_ok && (c->defer_logl >= 0 ? c->defer_logl
+        const int defer = c->tab.phi_gemm ? 2 : (c->defer_logl >= 0 ? c->defer_logl
                           : (c->cfg.ntrc > 1 ? blocks >= 2 * round : blocks >= 4 * round));
         hipEvent_t e = prof_begin(c, 0, s);
         if (use_fused8(c))
@@ -720,7 +765,7 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         else
             launch_fused(c->tab, b, c->ws, c->chain, c->slow_count, c->ablate, defer, order_next, c->single_trace_out, s);
         if (e) (void)hipEventRecord(e, s);
-        if (defer) launch_logl_deferred(c->tab, b, c->ws, s);
+        if (finish_likelihood(c, b, defer, s)) return 1;
     } else {
         if (!c->spec) {
             void *p = nullptr;
@@ -732,11 +777,13 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
                        c->slow_count, c->ws, s);
         if (e) (void)hipEventRecord(e, s);
         e = prof_begin(c, 1, s);
+        const int defer = c->tab.phi_gemm ? 2 : 0;
         if (c->long_series)
-            launch_trace_long(c->tab, b, c->spec, c->ws, c->slow_count, c->longt, c->long_rows, s);
+            launch_trace_long(c->tab, b, c->spec, c->ws, c->slow_count, c->longt, c->long_rows, defer, s);
         else
-            launch_trace(c->tab, b, c->spec, c->ws, c->slow_count, c->anyn_scratch, s);   // also forms logL
+            launch_trace(c->tab, b, c->spec, c->ws, c->slow_count, c->anyn_scratch, defer, s);   // also forms logL (short windows)
         if (e) (void)hipEventRecord(e, s);
+        if (finish_likelihood(c, b, defer, s)) return 1;
     }
     if (c->prof_this) c->prof_n[0] += 1;
     HIP_TRY(hipGetLastError());
@@ -913,6 +960,10 @@ extern "C" int rf_set_r_inv(rf_ctx *c, const double *r_inv)
     const std::vector<double> t = transpose_r_inv(c->r_inv, c->cfg.ntrc, c->cfg.nsmp);
     HIP_TRY(hipMemcpy(const_cast<double *>(c->tab.r_inv_t), t.data(), sizeof(double) * t.size(),
                       hipMemcpyHostToDevice));
+    if (c->tab.phi_gemm) {
+        const std::vector<double> rg = pad_r_inv(c->r_inv, c->cfg.ntrc, c->cfg.nsmp, c->pg.kp, c->pg.np);
+        HIP_TRY(hipMemcpy(const_cast<double *>(c->pg.rg), rg.data(), sizeof(double) * rg.size(), hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -932,9 +983,15 @@ extern "C" int rf_calc_likelihood_of_trace(rf_ctx *c, const double *rft, const d
     HIP_TRY(hipMemcpyAsync(c->d_ids, &wk, sizeof(int), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_fwd, &one, sizeof(int), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_sig, sig, sizeof(double) * ntrc, hipMemcpyHostToDevice, s));
-    launch_phi(c->tab, c->ws, wk, s);
     BatchArgs b{1, 2, c->d_ids, c->d_fwd, c->d_nlay, c->d_layers, c->d_sig, c->d_logl, nullptr};
-    launch_logl(c->tab, b, c->ws, s);
+    if (c->tab.phi_gemm) {
+        // long windows: the same GEMM the batched path runs, on one row (bit-identical to the chain's own evaluation)
+        launch_misfit_of_trace(c->tab, c->ws, wk, s);
+        launch_phi_gemm(c->tab, b, c->ws, c->pg, s);
+    } else {
+        launch_phi(c->tab, c->ws, wk, s);
+        launch_logl(c->tab, b, c->ws, s);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(logl, c->d_logl, sizeof(double), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
@@ -1325,6 +1382,8 @@ extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
 #endif
     plan[10] = c->block_threads;
     plan[11] = (c->fusedc || use_fused8(c)) ? 512 : 256;
+    plan[12] = c->tab.phi_gemm;
+    plan[13] = plan[14] = plan[15] = 0;
     return 0;
 }
 

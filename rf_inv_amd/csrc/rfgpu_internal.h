@@ -24,6 +24,19 @@ struct DeviceTables {
     const double2 *twiddle; // [nfft]  exp(+2 pi i k / nfft), the full turn (power-of-two nfft: the in-LDS FFT)
     const double2 *twiddle_any; // [nfft] exp(+2 pi i k / nfft) for any other nfft (direct DFT, trace_anyn_kernel), else nullptr
     const int *nh_active;   // [ntrc] bins with a non-negligible filter weight, or nullptr (all bins)
+    // Long time windows (nsmp beyond what phi_deferred_kernel's LDS holds): every kernel that ends with a trace writes
+    // its misfits to HBM (rows zero-padded to mis_stride) and the quadratic forms of the whole batch are ONE tiled
+    // GEMM on the FP64 matrix cores (phi_gemm_kernel).  The trace kernels then keep no misfits / partial sums in LDS.
+    int phi_gemm;           // 1: the plan above (fixed per context from nsmp, never per launch)
+    int lds_nsmp;           // nsmp as far as the trace kernels' LDS layouts are concerned: nsmp, or 0 with phi_gemm
+    int mis_stride;         // doubles between consecutive misfit rows of WalkerState::misfit: nsmp, or kp with phi_gemm
+};
+
+// tables of the long-window plan (phi_gemm_kernel)
+struct PhiGemmTables {
+    const double *rg;       // [ntrc][kp][np] R^-1(i, j) at [i][j], zero-padded: kp = nsmp rounded up to 16, np to 128
+    double *part;           // [ntrc][nchunk][pstride] per 64-column chunk partial sums of misfit . R^-1 . misfit
+    int kp, np, nchunk, pstride;
 };
 
 struct BatchArgs {
@@ -43,7 +56,7 @@ struct WalkerState {
     int *cur_slot;    // [nslots] 0/1: which half holds the current trace
     int *prop_fwd;    // [nslots] last proposal ran the forward model
     int *done;        // [nslots] per batch item: traces finished (last one forms logL), self-resetting
-    double *misfit;   // [nslots][ntrc][nsmp] per batch item: misfits handed to phi_deferred_kernel
+    double *misfit;   // [nslots][ntrc][mis_stride] per batch item: misfits handed to phi_deferred_kernel / phi_gemm_kernel
     double *gcoef;    // [nslots * nfwd][nlay_max][NCOEF] per batch item: stage_kernel's per-layer constants
     double *gtail;    // [nslots * nfwd][GTAIL]           ... walker constants + direct-arrival time
     int *gflag;       // [nslots * nfwd]                  ... bit 0 sea, bit 1 phases beyond the fast sincos range
@@ -57,7 +70,7 @@ void launch_spectra(const DeviceTables &t, const BatchArgs &b, double2 *spec, in
 // K2: decon / filter / c2r / shift / normalise / write trace / quadratic form
 // (xbuf: nullptr, or the scratch of the long non-power-of-two variant, trace_anyn_scratch_entries per block)
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec,
-                  const WalkerState &w, int *slow_count, double2 *xbuf, hipStream_t s);
+                  const WalkerState &w, int *slow_count, double2 *xbuf, int defer_logl, hipStream_t s);
 // log-likelihood from cached quadratic forms (used for host-owned traces; the batched path
 // forms logL inside trace_kernel)
 void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
@@ -77,6 +90,10 @@ void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &
 // logL of a batch launched with defer_logl (one thread per batch item, after the fused kernel)
 void launch_logl_deferred(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s);
 size_t phi_deferred_lds_bytes(int nsmp);
+// long windows: quadratic forms of the batch as one FP64-MFMA GEMM + logL (phi_gemm_kernel, phi_gemm_finish_kernel)
+void launch_phi_gemm(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, const PhiGemmTables &g, hipStream_t s);
+// misfits of the scratch walker's proposal slot -> misfit row of batch item 0 (host-owned traces, long windows)
+void launch_misfit_of_trace(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s);
 size_t fused_lds_bytes(int nfft, int nsmp, int nlay_pad);
 void launch_phi(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s);
 struct ModelConfig {
@@ -151,7 +168,7 @@ struct LongTables {
 size_t long_row_entries(int nfft, int m, int nsmp);
 size_t trace_long_lds_bytes(int nsmp);
 void launch_trace_long(const DeviceTables &t, const BatchArgs &b, const double2 *spec, const WalkerState &w, int *slow_count,
-                       const LongTables &L, int rows, hipStream_t s);
+                       const LongTables &L, int rows, int defer_logl, hipStream_t s);
 
 size_t spectra_lds_bytes(int nlay_pad);
 size_t trace_anyn_lds_bytes(int nfft, int nsmp, int nlay_pad);

@@ -1667,7 +1667,8 @@ struct TraceParams {
     FftPlan plan;
     int *slow_count;   // re-armed here for the next batch (the slow kernel ran earlier on the stream)
     int ablate;        // RFGPU_DIAGNOSTICS builds only: stop the tail after phase N (timing split, results invalid)
-    int defer_logl;    // misfits to HBM; quadratic form + logL by phi_deferred_kernel after this launch
+    int defer_logl;    // 1: misfits to HBM; quadratic form + logL by phi_deferred_kernel after this launch
+                       // 2: the same for phi_gemm_kernel (long windows: no misfits in LDS at all, t.lds_nsmp = 0)
     double *extra_out; // nullptr, or [ntrc][nfft] (device-mapped host memory): second copy of the proposed trace of
                        // batch item 0 -- the per-call drop-in gets prop_rft without a gather kernel
     double2 *xbuf;     // nullptr, or [nslots * ntrc][fft_pad(nfft)]: the time series of trace_anyn_kernel<true>
@@ -1751,7 +1752,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
     double *__restrict__ dst =
         P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
-    double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
+    double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * t.mis_stride;   // defer mode only
     double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
     if (TRACE_THREADS == 256 && n >= 512 && n <= 4096 && !transformed) {
         // nfft 512 .. 4096: the last pass has exactly one butterfly (radix nfft / 256) per thread; its
@@ -1843,10 +1844,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
 {
     extern __shared__ double2 lds2[];
     const DeviceTables &t = P.t;
-    const int n = t.nfft, nh = t.nh, nsmp = t.nsmp;
+    const int n = t.nfft, nh = t.nh;
     double2 *a = lds2;                                   // [fft_pad(n)] FFT work array (padded index)
-    double *mis = reinterpret_cast<double *>(a) + trace_work_doubles(n, nsmp, P.b.nlay_pad); // [nsmp] misfits
-    double *red = mis + ((nsmp + 1) & ~1);               // [8] reductions / broadcasts
+    double *mis = reinterpret_cast<double *>(a) + trace_work_doubles(n, t.lds_nsmp, P.b.nlay_pad); // [nsmp] misfits
+    double *red = mis + ((t.lds_nsmp + 1) & ~1);         // [8] reductions / broadcasts
 
     const int tid = threadIdx.x;
     const int itrc = blockIdx.x % t.ntrc;
@@ -1986,13 +1987,13 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_anyn_kernel(TraceParams P
     if (BIG) {
         a = P.xbuf + (size_t)blockIdx.x * trace_anyn_scratch_entries(n, nsmp);
         mis = reinterpret_cast<double *>(lds2);
-        zr = reinterpret_cast<double2 *>(mis + ((nsmp + 1) & ~1) + 8);
+        zr = reinterpret_cast<double2 *>(mis + ((t.lds_nsmp + 1) & ~1) + 8);
     } else {
         a = lds2;
-        mis = reinterpret_cast<double *>(a) + trace_work_doubles(n, nsmp, P.b.nlay_pad);
-        zr = reinterpret_cast<double2 *>(reinterpret_cast<double *>(a) + anyn_spec_offset(n, nsmp, P.b.nlay_pad));
+        mis = reinterpret_cast<double *>(a) + trace_work_doubles(n, t.lds_nsmp, P.b.nlay_pad);
+        zr = reinterpret_cast<double2 *>(reinterpret_cast<double *>(a) + anyn_spec_offset(n, t.lds_nsmp, P.b.nlay_pad));
     }
-    double *red = mis + ((nsmp + 1) & ~1);
+    double *red = mis + ((t.lds_nsmp + 1) & ~1);
     double2 *zv = zr + nh;                               // filtered RF and vertical spectra, bins 0 .. nh-1
     double2 *tw_lds = zv + nh;                           // (!BIG) exp(+2 pi i k / n), k = 0 .. n-1
     const double2 *tw = BIG ? t.twiddle_any : tw_lds;
@@ -2163,10 +2164,10 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_long_kernel(LongParams Q)
     const TraceParams &P = Q.tp;
     const LongTables &L = Q.L;
     const DeviceTables &t = P.t;
-    const int n = t.nfft, nh = t.nh, nsmp = t.nsmp;
+    const int n = t.nfft, nh = t.nh;
     double2 *a = lds2;                                                   // [fft_pad(4096)] the 4096-point work array
     double *mis = reinterpret_cast<double *>(a + ((fft_pad(4095) + 2) & ~1));   // [nsmp] misfits
-    double *red = mis + ((nsmp + 1) & ~1);                               // [8] reductions
+    double *red = mis + ((t.lds_nsmp + 1) & ~1);                         // [8] reductions
     const int tid = threadIdx.x;
     double2 *Y = L.scratch + (size_t)blockIdx.x * 2 * L.row_entries;      // stage-1 outputs
     double2 *W = Y + L.row_entries;                                       // Bluestein: V = U Bhat; finally the time series
@@ -2265,16 +2266,16 @@ size_t trace_long_lds_bytes(int nsmp)
 }
 
 void launch_trace_long(const DeviceTables &t, const BatchArgs &b, const double2 *spec, const WalkerState &w, int *slow_count,
-                       const LongTables &L, int rows, hipStream_t s)
+                       const LongTables &L, int rows, int defer_logl, hipStream_t s)
 {
     LongParams Q{};
-    Q.tp = TraceParams{t, b, spec, w, 12, make_fft_plan(12), slow_count, 0, 0, nullptr, nullptr};
+    Q.tp = TraceParams{t, b, spec, w, 12, make_fft_plan(12), slow_count, 0, defer_logl, nullptr, nullptr};
     Q.L = L;
     const int units = b.nb * t.ntrc;
     static LdsOptIn opt;
     opt(reinterpret_cast<const void *>(trace_long_kernel));
     hipLaunchKernelGGL(trace_long_kernel, dim3((unsigned)(units < rows ? units : rows)), dim3(TRACE_THREADS),
-                       trace_long_lds_bytes(t.nsmp), s, Q);
+                       trace_long_lds_bytes(t.lds_nsmp), s, Q);
 }
 
 // ---------------------------------------------------------------------------
@@ -2365,10 +2366,10 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
     extern __shared__ double2 lds2[];
     const TraceParams &P = F.tp;
     const DeviceTables &t = P.t;
-    const int n = t.nfft, nh = t.nh, nsmp = t.nsmp;
+    const int n = t.nfft, nh = t.nh;
     double2 *a = lds2;
-    double *mis = reinterpret_cast<double *>(a) + trace_work_doubles(n, nsmp, P.b.nlay_pad);
-    double *red = mis + ((nsmp + 1) & ~1);
+    double *mis = reinterpret_cast<double *>(a) + trace_work_doubles(n, t.lds_nsmp, P.b.nlay_pad);
+    double *red = mis + ((t.lds_nsmp + 1) & ~1);
     double2 *side = reinterpret_cast<double2 *>(red + 8);
     double *coef = reinterpret_cast<double *>(side + 2);
     double *tail = coef + (size_t)P.b.nlay_pad * NCOEF;
@@ -2717,7 +2718,7 @@ __device__ __forceinline__ void w8_fft_store(const TraceParams &P, double2 *a, d
     }
     double *__restrict__ dst = P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
-    double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * nsmp;   // defer mode only
+    double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * t.mis_stride;   // defer mode only
     double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
     // (the same store loop as tail_in_registers: one signed reciprocal per thread, 0-based masked sample index)
     const double rfac = (ipha == 1 ? 1.0 : -1.0) / fac;
@@ -2735,7 +2736,7 @@ __device__ __forceinline__ void w8_fft_store(const TraceParams &P, double2 *a, d
             // global and an LDS pointer -- a flat store -- and its backend then fails on the common-ray kernel
             // ("Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base", ROCm 7.2); the LDS copy is one
             // ds_write for the first nsmp samples)
-            mis[i0] = m;
+            if (P.defer_logl != 2) mis[i0] = m;      // (2: long windows, no misfit rows in LDS)
             if (P.defer_logl) mis_g[i0] = m;
         }
     }
@@ -2756,10 +2757,9 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
     const TraceParams &P = F.tp;
     const DeviceTables &t = P.t;
     constexpr int n = 4096, nh = 2049;
-    const int nsmp = t.nsmp;
     double2 *a = lds2;
     double *mis = reinterpret_cast<double *>(a + ((w8_pad(4095) + 2) & ~1));
-    double *red = mis + ((nsmp + 1) & ~1);
+    double *red = mis + ((t.lds_nsmp + 1) & ~1);
     double2 *side = reinterpret_cast<double2 *>(red + 8);
     double *coef = reinterpret_cast<double *>(side + 4);          // generic path only
     double *tail = coef + (size_t)P.b.nlay_pad * NCOEF;
@@ -2917,7 +2917,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fusedc_kernel(FusedParams F)
     const int nsmp = t.nsmp, ntrc = t.ntrc;
     double2 *a = lds2;
     double *mis = reinterpret_cast<double *>(a + ((w8_pad(4095) + 2) & ~1));
-    double *red = mis + ((nsmp + 1) & ~1);
+    double *red = mis + ((t.lds_nsmp + 1) & ~1);
     double2 *side = reinterpret_cast<double2 *>(red + 8);
     double *coef = reinterpret_cast<double *>(side + 4);          // generic path only
     double *tail = coef + (size_t)P.b.nlay_pad * NCOEF;
@@ -3048,7 +3048,7 @@ void launch_fusedc(const DeviceTables &t, const BatchArgs &b, const WalkerState 
     F.order_next = order_next;
     F.sp = SpectraParams{t, b, nullptr, W8_THREADS / 64, nullptr, slow_count, w};
     F.tp = TraceParams{t, b, nullptr, w, 12, {}, slow_count, ablate, defer_logl, extra_out};
-    const size_t lds = fused8_lds_bytes(t.nsmp, b.nlay_pad);
+    const size_t lds = fused8_lds_bytes(t.lds_nsmp, b.nlay_pad);
     const dim3 grid((unsigned)b.nb + (order_next ? 1u : 0u));
     static LdsOptIn opt;
     opt(reinterpret_cast<const void *>(fusedc_kernel<2>));
@@ -3062,7 +3062,7 @@ void launch_fused8(const DeviceTables &t, const BatchArgs &b, const WalkerState 
     F.order_next = order_next;
     F.sp = SpectraParams{t, b, nullptr, W8_THREADS / 64, nullptr, slow_count, w};
     F.tp = TraceParams{t, b, nullptr, w, 12, {}, slow_count, ablate, defer_logl, extra_out};
-    const size_t lds = fused8_lds_bytes(t.nsmp, b.nlay_pad);
+    const size_t lds = fused8_lds_bytes(t.lds_nsmp, b.nlay_pad);
     const dim3 grid((unsigned)(b.nb * t.ntrc) + (order_next ? 1u : 0u));
     static LdsOptIn opt;
     opt(reinterpret_cast<const void *>(fused8_kernel<2>));
@@ -3098,7 +3098,7 @@ void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &
     F.tp = TraceParams{t, b, nullptr, w, 0, {}, slow_count, ablate, defer_logl, extra_out};
     while ((1 << F.tp.log2n) < t.nfft) ++F.tp.log2n;
     F.tp.plan = make_fft_plan(F.tp.log2n);
-    const size_t lds = fused_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
+    const size_t lds = fused_lds_bytes(t.nfft, t.lds_nsmp, b.nlay_pad);
     const dim3 grid((unsigned)(b.nb * t.ntrc) + (order_next ? 1u : 0u));
     if (t.sdep > 0.0)
         launch_fused_ncol<3>(chain, grid, lds, s, F);
@@ -3140,26 +3140,26 @@ size_t trace_lds_bytes(int nfft, int nsmp, int nlay_pad)
 }
 
 void launch_trace(const DeviceTables &t, const BatchArgs &b, const double2 *spec, const WalkerState &w,
-                  int *slow_count, double2 *xbuf, hipStream_t s)
+                  int *slow_count, double2 *xbuf, int defer_logl, hipStream_t s)
 {
-    TraceParams P{t, b, spec, w, 0, {}, slow_count, 0, 0, nullptr, xbuf};
+    TraceParams P{t, b, spec, w, 0, {}, slow_count, 0, defer_logl, nullptr, xbuf};
     if (t.twiddle_any) {   // nfft is not a power of two: direct-DFT variants
         if (xbuf) {
             static LdsOptIn opt_big;
             opt_big(reinterpret_cast<const void *>(trace_anyn_kernel<true>));
             hipLaunchKernelGGL(trace_anyn_kernel<true>, dim3((unsigned)(b.nb * t.ntrc)), dim3(TRACE_THREADS),
-                               trace_anyn_big_lds_bytes(t.nfft, t.nsmp), s, P);
+                               trace_anyn_big_lds_bytes(t.nfft, t.lds_nsmp), s, P);
         } else {
             static LdsOptIn opt_any;
             opt_any(reinterpret_cast<const void *>(trace_anyn_kernel<false>));
             hipLaunchKernelGGL(trace_anyn_kernel<false>, dim3((unsigned)(b.nb * t.ntrc)), dim3(TRACE_THREADS),
-                               trace_anyn_lds_bytes(t.nfft, t.nsmp, b.nlay_pad), s, P);
+                               trace_anyn_lds_bytes(t.nfft, t.lds_nsmp, b.nlay_pad), s, P);
         }
         return;
     }
     while ((1 << P.log2n) < t.nfft) ++P.log2n;
     P.plan = make_fft_plan(P.log2n);
-    const size_t lds = trace_lds_bytes(t.nfft, t.nsmp, b.nlay_pad);
+    const size_t lds = trace_lds_bytes(t.nfft, t.lds_nsmp, b.nlay_pad);
     static LdsOptIn opt;
     opt(reinterpret_cast<const void *>(trace_kernel));
     hipLaunchKernelGGL(trace_kernel, dim3((unsigned)(b.nb * t.ntrc)), dim3(TRACE_THREADS), lds, s, P);
@@ -3226,7 +3226,7 @@ __global__ __launch_bounds__(256) void phi_deferred_kernel(LoglParams P)
     for (int e = tid; e < PHI_W * nsmp; e += 256) {
         const int w = e / nsmp, i = e - w * nsmp, ib = ib0 + w;
         const bool live = ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1);
-        mis[e] = live ? P.w.misfit[((size_t)ib * ntrc + it) * nsmp + i] : 0.0;
+        mis[e] = live ? P.w.misfit[((size_t)ib * ntrc + it) * P.t.mis_stride + i] : 0.0;
     }
     __syncthreads();
     const double *__restrict__ RT = P.t.r_inv_t + (size_t)it * nsmp * nsmp;
@@ -3333,6 +3333,205 @@ void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w
 {
     LoglParams P{t, b, w};
     hipLaunchKernelGGL(logl_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P);
+}
+
+// ---------------------------------------------------------------------------
+// Long time windows: phi_gemm_kernel.  The reference evaluates phi1 = matmul(misfits, r_inv) for any window up to
+// npts_max = 2000 samples (src/likelihood.f90:92-93, src/params.f90:44); r_inv is dense, so the work grows with
+// nsmp^2 (1201 samples, a 60 s window: 11.5 MB of R^-1 per trace, 2.9 Mflop per (walker, trace)).  quad_form re-reads
+// the whole matrix per block and phi_deferred_kernel once per 8 walkers -- a matrix-vector product at 0.25 flop per
+// byte.  Beyond what phi_deferred_kernel's LDS holds (nsmp > 191) the quadratic forms of a batch are instead ONE GEMM
+//     Phi1[nb x nsmp] = M_t[nb x nsmp] . R^-1_t[nsmp x nsmp]      per trace t, then  phi = rowsum(Phi1 o M_t)
+// on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), the only dense contraction of the path.
+// R^-1 is NOT assumed symmetric (it is only to ~1e-10): the sum runs over its row index exactly as in
+// the reference's row-vector x matrix product.
+//
+// Tiling: a 256-thread block owns 128 walkers x 128 columns; its four waves 64 x 64 each (4 x 4 MFMA tiles, 16
+// accumulators of 4 doubles per lane).  K advances in steps of 16 through LDS: the A tile (128 misfit rows x 16) and
+// the B tile (16 rows of R^-1 x 128) are fetched once per block and step -- R^-1 once per 128 walkers instead of once
+// per 1 .. 8 -- with the next step's global loads in flight behind the current step's 64 MFMAs per wave; two blocks per
+// CU cover each other's barriers.  Operand layout of the instruction (lane l): A[row l & 15][k = l >> 4],
+// B[k = l >> 4][col l & 15], D[row (l >> 4) + 4 r][col l & 15] in register r = 0 .. 3.
+// Both operands are zero-padded in HBM (misfit rows to kp = nsmp rounded up to 16, the R^-1 image to kp x np, np =
+// nsmp rounded up to 128), so the loop has no edge cases; sub-tiles wholly outside the batch or the window are skipped.
+// Epilogue: each lane multiplies its accumulators by the matching misfits and adds them up over its four column tiles
+// (ascending), a 16-lane butterfly finishes the row's sum over the wave's 64 columns, and the per-chunk partial goes to
+// part[trace][chunk][item]; phi_gemm_finish_kernel adds the chunks in ascending order and forms logL
+// (likelihood.f90:94-96).  Every step has a fixed order that does not depend on the batch: a chain evaluated alone or
+// in a full batch gets bit-identical values.
+// ---------------------------------------------------------------------------
+constexpr int PG_BM = 128, PG_BN = 128, PG_BK = 16;
+constexpr int PG_LDA = PG_BK + 1;      // doubles per LDS row of the A tile ([row][k]; odd: the fragment reads spread over the banks)
+constexpr int PG_LDB = PG_BN + 16;     // ... of the B tile ([k][col]; rows 16 doubles apart modulo the banks)
+
+struct PhiGemmParams {
+    const double *mis;     // [>= nb][ntrc][ld] misfits, rows zero-padded to ld = kp
+    const double *rg;      // [ntrc][kp][np]
+    double *part;          // [ntrc][nchunk][pstride]
+    int nb, ntrc, ld, kp, np, nchunk, pstride;
+};
+
+typedef double pg_acc_t __attribute__((ext_vector_type(4)));
+typedef double pg_v2_t __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256, 2) void phi_gemm_kernel(PhiGemmParams G)
+{
+    __shared__ double As[PG_BM * PG_LDA];
+    __shared__ __attribute__((aligned(16))) double Bs[PG_BK * PG_LDB];
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    // blocks of one (trace, column block) are consecutive: they share the B tile (L2) and stream their own A tiles
+    const int nmb = (G.nb + PG_BM - 1) / PG_BM, nnb = G.np / PG_BN;
+    int bid = blockIdx.x;
+    const int mblk = bid % nmb;
+    bid /= nmb;
+    const int nblk = bid % nnb, it = bid / nnb;
+    const int m0 = mblk * PG_BM, n0 = nblk * PG_BN;
+    const int wm = wv & 1, wn = wv >> 1;
+    const int mw = m0 + 64 * wm, nw = n0 + 64 * wn;
+    // live 16-row / 16-column sub-tiles of this wave (wave-uniform)
+    const int mt_live = min(4, max(0, (G.nb - mw + 15) >> 4));
+    const int nt_live = min(4, max(0, (G.kp - nw) >> 4));
+    const bool full = mt_live == 4 && nt_live == 4;
+
+    const size_t a_rs = (size_t)G.ntrc * G.ld;                                   // doubles between the rows of two items
+    const double *__restrict__ Ag = G.mis + (size_t)it * G.ld;
+    const double *__restrict__ Bg = G.rg + (size_t)it * G.kp * G.np + n0;
+    // staging: A tile 128 rows x 8 double2, B tile 16 rows x 64 double2 -- four of each per thread.  Rows beyond the
+    // batch re-read its last row: their accumulators are never written anywhere.
+    const pg_v2_t *ap[4], *bp[4];
+    pg_v2_t pa[4], pb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = tid + 256 * i;
+        const int row = min(m0 + (e >> 3), G.nb - 1);
+        ap[i] = reinterpret_cast<const pg_v2_t *>(Ag + (size_t)row * a_rs + 2 * (e & 7));
+        bp[i] = reinterpret_cast<const pg_v2_t *>(Bg + (size_t)(e >> 6) * G.np + 2 * (e & 63));
+    }
+    const size_t b_step = (size_t)(PG_BK / 2) * G.np;      // double2 per K step of the B image
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        pa[i] = *ap[i];
+        pb[i] = *bp[i];
+    }
+    pg_acc_t acc[4][4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = pg_acc_t{0.0, 0.0, 0.0, 0.0};
+
+    const int nkt = G.kp / PG_BK;
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                                  // the previous step's fragments are read
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
+            double *da = As + (e >> 3) * PG_LDA + 2 * (e & 7);
+            da[0] = pa[i].x;
+            da[1] = pa[i].y;
+            *reinterpret_cast<pg_v2_t *>(Bs + (e >> 6) * PG_LDB + 2 * (e & 63)) = pb[i];
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) {                               // the next step's tiles: in flight behind this step's MFMAs
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ap[i] += PG_BK / 2;
+                bp[i] += b_step;
+                pa[i] = *ap[i];
+                pb[i] = *bp[i];
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < PG_BK / 4; ++kk) {
+            double av[4], bv[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) av[mt] = As[(64 * wm + 16 * mt + l15) * PG_LDA + 4 * kk + l4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bv[nt] = Bs[(4 * kk + l4) * PG_LDB + 64 * wn + 16 * nt + l15];
+            if (full) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        if (mt < mt_live && nt < nt_live)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- phi partial of the wave's 64 columns for each of its 64 rows ------------------------------------------------
+    double *__restrict__ pout = G.part + ((size_t)it * G.nchunk + (nw >> 6)) * G.pstride;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = mw + 16 * mt + l4 + 4 * r;
+            const bool live = row < G.nb;
+            const double *__restrict__ mrow = Ag + (size_t)(live ? row : 0) * a_rs + nw + l15;
+            double sum = 0.0;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (nt < nt_live) sum = fma(acc[mt][nt][r], live ? mrow[16 * nt] : 0.0, sum);
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 8, 64);
+            if (l15 == 0 && live) pout[row] = sum;
+        }
+    }
+}
+
+// phi = the chunk partials in ascending order, then logL (likelihood.f90:94-96): one thread per batch item.  Items
+// that did not run the forward model were finished by the trace kernels themselves (cached phi / NaN).
+__global__ __launch_bounds__(256) void phi_gemm_finish_kernel(LoglParams P, const double *__restrict__ part, int nlive,
+                                                              int nchunk, int pstride)
+{
+#pragma clang fp contract(off)
+    const int ib = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ib >= P.b.nb) return;
+    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) return;
+    const int ntrc = P.t.ntrc, walker = P.b.walker_ids[ib];
+    double *phis = P.w.phi + ((size_t)(1 - P.w.cur_slot[walker]) * P.w.nslots + walker) * ntrc;
+    for (int it = 0; it < ntrc; ++it) {
+        const double *q = part + (size_t)it * nchunk * pstride + ib;
+        double s = 0.0;
+        for (int c = 0; c < nlive; ++c) s = s + q[(size_t)c * pstride];
+        phis[it] = s;
+    }
+    P.b.logl[ib] = logl_from_phi(phis, P.b.sig + (size_t)ib * ntrc, ntrc, P.t.nsmp, false);
+    P.w.prop_fwd[walker] = 1;
+}
+
+void launch_phi_gemm(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, const PhiGemmTables &g, hipStream_t s)
+{
+    PhiGemmParams G{w.misfit, g.rg, g.part, b.nb, t.ntrc, t.mis_stride, g.kp, g.np, g.nchunk, g.pstride};
+    const unsigned nmb = (unsigned)((b.nb + PG_BM - 1) / PG_BM), nnb = (unsigned)(g.np / PG_BN);
+    hipLaunchKernelGGL(phi_gemm_kernel, dim3(nmb * nnb * (unsigned)t.ntrc), dim3(256), 0, s, G);
+    LoglParams P{t, b, w};
+    hipLaunchKernelGGL(phi_gemm_finish_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P, g.part,
+                       (g.kp + 63) / 64, g.nchunk, g.pstride);
+}
+
+// likelihood.f90:88 for a trace supplied by the host, long windows: the misfits of the scratch walker's proposal slot
+// go to the misfit row of batch item 0 (phi_gemm_kernel with nb = 1 follows)
+__global__ __launch_bounds__(256) void misfit_of_trace_kernel(DeviceTables t, WalkerState w, int walker)
+{
+    const int itrc = blockIdx.x;
+    const int slot = 1 - w.cur_slot[walker];
+    const double *src = w.rft + (((size_t)slot * w.nslots + walker) * t.ntrc + itrc) * (size_t)t.nfft;
+    const double *obs = t.obs + (size_t)itrc * t.nsmp;
+    double *dst = w.misfit + (size_t)itrc * t.mis_stride;
+    for (int i = threadIdx.x; i < t.nsmp; i += 256) dst[i] = src[i] - obs[i];
+}
+
+void launch_misfit_of_trace(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s)
+{
+    hipLaunchKernelGGL(misfit_of_trace_kernel, dim3((unsigned)t.ntrc), dim3(256), 0, s, t, w, walker);
 }
 
 // ---------------------------------------------------------------------------

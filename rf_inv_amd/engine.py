@@ -333,13 +333,14 @@ class RFEngine:
     # ---- instrumentation -----------------------------------------------------
     @property
     def launch_plan(self):
-        plan = (C.c_int32 * 12)()
+        plan = (C.c_int32 * 16)()
         self._chk(self._lib.rf_get_launch_plan(self._ctx, plan))
         return {"fused": bool(plan[0]), "common_ray_fused": plan[0] == 2, "chain": plan[1], "waves_per_block": plan[2], "nsplit": plan[3],
                 "lpt": bool(plan[4]), "order_reuse": bool(plan[5]), "defer_logl": plan[6],
                 "bin_cutoff": bool(plan[7]), "overrides": plan[8],
                 "build": ("production", "diagnostics", "diagnostics+ablate")[plan[9]],
-                "block_threads_option": plan[10], "block_threads_full_batch": plan[11]}
+                "block_threads_option": plan[10], "block_threads_full_batch": plan[11],
+                "long_window_gemm": bool(plan[12])}
 
     def profile_enable(self, on=True):
         """on: False / True (every batch) / k > 1 (every k-th batch is timed)."""

@@ -26,7 +26,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in rfgpu.h but not exported by librfgpu.so"
         assert n in _lib.SYMBOLS, f"{n} not bound in rf_inv_amd/_lib.py"
     assert sorted(_lib.SYMBOLS) == names
-    assert lib.rf_abi_version() == 4
+    assert lib.rf_abi_version() == 5
 
 
 def test_config_struct_layout_matches_header():
@@ -111,7 +111,7 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
                            "-lm", f"-Wl,-rpath,{libdir}"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi 4 rank" in r.stdout
+    assert "abi 5 rank" in r.stdout
     assert "no context: rf_ctx_create: no HIP device" in r.stdout or "calc_rf rc 0" in r.stdout
 
 

@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 KAPPA_MIN, KAPPA_SCALE = 100.0, 10.0      # the conditioning rule (see above test_randomised_contexts_against_oracle)
 
 
-def _workload(name):
+def _workload(name, walkers=None):
     """The bench.py workload of that name: params, walker models of rank 0, observed traces (noise-free
     synthetic of a fixed 3-interface model through the ORACLE here), R^-1."""
     import bench
@@ -33,6 +33,8 @@ def _workload(name):
 
     oracle.build()
     w = dict(bench.WORKLOADS[name])
+    if walkers:
+        w["walkers"] = walkers
     p = bench.make_params(w)
     ref = read_ref_model(os.path.join(ROOT, "tests", "golden", "sample_syn", "model", "sample.velmod"))
     nb = w["walkers"]
@@ -54,14 +56,14 @@ def _workload(name):
     return w, p, cfg, obs, r_inv, nlay, layers
 
 
-def _run_config(name, expect_defer, nsample, extra_check=None):
+def _run_config(name, expect_defer, nsample, extra_check=None, walkers=None):
     import torch
 
     from oracle import rf_oracle as oracle
     from rf_inv_amd import RFEngine
     from rf_inv_amd.pt import PairSchedule, PTSwap, init_temps, judge_pt
 
-    w, p, cfg, obs, r_inv, nlay, layers = _workload(name)
+    w, p, cfg, obs, r_inv, nlay, layers = _workload(name, walkers)
     nb, ntrc, nsmp = w["walkers"], p.ntrc, p.nsmp
     rng = np.random.default_rng(zlib.crc32(name.encode()))
     sigv = np.linspace(0.01, 0.02, ntrc)
@@ -77,7 +79,12 @@ def _run_config(name, expect_defer, nsample, extra_check=None):
         # by batch size the library defers the quadratic form + logL to the follow-up kernel(s) here
         # (rfgpu_api.cpp run_batch: >= 2 rounds of blocks with several traces, >= 4 rounds with one)
         blocks, rnd = nb * ntrc, 2 * 256
-        assert (blocks >= (2 if ntrc > 1 else 4) * rnd) == expect_defer
+        if expect_defer == "gemm":
+            # long time windows: the misfits always go to HBM and the batch's quadratic forms are one FP64-MFMA GEMM
+            assert plan["long_window_gemm"] and nsmp >= 192
+        else:
+            assert not plan["long_window_gemm"]
+            assert (blocks >= (2 if ntrc > 1 else 4) * rnd) == expect_defer
         stream = torch.cuda.Stream(device=dev)
         d_ids = torch.arange(nb, dtype=torch.int32, device=dev)
         d_nlay, d_layers = torch.from_numpy(nlay).to(dev), torch.from_numpy(layers).to(dev)
@@ -193,6 +200,18 @@ def test_c5_default_plan_full_batch():
     _run_config("c5", expect_defer=True, nsample=64, extra_check=land_in_ocean_context)
 
 
+def test_c4_20s_window_full_batch():
+    """C4 with a 20 s time window (nsmp 401, bench.py's c4w20) at the full 8192 walkers: fused_kernel<8,2> leaves the
+    misfits in HBM, phi_gemm_kernel forms the 24576 quadratic forms as one GEMM on the FP64 matrix cores.  Every
+    walker against the oracle + the size-independent properties + the swap replay, like the BASELINE configs."""
+    _run_config("c4w20", expect_defer="gemm", nsample=24)
+
+
+def test_c4_60s_window_2048_walkers():
+    """C4 with a 60 s time window (nsmp 1201: 11.5 MB of R^-1 per trace, bench.py's c4w60), 2048 walkers."""
+    _run_config("c4w60", expect_defer="gemm", nsample=12, walkers=2048)
+
+
 # ---------------------------------------------------------------------------------------------------------
 # Seeded randomised sweep (promoted from tests/tools/fuzz_parity.py).
 #
@@ -218,8 +237,9 @@ def _kappa(oracle, cfg, stack):
     return k
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5])
 def test_randomised_contexts_against_oracle(oracle, seed):
+    """(seeds 4 and 5: time windows of 12 .. 32 s -- the long-window plan, quadratic forms as one FP64-MFMA GEMM)"""
     from rf_inv_amd import RFEngine
 
     rng = np.random.default_rng(seed)
@@ -236,7 +256,7 @@ def test_randomised_contexts_against_oracle(oracle, seed):
             rayps, ipha = [rayps[0]] * ntrc, [ipha[0]] * ntrc
         a_gus = [float(rng.choice([2.5, 4.0, 6.0])) for _ in range(ntrc)]
         t_start = float(rng.choice([0.0, -1.0, -3.0]))
-        nsmp = int(rng.choice([61, 101, 161]))
+        nsmp = min(nfft, int(rng.choice([61, 101, 161] if seed <= 3 else [250, 401, 640])))
         kmax = int(rng.choice([6, 15, 30]))
         nb = int(rng.choice([1, 3, 17, 130, 300]))
         cfg = make_cfg(nfft=nfft, deconv_mode=deconv, t_start=t_start, sdep=sdep, rayps=rayps, a_gus=a_gus, ipha=ipha)

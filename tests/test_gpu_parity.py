@@ -29,7 +29,7 @@ def test_library_is_the_hip_one():
     from rf_inv_amd import _lib
 
     lib = _lib.load()
-    assert lib.rf_abi_version() == 4
+    assert lib.rf_abi_version() == 5
     assert os.path.basename(_lib.LIB_PATH) == "librfgpu.so"
 
 
@@ -868,6 +868,93 @@ def test_long_time_window(oracle):
     with _engine(cfg, obs, nsmp, r_inv, max_walkers=4, nlay_max=30) as eng:
         ll = eng.eval_batch(np.arange(4), nlay, layers, sig)
     assert np.all(np.abs(ll - ref) <= logl_tol(ref)), np.abs(ll - ref)
+
+
+@pytest.mark.parametrize("nsmp", [191, 192, 401, 1201, 2000])
+def test_long_window_plan_boundary_and_sizes(oracle, nsmp):
+    """nsmp <= 191: phi_deferred_kernel's LDS still holds eight misfit rows and the path of the short windows is
+    untouched; from 192 on the context takes the long-window plan (one FP64-MFMA GEMM per batch, phi_gemm_kernel) up to
+    the reference's npts_max = 2000 (src/params.f90:44).  Window lengths that are / are not multiples of the GEMM's
+    16-sample and 128-column tiles, a batch that is not a multiple of its 128-row tile, sigma-only items, an invalid
+    item, a second evaluation after a commit."""
+    rng = np.random.default_rng(1000 + nsmp)
+    cfg = make_cfg(nfft=4096, rayps=[0.06, 0.09], ipha=[1, -1], t_start=-3.0)
+    true = random_stack(rng, 5)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    nb = 150
+    stacks = [random_stack(rng, int(n)) for n in rng.integers(2, 20, nb - 1)] + [true]
+    nlay, layers = pack_layers(stacks, 22)
+    sig = np.column_stack([np.full(nb, 0.01), rng.uniform(0.01, 0.05, nb)])
+    ref = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads())
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=22) as eng:
+        assert eng.launch_plan["long_window_gemm"] == (nsmp >= 192)
+        ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+        assert np.all(np.abs(ll - ref) <= logl_tol(ref)), (np.abs(ll - ref).max(), int(np.argmax(np.abs(ll - ref) / logl_tol(ref))))
+        # the true model: zero misfit, logL = -nsmp sum(log sigma)
+        assert abs(ll[-1] + nsmp * np.log(sig[-1]).sum()) < 1e-6
+        eng.commit(np.arange(nb), np.ones(nb, dtype=np.int32))
+        ff = (np.arange(nb) % 3 != 0).astype(np.int32)          # every third walker: a sigma-only proposal
+        ff[5] = -1                                               # and one item skipped altogether
+        sig2 = sig * 1.5
+        stacks2 = [random_stack(rng, int(n)) for n in rng.integers(2, 20, nb)]
+        nlay2, layers2 = pack_layers(stacks2, 22)
+        ll2 = eng.eval_batch(np.arange(nb), nlay2, layers2, sig2, fwd_flag=ff)
+        use_l = np.where(ff[:, None, None] == 1, layers2, layers)
+        use_n = np.where(ff == 1, nlay2, nlay)
+        ref2 = oracle.eval_batch(cfg, obs, r_inv, use_n, use_l, sig2, nsmp, nthreads=oracle.max_threads())
+        live = ff >= 0
+        assert np.isnan(ll2[5]) and np.all(np.abs(ll2[live] - ref2[live]) <= logl_tol(ref2[live])), np.abs(ll2[live] - ref2[live]).max()
+
+
+@pytest.mark.parametrize("shape", ["fused8", "fused256", "split", "common", "ocean", "decon", "nfft512", "anyn", "long"])
+def test_long_window_plan_every_trace_kernel(oracle, shape):
+    """Every kernel that ends with a trace hands its misfits to the long-window GEMM: the 8-wave and the 4-wave fused
+    kernels, the split plan's trace kernel, the common-ray kernel, the ocean kernel, deconvolution, a short series,
+    the direct-DFT and the long-series kernels.  logL of every item against the oracle; a chain evaluated ALONE (the
+    per-call drop-in, batch of one) gets the same bits as inside the batch, and so does the host-owned-trace call."""
+    nsmp = 333
+    kw = {"fused8": dict(nfft=4096, rayps=[0.06], ipha=[1]),
+          "fused256": dict(nfft=4096, rayps=[0.06, 0.08, 0.1], ipha=[1, 1, -1]),
+          "split": dict(nfft=4096, rayps=[0.06, 0.08], ipha=[1, -1]),
+          "common": dict(nfft=4096, rayps=[0.07, 0.07, 0.07], ipha=[1, 1, 1], a_gus=[4.0, 2.5, 1.5]),
+          "ocean": dict(nfft=4096, rayps=[0.06, 0.1], ipha=[1, -1], sdep=2.0),
+          "decon": dict(nfft=4096, rayps=[0.06, 0.07], ipha=[1, 1], deconv_mode=1),
+          "nfft512": dict(nfft=512, rayps=[0.06, 0.07], ipha=[1, -1]),
+          "anyn": dict(nfft=1000, rayps=[0.06], ipha=[1]),
+          "long": dict(nfft=16384, rayps=[0.06], ipha=[-1])}[shape]
+    rng = np.random.default_rng(zlib.crc32(("lw" + shape).encode()))
+    cfg = make_cfg(t_start=-2.0, **kw)
+    ocean = cfg["sdep"] > 0
+    ntrc = len(cfg["rayps"])
+    true = random_stack(rng, 6, ocean, cfg["sdep"])
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    nb = 40 if shape in ("anyn", "long") else 700       # 700 x 3 blocks: beyond three rounds -> the 4-wave fused kernel
+    stacks = [random_stack(rng, int(n), ocean, cfg["sdep"]) for n in rng.integers(3 if ocean else 2, 20, nb)]
+    nlay, layers = pack_layers(stacks, 22)
+    sig = rng.uniform(0.01, 0.05, (nb, ntrc))
+    ref = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads())
+    opts = {"fused": 0} if shape == "split" else {}
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=22, options=opts) as eng:
+        plan = eng.launch_plan
+        assert plan["long_window_gemm"]
+        assert plan["fused"] == (shape not in ("split", "anyn", "long"))
+        if shape == "fused8":
+            assert plan["block_threads_full_batch"] == 512
+        if shape == "fused256":
+            assert plan["block_threads_full_batch"] == 256
+        assert plan["common_ray_fused"] == (shape == "common")
+        ll = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+        assert np.all(np.abs(ll - ref) <= logl_tol(ref)), (shape, np.abs(ll - ref).max())
+        # alone = in the batch, bit for bit (walker slots 3 and 17; the second through the per-call drop-in)
+        one = eng.eval_batch(np.array([3]), nlay[3:4], layers[3:4], sig[3:4])
+        assert one[0] == ll[3]
+        n17 = int(nlay[17])
+        l17, rft17 = eng.calc_likelihood(17, True, n17, *[layers[17, r, :n17] for r in range(4)], sig[17])
+        assert l17 == ll[17]
+        # ... and the fwd_flag = .false. branch for a trace the host owns (src/likelihood.f90:81-98)
+        assert eng.calc_likelihood_of_trace(rft17, sig[17]) == ll[17]
 
 
 @pytest.mark.parametrize("shape", ["land3", "ocean4", "common3", "decon2"])
