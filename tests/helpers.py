@@ -54,3 +54,18 @@ def logl_tol(ref):
     """|dlogL| bound: 1e-9 absolute (north star, stated at sigma = 0.01 and |logL| <~ 1e3),
     relaxed to 1e-12 relative for large |logL|."""
     return np.maximum(1e-9, 1e-12 * np.abs(ref))
+
+
+KAPPA_MIN, KAPPA_SCALE = 100.0, 10.0
+
+
+def assert_logl_parity(got, ref, kappa, what=""):
+    """|dlogL| <= logl_tol for every item; an item may exceed it only under the conditioning rule of
+    tests/test_gpu_configs.py: kappa = max|rx| / |maxval(rx)| of the oracle's own vertical trace
+    >= 100, and then within tolerance * kappa / 10.  Items below kappa = 100 get no allowance."""
+    got, ref, kappa = np.asarray(got), np.asarray(ref), np.asarray(kappa)
+    d = np.abs(got - ref)
+    tol = logl_tol(ref)
+    for i in np.nonzero(~(d <= tol))[0]:
+        assert kappa[i] >= KAPPA_MIN, (what, int(i), "well-conditioned item off tolerance", got[i], ref[i], kappa[i])
+        assert d[i] <= tol[i] * kappa[i] / KAPPA_SCALE, (what, int(i), got[i], ref[i], kappa[i])
