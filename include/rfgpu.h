@@ -27,6 +27,7 @@
 #ifndef RFGPU_H
 #define RFGPU_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -146,7 +147,10 @@ int rf_eval_batch_device(rf_ctx *ctx, int32_t nb, const int32_t *d_walker_ids,
                          void *stream);
 
 /* accept step of src/pt_mcmc.f90:182-191: for accept[i] != 0 the proposed trace
- * of walker_ids[i] becomes its current trace (`rft(:,:,ichain) = prop_rft`). */
+ * of walker_ids[i] becomes its current trace (`rft(:,:,ichain) = prop_rft`).
+ * rf_commit returns nothing from the device and does not wait for it: the arrays are copied before it returns (the
+ * caller may reuse them at once) and every later call on the context -- host-buffer or *_device, on any stream --
+ * is ordered behind the flip. */
 int rf_commit(rf_ctx *ctx, int32_t nb, const int32_t *walker_ids, const int32_t *accept);
 int rf_commit_device(rf_ctx *ctx, int32_t nb, const int32_t *d_walker_ids,
                      const int32_t *d_accept, void *stream);
@@ -192,6 +196,22 @@ int rf_format_models_device(rf_ctx *ctx, int32_t nb, const int32_t *d_k, const d
 int rf_eval_models_device(rf_ctx *ctx, int32_t nb, const int32_t *d_walker_ids, const int32_t *d_fwd_flag,
                           const int32_t *d_k, const double *d_z, const double *d_dvp, const double *d_dvs,
                           const double *d_sig, double *d_logl, int32_t *d_valid, void *stream);
+
+/* the same from HOST arrays in the layout the batched sampler keeps its proposals in (one column per chain, as
+ * module model's z(k_max-1, nchains), dvp/dvs(k_max, nchains), src/model.f90:33-34): k[nb]; z(ldz, nb), rows 1 .. k_max-1
+ * used, ldz = k_max - 1 or k_max; dvp(k_max, nb) (read only when vp_mode = 1); dvs(k_max, nb); sig(ntrc, nb);
+ * fwd_flag[nb] or NULL (1 forward model, 0 sigma-only, < 0 skip: the reference's null proposals); logl[nb] out;
+ * valid[nb] out, may be NULL.  Synchronous at return.  One iteration of pt_control_batched is one such call: the
+ * host keeps format_model only for the validity verdict its random stream depends on (src/pt_mcmc.f90:163-169). */
+int rf_eval_models(rf_ctx *ctx, int32_t nb, const int32_t *walker_ids, const int32_t *fwd_flag, const int32_t *k,
+                   const double *z, int32_t ldz, const double *dvp, const double *dvs, const double *sig,
+                   double *logl, int32_t *valid);
+
+/* Pinned (page-locked, device-mapped) host memory.  Host arrays handed to rf_eval_batch / rf_eval_models from such
+ * memory go to the device by DMA as they are; pageable arrays are first copied into the context's own pinned staging
+ * area (one host memcpy per array and call: ~1 KB per chain at k_max 30).  Optional; any host memory works. */
+int rf_host_alloc(size_t bytes, void **ptr);
+int rf_host_free(void *ptr);
 
 /* ---- parallel tempering ------------------------------------------------ */
 /* judge_pt (src/pt_mcmc.f90:580-595) for npairs DISJOINT chain pairs: swap

@@ -53,6 +53,18 @@ struct rf_ctx {
     int *d_ids = nullptr, *d_fwd = nullptr, *d_nlay = nullptr, *d_acc = nullptr;
     double *d_layers = nullptr, *d_sig = nullptr, *d_logl = nullptr;
     int stage_nb = 0, stage_pad = 0;
+    // Host buffers of the host-pointer entry points travel by DMA from PINNED memory: the caller's own arrays when
+    // they come from rf_host_alloc, else a copy in this arena (a bump allocator, rewound by every call that uses it).
+    // Outputs (logL, valid) are written by the kernels straight into device-mapped pinned memory (h_out).
+    char *pin = nullptr;          // the arena
+    size_t pin_cap = 0, pin_off = 0;
+    hipEvent_t pin_ev = nullptr;  // recorded after the last asynchronous use of the arena (rf_commit returns early)
+    bool pin_pending = false;
+    double *h_out = nullptr, *d_out = nullptr;   // [out_cap] logL | [out_cap] valid (as int), host pointer and its device alias
+    int out_cap = 0;
+    // device images of the proposals of rf_eval_models: k | z(ldz = k_max) | dvp | dvs
+    int *d_m_k = nullptr;
+    double *d_m_z = nullptr, *d_m_dvp = nullptr, *d_m_dvs = nullptr;
     // device format_model (row f-2): model tables + per-batch outputs
     bool have_model = false;
     ModelConfig model{};
@@ -97,7 +109,6 @@ struct rf_ctx {
     std::vector<double> flt, r_inv;
     std::vector<int> r_inv_rank;        // per trace: rank of the library-built pseudo-inverse (-1: caller's r_inv)
     std::vector<double> r_inv_gap;      // per trace: relative gap at the 1e-3 cut-off (NaN: caller's r_inv)
-    std::vector<int> h_order;
     // launch policy
     bool fused = false;       // one launch for spectra + trace (needs one forward computation per trace)
     int chain = 0;            // bins per phase chain in the spectra kernel (0: direct sincos)
@@ -272,6 +283,73 @@ static int ensure_stage(rf_ctx *c, int nb, int pad)
     c->d_logl = (double *)p;
     c->stage_nb = nnb;
     c->stage_pad = npad;
+    return 0;
+}
+
+// ---- pinned staging of host buffers ---------------------------------------------------------------------------
+static bool is_pinned_host(const void *p)
+{
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();       // pageable memory is "an invalid value" to this query: not an error of ours
+        return false;
+    }
+    return a.type == hipMemoryTypeHost;
+}
+
+// Start of a host-pointer call: waits for an earlier asynchronous user of the arena, makes room for `bytes`, rewinds.
+static int arena_begin(rf_ctx *c, size_t bytes)
+{
+    if (c->pin_pending) {
+        HIP_TRY(hipEventSynchronize(c->pin_ev));
+        c->pin_pending = false;
+    }
+    bytes += 8 * 256;                  // alignment slack of up to eight takes
+    if (bytes > c->pin_cap) {
+        if (c->pin) HIP_TRY(hipHostFree(c->pin));
+        c->pin = nullptr;
+        c->pin_cap = 0;
+        const size_t cap = std::max(bytes + bytes / 2, (size_t)1 << 20);
+        HIP_TRY(hipHostMalloc((void **)&c->pin, cap, hipHostMallocDefault));
+        c->pin_cap = cap;
+    }
+    c->pin_off = 0;
+    return 0;
+}
+
+static void *arena_take(rf_ctx *c, size_t bytes)
+{
+    const size_t at = (c->pin_off + 255) & ~(size_t)255;
+    c->pin_off = at + bytes;
+    return c->pin + at;                // (arena_begin sized the arena for every take of the call)
+}
+
+// host -> device on stream s: DMA straight from the caller's array when it is pinned, else through the arena
+static int h2d(rf_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s)
+{
+    if (!bytes) return 0;
+    const void *from = src;
+    if (!is_pinned_host(src)) {
+        void *stage = arena_take(c, bytes);
+        std::memcpy(stage, src, bytes);
+        from = stage;
+    }
+    HIP_TRY(hipMemcpyAsync(dst, from, bytes, hipMemcpyHostToDevice, s));
+    return 0;
+}
+
+// device-mapped pinned memory the kernels write a batch's logL (and validity flags) into
+static int ensure_out(rf_ctx *c, int nb)
+{
+    if (nb <= c->out_cap) return 0;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (c->h_out) HIP_TRY(hipHostFree(c->h_out));
+    c->h_out = nullptr;
+    c->out_cap = 0;
+    const int cap = std::max(nb, c->nslots);
+    HIP_TRY(hipHostMalloc((void **)&c->h_out, sizeof(double) * 2 * (size_t)cap, hipHostMallocMapped));
+    HIP_TRY(hipHostGetDevicePointer((void **)&c->d_out, c->h_out, 0));
+    c->out_cap = cap;
     return 0;
 }
 
@@ -587,6 +665,9 @@ extern "C" int rf_ctx_destroy(rf_ctx *c)
     for (void *p : c->owned) (void)hipFree(p);
     if (c->h_single_in) (void)hipHostFree(c->h_single_in);
     if (c->h_single_out) (void)hipHostFree(c->h_single_out);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (c->h_out) (void)hipHostFree(c->h_out);
+    if (c->pin_ev) (void)hipEventDestroy(c->pin_ev);
     for (auto &q : c->ev_pool) {
         (void)hipEventDestroy(q.e0);
         (void)hipEventDestroy(q.e1);
@@ -708,9 +789,18 @@ static int finish_likelihood(rf_ctx *c, const BatchArgs &b, int defer, hipStream
     return 0;
 }
 
+// rf_commit (host arrays) returns before the device has flipped the trace slots; a *_device call on ANOTHER stream
+// that reads or writes walker state is put behind it
+static int order_after_commit(rf_ctx *c, hipStream_t s)
+{
+    if (c->pin_pending && s != c->stream) HIP_TRY(hipStreamWaitEvent(s, c->pin_ev, 0));
+    return 0;
+}
+
 static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
 {
     if (b_in.nb <= 0) return 0;
+    if (order_after_commit(c, s)) return 1;
     if (b_in.nb > c->nslots) return fail("batch larger than max_walkers + 1");
     if (b_in.nlay_pad > c->cfg.nlay_max) return fail("nlay_pad exceeds nlay_max of the context");
     HIP_TRY(hipSetDevice(c->device));
@@ -811,28 +901,32 @@ extern "C" int rf_eval_batch(rf_ctx *c, int32_t nb, const int32_t *walker_ids, c
         if (nlay[i] < 2 || nlay[i] > nlay_pad) return fail("rf_eval_batch: nlay out of range");
     }
     HIP_TRY(hipSetDevice(c->device));
-    if (ensure_stage(c, nb, nlay_pad)) return 1;
+    if (ensure_stage(c, nb, nlay_pad) || ensure_out(c, nb)) return 1;
     hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->d_ids, walker_ids, sizeof(int) * nb, hipMemcpyHostToDevice, s));
-    if (fwd_flag) HIP_TRY(hipMemcpyAsync(c->d_fwd, fwd_flag, sizeof(int) * nb, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->d_nlay, nlay, sizeof(int) * nb, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->d_layers, layers, sizeof(double) * (size_t)nb * 4 * nlay_pad, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->d_sig, sig, sizeof(double) * (size_t)nb * c->cfg.ntrc, hipMemcpyHostToDevice, s));
-    BatchArgs b{nb, nlay_pad, c->d_ids, fwd_flag ? c->d_fwd : nullptr, c->d_nlay, c->d_layers, c->d_sig, c->d_logl, nullptr};
+    // inputs: one DMA per array from pinned memory (the caller's, or the arena's copy of a pageable array); output:
+    // the kernels write logL into device-mapped pinned memory -- no copy launch on either side of the evaluation
+    const size_t b_lay = sizeof(double) * (size_t)nb * 4 * nlay_pad, b_sig = sizeof(double) * (size_t)nb * c->cfg.ntrc;
+    if (arena_begin(c, 4 * sizeof(int) * (size_t)nb + b_lay + b_sig)) return 1;
+    if (h2d(c, c->d_ids, walker_ids, sizeof(int) * nb, s)) return 1;
+    if (fwd_flag && h2d(c, c->d_fwd, fwd_flag, sizeof(int) * nb, s)) return 1;
+    if (h2d(c, c->d_nlay, nlay, sizeof(int) * nb, s) || h2d(c, c->d_layers, layers, b_lay, s) ||
+        h2d(c, c->d_sig, sig, b_sig, s))
+        return 1;
+    BatchArgs b{nb, nlay_pad, c->d_ids, fwd_flag ? c->d_fwd : nullptr, c->d_nlay, c->d_layers, c->d_sig, c->d_out, nullptr};
     if (c->lpt && nb >= 2 * c->num_cu) {
-        // host buffers: the longest-first order is a counting sort here, no extra launch
-        c->h_order.resize(nb);
+        // host buffers: the longest-first order is a counting sort here (straight into the arena), no extra launch
+        int *ord = static_cast<int *>(arena_take(c, sizeof(int) * nb));
         int hist[257] = {0};
         auto key = [&](int i) { return (fwd_flag && fwd_flag[i] != 1) ? 0 : std::min(nlay[i], 255); };
         for (int i = 0; i < nb; ++i) ++hist[256 - key(i)];          // descending keys first
         for (int k = 1; k <= 256; ++k) hist[k] += hist[k - 1];
-        for (int i = nb - 1; i >= 0; --i) c->h_order[--hist[256 - key(i)]] = i;
-        HIP_TRY(hipMemcpyAsync(c->d_order, c->h_order.data(), sizeof(int) * nb, hipMemcpyHostToDevice, s));
+        for (int i = nb - 1; i >= 0; --i) ord[--hist[256 - key(i)]] = i;
+        HIP_TRY(hipMemcpyAsync(c->d_order, ord, sizeof(int) * nb, hipMemcpyHostToDevice, s));
         b.order = c->d_order;
     }
     if (run_batch(c, b, s)) return 1;
-    HIP_TRY(hipMemcpyAsync(logl, c->d_logl, sizeof(double) * nb, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(logl, c->h_out, sizeof(double) * nb);
     return 0;
 }
 
@@ -1019,6 +1113,13 @@ extern "C" int rf_set_model(rf_ctx *c, const rf_model_config *m)
     c->d_fm_layers = (double *)p;
     if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * 3 * m->k_max)) return 1;
     c->d_fm_scratch = (double *)p;
+    // device images of the host arrays of rf_eval_models
+    if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return 1;
+    c->d_m_k = (int *)p;
+    if (dev_alloc(c, &p, sizeof(double) * (size_t)c->nslots * 3 * m->k_max)) return 1;
+    c->d_m_z = (double *)p;
+    c->d_m_dvp = c->d_m_z + (size_t)c->nslots * m->k_max;
+    c->d_m_dvs = c->d_m_dvp + (size_t)c->nslots * m->k_max;
     c->have_model = true;
     return 0;
 }
@@ -1058,12 +1159,67 @@ extern "C" int rf_eval_models_device(rf_ctx *c, int32_t nb, const int32_t *d_wal
     return run_batch(c, b, s);
 }
 
+// The same from HOST arrays in the batched sampler's own layout (one column per chain): what an iteration of
+// pt_control_batched hands over.  Pinned arrays (rf_host_alloc) go down by DMA as they are.
+extern "C" int rf_eval_models(rf_ctx *c, int32_t nb, const int32_t *walker_ids, const int32_t *fwd_flag, const int32_t *k,
+                              const double *z, int32_t ldz, const double *dvp, const double *dvs, const double *sig,
+                              double *logl, int32_t *valid)
+{
+    if (!c || !walker_ids || !k || !z || !dvp || !dvs || !sig || !logl) return fail("rf_eval_models: null argument");
+    if (!c->have_model) return fail("rf_eval_models: rf_set_model has not been called");
+    if (nb <= 0) return 0;
+    if (nb > c->nslots) return fail("rf_eval_models: batch larger than max_walkers + 1");
+    const int kmax = c->model.k_max, ntrc = c->cfg.ntrc;
+    if (ldz < kmax - 1 || ldz > kmax) return fail("rf_eval_models: ldz must be k_max - 1 or k_max");
+    for (int i = 0; i < nb; ++i) {
+        if (walker_ids[i] < 0 || walker_ids[i] >= c->nslots) return fail("rf_eval_models: walker id out of range");
+        if ((!fwd_flag || fwd_flag[i] == 1) && (k[i] < 1 || k[i] >= kmax)) return fail("rf_eval_models: k out of range");
+    }
+    HIP_TRY(hipSetDevice(c->device));
+    if (ensure_stage(c, nb, 2) || ensure_out(c, nb)) return 1;
+    hipStream_t s = c->stream;
+    const size_t N = (size_t)nb;
+    if (arena_begin(c, sizeof(int) * 3 * N + sizeof(double) * N * (ldz + 2 * (size_t)kmax + ntrc))) return 1;
+    if (h2d(c, c->d_ids, walker_ids, sizeof(int) * N, s) || h2d(c, c->d_m_k, k, sizeof(int) * N, s)) return 1;
+    if (fwd_flag && h2d(c, c->d_fwd, fwd_flag, sizeof(int) * N, s)) return 1;
+    if (h2d(c, c->d_m_z, z, sizeof(double) * N * ldz, s) || h2d(c, c->d_m_dvs, dvs, sizeof(double) * N * kmax, s) ||
+        h2d(c, c->d_sig, sig, sizeof(double) * N * ntrc, s))
+        return 1;
+    // (dVp enters format_model only when it is solved for, src/model.f90:216-217)
+    if (c->model.vp_mode == 1 && h2d(c, c->d_m_dvp, dvp, sizeof(double) * N * kmax, s)) return 1;
+    int *d_valid = reinterpret_cast<int *>(c->d_out + c->out_cap);
+    FormatParams P{c->model, nb, c->fm_pad, c->d_m_k, c->d_m_z, c->d_m_dvp, c->d_m_dvs, fwd_flag ? c->d_fwd : nullptr,
+                   c->d_fm_nlay, c->d_fm_layers, c->d_fm_flag, valid ? d_valid : nullptr, c->d_fm_scratch, ldz};
+    launch_format_model(P, s);
+    BatchArgs b{nb, c->fm_pad, c->d_ids, c->d_fm_flag, c->d_fm_nlay, c->d_fm_layers, c->d_sig, c->d_out, nullptr};
+    if (run_batch(c, b, s)) return 1;
+    HIP_TRY(hipStreamSynchronize(s));
+    std::memcpy(logl, c->h_out, sizeof(double) * N);
+    if (valid) std::memcpy(valid, reinterpret_cast<const int *>(c->h_out + c->out_cap), sizeof(int) * N);
+    return 0;
+}
+
+extern "C" int rf_host_alloc(size_t bytes, void **ptr)
+{
+    if (!ptr) return fail("rf_host_alloc: null argument");
+    *ptr = nullptr;
+    HIP_TRY(hipHostMalloc(ptr, bytes ? bytes : 8, hipHostMallocMapped));
+    return 0;
+}
+
+extern "C" int rf_host_free(void *ptr)
+{
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return 0;
+}
+
 extern "C" int rf_commit_device(rf_ctx *c, int32_t nb, const int32_t *d_walker_ids, const int32_t *d_accept,
                                 void *stream)
 {
     if (!c || !d_walker_ids || !d_accept) return fail("rf_commit_device: null argument");
     if (nb <= 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
+    if (order_after_commit(c, (hipStream_t)stream)) return 1;
     launch_commit(c->ws, nb, d_walker_ids, d_accept, c->cfg.ntrc, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -1078,11 +1234,20 @@ extern "C" int rf_commit(rf_ctx *c, int32_t nb, const int32_t *walker_ids, const
     HIP_TRY(hipSetDevice(c->device));
     if (ensure_stage(c, nb, 2)) return 1;
     hipStream_t s = c->stream;
-    HIP_TRY(hipMemcpyAsync(c->d_ids, walker_ids, sizeof(int) * nb, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(c->d_acc, accept, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+    // Nothing comes back from a commit, so the call does not wait for the device: the two arrays are copied into the
+    // pinned arena (the caller may reuse its own at once) and everything else is stream-ordered -- every later call
+    // on the context runs behind it.  The next user of the arena waits for this copy (pin_ev).
+    if (arena_begin(c, 2 * sizeof(int) * (size_t)nb)) return 1;
+    int *st = static_cast<int *>(arena_take(c, sizeof(int) * nb)), *sa = static_cast<int *>(arena_take(c, sizeof(int) * nb));
+    std::memcpy(st, walker_ids, sizeof(int) * nb);
+    std::memcpy(sa, accept, sizeof(int) * nb);
+    HIP_TRY(hipMemcpyAsync(c->d_ids, st, sizeof(int) * nb, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(c->d_acc, sa, sizeof(int) * nb, hipMemcpyHostToDevice, s));
     launch_commit(c->ws, nb, c->d_ids, c->d_acc, c->cfg.ntrc, s);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(s));
+    if (!c->pin_ev) HIP_TRY(hipEventCreateWithFlags(&c->pin_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(c->pin_ev, s));
+    c->pin_pending = true;
     return 0;
 }
 
@@ -1200,6 +1365,7 @@ extern "C" int rf_post_record_device(rf_ctx *c, int32_t n, const int32_t *d_walk
     if (n > c->nslots) return fail("rf_post_record_device: batch larger than max_walkers + 1");
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t s = (hipStream_t)stream;
+    if (order_after_commit(c, s)) return 1;
     // format_model of every chain in the batch (:240-242); rows of filtered-out chains are unused
     FormatParams P{c->model, n, c->fm_pad, d_k, d_z, d_dvp, d_dvs, nullptr, c->d_post_nlay, c->d_post_layers,
                    c->d_post_flag, nullptr, c->d_post_scratch};

@@ -113,6 +113,7 @@ struct FormatParams {
     int *flag;
     int *valid;
     double *scratch;
+    int ldz;            // doubles between the z rows of consecutive items; 0 = k_max - 1 (packed)
 };
 void launch_format_model(const FormatParams &P, hipStream_t s);
 void launch_order(int nb, const int *nlay, const int *fwd_flag, int *order, hipStream_t s);

@@ -3608,7 +3608,8 @@ __global__ __launch_bounds__(128) void format_model_kernel(FormatParams P)
         return;
     }
     double *tz = P.scratch + (size_t)ib * 3 * kmax, *tvp = tz + kmax, *tvs = tvp + kmax;
-    for (int i = 0; i < kmax - 1; ++i) tz[i] = P.z[(size_t)ib * (kmax - 1) + i];
+    const int ldz = P.ldz > 0 ? P.ldz : kmax - 1;   // (the batched Fortran host keeps z(k_max, nchains))
+    for (int i = 0; i < kmax - 1; ++i) tz[i] = P.z[(size_t)ib * ldz + i];
     for (int i = 0; i < kmax; ++i) {
         tvp[i] = P.dvp[(size_t)ib * kmax + i];
         tvs[i] = P.dvs[(size_t)ib * kmax + i];

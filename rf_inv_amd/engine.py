@@ -247,6 +247,26 @@ class RFEngine:
             dvs.data_ptr(), sig.data_ptr(), logl.data_ptr(), valid.data_ptr() if valid is not None else None,
             st.cuda_stream))
 
+    def eval_models(self, walker_ids, k, z, dvp, dvs, sig, fwd_flag=None, want_valid=False):
+        """rf_eval_models: format_model + forward + likelihood from HOST arrays in the batched sampler's layout --
+        k[nb] int32, z[nb, k_max - 1 or k_max], dvp / dvs[nb, k_max], sig[nb, ntrc] (row i = chain i, i.e. the
+        memory of Fortran's z(ldz, nb) ...).  Arrays from host_alloc() go down by DMA as they are.
+        Returns logL[nb] (and valid[nb])."""
+        ids = np.ascontiguousarray(walker_ids, dtype=np.int32)
+        nb = ids.size
+        kk = np.ascontiguousarray(k, dtype=np.int32)
+        zz, vp, vs = (np.ascontiguousarray(a, dtype=np.float64) for a in (z, dvp, dvs))
+        s = np.ascontiguousarray(sig, dtype=np.float64)
+        ff = None if fwd_flag is None else np.ascontiguousarray(fwd_flag, dtype=np.int32)
+        if zz.shape[0] != nb or vp.shape != vs.shape or vp.shape[0] != nb or s.shape != (nb, self.ntrc):
+            raise ValueError("bad batch shapes")
+        out = np.empty(nb)
+        valid = np.empty(nb, dtype=np.int32) if want_valid else None
+        self._chk(self._lib.rf_eval_models(self._ctx, nb, _iptr(ids), _iptr(ff) if ff is not None else None, _iptr(kk),
+                                           _dptr(zz), int(zz.shape[1]), _dptr(vp), _dptr(vs), _dptr(s), _dptr(out),
+                                           _iptr(valid) if want_valid else None))
+        return (out, valid) if want_valid else out
+
     def pt_swap_device(self, pairs, log_u, temps, logl, accepted=None, stream=None):
         """judge_pt over pairs[npairs, 2] (torch int32), applied in order."""
         import torch
@@ -364,3 +384,20 @@ def compute_r_inv(nsmp, a_gus, delta, with_gap=False):
     if lib.rf_compute_r_inv(int(nsmp), float(a_gus), float(delta), _dptr(out), C.byref(rank), C.byref(gap)):
         raise RFGPUError(lib.rf_last_error().decode())
     return (out, rank.value, gap.value) if with_gap else (out, rank.value)
+
+
+def host_alloc(shape, dtype=np.float64):
+    """A numpy array in pinned (page-locked, device-mapped) host memory (rf_host_alloc): host arrays handed to
+    eval_batch / eval_models from such memory travel to the GPU by DMA without a staging copy.  Freed with the array."""
+    import weakref
+
+    lib = _lib.load()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape))
+    ptr = C.c_void_p()
+    if lib.rf_host_alloc(max(1, n * dt.itemsize), C.byref(ptr)):
+        raise RFGPUError(lib.rf_last_error().decode())
+    buf = (C.c_char * max(1, n * dt.itemsize)).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    weakref.finalize(buf, lib.rf_host_free, ptr)
+    return arr

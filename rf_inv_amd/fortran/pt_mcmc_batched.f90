@@ -3,10 +3,14 @@
 !
 !   call pt_control_batched(verb)     ! instead of  call pt_control(verb)
 !
-! One iteration = propose every chain -> ONE batched forward+likelihood call
-! on the GPU (rf_eval_batch) -> accept/reject every chain -> rf_commit ->
-! temperature swap.  It shares all state with the reference's modules
-! (model: k, z, dvp, dvs; likelihood: sig, log_likelihood; params: temps;
+! One iteration = propose every chain -> ONE batched format_model + forward +
+! likelihood call on the GPU (rf_eval_models: the proposals go down as
+! (k, z, dVp, dVs), ~0.75 KB per chain at k_max 30, from pinned host arrays
+! the proposal step writes in place -- no layer stacks are packed or
+! uploaded) -> accept/reject every chain -> rf_commit (does not wait for the
+! device) -> temperature swap.  The host keeps format_model only for the
+! validity verdict its random stream depends on (src/pt_mcmc.f90:163-169).
+! It shares all state with the reference's modules (model: k, z, dvp, dvs; likelihood: sig, log_likelihood; params: temps;
 ! pt_mcmc: every counter and histogram), so init_pt_mcmc before it and
 ! output_results after it work unchanged.
 !
@@ -49,19 +53,20 @@ contains
     use pt_mcmc
     include "mpif.h"
     logical, intent(in) :: verb
-    integer :: nproc, rank, ierr, it, n_tot_iter, n_all, ichain, nb, ib, i
-    integer :: itype, nlay, nlay_pad, cand_k
+    integer :: nproc, rank, ierr, it, n_tot_iter, n_all, ichain, nb, i
+    integer :: itype, nlay, cand_k
     logical :: live, yn
     real(8) :: alpha(nlay_max), beta(nlay_max), rho(nlay_max), h(nlay_max)
-    real(8) :: cand_z(k_max), cand_dvp(k_max), cand_dvs(k_max), cand_sig(ntrc)
     real(8) :: lpr, r, del_s, t_cold
-    ! per-chain proposals of the current iteration
-    integer, allocatable :: p_k(:), p_type(:)
+    ! per-chain proposals of the current iteration.  The arrays the engine reads live in pinned host memory
+    ! (rf_host_alloc): they travel to the GPU by DMA as the proposal step left them.
+    integer, allocatable :: p_type(:)
     logical, allocatable :: p_live(:), p_acc(:)
-    real(8), allocatable :: p_z(:,:), p_dvp(:,:), p_dvs(:,:), p_sig(:,:), p_lp(:), p_logr(:)
-    ! the batch handed to the engine
-    integer(c_int32_t), allocatable :: b_id(:), b_fwd(:), b_nlay(:), b_acc(:)
-    real(c_double), allocatable :: b_layers(:,:,:), b_sig(:,:), b_logl(:)
+    real(8), allocatable :: p_lp(:), p_logr(:)
+    integer(c_int32_t), pointer :: p_k(:), b_id(:), b_fwd(:)
+    real(c_double), pointer :: p_z(:,:), p_dvp(:,:), p_dvs(:,:), p_sig(:,:), b_logl(:)
+    type(c_ptr) :: pin(8)
+    integer(c_int32_t), allocatable :: b_acc(:)
     ! device-side posterior accumulation
     integer(c_int32_t), allocatable :: r_id(:)
     real(c_double), allocatable, target :: r_temps(:)
@@ -73,21 +78,25 @@ contains
     call mpi_comm_rank(MPI_COMM_WORLD, rank, ierr)
     n_all = nproc * nchains
     n_tot_iter = nburn + niter
-    nlay_pad = k_max + 2
     t_cold = 1.d0 + 1.0e-6
 
-    allocate(p_k(nchains), p_type(nchains), p_live(nchains), p_acc(nchains))
-    allocate(p_z(k_max, nchains), p_dvp(k_max, nchains), p_dvs(k_max, nchains))
-    allocate(p_sig(ntrc, nchains), p_lp(nchains), p_logr(nchains))
-    allocate(b_id(nchains), b_fwd(nchains), b_nlay(nchains), b_acc(nchains))
-    allocate(b_layers(nlay_pad, 4, nchains), b_sig(ntrc, nchains), b_logl(nchains))
+    allocate(p_type(nchains), p_live(nchains), p_acc(nchains), p_lp(nchains), p_logr(nchains), b_acc(nchains))
+    call pinned_i32(pin(1), p_k, nchains)
+    call pinned_i32(pin(2), b_id, nchains)
+    call pinned_i32(pin(3), b_fwd, nchains)
+    call pinned_f64_2d(pin(4), p_z, k_max, nchains)
+    call pinned_f64_2d(pin(5), p_dvp, k_max, nchains)
+    call pinned_f64_2d(pin(6), p_dvs, k_max, nchains)
+    call pinned_f64_2d(pin(7), p_sig, ntrc, nchains)
+    call pinned_f64_1d(pin(8), b_logl, nchains)
+    p_z = 0.d0;  p_dvp = 0.d0;  p_dvs = 0.d0
     allocate(r_id(nchains), r_temps(nchains))
     call setup_device_posterior()
     call open_temperature_exchange()
 
     ! the first evaluation of every chain (init_likelihood) becomes its current trace
     do ichain = 1, nchains
-       b_id(ichain) = ichain - 1
+       b_id(ichain) = ichain - 1            ! (constant: every iteration hands over all chains, null proposals flagged)
        b_acc(ichain) = 1
     end do
     call rfgpu_check(rf_commit(rf_ctx, int(nchains, c_int32_t), b_id, b_acc), "rf_commit")
@@ -100,10 +109,11 @@ contains
        !----------------------------------------------------------------
        nb = 0
        do ichain = 1, nchains
-          call draw_candidate(ichain)
+          call draw_candidate(ichain)          ! writes the candidate into column ichain of p_k, p_z, p_dvp, p_dvs, p_sig
           p_type(ichain) = itype
           p_live(ichain) = live
           p_acc(ichain) = .false.
+          b_fwd(ichain) = -1                   ! a null proposal: the engine skips the item
           if (.not. live) cycle
           ! the acceptance uniform of the Metropolis-Hastings test, drawn at its place in the
           ! reference's stream (it does not depend on the likelihood)
@@ -113,47 +123,29 @@ contains
           end do
           p_logr(ichain) = log(r)
           p_lp(ichain) = lpr
-          p_k(ichain) = cand_k
-          p_z(1:k_max-1, ichain) = cand_z(1:k_max-1)
-          p_dvp(:, ichain) = cand_dvp
-          p_dvs(:, ichain) = cand_dvs
-          p_sig(:, ichain) = cand_sig
           nb = nb + 1
-          b_id(nb) = ichain - 1
-          b_sig(:, nb) = cand_sig
-          b_layers(:, :, nb) = 1.d0
-          if (itype == itype_sig) then
-             b_fwd(nb) = 0          ! noise-level move: the chain's stored trace is re-used
-             b_nlay(nb) = 2
-          else
-             b_fwd(nb) = 1
-             b_nlay(nb) = nlay
-             b_layers(1:nlay, 1, nb) = alpha(1:nlay)
-             b_layers(1:nlay, 2, nb) = beta(1:nlay)
-             b_layers(1:nlay, 3, nb) = rho(1:nlay)
-             b_layers(1:nlay, 4, nb) = h(1:nlay)
-          end if
+          b_fwd(ichain) = merge(0, 1, itype == itype_sig)   ! noise-level move: the chain's stored trace is re-used
        end do
 
        !----------------------------------------------------------------
-       ! 2. one batched forward + likelihood evaluation on the GPU
+       ! 2. one batched format_model + forward + likelihood evaluation on the GPU
        !----------------------------------------------------------------
        if (nb > 0) then
-          call rfgpu_check(rf_eval_batch(rf_ctx, int(nb, c_int32_t), b_id, b_fwd, b_nlay, &
-               & int(nlay_pad, c_int32_t), b_layers, b_sig, b_logl), "rf_eval_batch")
+          call rfgpu_check(rf_eval_models(rf_ctx, int(nchains, c_int32_t), b_id, b_fwd, p_k, p_z, int(k_max, c_int32_t), &
+               & p_dvp, p_dvs, p_sig, b_logl, c_null_ptr), "rf_eval_models")
        end if
 
        !----------------------------------------------------------------
        ! 3. Metropolis-Hastings decisions and state update
        !----------------------------------------------------------------
-       do ib = 1, nb
-          ichain = b_id(ib) + 1
-          del_s = (b_logl(ib) - log_likelihood(ichain)) / temps(ichain) + p_lp(ichain)
+       do ichain = 1, nchains
+          b_acc(ichain) = 0
+          if (.not. p_live(ichain)) cycle
+          del_s = (b_logl(ichain) - log_likelihood(ichain)) / temps(ichain) + p_lp(ichain)
           yn = (p_logr(ichain) <= del_s)
-          b_acc(ib) = 0
           if (yn) then
-             b_acc(ib) = 1
-             log_likelihood(ichain) = b_logl(ib)
+             b_acc(ichain) = 1
+             log_likelihood(ichain) = b_logl(ichain)
              k(ichain) = p_k(ichain)
              dvp(1:k_max, ichain) = p_dvp(1:k_max, ichain)
              dvs(1:k_max, ichain) = p_dvs(1:k_max, ichain)
@@ -162,7 +154,7 @@ contains
           end if
           p_acc(ichain) = yn
        end do
-       if (nb > 0) call rfgpu_check(rf_commit(rf_ctx, int(nb, c_int32_t), b_id, b_acc), "rf_commit")
+       if (nb > 0) call rfgpu_check(rf_commit(rf_ctx, int(nchains, c_int32_t), b_id, b_acc), "rf_commit")
 
        !----------------------------------------------------------------
        ! 4. counters and posterior records of the non-tempered chains
@@ -191,8 +183,36 @@ contains
 
     if (over_rccl) call rfgpu_check(rf_comm_destroy(rf_ctx), "rf_comm_destroy")
     call fetch_device_posterior()
+    do i = 1, size(pin)
+       call rfgpu_check(rf_host_free(pin(i)), "rf_host_free")
+    end do
 
   contains
+
+    ! arrays in pinned host memory (rf_host_alloc)
+    subroutine pinned_i32(handle, a, n)
+      type(c_ptr), intent(out) :: handle
+      integer(c_int32_t), pointer, intent(out) :: a(:)
+      integer, intent(in) :: n
+      call rfgpu_check(rf_host_alloc(int(4 * max(n, 1), c_size_t), handle), "rf_host_alloc")
+      call c_f_pointer(handle, a, [n])
+    end subroutine pinned_i32
+
+    subroutine pinned_f64_1d(handle, a, n)
+      type(c_ptr), intent(out) :: handle
+      real(c_double), pointer, intent(out) :: a(:)
+      integer, intent(in) :: n
+      call rfgpu_check(rf_host_alloc(int(8 * max(n, 1), c_size_t), handle), "rf_host_alloc")
+      call c_f_pointer(handle, a, [n])
+    end subroutine pinned_f64_1d
+
+    subroutine pinned_f64_2d(handle, a, m, n)
+      type(c_ptr), intent(out) :: handle
+      real(c_double), pointer, intent(out) :: a(:,:)
+      integer, intent(in) :: m, n
+      call rfgpu_check(rf_host_alloc(int(8, c_size_t) * int(max(m * n, 1), c_size_t), handle), "rf_host_alloc")
+      call c_f_pointer(handle, a, [m, n])
+    end subroutine pinned_f64_2d
 
     ! One chain's trans-dimensional proposal.  Sets (host-associated) itype, cand_*, lpr,
     ! live and -- for live candidates -- the formatted layer stack nlay/alpha/beta/rho/h.
@@ -203,6 +223,10 @@ contains
       integer :: pick
       logical :: ok
 
+      ! the candidate is built in place, in column jc of the pinned proposal arrays
+      real(c_double), pointer :: cand_z(:), cand_dvp(:), cand_dvs(:), cand_sig(:)
+
+      cand_z => p_z(:, jc);  cand_dvp => p_dvp(:, jc);  cand_dvs => p_dvs(:, jc);  cand_sig => p_sig(:, jc)
       cand_k = k(jc)
       cand_dvp(:) = dvp(1:k_max, jc)
       cand_dvs(:) = dvs(1:k_max, jc)
@@ -264,9 +288,11 @@ contains
       end if
 
       if (live) then
+         ! (only the verdict is used: the engine formats the model itself, bit for bit the same)
          call format_model(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs, nlay, alpha, beta, rho, h, ok)
          live = ok
       end if
+      p_k(jc) = cand_k
     end subroutine draw_candidate
 
     ! ------------------------------------------------------------------------------------------------

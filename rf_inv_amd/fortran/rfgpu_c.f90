@@ -115,6 +115,30 @@ module rfgpu_c
        real(c_double), intent(out) :: logl(*)
      end function rf_eval_batch
 
+     ! format_model + calc_likelihood for nb proposals (k, z, dVp, dVs) in the sampler's own column-per-chain arrays
+     integer(c_int) function rf_eval_models(ctx, nb, walker_ids, fwd_flag, k, z, ldz, dvp, dvs, sig, logl, valid) &
+          & bind(C, name="rf_eval_models")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: nb, ldz
+       integer(c_int32_t), intent(in) :: walker_ids(*), fwd_flag(*), k(*)
+       real(c_double), intent(in) :: z(*), dvp(*), dvs(*), sig(*)
+       real(c_double), intent(out) :: logl(*)
+       type(c_ptr), value :: valid          ! c_null_ptr: not wanted
+     end function rf_eval_models
+
+     ! pinned host memory (arrays from it travel to the GPU by DMA as they are)
+     integer(c_int) function rf_host_alloc(bytes, ptr) bind(C, name="rf_host_alloc")
+       import :: c_int, c_ptr, c_size_t
+       integer(c_size_t), value :: bytes
+       type(c_ptr), intent(out) :: ptr
+     end function rf_host_alloc
+
+     integer(c_int) function rf_host_free(ptr) bind(C, name="rf_host_free")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ptr
+     end function rf_host_free
+
      integer(c_int) function rf_commit(ctx, nb, walker_ids, accept) bind(C, name="rf_commit")
        import :: c_int, c_ptr, c_int32_t
        type(c_ptr), value :: ctx

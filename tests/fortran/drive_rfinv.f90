@@ -22,6 +22,7 @@ program drive_rfinv
   implicit none
   include "mpif.h"
   integer :: nproc, rank, ierr, it, u, n_it, mode
+  real(8) :: t_loop0, t_loop1
   character(clen_max) :: param_file, arg, dump_file
 
   call mpi_init(ierr)
@@ -54,11 +55,18 @@ program drive_rfinv
   call init_model(.false.)
   call init_likelihood(.false.)
   call init_pt_mcmc(.false.)
+  call mpi_barrier(MPI_COMM_WORLD, ierr)
+  t_loop0 = mpi_wtime()
   if (mode == 0) then
      call pt_control(.false.)
   else
      call pt_control_batched(.false.)
   end if
+  call mpi_barrier(MPI_COMM_WORLD, ierr)
+  t_loop1 = mpi_wtime()
+  ! (tests/tools/sampler_rate*.sh: wall time of the sampler loop alone, all ranks)
+  if (rank == 0) write(*,'(A,F12.6,A,I0,A,I0,A,I0)') " drive_rfinv: loop seconds ", t_loop1 - t_loop0, " ranks ", nproc, &
+       & " chains_per_rank ", nchains, " iterations ", nburn + niter
 
   u = 79
   if (nproc == 1) then

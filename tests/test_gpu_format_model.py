@@ -119,3 +119,64 @@ def test_eval_models_device_matches_host_format_plus_eval(oracle, golden_dir):
         phi = -2 * (ll[rows] + 2 * p.nsmp * np.log(0.02)) * 0.02 ** 2     # sum over the 2 traces
         want = -0.5 * phi / 0.04 ** 2 - 2 * p.nsmp * np.log(0.04)
         assert np.allclose(ll2[rows], want, rtol=1e-11, atol=1e-8)
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("ldz_full", [False, True])
+def test_eval_models_from_host_arrays(oracle, golden_dir, pinned, ldz_full):
+    """rf_eval_models (host arrays in the batched sampler's column-per-chain layout; pageable, or pinned through
+    rf_host_alloc; z with leading dimension k_max - 1 or k_max) == host format_model + rf_eval_batch, bit for bit;
+    null proposals (fwd_flag < 0) and invalid models come back NaN, sigma-only items re-use the committed trace; and
+    rf_commit, which no longer waits for the device, is ordered in front of everything that follows it."""
+    from rf_inv_amd import RFEngine, format_model, read_ref_model
+    from rf_inv_amd.engine import host_alloc
+    from rf_inv_amd.likelihood import init_r_inv
+    from helpers import pack_layers
+
+    p, ref, mcfg = _setup(golden_dir, 0.0, 0, 12)
+    ref = read_ref_model(os.path.join(p.base_dir, p.vel_file))
+    rng = np.random.default_rng(7)
+    nb = 700
+    k, z, dvp, dvs = _proposals(rng, p, nb)
+    if ldz_full:
+        z = np.concatenate([z, rng.uniform(0, 20, (nb, 1))], axis=1)      # z(k_max, nb): the last row is never read
+    sig = rng.uniform(0.01, 0.03, (nb, p.ntrc))
+    ff = np.ones(nb, dtype=np.int32)
+    ff[::7] = -1
+    if pinned:
+        def pin(a):
+            b = host_alloc(a.shape, a.dtype)
+            b[...] = a
+            return b
+        k, z, dvp, dvs, sig, ff = (pin(a) for a in (k, z, dvp, dvs, sig, ff))
+    with RFEngine.from_params(p, r_inv=init_r_inv(p.nsmp, p.a_gus, p.delta), max_walkers=nb) as eng:
+        eng.set_model(p, ref)
+        ll, ok = eng.eval_models(np.arange(nb), k, z, dvp, dvs, sig, fwd_flag=ff, want_valid=True)
+        stacks, rows = [], []
+        for i in range(nb):
+            if ff[i] < 0:
+                assert np.isnan(ll[i])
+                continue
+            nl, a, b, r, h, v = format_model(p, ref, k[i], z[i, :p.k_max - 1], dvp[i], dvs[i])
+            assert v == bool(ok[i]), i
+            if v:
+                rows.append(i); stacks.append((a, b, r, h))
+            else:
+                assert np.isnan(ll[i])
+        assert 30 < len(rows) < nb
+        rows = np.array(rows)
+        nlay, layers = pack_layers(stacks, p.k_max + 2)
+        acc = np.zeros(nb, dtype=np.int32)
+        acc[rows[::2]] = 1
+        eng.commit(np.arange(nb), acc)                   # returns at once; what follows is ordered behind it
+        ref_ll = eng.eval_batch(rows, nlay, layers, sig[rows])
+        assert np.array_equal(ll[rows], ref_ll)
+        # the committed half: a sigma-only proposal re-uses the committed trace
+        ff2 = np.zeros(nb, dtype=np.int32)
+        ll2 = eng.eval_models(np.arange(nb), k, z, dvp, dvs, 2 * sig, fwd_flag=ff2)
+        got = rows[::2]
+        tr = eng.get_rft_batch(got, which=0, n=p.nsmp)                 # [n, ntrc, nsmp] current traces
+        obs, r_inv = p.obs[:, :p.nsmp], init_r_inv(p.nsmp, p.a_gus, p.delta)
+        for j, i in enumerate(got[:40]):
+            want = oracle.log_likelihood(np.pad(tr[j], ((0, 0), (0, p.nfft - p.nsmp))), obs, r_inv, 2 * sig[i], p.nsmp)
+            assert abs(ll2[i] - want) <= logl_tol(want), (i, ll2[i], want)
