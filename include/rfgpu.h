@@ -207,6 +207,19 @@ int rf_eval_models(rf_ctx *ctx, int32_t nb, const int32_t *walker_ids, const int
                    const double *z, int32_t ldz, const double *dvp, const double *dvs, const double *sig,
                    double *logl, int32_t *valid);
 
+/* Asynchronous form, for a host that overlaps its own work with the evaluation (pt_control_batched proposes one half
+ * of its chains while the other half is being evaluated): rf_eval_models_begin enqueues the transfers and kernels on
+ * the context's stream and returns a ticket; rf_eval_wait blocks until that evaluation has finished and delivers
+ * logl[nb] (and valid[nb] if want_valid was set).  Evaluations of a context execute in submission order; up to
+ * RF_EVAL_MAX_IN_FLIGHT may be outstanding.  Pageable input arrays are copied before rf_eval_models_begin returns;
+ * PINNED ones (rf_host_alloc) are read by DMA afterwards and must stay untouched until the matching rf_eval_wait.
+ * Other host-buffer calls on the context (rf_commit, rf_post_record ...) may be issued in between: stream-ordered. */
+#define RF_EVAL_MAX_IN_FLIGHT 4
+int rf_eval_models_begin(rf_ctx *ctx, int32_t nb, const int32_t *walker_ids, const int32_t *fwd_flag, const int32_t *k,
+                         const double *z, int32_t ldz, const double *dvp, const double *dvs, const double *sig,
+                         int32_t want_valid, int32_t *ticket);
+int rf_eval_wait(rf_ctx *ctx, int32_t ticket, double *logl, int32_t *valid);
+
 /* Pinned (page-locked, device-mapped) host memory.  Host arrays handed to rf_eval_batch / rf_eval_models from such
  * memory go to the device by DMA as they are; pageable arrays are first copied into the context's own pinned staging
  * area (one host memcpy per array and call: ~1 KB per chain at k_max 30).  Optional; any host memory works. */

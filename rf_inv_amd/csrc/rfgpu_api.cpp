@@ -56,11 +56,21 @@ struct rf_ctx {
     // Host buffers of the host-pointer entry points travel by DMA from PINNED memory: the caller's own arrays when
     // they come from rf_host_alloc, else a copy in this arena (a bump allocator, rewound by every call that uses it).
     // Outputs (logL, valid) are written by the kernels straight into device-mapped pinned memory (h_out).
-    char *pin = nullptr;          // the arena
-    size_t pin_cap = 0, pin_off = 0;
-    hipEvent_t pin_ev = nullptr;  // recorded after the last asynchronous use of the arena (rf_commit returns early)
-    bool pin_pending = false;
-    double *h_out = nullptr, *d_out = nullptr;   // [out_cap] logL | [out_cap] valid (as int), host pointer and its device alias
+    // One arena and one output region per evaluation that can be in flight (rf_eval_models_begin / rf_eval_wait)
+    // plus one for the synchronous calls and rf_commit (index RF_EVAL_MAX_IN_FLIGHT).
+    struct Arena {
+        char *p = nullptr;
+        size_t cap = 0, off = 0;
+        hipEvent_t ev = nullptr;  // recorded after the last asynchronous use (an evaluation in flight; rf_commit returns early)
+        bool pending = false;
+    } arena[RF_EVAL_MAX_IN_FLIGHT + 1];
+    struct Ticket {
+        bool busy = false;
+        int nb = 0;
+        bool want_valid = false;
+    } ticket[RF_EVAL_MAX_IN_FLIGHT];
+    int ticket_next = 0;
+    double *h_out = nullptr, *d_out = nullptr;   // [RF_EVAL_MAX_IN_FLIGHT + 1][2][out_cap]: logL | valid (as int) per region; host pointer and its device alias
     int out_cap = 0;
     // device images of the proposals of rf_eval_models: k | z(ldz = k_max) | dvp | dvs
     int *d_m_k = nullptr;
@@ -298,39 +308,48 @@ static bool is_pinned_host(const void *p)
 }
 
 // Start of a host-pointer call: waits for an earlier asynchronous user of the arena, makes room for `bytes`, rewinds.
-static int arena_begin(rf_ctx *c, size_t bytes)
+static int arena_begin(rf_ctx::Arena &A, size_t bytes)
 {
-    if (c->pin_pending) {
-        HIP_TRY(hipEventSynchronize(c->pin_ev));
-        c->pin_pending = false;
+    if (A.pending) {
+        HIP_TRY(hipEventSynchronize(A.ev));
+        A.pending = false;
     }
     bytes += 8 * 256;                  // alignment slack of up to eight takes
-    if (bytes > c->pin_cap) {
-        if (c->pin) HIP_TRY(hipHostFree(c->pin));
-        c->pin = nullptr;
-        c->pin_cap = 0;
-        const size_t cap = std::max(bytes + bytes / 2, (size_t)1 << 20);
-        HIP_TRY(hipHostMalloc((void **)&c->pin, cap, hipHostMallocDefault));
-        c->pin_cap = cap;
+    if (bytes > A.cap) {
+        if (A.p) HIP_TRY(hipHostFree(A.p));
+        A.p = nullptr;
+        A.cap = 0;
+        const size_t cap = std::max(bytes + bytes / 2, (size_t)1 << 16);
+        HIP_TRY(hipHostMalloc((void **)&A.p, cap, hipHostMallocDefault));
+        A.cap = cap;
     }
-    c->pin_off = 0;
+    A.off = 0;
     return 0;
 }
 
-static void *arena_take(rf_ctx *c, size_t bytes)
+static void *arena_take(rf_ctx::Arena &A, size_t bytes)
 {
-    const size_t at = (c->pin_off + 255) & ~(size_t)255;
-    c->pin_off = at + bytes;
-    return c->pin + at;                // (arena_begin sized the arena for every take of the call)
+    const size_t at = (A.off + 255) & ~(size_t)255;
+    A.off = at + bytes;
+    return A.p + at;                   // (arena_begin sized the arena for every take of the call)
+}
+
+// after the last stream operation that reads the arena: its next user waits for this
+static int arena_mark(rf_ctx::Arena &A, hipStream_t s)
+{
+    if (!A.ev) HIP_TRY(hipEventCreateWithFlags(&A.ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(A.ev, s));
+    A.pending = true;
+    return 0;
 }
 
 // host -> device on stream s: DMA straight from the caller's array when it is pinned, else through the arena
-static int h2d(rf_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t s)
+static int h2d(rf_ctx::Arena &A, void *dst, const void *src, size_t bytes, hipStream_t s)
 {
     if (!bytes) return 0;
     const void *from = src;
     if (!is_pinned_host(src)) {
-        void *stage = arena_take(c, bytes);
+        void *stage = arena_take(A, bytes);
         std::memcpy(stage, src, bytes);
         from = stage;
     }
@@ -338,7 +357,8 @@ static int h2d(rf_ctx *c, void *dst, const void *src, size_t bytes, hipStream_t 
     return 0;
 }
 
-// device-mapped pinned memory the kernels write a batch's logL (and validity flags) into
+// device-mapped pinned memory the kernels write a batch's logL (and validity flags) into: one region per evaluation
+// that can be in flight + one for the synchronous calls
 static int ensure_out(rf_ctx *c, int nb)
 {
     if (nb <= c->out_cap) return 0;
@@ -347,11 +367,12 @@ static int ensure_out(rf_ctx *c, int nb)
     c->h_out = nullptr;
     c->out_cap = 0;
     const int cap = std::max(nb, c->nslots);
-    HIP_TRY(hipHostMalloc((void **)&c->h_out, sizeof(double) * 2 * (size_t)cap, hipHostMallocMapped));
+    HIP_TRY(hipHostMalloc((void **)&c->h_out, sizeof(double) * 2 * (size_t)cap * (RF_EVAL_MAX_IN_FLIGHT + 1), hipHostMallocMapped));
     HIP_TRY(hipHostGetDevicePointer((void **)&c->d_out, c->h_out, 0));
     c->out_cap = cap;
     return 0;
 }
+static size_t out_region(const rf_ctx *c, int region) { return (size_t)region * 2 * c->out_cap; }   // in doubles
 
 // Launch plan from the context's shape, then the explicit options on top.
 static void default_plan(rf_ctx *c)
@@ -665,9 +686,11 @@ extern "C" int rf_ctx_destroy(rf_ctx *c)
     for (void *p : c->owned) (void)hipFree(p);
     if (c->h_single_in) (void)hipHostFree(c->h_single_in);
     if (c->h_single_out) (void)hipHostFree(c->h_single_out);
-    if (c->pin) (void)hipHostFree(c->pin);
+    for (auto &A : c->arena) {
+        if (A.p) (void)hipHostFree(A.p);
+        if (A.ev) (void)hipEventDestroy(A.ev);
+    }
     if (c->h_out) (void)hipHostFree(c->h_out);
-    if (c->pin_ev) (void)hipEventDestroy(c->pin_ev);
     for (auto &q : c->ev_pool) {
         (void)hipEventDestroy(q.e0);
         (void)hipEventDestroy(q.e1);
@@ -793,7 +816,8 @@ static int finish_likelihood(rf_ctx *c, const BatchArgs &b, int defer, hipStream
 // that reads or writes walker state is put behind it
 static int order_after_commit(rf_ctx *c, hipStream_t s)
 {
-    if (c->pin_pending && s != c->stream) HIP_TRY(hipStreamWaitEvent(s, c->pin_ev, 0));
+    const rf_ctx::Arena &A = c->arena[RF_EVAL_MAX_IN_FLIGHT];
+    if (A.pending && s != c->stream) HIP_TRY(hipStreamWaitEvent(s, A.ev, 0));
     return 0;
 }
 
@@ -906,16 +930,18 @@ extern "C" int rf_eval_batch(rf_ctx *c, int32_t nb, const int32_t *walker_ids, c
     // inputs: one DMA per array from pinned memory (the caller's, or the arena's copy of a pageable array); output:
     // the kernels write logL into device-mapped pinned memory -- no copy launch on either side of the evaluation
     const size_t b_lay = sizeof(double) * (size_t)nb * 4 * nlay_pad, b_sig = sizeof(double) * (size_t)nb * c->cfg.ntrc;
-    if (arena_begin(c, 4 * sizeof(int) * (size_t)nb + b_lay + b_sig)) return 1;
-    if (h2d(c, c->d_ids, walker_ids, sizeof(int) * nb, s)) return 1;
-    if (fwd_flag && h2d(c, c->d_fwd, fwd_flag, sizeof(int) * nb, s)) return 1;
-    if (h2d(c, c->d_nlay, nlay, sizeof(int) * nb, s) || h2d(c, c->d_layers, layers, b_lay, s) ||
-        h2d(c, c->d_sig, sig, b_sig, s))
+    rf_ctx::Arena &A = c->arena[RF_EVAL_MAX_IN_FLIGHT];
+    double *h_logl = c->h_out + out_region(c, RF_EVAL_MAX_IN_FLIGHT), *d_logl = c->d_out + out_region(c, RF_EVAL_MAX_IN_FLIGHT);
+    if (arena_begin(A, 4 * sizeof(int) * (size_t)nb + b_lay + b_sig)) return 1;
+    if (h2d(A, c->d_ids, walker_ids, sizeof(int) * nb, s)) return 1;
+    if (fwd_flag && h2d(A, c->d_fwd, fwd_flag, sizeof(int) * nb, s)) return 1;
+    if (h2d(A, c->d_nlay, nlay, sizeof(int) * nb, s) || h2d(A, c->d_layers, layers, b_lay, s) ||
+        h2d(A, c->d_sig, sig, b_sig, s))
         return 1;
-    BatchArgs b{nb, nlay_pad, c->d_ids, fwd_flag ? c->d_fwd : nullptr, c->d_nlay, c->d_layers, c->d_sig, c->d_out, nullptr};
+    BatchArgs b{nb, nlay_pad, c->d_ids, fwd_flag ? c->d_fwd : nullptr, c->d_nlay, c->d_layers, c->d_sig, d_logl, nullptr};
     if (c->lpt && nb >= 2 * c->num_cu) {
         // host buffers: the longest-first order is a counting sort here (straight into the arena), no extra launch
-        int *ord = static_cast<int *>(arena_take(c, sizeof(int) * nb));
+        int *ord = static_cast<int *>(arena_take(A, sizeof(int) * nb));
         int hist[257] = {0};
         auto key = [&](int i) { return (fwd_flag && fwd_flag[i] != 1) ? 0 : std::min(nlay[i], 255); };
         for (int i = 0; i < nb; ++i) ++hist[256 - key(i)];          // descending keys first
@@ -926,7 +952,7 @@ extern "C" int rf_eval_batch(rf_ctx *c, int32_t nb, const int32_t *walker_ids, c
     }
     if (run_batch(c, b, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
-    std::memcpy(logl, c->h_out, sizeof(double) * nb);
+    std::memcpy(logl, h_logl, sizeof(double) * nb);
     return 0;
 }
 
@@ -1160,43 +1186,79 @@ extern "C" int rf_eval_models_device(rf_ctx *c, int32_t nb, const int32_t *d_wal
 }
 
 // The same from HOST arrays in the batched sampler's own layout (one column per chain): what an iteration of
-// pt_control_batched hands over.  Pinned arrays (rf_host_alloc) go down by DMA as they are.
-extern "C" int rf_eval_models(rf_ctx *c, int32_t nb, const int32_t *walker_ids, const int32_t *fwd_flag, const int32_t *k,
-                              const double *z, int32_t ldz, const double *dvp, const double *dvs, const double *sig,
-                              double *logl, int32_t *valid)
+// pt_control_batched hands over.  Pinned arrays (rf_host_alloc) go down by DMA as they are.  rf_eval_models_begin
+// enqueues transfers and kernels and returns; rf_eval_wait delivers the results of that ticket.
+extern "C" int rf_eval_models_begin(rf_ctx *c, int32_t nb, const int32_t *walker_ids, const int32_t *fwd_flag,
+                                    const int32_t *k, const double *z, int32_t ldz, const double *dvp, const double *dvs,
+                                    const double *sig, int32_t want_valid, int32_t *ticket)
 {
-    if (!c || !walker_ids || !k || !z || !dvp || !dvs || !sig || !logl) return fail("rf_eval_models: null argument");
+    if (!c || !walker_ids || !k || !z || !dvp || !dvs || !sig || !ticket) return fail("rf_eval_models_begin: null argument");
     if (!c->have_model) return fail("rf_eval_models: rf_set_model has not been called");
-    if (nb <= 0) return 0;
-    if (nb > c->nslots) return fail("rf_eval_models: batch larger than max_walkers + 1");
+    if (nb <= 0 || nb > c->nslots) return fail("rf_eval_models: batch size must be 1 .. max_walkers + 1");
     const int kmax = c->model.k_max, ntrc = c->cfg.ntrc;
     if (ldz < kmax - 1 || ldz > kmax) return fail("rf_eval_models: ldz must be k_max - 1 or k_max");
     for (int i = 0; i < nb; ++i) {
         if (walker_ids[i] < 0 || walker_ids[i] >= c->nslots) return fail("rf_eval_models: walker id out of range");
         if ((!fwd_flag || fwd_flag[i] == 1) && (k[i] < 1 || k[i] >= kmax)) return fail("rf_eval_models: k out of range");
     }
+    const int slot = c->ticket_next;
+    if (c->ticket[slot].busy) return fail("rf_eval_models_begin: RF_EVAL_MAX_IN_FLIGHT evaluations are already in flight");
     HIP_TRY(hipSetDevice(c->device));
     if (ensure_stage(c, nb, 2) || ensure_out(c, nb)) return 1;
     hipStream_t s = c->stream;
     const size_t N = (size_t)nb;
-    if (arena_begin(c, sizeof(int) * 3 * N + sizeof(double) * N * (ldz + 2 * (size_t)kmax + ntrc))) return 1;
-    if (h2d(c, c->d_ids, walker_ids, sizeof(int) * N, s) || h2d(c, c->d_m_k, k, sizeof(int) * N, s)) return 1;
-    if (fwd_flag && h2d(c, c->d_fwd, fwd_flag, sizeof(int) * N, s)) return 1;
-    if (h2d(c, c->d_m_z, z, sizeof(double) * N * ldz, s) || h2d(c, c->d_m_dvs, dvs, sizeof(double) * N * kmax, s) ||
-        h2d(c, c->d_sig, sig, sizeof(double) * N * ntrc, s))
+    rf_ctx::Arena &A = c->arena[slot];
+    if (arena_begin(A, sizeof(int) * 3 * N + sizeof(double) * N * (ldz + 2 * (size_t)kmax + ntrc))) return 1;
+    if (h2d(A, c->d_ids, walker_ids, sizeof(int) * N, s) || h2d(A, c->d_m_k, k, sizeof(int) * N, s)) return 1;
+    if (fwd_flag && h2d(A, c->d_fwd, fwd_flag, sizeof(int) * N, s)) return 1;
+    if (h2d(A, c->d_m_z, z, sizeof(double) * N * ldz, s) || h2d(A, c->d_m_dvs, dvs, sizeof(double) * N * kmax, s) ||
+        h2d(A, c->d_sig, sig, sizeof(double) * N * ntrc, s))
         return 1;
     // (dVp enters format_model only when it is solved for, src/model.f90:216-217)
-    if (c->model.vp_mode == 1 && h2d(c, c->d_m_dvp, dvp, sizeof(double) * N * kmax, s)) return 1;
-    int *d_valid = reinterpret_cast<int *>(c->d_out + c->out_cap);
+    if (c->model.vp_mode == 1 && h2d(A, c->d_m_dvp, dvp, sizeof(double) * N * kmax, s)) return 1;
+    double *d_logl = c->d_out + out_region(c, slot);
+    int *d_valid = reinterpret_cast<int *>(d_logl + c->out_cap);
     FormatParams P{c->model, nb, c->fm_pad, c->d_m_k, c->d_m_z, c->d_m_dvp, c->d_m_dvs, fwd_flag ? c->d_fwd : nullptr,
-                   c->d_fm_nlay, c->d_fm_layers, c->d_fm_flag, valid ? d_valid : nullptr, c->d_fm_scratch, ldz};
+                   c->d_fm_nlay, c->d_fm_layers, c->d_fm_flag, want_valid ? d_valid : nullptr, c->d_fm_scratch, ldz};
     launch_format_model(P, s);
-    BatchArgs b{nb, c->fm_pad, c->d_ids, c->d_fm_flag, c->d_fm_nlay, c->d_fm_layers, c->d_sig, c->d_out, nullptr};
+    BatchArgs b{nb, c->fm_pad, c->d_ids, c->d_fm_flag, c->d_fm_nlay, c->d_fm_layers, c->d_sig, d_logl, nullptr};
+    // (consecutive evaluations of a context may be different sets of chains -- the halves of pt_control_batched's
+    // pipeline: the dispatch order the previous launch prepared is not this batch's)
+    c->order_next_nb = 0;
     if (run_batch(c, b, s)) return 1;
-    HIP_TRY(hipStreamSynchronize(s));
-    std::memcpy(logl, c->h_out, sizeof(double) * N);
-    if (valid) std::memcpy(valid, reinterpret_cast<const int *>(c->h_out + c->out_cap), sizeof(int) * N);
+    if (arena_mark(A, s)) return 1;      // the ticket's completion event
+    c->ticket[slot] = rf_ctx::Ticket{true, nb, want_valid != 0};
+    c->ticket_next = (slot + 1) % RF_EVAL_MAX_IN_FLIGHT;
+    *ticket = slot;
     return 0;
+}
+
+extern "C" int rf_eval_wait(rf_ctx *c, int32_t ticket, double *logl, int32_t *valid)
+{
+    if (!c || !logl) return fail("rf_eval_wait: null argument");
+    if (ticket < 0 || ticket >= RF_EVAL_MAX_IN_FLIGHT || !c->ticket[ticket].busy) return fail("rf_eval_wait: no such evaluation in flight");
+    rf_ctx::Ticket &T = c->ticket[ticket];
+    if (valid && !T.want_valid) return fail("rf_eval_wait: validity flags were not asked for at rf_eval_models_begin");
+    HIP_TRY(hipSetDevice(c->device));
+    rf_ctx::Arena &A = c->arena[ticket];
+    HIP_TRY(hipEventSynchronize(A.ev));
+    A.pending = false;
+    const double *h_logl = c->h_out + out_region(c, ticket);
+    std::memcpy(logl, h_logl, sizeof(double) * (size_t)T.nb);
+    if (valid) std::memcpy(valid, reinterpret_cast<const int *>(h_logl + c->out_cap), sizeof(int) * (size_t)T.nb);
+    T.busy = false;
+    return 0;
+}
+
+extern "C" int rf_eval_models(rf_ctx *c, int32_t nb, const int32_t *walker_ids, const int32_t *fwd_flag, const int32_t *k,
+                              const double *z, int32_t ldz, const double *dvp, const double *dvs, const double *sig,
+                              double *logl, int32_t *valid)
+{
+    if (!logl) return fail("rf_eval_models: null argument");
+    if (nb <= 0) return 0;
+    int32_t t = -1;
+    if (rf_eval_models_begin(c, nb, walker_ids, fwd_flag, k, z, ldz, dvp, dvs, sig, valid ? 1 : 0, &t)) return 1;
+    return rf_eval_wait(c, t, logl, valid);
 }
 
 extern "C" int rf_host_alloc(size_t bytes, void **ptr)
@@ -1237,18 +1299,16 @@ extern "C" int rf_commit(rf_ctx *c, int32_t nb, const int32_t *walker_ids, const
     // Nothing comes back from a commit, so the call does not wait for the device: the two arrays are copied into the
     // pinned arena (the caller may reuse its own at once) and everything else is stream-ordered -- every later call
     // on the context runs behind it.  The next user of the arena waits for this copy (pin_ev).
-    if (arena_begin(c, 2 * sizeof(int) * (size_t)nb)) return 1;
-    int *st = static_cast<int *>(arena_take(c, sizeof(int) * nb)), *sa = static_cast<int *>(arena_take(c, sizeof(int) * nb));
+    rf_ctx::Arena &A = c->arena[RF_EVAL_MAX_IN_FLIGHT];
+    if (arena_begin(A, 2 * sizeof(int) * (size_t)nb)) return 1;
+    int *st = static_cast<int *>(arena_take(A, sizeof(int) * nb)), *sa = static_cast<int *>(arena_take(A, sizeof(int) * nb));
     std::memcpy(st, walker_ids, sizeof(int) * nb);
     std::memcpy(sa, accept, sizeof(int) * nb);
     HIP_TRY(hipMemcpyAsync(c->d_ids, st, sizeof(int) * nb, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_acc, sa, sizeof(int) * nb, hipMemcpyHostToDevice, s));
     launch_commit(c->ws, nb, c->d_ids, c->d_acc, c->cfg.ntrc, s);
     HIP_TRY(hipGetLastError());
-    if (!c->pin_ev) HIP_TRY(hipEventCreateWithFlags(&c->pin_ev, hipEventDisableTiming));
-    HIP_TRY(hipEventRecord(c->pin_ev, s));
-    c->pin_pending = true;
-    return 0;
+    return arena_mark(A, s);
 }
 
 extern "C" int rf_pt_swap_device(rf_ctx *c, int32_t npairs, const int32_t *d_pairs, const double *d_log_u,

@@ -39,6 +39,12 @@ module pt_mcmc_batched
   ! test double of RCCL (real RCCL refuses two ranks on one device).
   character(len=1024), public :: rf_rccl_library = ""
   logical, public :: rf_exchange_shared_gpu_ok = .false.
+  ! wall-clock seconds of the last pt_control_batched by phase: 1 proposals (host), 2 rf_eval_models (copies, kernels,
+  ! wait), 3 accept / reject + rf_commit, 4 counters + posterior records, 5 temperature swap (incl. waiting for peers)
+  real(8), public :: rf_phase_seconds(5) = 0.d0
+  ! 2 (default): the chains of a rank are worked in two halves, one being evaluated on the GPU while the host judges and
+  ! re-proposes the other (same trajectory: see the loop); 1: propose all, evaluate all, judge all
+  integer, public :: rf_pipeline_segments = 2
 
 contains
 
@@ -63,8 +69,8 @@ contains
     integer, allocatable :: p_type(:)
     logical, allocatable :: p_live(:), p_acc(:)
     real(8), allocatable :: p_lp(:), p_logr(:)
-    integer(c_int32_t), pointer :: p_k(:), b_id(:), b_fwd(:)
-    real(c_double), pointer :: p_z(:,:), p_dvp(:,:), p_dvs(:,:), p_sig(:,:), b_logl(:)
+    integer(c_int32_t), pointer, contiguous :: p_k(:), b_id(:), b_fwd(:)
+    real(c_double), pointer, contiguous :: p_z(:,:), p_dvp(:,:), p_dvs(:,:), p_sig(:,:), b_logl(:)
     type(c_ptr) :: pin(8)
     integer(c_int32_t), allocatable :: b_acc(:)
     ! device-side posterior accumulation
@@ -73,7 +79,15 @@ contains
     logical :: record_now
     ! temperature exchange between ranks: RCCL (one GPU per rank) or MPI (ranks sharing a GPU)
     logical :: over_rccl
+    real(8) :: tick(6)
+    ! the pipeline: segments of the chains, the evaluation in flight for each, the swap proposal drawn but not yet decided
+    integer :: nseg, iseg, lo, hi, seg_lo(2), seg_hi(2)
+    integer(c_int32_t) :: seg_ticket(2)
+    logical :: seg_busy(2), swap_drawn
+    integer(c_int32_t) :: sw_pick(2)
+    real(8) :: sw_logu
 
+    rf_phase_seconds = 0.d0
     call mpi_comm_size(MPI_COMM_WORLD, nproc, ierr)
     call mpi_comm_rank(MPI_COMM_WORLD, rank, ierr)
     n_all = nproc * nchains
@@ -101,84 +115,138 @@ contains
     end do
     call rfgpu_check(rf_commit(rf_ctx, int(nchains, c_int32_t), b_id, b_acc), "rf_commit")
 
-    do it = 1, n_tot_iter
-       if (verb .and. mod(it, ncorr) == 0) write(*,*) "Iteration #:", it, "/", n_tot_iter
+    ! ------------------------------------------------------------------------------------------------------
+    ! The loop, software-pipelined over nseg segments of the chains (rf_pipeline_segments; 1 = no overlap).
+    ! While segment s of iteration `it` is being evaluated on the GPU the host finishes and re-proposes the
+    ! next segment.  Order of events, with S = nseg:
+    !   slot (it, s):  wait for + accept + commit segment s of iteration it-1
+    !                  [s = S: posterior records of it-1, then the swap DECISION of it-1]
+    !                  propose segment s of iteration it, hand it to the engine (rf_eval_models_begin)
+    !                  [s = S: the swap DRAWS of iteration it]
+    ! Every random draw sits where the reference's sequential loop makes it (chains 1 .. n of an iteration, then
+    ! the swap's draws, src/pt_mcmc.f90:488-571) and none depends on a likelihood; a chain is re-proposed only
+    ! after its previous proposal has been judged; an iteration's acceptance tests see the temperatures left by
+    ! the previous iteration's swap and its swap sees every chain's state after that iteration.  The trajectory
+    ! is the reference's.
+    ! ------------------------------------------------------------------------------------------------------
+    nseg = max(1, min(rf_pipeline_segments, 2, nchains))
+    do i = 1, nseg
+       seg_lo(i) = (i - 1) * nchains / nseg + 1
+       seg_hi(i) = i * nchains / nseg
+    end do
+    seg_busy = .false.
+    swap_drawn = .false.
 
-       !----------------------------------------------------------------
-       ! 1. proposals, chain by chain, in the reference's draw order
-       !----------------------------------------------------------------
-       nb = 0
-       do ichain = 1, nchains
-          call draw_candidate(ichain)          ! writes the candidate into column ichain of p_k, p_z, p_dvp, p_dvs, p_sig
-          p_type(ichain) = itype
-          p_live(ichain) = live
-          p_acc(ichain) = .false.
-          b_fwd(ichain) = -1                   ! a null proposal: the engine skips the item
-          if (.not. live) cycle
-          ! the acceptance uniform of the Metropolis-Hastings test, drawn at its place in the
-          ! reference's stream (it does not depend on the likelihood)
-          do
-             r = grnd()
-             if (r >= epsilon(1.d0)) exit
+    do it = 1, n_tot_iter + 1
+       if (verb .and. it <= n_tot_iter .and. mod(it, ncorr) == 0) write(*,*) "Iteration #:", it, "/", n_tot_iter
+       do iseg = 1, nseg
+          lo = seg_lo(iseg)
+          hi = seg_hi(iseg)
+          !----------------------------------------------------------------
+          ! a. the segment's previous proposals: results, Metropolis-Hastings decisions, state update
+          !----------------------------------------------------------------
+          tick(1) = mpi_wtime()
+          if (it > 1) then
+             if (seg_busy(iseg)) then
+                call rfgpu_check(rf_eval_wait(rf_ctx, seg_ticket(iseg), b_logl(lo), c_null_ptr), "rf_eval_wait")
+             end if
+             tick(2) = mpi_wtime()
+             do ichain = lo, hi
+                b_acc(ichain) = 0
+                if (.not. p_live(ichain)) cycle
+                del_s = (b_logl(ichain) - log_likelihood(ichain)) / temps(ichain) + p_lp(ichain)
+                yn = (p_logr(ichain) <= del_s)
+                if (yn) then
+                   b_acc(ichain) = 1
+                   log_likelihood(ichain) = b_logl(ichain)
+                   k(ichain) = p_k(ichain)
+                   dvp(1:k_max, ichain) = p_dvp(1:k_max, ichain)
+                   dvs(1:k_max, ichain) = p_dvs(1:k_max, ichain)
+                   z(1:k_max-1, ichain) = p_z(1:k_max-1, ichain)
+                   sig(1:ntrc, ichain) = p_sig(1:ntrc, ichain)
+                end if
+                p_acc(ichain) = yn
+             end do
+             if (seg_busy(iseg)) then
+                call rfgpu_check(rf_commit(rf_ctx, int(hi - lo + 1, c_int32_t), b_id(lo), b_acc(lo)), "rf_commit")
+             end if
+             seg_busy(iseg) = .false.
+             ! counters of the non-tempered chains (iteration it-1)
+             do ichain = lo, hi
+                if (temps(ichain) <= t_cold) then
+                   nprop(p_type(ichain)) = nprop(p_type(ichain)) + 1
+                   if (p_acc(ichain)) naccept(p_type(ichain)) = naccept(p_type(ichain)) + 1
+                   likelihood_hist(it - 1) = likelihood_hist(it - 1) + log_likelihood(ichain)
+                end if
+             end do
+             tick(3) = mpi_wtime()
+             rf_phase_seconds(2) = rf_phase_seconds(2) + (tick(2) - tick(1))
+             rf_phase_seconds(3) = rf_phase_seconds(3) + (tick(3) - tick(2))
+             if (iseg == nseg) then
+                ! every chain has finished iteration it-1: posterior records, then its temperature swap
+                record_now = (it - 1 > nburn .and. mod(it - 1, ncorr) == 0)
+                if (record_now) then
+                   ! every chain's state goes down; the device keeps the non-tempered ones (temps filter)
+                   ! and reads their current traces where the evaluation left them
+                   r_temps(1:nchains) = temps(1:nchains)
+                   call rfgpu_check(rf_post_record(rf_ctx, int(nchains, c_int32_t), r_id, k, z, dvp, dvs, sig, &
+                        & log_likelihood, c_loc(r_temps)), "rf_post_record")
+                end if
+                tick(4) = mpi_wtime()
+                if (swap_drawn) call decide_temperature_swap()
+                swap_drawn = .false.
+                tick(5) = mpi_wtime()
+                rf_phase_seconds(4) = rf_phase_seconds(4) + (tick(4) - tick(3))
+                rf_phase_seconds(5) = rf_phase_seconds(5) + (tick(5) - tick(4))
+             end if
+          end if
+          if (it > n_tot_iter) cycle          ! (the last pass only drains the pipeline)
+
+          !----------------------------------------------------------------
+          ! b. the segment's proposals of iteration `it`, chain by chain, in the reference's draw order
+          !----------------------------------------------------------------
+          tick(1) = mpi_wtime()
+          nb = 0
+          do ichain = lo, hi
+             call draw_candidate(ichain)       ! writes the candidate into column ichain of p_k, p_z, p_dvp, p_dvs, p_sig
+             p_type(ichain) = itype
+             p_live(ichain) = live
+             p_acc(ichain) = .false.
+             b_fwd(ichain) = -1                ! a null proposal: the engine skips the item
+             if (.not. live) cycle
+             ! the acceptance uniform of the Metropolis-Hastings test, drawn at its place in the
+             ! reference's stream (it does not depend on the likelihood)
+             do
+                r = grnd()
+                if (r >= epsilon(1.d0)) exit
+             end do
+             p_logr(ichain) = log(r)
+             p_lp(ichain) = lpr
+             nb = nb + 1
+             b_fwd(ichain) = merge(0, 1, itype == itype_sig)   ! noise-level move: the chain's stored trace is re-used
           end do
-          p_logr(ichain) = log(r)
-          p_lp(ichain) = lpr
-          nb = nb + 1
-          b_fwd(ichain) = merge(0, 1, itype == itype_sig)   ! noise-level move: the chain's stored trace is re-used
-       end do
-
-       !----------------------------------------------------------------
-       ! 2. one batched format_model + forward + likelihood evaluation on the GPU
-       !----------------------------------------------------------------
-       if (nb > 0) then
-          call rfgpu_check(rf_eval_models(rf_ctx, int(nchains, c_int32_t), b_id, b_fwd, p_k, p_z, int(k_max, c_int32_t), &
-               & p_dvp, p_dvs, p_sig, b_logl, c_null_ptr), "rf_eval_models")
-       end if
-
-       !----------------------------------------------------------------
-       ! 3. Metropolis-Hastings decisions and state update
-       !----------------------------------------------------------------
-       do ichain = 1, nchains
-          b_acc(ichain) = 0
-          if (.not. p_live(ichain)) cycle
-          del_s = (b_logl(ichain) - log_likelihood(ichain)) / temps(ichain) + p_lp(ichain)
-          yn = (p_logr(ichain) <= del_s)
-          if (yn) then
-             b_acc(ichain) = 1
-             log_likelihood(ichain) = b_logl(ichain)
-             k(ichain) = p_k(ichain)
-             dvp(1:k_max, ichain) = p_dvp(1:k_max, ichain)
-             dvs(1:k_max, ichain) = p_dvs(1:k_max, ichain)
-             z(1:k_max-1, ichain) = p_z(1:k_max-1, ichain)
-             sig(1:ntrc, ichain) = p_sig(1:ntrc, ichain)
+          tick(2) = mpi_wtime()
+          !----------------------------------------------------------------
+          ! c. format_model + forward + likelihood of the segment: enqueued, collected at this segment's next slot
+          !----------------------------------------------------------------
+          if (nb > 0) then
+             call rfgpu_check(rf_eval_models_begin(rf_ctx, int(hi - lo + 1, c_int32_t), b_id(lo), b_fwd(lo), p_k(lo), &
+                  & p_z(1, lo), int(k_max, c_int32_t), p_dvp(1, lo), p_dvs(1, lo), p_sig(1, lo), 0_c_int32_t, &
+                  & seg_ticket(iseg)), "rf_eval_models_begin")
+             seg_busy(iseg) = .true.
           end if
-          p_acc(ichain) = yn
-       end do
-       if (nb > 0) call rfgpu_check(rf_commit(rf_ctx, int(nchains, c_int32_t), b_id, b_acc), "rf_commit")
-
-       !----------------------------------------------------------------
-       ! 4. counters and posterior records of the non-tempered chains
-       !----------------------------------------------------------------
-       record_now = (it > nburn .and. mod(it, ncorr) == 0)
-       do ichain = 1, nchains
-          if (temps(ichain) <= t_cold) then
-             nprop(p_type(ichain)) = nprop(p_type(ichain)) + 1
-             if (p_acc(ichain)) naccept(p_type(ichain)) = naccept(p_type(ichain)) + 1
-             likelihood_hist(it) = likelihood_hist(it) + log_likelihood(ichain)
+          tick(3) = mpi_wtime()
+          rf_phase_seconds(1) = rf_phase_seconds(1) + (tick(2) - tick(1))
+          rf_phase_seconds(2) = rf_phase_seconds(2) + (tick(3) - tick(2))
+          !----------------------------------------------------------------
+          ! d. the draws of this iteration's temperature-swap proposal (decided once every chain is through)
+          !----------------------------------------------------------------
+          if (iseg == nseg .and. nchains >= 2) then
+             call draw_temperature_swap()
+             swap_drawn = .true.
+             rf_phase_seconds(5) = rf_phase_seconds(5) + (mpi_wtime() - tick(3))
           end if
        end do
-       if (record_now) then
-          ! every chain's state goes down; the device keeps the non-tempered ones (temps filter)
-          ! and reads their current traces where the evaluation left them
-          r_temps(1:nchains) = temps(1:nchains)
-          call rfgpu_check(rf_post_record(rf_ctx, int(nchains, c_int32_t), r_id, k, z, dvp, dvs, sig, &
-               & log_likelihood, c_loc(r_temps)), "rf_post_record")
-       end if
-
-       !----------------------------------------------------------------
-       ! 5. one temperature-swap proposal for the whole ensemble
-       !----------------------------------------------------------------
-       if (nchains >= 2) call propose_temperature_swap()
     end do
 
     if (over_rccl) call rfgpu_check(rf_comm_destroy(rf_ctx), "rf_comm_destroy")
@@ -347,34 +415,45 @@ contains
       end if
     end subroutine open_temperature_exchange
 
-    subroutine propose_temperature_swap()
-      integer(c_int32_t) :: pick(2), verdict
-      integer :: owner(2), slot(2), mine, theirs
-      real(8) :: logu, gain, t_now
+    ! The swap proposal of an iteration in two parts.  draw_temperature_swap: everything that touches the random
+    ! stream or names the pair -- rank 0 draws two distinct walkers of the whole ensemble by global id, everybody
+    ! learns the pair, and the rank of the first walker draws the uniform of the test (src/pt_mcmc.f90:501-519,
+    ! :529,:548: none of it depends on a likelihood).  decide_temperature_swap: the Metropolis test itself, once
+    ! every chain of this rank has finished the iteration.
+    subroutine draw_temperature_swap()
+      integer :: owner(2)
 
-      ! rank 0 names two distinct walkers of the whole ensemble by global id; everybody learns the pair
-      pick = 0
+      sw_pick = 0
+      sw_logu = 0.d0
       if (rank == 0) then
-         pick(1) = int(grnd() * n_all, c_int32_t)
+         sw_pick(1) = int(grnd() * n_all, c_int32_t)
          do
-            pick(2) = int(grnd() * n_all, c_int32_t)
-            if (pick(2) /= pick(1)) exit
+            sw_pick(2) = int(grnd() * n_all, c_int32_t)
+            if (sw_pick(2) /= sw_pick(1)) exit
          end do
       end if
       if (over_rccl) then
-         call rfgpu_check(rf_comm_bcast_i32(rf_ctx, pick, 2_c_int32_t, 0_c_int32_t), "rf_comm_bcast_i32")
+         call rfgpu_check(rf_comm_bcast_i32(rf_ctx, sw_pick, 2_c_int32_t, 0_c_int32_t), "rf_comm_bcast_i32")
       else if (nproc > 1) then
-         call mpi_bcast(pick, 2, MPI_INTEGER4, 0, MPI_COMM_WORLD, ierr)
+         call mpi_bcast(sw_pick, 2, MPI_INTEGER4, 0, MPI_COMM_WORLD, ierr)
       end if
-      owner = pick / nchains                 ! global id -> (rank, chain), src/pt_mcmc.f90:508-511
-      slot = mod(pick, nchains) + 1
+      owner = sw_pick / nchains              ! global id -> (rank, chain), src/pt_mcmc.f90:508-511
+      if (owner(1) == rank) sw_logu = log(grnd())   ! the first walker's rank supplies the uniform (both local, or cross-rank)
+    end subroutine draw_temperature_swap
+
+    subroutine decide_temperature_swap()
+      integer(c_int32_t) :: verdict
+      integer :: owner(2), slot(2), mine, theirs
+      real(8) :: gain, t_now
+
+      owner = sw_pick / nchains
+      slot = mod(sw_pick, nchains) + 1
       if (owner(1) /= rank .and. owner(2) /= rank) return
 
       if (owner(1) == owner(2)) then
          ! both walkers live here
-         logu = log(grnd())
          gain = (log_likelihood(slot(2)) - log_likelihood(slot(1))) * (1.d0 / temps(slot(1)) - 1.d0 / temps(slot(2)))
-         if (logu <= gain) then
+         if (sw_logu <= gain) then
             t_now = temps(slot(1))
             temps(slot(1)) = temps(slot(2))
             temps(slot(2)) = t_now
@@ -384,16 +463,14 @@ contains
 
       mine = merge(1, 2, owner(1) == rank)   ! which walker of the pair is on this rank
       theirs = 3 - mine
-      logu = 0.d0
-      if (mine == 1) logu = log(grnd())      ! the first walker's rank supplies the uniform
       if (over_rccl) then
          call rfgpu_check(rf_pt_swap_exchange(rf_ctx, int(owner(theirs), c_int32_t), int(2 - mine, c_int32_t), &
-              & temps(slot(mine)), log_likelihood(slot(mine)), logu, t_now, verdict), "rf_pt_swap_exchange")
+              & temps(slot(mine)), log_likelihood(slot(mine)), sw_logu, t_now, verdict), "rf_pt_swap_exchange")
       else
-         call exchange_over_mpi(owner(theirs), mine == 1, temps(slot(mine)), log_likelihood(slot(mine)), logu, t_now)
+         call exchange_over_mpi(owner(theirs), mine == 1, temps(slot(mine)), log_likelihood(slot(mine)), sw_logu, t_now)
       end if
       temps(slot(mine)) = t_now
-    end subroutine propose_temperature_swap
+    end subroutine decide_temperature_swap
 
     ! the same symmetric exchange as rf_pt_swap_exchange, for ranks that share a GPU
     subroutine exchange_over_mpi(peer, first, t_mine, l_mine, logu, t_after)

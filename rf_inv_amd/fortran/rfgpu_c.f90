@@ -127,6 +127,25 @@ module rfgpu_c
        type(c_ptr), value :: valid          ! c_null_ptr: not wanted
      end function rf_eval_models
 
+     ! the asynchronous pair: enqueue an evaluation, collect it later (up to 4 in flight, executed in order)
+     integer(c_int) function rf_eval_models_begin(ctx, nb, walker_ids, fwd_flag, k, z, ldz, dvp, dvs, sig, &
+          & want_valid, ticket) bind(C, name="rf_eval_models_begin")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: nb, ldz, want_valid
+       integer(c_int32_t), intent(in) :: walker_ids(*), fwd_flag(*), k(*)
+       real(c_double), intent(in) :: z(*), dvp(*), dvs(*), sig(*)
+       integer(c_int32_t), intent(out) :: ticket
+     end function rf_eval_models_begin
+
+     integer(c_int) function rf_eval_wait(ctx, ticket, logl, valid) bind(C, name="rf_eval_wait")
+       import :: c_int, c_ptr, c_double, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: ticket
+       real(c_double), intent(out) :: logl(*)
+       type(c_ptr), value :: valid          ! c_null_ptr: not wanted
+     end function rf_eval_wait
+
      ! pinned host memory (arrays from it travel to the GPU by DMA as they are)
      integer(c_int) function rf_host_alloc(bytes, ptr) bind(C, name="rf_host_alloc")
        import :: c_int, c_ptr, c_size_t

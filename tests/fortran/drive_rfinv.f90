@@ -6,7 +6,7 @@
 ! per-iteration mean T=1 log-likelihood (what mcmc_out writes to
 ! rslt/likelihood, src/mcmc_out.f90:142) and the proposal counters.
 !   usage: drive_rfinv params.in n_burn n_iter mode [out [rccl_library]]  (mode 0: the reference's
-!          pt_control, 1: our pt_control_batched; a fifth argument makes the reference's own
+!          pt_control, 1: our pt_control_batched, 2: the same without its two-segment pipeline; a fifth argument makes the reference's own
 !          output_results (src/mcmc_out.f90, compiled unmodified) write its result files
 !          into params.in's output directory)
 !=======================================================================
@@ -60,6 +60,7 @@ program drive_rfinv
   if (mode == 0) then
      call pt_control(.false.)
   else
+     if (mode == 2) rf_pipeline_segments = 1     ! propose all, evaluate all, judge all (no host / GPU overlap)
      call pt_control_batched(.false.)
   end if
   call mpi_barrier(MPI_COMM_WORLD, ierr)
@@ -67,6 +68,8 @@ program drive_rfinv
   ! (tests/tools/sampler_rate*.sh: wall time of the sampler loop alone, all ranks)
   if (rank == 0) write(*,'(A,F12.6,A,I0,A,I0,A,I0)') " drive_rfinv: loop seconds ", t_loop1 - t_loop0, " ranks ", nproc, &
        & " chains_per_rank ", nchains, " iterations ", nburn + niter
+  if (rank == 0 .and. mode /= 0) write(*,'(A,5F10.4)') " drive_rfinv: phase seconds (propose, eval, accept+commit, record, swap) ", &
+       & rf_phase_seconds
 
   u = 79
   if (nproc == 1) then

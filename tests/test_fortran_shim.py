@@ -134,7 +134,10 @@ def test_reference_sampler_on_top_of_the_dropin_modules(oracle, golden_dir, tmp_
 
 @pytest.mark.gpu
 def test_fortran_batched_sampler_equals_reference_sampler(golden_dir, tmp_path):
-    """rf_inv_amd/fortran/pt_mcmc_batched.f90 (propose-all -> rf_eval_batch -> accept-all) against
+    """rf_inv_amd/fortran/pt_mcmc_batched.f90 -- mode 1: its default two-segment pipeline (one half of the chains is
+    being evaluated through rf_eval_models_begin / rf_eval_wait while the host judges and re-proposes the other, the
+    swap's draws made at their place in the stream and its decision once both halves are through); mode 2: propose
+    all -> evaluate all -> judge all -- against
     the reference's own sequential pt_control on the same GPU engine: the complete dumps --
     likelihood history, proposal/accept counters, posterior checksums, final temperatures and
     log-likelihoods -- are identical, burn-in and recording phases included; and so is every result
@@ -144,7 +147,7 @@ def test_fortran_batched_sampler_equals_reference_sampler(golden_dir, tmp_path):
     if not os.path.exists(RFINV):
         pytest.skip("oracle/_ref/drive_rfinv not built (no Fortran compiler / reference tree at build time)")
     dumps = []
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         work = tmp_path / f"run{mode}"
         shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
         os.makedirs(work / "rslt")
@@ -153,10 +156,11 @@ def test_fortran_batched_sampler_equals_reference_sampler(golden_dir, tmp_path):
         assert r.returncode == 0 and "drive_rfinv: ok" in r.stdout, r.stdout + r.stderr
         dumps.append(open(work / "rfinv_dump.txt").read())
     assert len(dumps[0].split()) > 300
-    assert dumps[0] == dumps[1]
+    assert dumps[0] == dumps[1] and dumps[0] == dumps[2]
     for name in RESULT_FILES:
         a, b = open(tmp_path / "run0" / "rslt" / name).read(), open(tmp_path / "run1" / "rslt" / name).read()
         assert a == b, name
+        assert a == open(tmp_path / "run2" / "rslt" / name).read(), name
         assert len(a) > 0 or name == "sigma.ppd", name
 
 

@@ -4,6 +4,8 @@
 # over R MPI ranks (ranks that share a GPU exchange temperatures over MPI; each has its own context and stream, so
 # one rank's proposal loop on the host overlaps another rank's kernels).
 #   usage: tests/tools/sampler_rate_shapes.sh <c3|c4|c4w20> <total chains> <iterations> ["1 2 4"] [driver mode]
+#          driver mode 1: pt_control_batched with its two-segment pipeline (default); 2: without it; 0: the reference's
+#          own pt_control on the per-call drop-in
 # The driver times its own loop (mpi_wtime around pt_control*, barriers on both sides); a short warm-up run comes
 # first so that the timed one does not pay the image's first page-in.  (ref: the loop timed is src/pt_mcmc.f90:488-571)
 SHAPE=${1:-c4}; TOTAL=${2:-8192}; NIT=${3:-200}; RANKS=${4:-"1 2 4"}; MODE=${5:-1}
@@ -24,6 +26,10 @@ for line in open(sys.argv[1]):
         sec, ranks, nch, nit = float(t[3]), int(t[5]), int(t[7]), int(t[9])
         print(f"shape {sys.argv[2]} mode {sys.argv[3]} ranks {ranks} x {nch} chains, {nit} iterations: {sec:.3f} s loop -> "
               f"{ranks * nch * nit / sec:.3e} MCMC steps/s, {1e3 * sec / nit:.3f} ms per iteration")
+    if "phase seconds" in line:
+        ph = [float(x) for x in line.split()[-5:]]
+        print("    rank 0, ms per iteration: propose %.3f  eval %.3f  accept+commit %.3f  record %.3f  swap %.3f"
+              % tuple(1e3 * x / nit for x in ph))
 PY
   rm -rf $W
 done
