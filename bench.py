@@ -290,9 +290,27 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
     return base, ll_all[:nuse], nuse
 
 
+def visible_gpus():
+    """GPUs this process may use, counted WITHOUT the HIP runtime (the launcher must never initialise a GPU): the
+    KFD topology's nodes that have SIMDs, cut down by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set."""
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            for line in open(f):
+                if line.startswith("simd_count") and int(line.split()[1]) > 0:
+                    n += 1
+        except OSError:
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(n, argv):
     """`bench.py --gpus N` without a launcher: start N rank processes, one per GPU, and relay rank 0's JSON line.
-    This parent never touches a GPU (torch.cuda.device_count() does not initialise one on this image) and never
+    This parent never touches a GPU (it counts them in sysfs, visible_gpus) and never
     exec()s: the ranks are ordinary children with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment,
     exactly what `python -m torch.distributed.run --nproc-per-node N` would give them.  Returns the exit code:
     non-zero if any rank failed."""
@@ -300,9 +318,7 @@ def spawn_ranks(n, argv):
     import socket
     import subprocess
 
-    import torch
-
-    have = torch.cuda.device_count()
+    have = visible_gpus()
     shared = os.environ.get("RFGPU_BENCH_BACKEND", "nccl") != "nccl"   # functional test: ranks may share a GPU
     if have < n and not shared:
         print(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have}: refusing to report a {n}-GPU "
@@ -318,15 +334,34 @@ def spawn_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for q in procs[1:]:
+    # every rank is watched: the first one that fails takes the others down at once (a rank that dies in its
+    # rendezvous would otherwise leave rank 0 waiting for the process group's timeout)
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    rc = 0
+    while True:
+        codes = [q.poll() for q in procs]
+        bad = [c for c in codes if c not in (None, 0)]
+        if bad:
+            rc = bad[0]
+            for q in procs:
+                if q.poll() is None:
+                    q.send_signal(signal.SIGTERM)
+            break
+        if all(c == 0 for c in codes):
+            break
+        time.sleep(0.05)
+    for q in procs:
         try:
-            q.wait(timeout=120 if rc == 0 else 5)
+            q.wait(timeout=10)
         except subprocess.TimeoutExpired:
-            q.send_signal(signal.SIGTERM)
+            q.kill()
             q.wait()
-        rc = rc or q.returncode
+    reader.join(timeout=10)
+    out0 = out0[0] if out0 else ""
     sys.stdout.write(out0 or "")
     sys.stdout.flush()
     if rc:
@@ -588,7 +623,11 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         ll_gpu = h_logl.numpy().copy()
-        if args.dump_state and workload == args.workload:
+        # A multi-rank run checks its own temperature exchange: every rank's final temperatures and logL are gathered
+        # (after the timed region) and rank 0 replays the replicated swap schedule serially
+        # (rf_inv_amd.pt.replay_swap_schedule) -- a wrong permutation of temperatures must not print a clean line
+        swap_check = None
+        if (world > 1 or args.dump_state) and workload == args.workload:
             t_loc = swap.temps.clone() if swap is not None else torch.ones(nb, dtype=torch.float64, device=dev)
             l_loc = torch.from_numpy(ll_gpu).to(dev)
             if world > 1:
@@ -601,9 +640,25 @@ def main():
             else:
                 all_t, all_l = [t_loc], [l_loc]
             if rank == 0:
-                np.savez(args.dump_state, temps=np.stack([t.cpu().numpy() for t in all_t]),
-                         logl=np.stack([t.cpu().numpy() for t in all_l]), swap_steps=n_pre + warmup + steps,
-                         pairs_per_step=swap.k if swap is not None else 0)
+                g_t = np.stack([t.cpu().numpy() for t in all_t])
+                g_l = np.stack([t.cpu().numpy() for t in all_l])
+                if args.dump_state:
+                    np.savez(args.dump_state, temps=g_t, logl=g_l, swap_steps=n_pre + warmup + steps,
+                             pairs_per_step=swap.k if swap is not None else 0)
+                if swap is not None and args.swap == "allgather" and nlay_var is None:
+                    from rf_inv_amd.pt import replay_swap_schedule
+
+                    swap_check = replay_swap_schedule(g_t, g_l, nb, w["temps"], n_pre + warmup + steps, swap.k, 1234, 15.0)
+                    swap_check["swap_steps"] = n_pre + warmup + steps
+        if world > 1 and over_rccl:
+            info = eng.comm_info()
+            assert info["nranks"] == world, (info, world)
+            if rank == 0:
+                print(f"bench.py: temperature exchange over librfgpu's RCCL communicator, {info['nranks']} ranks, RCCL "
+                      f"{info['rccl_version']}", file=sys.stderr)
+        elif world > 1 and rank == 0:
+            print("bench.py: temperature exchange over the launcher's process group (ranks share a GPU, or RCCL's "
+                  "bootstrap failed)", file=sys.stderr)
         plan = eng.launch_plan
         assert plan["build"] == "production" or overrides or args.lib, plan
         assert np.all(np.isfinite(ll_gpu)), "non-finite logL in the benchmark batch"
@@ -708,6 +763,10 @@ def main():
                               **({"quadratic_form_logl": prof["logl_ms"] / n_l} if prof["logl_launches"] else {})),
             "alg_gflop_per_step": float(f_tot.sum()) / 1e9,
         }
+        if swap_check is not None:
+            res["swap_replay_ok"] = swap_check["ok"]
+            res["cross_rank_swaps"] = swap_check["cross_rank_swaps"]
+            res["swap_replay"] = swap_check
         if plan["long_window_gemm"] and prof["logl_launches"]:
             # the long-window plan's GEMM: Phi1 = M_t R^-1_t per trace on the FP64 matrix cores, 2 nb ntrc nsmp^2
             # algorithmic flops (src/likelihood.f90:92: matmul(misfits, r_inv)); the time includes the logL kernel
@@ -772,8 +831,14 @@ def main():
         if also:
             out["also"] = also
         print(json.dumps(out))
+    failed = rank == 0 and main_res.get("swap_replay_ok") is False
+    if failed:
+        print("bench.py: the final temperatures do NOT equal the serial replay of the swap schedule: the temperature "
+              "exchange is wrong (the JSON line above carries swap_replay_ok = false)", file=sys.stderr)
     if world > 1:
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

@@ -245,9 +245,12 @@ int rf_pt_swap_device(rf_ctx *ctx, int32_t npairs, const int32_t *d_pairs, const
  * RCCL needs one GPU per rank (it refuses two ranks on one device): rf_comm_init then fails and the host keeps
  * its own transport (the Fortran batched host: mpi_sendrecv). */
 #define RF_COMM_ID_BYTES 128
-/* 0 when this rank can join an RCCL communicator (librccl.so.1 loads); device_key = the physical GPU of the
- * context (hash of the host name over PCI domain/bus/device, >= 0).  ncclCommInitRank is collective: the host
- * gathers (result, key) of all ranks and calls rf_comm_init only if every rank returned 0 and all keys differ. */
+/* device_key = the physical GPU of the context (hash of host name + boot id over PCI domain/bus/device, >= 0); loads
+ * nothing: hosts compare the keys of their ranks first and only probe RCCL when every rank has a GPU of its own. */
+int rf_comm_device_key(rf_ctx *ctx, int64_t *device_key);
+/* the same key, and 0 when this rank can join an RCCL communicator (librccl.so.1 loads; takes ~1 s).  ncclCommInitRank
+ * is collective: the host gathers (result, key) of all ranks and calls rf_comm_init only if every rank returned 0 and
+ * all keys differ. */
 int rf_comm_probe(rf_ctx *ctx, int64_t *device_key);
 /* optional, process-wide, before anything else of this section: load RCCL from this file instead of the default search
  * (librccl.so.1 by soname -- inside a PyTorch process the RCCL torch loaded -- then /opt/rocm/lib/librccl.so.1) */
@@ -271,7 +274,8 @@ int rf_pt_swap_exchange(rf_ctx *ctx, int32_t peer, int32_t judge, double temp, d
 /* throughput form: npairs DISJOINT pairs of GLOBAL walker ids per iteration: ONE RCCL group (two all-gathers
  * straight from d_temps / d_logl: 16 B per walker, no staging copies), then ONE kernel that judges every pair on
  * the gathered snapshot and writes this rank's own temperatures, d_temps[nchains], in place.
- * d_pairs[npairs][2], d_log_u[npairs] replicated on every rank. */
+ * d_pairs[npairs][2], d_log_u[npairs] replicated on every rank; a pair with an id outside [0, nranks * nchains) is
+ * ignored (nothing read, nothing moved). */
 int rf_pt_swap_allgather_device(rf_ctx *ctx, int32_t nchains, int32_t npairs, const int32_t *d_pairs,
                                 const double *d_log_u, double *d_temps, const double *d_logl, void *stream);
 /* the kernel of the form above on arrays some other transport gathered (the host's MPI / gloo when ranks share a

@@ -88,6 +88,7 @@ SYMBOLS = {
     "rf_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "rf_host_free": (C.c_int, [_vp]),
     "rf_pt_swap_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "rf_comm_device_key": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rf_comm_probe": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rf_comm_set_library": (C.c_int, [C.c_char_p]),
     "rf_comm_get_unique_id": (C.c_int, [C.c_char_p]),

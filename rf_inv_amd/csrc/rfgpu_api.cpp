@@ -1331,8 +1331,9 @@ extern "C" int rf_pt_swap_gathered_device(rf_ctx *c, int32_t nchains, int32_t ra
     if (nchains < 1 || nranks < 1 || rank < 0 || rank >= nranks) return fail("rf_pt_swap_gathered_device: bad rank / nranks / nchains");
     if (npairs <= 0) return 0;
     HIP_TRY(hipSetDevice(c->device));
-    launch_pt_swap_gathered(npairs, d_pairs, d_log_u, d_g_temps, d_g_logl, nchains, rank, d_temps, d_accepted,
+    launch_pt_swap_gathered(npairs, d_pairs, d_log_u, d_g_temps, d_g_logl, nchains, rank, nranks, d_temps, d_accepted,
                             (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

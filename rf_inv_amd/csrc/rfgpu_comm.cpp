@@ -12,6 +12,7 @@
 #include <dlfcn.h>
 #include <unistd.h>
 
+#include <cstdio>
 #include <cstring>
 #include <string>
 
@@ -104,22 +105,36 @@ extern "C" int rf_comm_set_library(const char *path)
     return 0;
 }
 
-// Can this rank take part in an RCCL communicator?  Returns 0 when librccl.so.1 loads; device_key identifies
-// the context's physical GPU -- a hash of the host name (ranks of different nodes with the same PCI address are
-// NOT the same GPU) over PCI domain / bus / device: the host gathers the keys of all ranks and uses RCCL only
-// when every rank answered 0 and all keys differ -- ncclCommInitRank is collective, so the decision has to be
-// unanimous BEFORE anyone enters it.
-extern "C" int rf_comm_probe(rf_ctx *c, int64_t *device_key)
+// rf_comm_device_key: the context's physical GPU -- a hash of the machine (host name and boot id: ranks of different
+// nodes with the same PCI address are NOT the same GPU) over PCI domain / bus / device.  Loads nothing.
+// rf_comm_probe: the same key, and can this rank take part in an RCCL communicator?  0 when librccl.so.1 loads (that
+// takes about a second: hosts compare the keys first and probe only when every rank has a GPU of its own).
+// The host gathers the answers of all ranks and uses RCCL only when every rank answered 0 and all keys differ --
+// ncclCommInitRank is collective, so the decision has to be unanimous BEFORE anyone enters it.
+extern "C" int rf_comm_device_key(rf_ctx *c, int64_t *device_key)
 {
-    if (!c || !device_key) return comm_fail("rf_comm_probe: null argument");
+    if (!c || !device_key) return comm_fail("rf_comm_device_key: null argument");
     hipDeviceProp_t prop;
     HIPC_TRY(hipGetDeviceProperties(&prop, ctx_device(c)));
+    // the machine: host name + boot id (containers of different nodes may share a host name; a boot id they do not)
     char host[256] = {0};
     (void)gethostname(host, sizeof host - 1);
     uint32_t hh = 2166136261u;                         // FNV-1a
     for (const char *q = host; *q; ++q) hh = (hh ^ (uint8_t)*q) * 16777619u;
+    if (FILE *fh = std::fopen("/proc/sys/kernel/random/boot_id", "r")) {
+        char id[64] = {0};
+        if (std::fgets(id, sizeof id, fh))
+            for (const char *q = id; *q && *q != '\n'; ++q) hh = (hh ^ (uint8_t)*q) * 16777619u;
+        std::fclose(fh);
+    }
     *device_key = ((int64_t)(hh & 0x7fffffffu) << 32) | ((int64_t)(prop.pciDomainID & 0xffff) << 16) |
                   ((int64_t)(prop.pciBusID & 0xff) << 8) | (int64_t)(prop.pciDeviceID & 0xff);
+    return 0;
+}
+
+extern "C" int rf_comm_probe(rf_ctx *c, int64_t *device_key)
+{
+    if (rf_comm_device_key(c, device_key)) return 1;
     if (!rccl()) return comm_fail("rf_comm_probe: librccl.so.1 cannot be loaded");
     return 0;
 }
@@ -290,6 +305,7 @@ extern "C" int rf_pt_swap_allgather_device(rf_ctx *c, int32_t nchains, int32_t n
     RCCL_TRY(R->AllGather(d_temps, g_t, (size_t)nchains, ncclDouble, s->comm, st));
     RCCL_TRY(R->AllGather(d_logl, g_l, (size_t)nchains, ncclDouble, s->comm, st));
     RCCL_TRY(R->GroupEnd());
-    launch_pt_swap_gathered(npairs, d_pairs, d_log_u, g_t, g_l, nchains, s->rank, d_temps, nullptr, st);
+    launch_pt_swap_gathered(npairs, d_pairs, d_log_u, g_t, g_l, nchains, s->rank, s->nranks, d_temps, nullptr, st);
+    HIPC_TRY(hipGetLastError());
     return 0;
 }

@@ -124,7 +124,8 @@ void launch_commit(const WalkerState &w, int nb, const int *walker_ids, const in
 void launch_pt_swap(int npairs, const int *pairs, const double *log_u, double *temps,
                     const double *logl, int *accepted, hipStream_t s);
 void launch_pt_swap_gathered(int npairs, const int *pairs, const double *log_u, const double *g_temps,
-                             const double *g_logl, int nchains, int rank, double *temps, int *accepted, hipStream_t s);
+                             const double *g_logl, int nchains, int rank, int nranks, double *temps, int *accepted,
+                             hipStream_t s);
 
 // ---- posterior accumulation (rfgpu_posterior.hip) --------------------------------
 struct PostConfig {

@@ -3796,12 +3796,18 @@ void launch_pt_swap(int npairs, const int *pairs, const double *log_u, double *t
 // rank's own chain holds afterwards straight into `temps` [nchains] (temperatures move, states stay: :532-535).
 // Pairs are disjoint, so every decision sees the pre-swap snapshot exactly as the in-place kernel does.
 __global__ void pt_swap_gathered_kernel(int npairs, const int *pairs, const double *log_u, const double *g_temps,
-                                        const double *g_logl, int nchains, int rank, double *temps, int *accepted)
+                                        const double *g_logl, int nchains, int rank, int nranks, double *temps, int *accepted)
 {
 #pragma clang fp contract(off)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npairs) return;
     const int c1 = pairs[2 * i], c2 = pairs[2 * i + 1];
+    // (a pair outside the gathered ensemble -- a schedule drawn for another nchains -- is no pair: nothing is read or moved)
+    const int n_all = nranks * nchains;
+    if (c1 < 0 || c2 < 0 || c1 >= n_all || c2 >= n_all) {
+        if (accepted) accepted[i] = 0;
+        return;
+    }
     const double t1 = g_temps[c1], t2 = g_temps[c2];
     const double del_s = (g_logl[c2] - g_logl[c1]) * (1.0 / t1 - 1.0 / t2);
     const int yn = log_u[i] <= del_s;
@@ -3814,10 +3820,11 @@ __global__ void pt_swap_gathered_kernel(int npairs, const int *pairs, const doub
 }
 
 void launch_pt_swap_gathered(int npairs, const int *pairs, const double *log_u, const double *g_temps,
-                             const double *g_logl, int nchains, int rank, double *temps, int *accepted, hipStream_t s)
+                             const double *g_logl, int nchains, int rank, int nranks, double *temps, int *accepted,
+                             hipStream_t s)
 {
     hipLaunchKernelGGL(pt_swap_gathered_kernel, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, s, npairs, pairs,
-                       log_u, g_temps, g_logl, nchains, rank, temps, accepted);
+                       log_u, g_temps, g_logl, nchains, rank, nranks, temps, accepted);
 }
 
 } // namespace rfgpu

@@ -295,6 +295,12 @@ class RFEngine:
         if lib.rf_comm_set_library(os.fsencode(path)):
             raise RFGPUError(lib.rf_last_error().decode())
 
+    def comm_device_key(self):
+        """The physical GPU this context drives (machine + PCI address); loads nothing."""
+        key = C.c_int64()
+        self._chk(self._lib.rf_comm_device_key(self._ctx, C.byref(key)))
+        return key.value
+
     def comm_probe(self):
         """(usable, device_key): can this rank join an RCCL communicator, and on which physical GPU it sits."""
         key = C.c_int64()
@@ -304,10 +310,11 @@ class RFEngine:
     def comm_init(self, unique_id: bytes, rank: int, nranks: int):
         self._chk(self._lib.rf_comm_init(self._ctx, unique_id, int(rank), int(nranks)))
 
-    def comm_info(self):
-        """{rank, nranks} of the context's communicator (0 of 1 without one) and the RCCL version in use."""
+    def comm_info(self, version=True):
+        """{rank, nranks} of the context's communicator (0 of 1 without one) and the RCCL version in use
+        (version=False: not asked for -- asking loads librccl)."""
         r, n, v = C.c_int32(), C.c_int32(), C.c_int32()
-        self._chk(self._lib.rf_comm_info(self._ctx, C.byref(r), C.byref(n), C.byref(v)))
+        self._chk(self._lib.rf_comm_info(self._ctx, C.byref(r), C.byref(n), C.byref(v) if version else None))
         ver = v.value
         return {"rank": r.value, "nranks": n.value,
                 "rccl_version": f"{ver // 10000}.{ver // 100 % 100}.{ver % 100}" if ver else None}

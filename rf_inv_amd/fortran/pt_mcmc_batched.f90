@@ -42,6 +42,9 @@ module pt_mcmc_batched
   ! wall-clock seconds of the last pt_control_batched by phase: 1 proposals (host), 2 rf_eval_models (copies, kernels,
   ! wait), 3 accept / reject + rf_commit, 4 counters + posterior records, 5 temperature swap (incl. waiting for peers)
   real(8), public :: rf_phase_seconds(5) = 0.d0
+  ! ... and of the iteration loop as a whole (first proposal to the last swap decision; set-up -- device tables, pinned
+  ! arrays, the exchange's bootstrap -- and the read-back of the posterior accumulators excluded)
+  real(8), public :: rf_loop_seconds = 0.d0
   ! 2 (default): the chains of a rank are worked in two halves, one being evaluated on the GPU while the host judges and
   ! re-proposes the other (same trajectory: see the loop); 1: propose all, evaluate all, judge all
   integer, public :: rf_pipeline_segments = 2
@@ -136,6 +139,8 @@ contains
     end do
     seg_busy = .false.
     swap_drawn = .false.
+    call mpi_barrier(MPI_COMM_WORLD, ierr)
+    rf_loop_seconds = mpi_wtime()
 
     do it = 1, n_tot_iter + 1
        if (verb .and. it <= n_tot_iter .and. mod(it, ncorr) == 0) write(*,*) "Iteration #:", it, "/", n_tot_iter
@@ -249,6 +254,8 @@ contains
        end do
     end do
 
+    call mpi_barrier(MPI_COMM_WORLD, ierr)
+    rf_loop_seconds = mpi_wtime() - rf_loop_seconds
     if (over_rccl) call rfgpu_check(rf_comm_destroy(rf_ctx), "rf_comm_destroy")
     call fetch_device_posterior()
     do i = 1, size(pin)
@@ -385,14 +392,19 @@ contains
       if (len_trim(rf_rccl_library) > 0) then
          call rfgpu_check(rf_comm_set_library(trim(rf_rccl_library) // c_null_char), "rf_comm_set_library")
       end if
-      if (rf_comm_probe(rf_ctx, my_key) == 0) usable = 1
+      ! which GPU every rank drives (costs nothing); RCCL itself -- a second to load -- only if each has its own
+      call rfgpu_check(rf_comm_device_key(rf_ctx, my_key), "rf_comm_device_key")
       allocate(keys(nproc))
       call mpi_allgather(my_key, 1, MPI_INTEGER8, keys, 1, MPI_INTEGER8, MPI_COMM_WORLD, ierr)
+      usable = 1
       do ia = 1, nproc - 1
          do ib2 = ia + 1, nproc
             if (keys(ia) == keys(ib2) .and. .not. rf_exchange_shared_gpu_ok) usable = 0      ! two ranks on one GPU
          end do
       end do
+      if (usable == 1) then
+         if (rf_comm_probe(rf_ctx, my_key) /= 0) usable = 0
+      end if
       token = 0
       if (rank == 0 .and. usable == 1) then
          if (rf_comm_get_unique_id(token) /= 0) usable = 0

@@ -209,6 +209,12 @@ module rfgpu_c
      end function rf_post_record
 
      ! ---- temperature exchange over RCCL (include/rfgpu.h, "multi-GPU") ----
+     integer(c_int) function rf_comm_device_key(ctx, device_key) bind(C, name="rf_comm_device_key")
+       import :: c_int, c_ptr, c_int64_t
+       type(c_ptr), value :: ctx
+       integer(c_int64_t), intent(out) :: device_key
+     end function rf_comm_device_key
+
      integer(c_int) function rf_comm_probe(ctx, device_key) bind(C, name="rf_comm_probe")
        import :: c_int, c_ptr, c_int64_t
        type(c_ptr), value :: ctx

@@ -63,6 +63,34 @@ class PairSchedule:
         return pairs, np.log(u)
 
 
+def replay_swap_schedule(temps_final, logl, nchains, ntemps, swap_steps, pairs_per_step, seed, t_high=15.0):
+    """Serial replay of the replicated swap schedule of a run whose walkers kept the same logL at every step
+    (bench.py: the same models are evaluated each step): start from every rank's initial temperatures (PTSwap's
+    draw), apply `swap_steps` steps of `pairs_per_step` disjoint pairs with judge_pt (src/pt_mcmc.f90:580-595) on
+    global walker ids (rank * nchains + chain, :508-511), compare with the temperatures the run ended with.
+    temps_final / logl: [nranks, nchains].  Returns {"ok", "moved", "cross_rank_swaps"}: the replay equals the run;
+    walkers that do not hold their initial temperature; accepted swaps whose two walkers live on different ranks."""
+    temps_final, logl = np.asarray(temps_final, dtype=np.float64), np.asarray(logl, dtype=np.float64)
+    nranks = temps_final.shape[0]
+    ref = np.concatenate([init_temps(nchains, max(1, nchains // max(1, int(ntemps))), t_high,
+                                     np.random.Generator(np.random.Philox(key=seed + 7919 * (rk + 1))))
+                          for rk in range(nranks)])
+    start = ref.copy()
+    sched = PairSchedule(nranks * nchains, seed, pairs_per_step)
+    ll = logl.reshape(-1)
+    cross = 0
+    for _ in range(int(swap_steps)):
+        pairs, logu = sched.draw()
+        i1, i2 = pairs[:, 0], pairs[:, 1]
+        t1, t2 = ref[i1], ref[i2]
+        yes = judge_pt(t1, t2, ll[i1], ll[i2], logu)              # pairs are disjoint: one vector step
+        ref[i1] = np.where(yes, t2, t1)
+        ref[i2] = np.where(yes, t1, t2)
+        cross += int(np.sum(yes & (i1 // nchains != i2 // nchains)))
+    return {"ok": bool(np.array_equal(temps_final.reshape(-1), ref)), "moved": int(np.sum(ref != start)),
+            "cross_rank_swaps": cross}
+
+
 def open_exchange(engine, dist, shared_gpu_ok=False):
     """Decide once, unanimously, how this run's ranks exchange temperatures -- the Python host's
     `open_temperature_exchange` (rf_inv_amd/fortran/pt_mcmc_batched.f90): every rank probes RCCL and names its
@@ -74,6 +102,11 @@ def open_exchange(engine, dist, shared_gpu_ok=False):
     shared_gpu_ok: functional tests only -- ranks on one GPU join too (over a test double of RCCL selected with
     RFEngine.comm_set_library; real RCCL refuses two ranks on one device)."""
     world, rank = dist.get_world_size(), dist.get_rank()
+    # which GPU every rank drives (loads nothing); RCCL itself -- about a second to load -- only if each has its own
+    keys = [None] * world
+    dist.all_gather_object(keys, int(engine.comm_device_key()))
+    if not shared_gpu_ok and len(set(keys)) != world:
+        return False
     usable, key = engine.comm_probe()
     seen = [None] * world
     dist.all_gather_object(seen, (bool(usable), int(key)))
@@ -129,7 +162,7 @@ class PTSwap:
         self.device = torch.device(device)
         self.mode = mode
         if rccl is None:
-            rccl = engine is not None and self.world > 1 and engine.comm_info()["nranks"] == self.world
+            rccl = engine is not None and self.world > 1 and engine.comm_info(version=False)["nranks"] == self.world
         self.rccl = bool(rccl) and self.world > 1
         n_all = self.world * self.nchains
         ncool = max(1, self.nchains // max(1, int(ntemps)))
@@ -175,10 +208,13 @@ class PTSwap:
             # one RCCL group (two all-gathers straight from temps / logl) + one kernel, all inside librfgpu
             self.engine.pt_swap_allgather_device(pairs, logu, self.temps, logl, stream)
         else:
-            # ranks share a GPU: the process group gathers, the same kernel judges
-            self._gather_global(self.temps, logl)
+            # ranks share a GPU: the process group gathers, the same kernel judges -- all of it on `stream`, the
+            # stream the producer of logl ran on (the gather must not overtake it, the kernel not the gather)
+            st = stream if stream is not None else self.torch.cuda.current_stream(self.device)
+            with self.torch.cuda.stream(st):
+                self._gather_global(self.temps, logl)
             self.engine.pt_swap_gathered_device(pairs, logu, self._g_t, self._g_l, self.temps, self.rank, self.world,
-                                                stream=stream)
+                                                stream=st)
 
     def _gather_global(self, temps, logl):
         """Every rank's T and logL -> self._g_t / self._g_l, indexed by global id = rank * nchains + chain

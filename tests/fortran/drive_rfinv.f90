@@ -68,6 +68,7 @@ program drive_rfinv
   ! (tests/tools/sampler_rate*.sh: wall time of the sampler loop alone, all ranks)
   if (rank == 0) write(*,'(A,F12.6,A,I0,A,I0,A,I0)') " drive_rfinv: loop seconds ", t_loop1 - t_loop0, " ranks ", nproc, &
        & " chains_per_rank ", nchains, " iterations ", nburn + niter
+  if (rank == 0 .and. mode /= 0) write(*,'(A,F12.6)') " drive_rfinv: batched loop seconds (set-up excluded) ", rf_loop_seconds
   if (rank == 0 .and. mode /= 0) write(*,'(A,5F10.4)') " drive_rfinv: phase seconds (propose, eval, accept+commit, record, swap) ", &
        & rf_phase_seconds
 

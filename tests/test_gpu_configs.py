@@ -302,26 +302,17 @@ def test_randomised_contexts_against_oracle(oracle, seed):
 
 def _replay_bench_state(dump, nb, ntemps, nranks):
     """Final temperatures of a bench.py run == serial replay of the replicated swap schedule on the logL the run
-    produced; swaps across the rank boundary present."""
-    from rf_inv_amd.pt import PairSchedule, init_temps, judge_pt
+    produced (rf_inv_amd.pt.replay_swap_schedule: the check bench.py applies to itself when N > 1); swaps across the
+    rank boundary present."""
+    from rf_inv_amd.pt import replay_swap_schedule
 
     st = np.load(dump)
     temps, logl = st["temps"], st["logl"]
     assert temps.shape == (nranks, nb)
-    ref = np.concatenate([init_temps(nb, max(1, nb // ntemps), 15.0,
-                                     np.random.Generator(np.random.Philox(key=1234 + 7919 * (rk + 1)))) for rk in range(nranks)])
-    start = ref.copy()
-    sched = PairSchedule(nranks * nb, 1234, int(st["pairs_per_step"]))
-    ll = logl.reshape(-1)                       # the same models every step: logL is the same every step
-    for _ in range(int(st["swap_steps"])):
-        pairs, logu = sched.draw()
-        for (i1, i2), lu in zip(pairs, logu):
-            if judge_pt(ref[i1], ref[i2], ll[i1], ll[i2], lu):
-                ref[i1], ref[i2] = ref[i2], ref[i1]
-    assert np.array_equal(temps.reshape(-1), ref)
-    assert np.sum(ref != start) > 0             # swaps did happen
-    cross = [(a, b) for a, b in np.argwhere(ref[:, None] == start[None, :]) if (a // nb) != (b // nb)]
-    assert len(cross) > 0                       # ... also across the ranks' blocks
+    r = replay_swap_schedule(temps, logl, nb, ntemps, int(st["swap_steps"]), int(st["pairs_per_step"]), 1234, 15.0)
+    assert r["ok"]
+    assert r["moved"] > 0                       # swaps did happen
+    assert r["cross_rank_swaps"] > 0            # ... also across the ranks' blocks
     return st
 
 
@@ -359,6 +350,7 @@ def test_bench_two_ranks_on_one_gpu_swap_matches_serial_replay(tmp_path, launche
     assert abs(d["value"] - 2 * nb * steps / (d["ms_per_step"] * 1e-3 * steps)) < 1e-6 * d["value"]
     assert d["config"]["parallelism"] == "walkers sharded x2"
     assert d["config"]["rccl"]["ranks"] == 0 and "share a GPU" in d["config"]["rccl"]["transport"]
+    assert d["swap_replay_ok"] is True and d["cross_rank_swaps"] > 0       # the run's own check of its exchange
     st = _replay_bench_state(dump, nb, ntemps, 2)
     assert int(st["swap_steps"]) == 16 + warm + steps
 
@@ -392,6 +384,7 @@ def test_bench_rccl_route_with_two_ranks_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "walkers sharded x2"
     assert d["config"]["rccl"]["ranks"] == 2 and d["config"]["rccl"]["library"] == lib
     assert "rf_pt_swap_allgather_device" in d["config"]["rccl"]["transport"]
+    assert d["swap_replay_ok"] is True and d["cross_rank_swaps"] > 0 and d["swap_replay"]["swap_steps"] == 16 + warm + steps
     st = _replay_bench_state(dump, nb, ntemps, 2)
     assert int(st["swap_steps"]) == 16 + warm + steps
 

@@ -257,3 +257,26 @@ def test_cross_rank_entry_points_with_several_ranks_on_one_gpu(tmp_path, world):
     subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-o", lib, os.path.join(ROOT, "tests", "c", "rccl_double.cpp")],
                    check=True, capture_output=True, timeout=300)
     _run_two_rank_exchange(tmp_path, world, [0] * world, rccl_library=lib)
+
+
+def test_swap_replay_detects_a_wrong_exchange():
+    """The self-check is a check: a run whose temperatures differ from the replay by one transposition fails it."""
+    from rf_inv_amd.pt import PairSchedule, init_temps, judge_pt, replay_swap_schedule
+
+    nb, nranks, ntemps, steps, k = 64, 2, 8, 7, 8
+    rng = np.random.default_rng(3)
+    logl = -rng.uniform(10, 1000, (nranks, nb))
+    ref = np.concatenate([init_temps(nb, nb // ntemps, 15.0, np.random.Generator(np.random.Philox(key=1234 + 7919 * (rk + 1))))
+                          for rk in range(nranks)])
+    sched = PairSchedule(nranks * nb, 1234, k)
+    for _ in range(steps):
+        pairs, logu = sched.draw()
+        for (i1, i2), lu in zip(pairs, logu):
+            if judge_pt(ref[i1], ref[i2], logl.reshape(-1)[i1], logl.reshape(-1)[i2], lu):
+                ref[i1], ref[i2] = ref[i2], ref[i1]
+    good = replay_swap_schedule(ref.reshape(nranks, nb), logl, nb, ntemps, steps, k, 1234, 15.0)
+    assert good["ok"] and good["moved"] > 0
+    bad = ref.copy()
+    i, j = np.argmax(bad), np.argmin(bad + (bad == bad.max()))
+    bad[[i, j]] = bad[[j, i]]
+    assert not replay_swap_schedule(bad.reshape(nranks, nb), logl, nb, ntemps, steps, k, 1234, 15.0)["ok"]

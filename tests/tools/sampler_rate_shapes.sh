@@ -26,6 +26,10 @@ for line in open(sys.argv[1]):
         sec, ranks, nch, nit = float(t[3]), int(t[5]), int(t[7]), int(t[9])
         print(f"shape {sys.argv[2]} mode {sys.argv[3]} ranks {ranks} x {nch} chains, {nit} iterations: {sec:.3f} s loop -> "
               f"{ranks * nch * nit / sec:.3e} MCMC steps/s, {1e3 * sec / nit:.3f} ms per iteration")
+    if "batched loop seconds" in line:
+        sec = float(line.split()[-1])
+        print(f"    the iteration loop alone (set-up excluded): {sec:.3f} s -> {ranks * nch * nit / sec:.3e} MCMC steps/s, "
+              f"{1e3 * sec / nit:.3f} ms per iteration")
     if "phase seconds" in line:
         ph = [float(x) for x in line.split()[-5:]]
         print("    rank 0, ms per iteration: propose %.3f  eval %.3f  accept+commit %.3f  record %.3f  swap %.3f"
