@@ -21,7 +21,7 @@ for np in $RANKS; do
   python3 - "$W/run_$NIT.log" $SHAPE $MODE <<'PY'
 import sys
 for line in open(sys.argv[1]):
-    if "loop seconds" in line:
+    if "loop seconds" in line and "batched" not in line:
         t = line.split()
         sec, ranks, nch, nit = float(t[3]), int(t[5]), int(t[7]), int(t[9])
         print(f"shape {sys.argv[2]} mode {sys.argv[3]} ranks {ranks} x {nch} chains, {nit} iterations: {sec:.3f} s loop -> "
