@@ -137,7 +137,12 @@ int rf_calc_likelihood_of_trace(rf_ctx *ctx, const double *rft, const double *si
 int rf_eval_batch(rf_ctx *ctx, int32_t nb, const int32_t *walker_ids, const int32_t *fwd_flag,
                   const int32_t *nlay, int32_t nlay_pad, const double *layers,
                   const double *sig, double *logl);
-/* same with every pointer a device pointer; asynchronous on `stream`.  d_logl may also be pinned
+/* same with every pointer a device pointer; asynchronous on `stream`.  The arrays cannot be checked on the host, so
+ * the first kernel of the batch checks every item on the device: nlay outside [2, nlay_pad], a walker id outside
+ * [0, max_walkers] or a fwd_flag > 1 makes that ITEM refused -- logl = NaN, nothing of it evaluated or written, the rest
+ * of the batch unaffected -- and the next call on the context that returns a status after the work has been
+ * synchronised (rf_commit*, rf_get_rft*, rf_eval_batch, rf_eval_wait, rf_calc_likelihood, rf_profile_read, rf_post_read,
+ * rf_ctx_destroy) fails once, rf_last_error naming the item and the reason.  d_logl may also be pinned
  * (device-mapped) host memory.  Calls on one context share per-context state (trace slots, the
  * dispatch order a launch prepares for the next one): issue them on one stream, or synchronise
  * between streams yourself. */

@@ -82,6 +82,7 @@ struct rf_ctx {
     int *d_fm_nlay = nullptr, *d_fm_flag = nullptr;
     double *d_fm_layers = nullptr, *d_fm_scratch = nullptr;
     int *d_nh_active = nullptr;   // [ntrc] "bin_cutoff": bins with a non-negligible filter weight
+    int *h_err = nullptr;     // [4] the error word stage_kernel's input check writes (device-mapped host memory; ws.err is its device alias)
     int *d_order = nullptr;   // [nslots] LPT dispatch order of the current batch
     int *d_order_alt = nullptr;   // [nslots] the order the running launch computes for the next one
     int order_next_nb = 0;    // d_order_alt holds an order for a batch of this size (0: none)
@@ -143,6 +144,8 @@ hipStream_t ctx_stream(rf_ctx *c) { return c->stream; }
 int ctx_device(rf_ctx *c) { return c->device; }
 CommState *&ctx_comm(rf_ctx *c) { return c->comm; }
 }
+
+static int device_error(rf_ctx *c, const char *where);
 
 extern "C" const char *rf_last_error(void) { return g_err.c_str(); }
 extern "C" int rf_abi_version(void) { return RFGPU_ABI_VERSION; }
@@ -569,6 +572,13 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     if (dev_alloc(c, &p, sizeof(int) * (size_t)c->nslots * c->nfwd)) return cleanup(1);
     c->ws.gflag = (int *)p;
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
+    c->ws.item_state = (int *)p;
+    (void)hipMemset(p, 0xff, sizeof(int) * c->nslots);     // "skipped" until a batch's stage_kernel says otherwise
+    if (hipHostMalloc((void **)&c->h_err, sizeof(int) * 4, hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer((void **)&c->ws.err, c->h_err, 0) != hipSuccess)
+        return cleanup(fail("rf_ctx_create: error word allocation failed"));
+    c->h_err[0] = c->h_err[1] = c->h_err[2] = c->h_err[3] = 0;
+    if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->d_order = (int *)p;
     if (dev_alloc(c, &p, sizeof(int) * c->nslots)) return cleanup(1);
     c->d_order_alt = (int *)p;
@@ -683,6 +693,8 @@ extern "C" int rf_ctx_destroy(rf_ctx *c)
     (void)rf_comm_destroy(c);
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    const int pending = device_error(c, "rf_ctx_destroy");   // (everything is released all the same)
+    if (c->h_err) (void)hipHostFree(c->h_err);
     for (void *p : c->owned) (void)hipFree(p);
     if (c->h_single_in) (void)hipHostFree(c->h_single_in);
     if (c->h_single_out) (void)hipHostFree(c->h_single_out);
@@ -697,7 +709,7 @@ extern "C" int rf_ctx_destroy(rf_ctx *c)
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
-    return 0;
+    return pending;
 }
 
 extern "C" int rf_get_flt(const rf_ctx *c, double *flt)
@@ -726,6 +738,22 @@ extern "C" int rf_get_r_inv(const rf_ctx *c, double *r_inv)
     if (!c || !r_inv) return fail("rf_get_r_inv: null argument");
     std::memcpy(r_inv, c->r_inv.data(), sizeof(double) * c->r_inv.size());
     return 0;
+}
+
+// The input check of the *_device entry points runs on the device (stage_kernel): what it refused is reported by the
+// next call that looks here -- after its own synchronisation where it has one (rf_eval_batch, rf_eval_wait,
+// rf_get_rft*, rf_calc_likelihood, rf_profile_read, rf_post_read, rf_ctx_destroy), on entry otherwise (rf_commit*: the
+// caller has synchronised the evaluation's stream to read logL).  Reading clears the word.
+static int device_error(rf_ctx *c, const char *where)
+{
+    if (!c->h_err || !c->h_err[0]) return 0;
+    const int why = c->h_err[0], item = c->h_err[1], what = c->h_err[2];
+    c->h_err[0] = 0;
+    static const char *reason[] = {"", "nlay outside [2, nlay_pad]", "walker id outside the context's slots", "fwd_flag > 1"};
+    char msg[320];
+    snprintf(msg, sizeof msg, "%s: an earlier batch carried a bad item: batch item %d: %s (value %d); the item was not "
+             "evaluated (logL = NaN), the rest of its batch was", where, item, reason[why >= 1 && why <= 3 ? why : 0], what);
+    return fail(msg);
 }
 
 // ---------------------------------------------------------------------------
@@ -953,7 +981,7 @@ extern "C" int rf_eval_batch(rf_ctx *c, int32_t nb, const int32_t *walker_ids, c
     if (run_batch(c, b, s)) return 1;
     HIP_TRY(hipStreamSynchronize(s));
     std::memcpy(logl, h_logl, sizeof(double) * nb);
-    return 0;
+    return device_error(c, "rf_eval_batch");
 }
 
 extern "C" int rf_get_rft(rf_ctx *c, int32_t walker, int32_t which, int32_t nout, double *out)
@@ -971,7 +999,7 @@ extern "C" int rf_get_rft(rf_ctx *c, int32_t walker, int32_t which, int32_t nout
     const double *src = c->ws.rft + (((size_t)slot * c->nslots + walker) * ntrc) * (size_t)n;
     HIP_TRY(hipMemcpy2D(out, sizeof(double) * nout, src, sizeof(double) * n, sizeof(double) * nout, ntrc,
                         hipMemcpyDeviceToHost));
-    return 0;
+    return device_error(c, "rf_get_rft");
 }
 
 extern "C" int rf_get_rft_batch(rf_ctx *c, int32_t n, const int32_t *walker_ids, int32_t which, int32_t nout,
@@ -997,7 +1025,7 @@ extern "C" int rf_get_rft_batch(rf_ctx *c, int32_t n, const int32_t *walker_ids,
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out, c->d_gather, bytes, hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    return 0;
+    return device_error(c, "rf_get_rft_batch");
 }
 
 // Per-call drop-in (one chain per call, src/pt_mcmc.f90:178-180).  Latency matters here, not
@@ -1059,7 +1087,7 @@ extern "C" int rf_calc_likelihood(rf_ctx *c, int32_t walker, int32_t fwd_flag, i
     HIP_TRY(hipStreamSynchronize(s));
     *prop_log_likelihood = c->h_single_out[0];
     if (prop_rft) std::memcpy(prop_rft, c->h_single_out + 1, sizeof(double) * (size_t)n * ntrc);
-    return 0;
+    return device_error(c, "rf_calc_likelihood");
 }
 
 extern "C" int rf_calc_rf(rf_ctx *c, int32_t nlay, const double *alpha, const double *beta, const double *rho,
@@ -1247,7 +1275,7 @@ extern "C" int rf_eval_wait(rf_ctx *c, int32_t ticket, double *logl, int32_t *va
     std::memcpy(logl, h_logl, sizeof(double) * (size_t)T.nb);
     if (valid) std::memcpy(valid, reinterpret_cast<const int *>(h_logl + c->out_cap), sizeof(int) * (size_t)T.nb);
     T.busy = false;
-    return 0;
+    return device_error(c, "rf_eval_wait");
 }
 
 extern "C" int rf_eval_models(rf_ctx *c, int32_t nb, const int32_t *walker_ids, const int32_t *fwd_flag, const int32_t *k,
@@ -1280,6 +1308,7 @@ extern "C" int rf_commit_device(rf_ctx *c, int32_t nb, const int32_t *d_walker_i
 {
     if (!c || !d_walker_ids || !d_accept) return fail("rf_commit_device: null argument");
     if (nb <= 0) return 0;
+    if (device_error(c, "rf_commit_device")) return 1;
     HIP_TRY(hipSetDevice(c->device));
     if (order_after_commit(c, (hipStream_t)stream)) return 1;
     launch_commit(c->ws, nb, d_walker_ids, d_accept, c->cfg.ntrc, (hipStream_t)stream);
@@ -1293,6 +1322,7 @@ extern "C" int rf_commit(rf_ctx *c, int32_t nb, const int32_t *walker_ids, const
     if (nb <= 0) return 0;
     for (int i = 0; i < nb; ++i)
         if (walker_ids[i] < 0 || walker_ids[i] >= c->nslots) return fail("rf_commit: walker id out of range");
+    if (device_error(c, "rf_commit")) return 1;
     HIP_TRY(hipSetDevice(c->device));
     if (ensure_stage(c, nb, 2)) return 1;
     hipStream_t s = c->stream;
@@ -1475,6 +1505,7 @@ extern "C" int rf_post_read(rf_ctx *c, const rf_post_result *o)
     if (!c->have_post) return fail("rf_post_read: rf_post_create has not been called");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (device_error(c, "rf_post_read")) return 1;
     const PostConfig &q = c->post;
     const PostState &st = c->pst;
     const size_t nz = q.nbin_z, nm = (size_t)q.max_models;
@@ -1628,6 +1659,7 @@ extern "C" int rf_profile_read(rf_ctx *c, double *ms, int64_t *launches, int32_t
 {
     if (!c || !ms || !launches) return fail("rf_profile_read: null argument");
     flush_profile(c);
+    if (device_error(c, "rf_profile_read")) return 1;
     for (int i = 0; i < 3; ++i) ms[i] = c->prof_ms[i];
     for (int i = 0; i < 4; ++i) launches[i] = c->prof_n[i];
     if (reset) {

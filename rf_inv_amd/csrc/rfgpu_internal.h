@@ -60,6 +60,8 @@ struct WalkerState {
     double *gcoef;    // [nslots * nfwd][nlay_max][NCOEF] per batch item: stage_kernel's per-layer constants
     double *gtail;    // [nslots * nfwd][GTAIL]           ... walker constants + direct-arrival time
     int *gflag;       // [nslots * nfwd]                  ... bit 0 sea, bit 1 phases beyond the fast sincos range
+    int *item_state;  // [nslots] per batch item, by stage_kernel: 1 evaluate, 0 sigma-only, -1 skipped, -2 refused (bad input)
+    int *err;         // [4] error word in device-mapped host memory: {reason (0 none), batch item, offending value, -}
     int nslots;
 };
 

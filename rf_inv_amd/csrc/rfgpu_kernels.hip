@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(256) void spectra_kernel(SpectraParams P)
     const int lane = threadIdx.x & 63;
     const int f = bf % P.t.nfwd;
     const int ib = P.b.order ? P.b.order[bf / P.t.nfwd] : bf / P.t.nfwd;
-    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) return;
+    if (P.w.item_state[ib] != 1) return;      // (stage_kernel's verdict: evaluate / sigma-only / skipped / refused)
 
     // stage_kernel's constants: the fast paths read them through the scalar data path; only a walker on the generic
     // path (rare) copies the image into LDS
@@ -1101,6 +1101,9 @@ struct StageParams {
     double *gcoef, *gtail;
     int *gflag;
     int spread;   // G = 16 only: the four 16-lane groups of a wave share ONE item, one part each (small batches)
+    int *item_state;   // [nb] out: what the following kernels do with the item (item_not_evaluated)
+    int *err;          // [4] the context's error word (device-mapped host memory): {reason, batch item, offending value, -}
+    int nslots;
 };
 
 // LDS of stage_kernel per (item, forward-trace) group: the direct-arrival terms [pad], the constants the Nyquist
@@ -1128,7 +1131,31 @@ __global__ __launch_bounds__(256) void stage_kernel(StageParams S)
     const bool live = pos < S.b.nb * S.t.nfwd;
     const int ib = live ? (S.b.order ? S.b.order[pos / S.t.nfwd] : pos / S.t.nfwd) : 0, f = live ? pos % S.t.nfwd : 0;
     const int bf = ib * S.t.nfwd + f;                  // index of the (item, forward-trace) images, batch order
-    const bool run = live && (!S.b.fwd_flag || S.b.fwd_flag[ib] == 1);
+    // The one place every item of a batch passes through: what the kernels that follow are to do with it, and the
+    // check of what the caller handed over.  The *_device entry points cannot look at their arrays on the host, and a
+    // layer count beyond nlay_pad or a walker id beyond the context's slots would index the constants' image, LDS rows
+    // and the trace array (8.6 GB at C5) out of bounds: such an item is REFUSED -- state -2, logL = NaN, nothing of it
+    // evaluated or written -- and the context's error word says which (rf_last_error at the next call that checks it).
+    int state = live ? (S.b.fwd_flag ? S.b.fwd_flag[ib] : 1) : -1;
+    if (live) {
+        const int wid = S.b.walker_ids[ib], nli = S.b.nlay[ib];
+        int why = 0, what = 0;
+        if (state > 1) { why = 3; what = state; }
+        else if (wid < 0 || wid >= S.nslots) { why = 2; what = wid; }
+        else if (state == 1 && (nli < 2 || nli > pad)) { why = 1; what = nli; }
+        if (why) {
+            state = -2;
+            if (f == 0 && sl == 0 && q <= 0 && S.err[0] == 0) {   // (the first report wins; a race between two is harmless)
+                S.err[1] = ib;
+                S.err[2] = what;
+                S.err[0] = why;
+            }
+        } else if (state < 0) {
+            state = -1;
+        }
+        if (f == 0 && sl == 0 && q <= 0) S.item_state[ib] = state;
+    }
+    const bool run = live && state == 1;
     const unsigned long long group_mask = (G == 64 ? ~0ull : ((1ull << (G & 63)) - 1)) << (grp * G);
     double *terms = lds + (size_t)(q >= 0 ? wave : wave * NG + grp) * stage_row_doubles(pad);
     double *nyq = terms + pad;                      // [pad][STAGE_NYQ]
@@ -1270,7 +1297,7 @@ static void launch_stage_g(const StageParams &S, unsigned nbf, int nlay_pad, hip
 
 void launch_stage(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, hipStream_t s)
 {
-    StageParams S{t, b, w.gcoef, w.gtail, w.gflag, 0};
+    StageParams S{t, b, w.gcoef, w.gtail, w.gflag, 0, w.item_state, w.err, w.nslots};
     const unsigned nbf = (unsigned)(b.nb * t.nfwd);
     // lanes per (item, trace): 16 up to 32 layers (a walker of more than 16 makes two passes over its lanes; with the
     // batch in depth order a wave's four walkers are alike, and the mean walker is half as deep as the deepest the
@@ -1658,6 +1685,30 @@ __device__ __noinline__ double logl_from_phi(const double *phi, const double *si
     return ll;
 }
 
+// What a trace kernel does with a batch item that is NOT to be evaluated.  item_state[ib] is written for every item of
+// a batch by stage_kernel, which also checks the item (StageParams): 1 evaluate; 0 sigma-only proposal -- the stored
+// trace is re-used (likelihood.f90:81), so is its cached quadratic form; -1 skipped (fwd_flag < 0: a null proposal, an
+// invalid model from rf_eval_models): logL = NaN; -2 refused by the input check (nlay / walker id / fwd_flag out of
+// range): logL = NaN and no walker state is touched.  `lead`: the one thread of the item that reports.
+__device__ __forceinline__ bool item_not_evaluated(const BatchArgs &b, const WalkerState &w, const DeviceTables &t, int ib,
+                                                   bool lead)
+{
+    const int st = w.item_state[ib];
+    if (st == 1) return false;
+    if (lead) {
+        if (st == 0) {
+            const int wk = b.walker_ids[ib];
+            const double *phi = w.phi + ((size_t)w.cur_slot[wk] * w.nslots + wk) * t.ntrc;
+            b.logl[ib] = logl_from_phi(phi, b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
+            w.prop_fwd[wk] = 0;
+        } else {
+            b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
+            if (st == -1) w.prop_fwd[b.walker_ids[ib]] = 0;
+        }
+    }
+    return true;
+}
+
 struct TraceParams {
     DeviceTables t;
     BatchArgs b;
@@ -1853,20 +1904,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_kernel(TraceParams P)
     const int itrc = blockIdx.x % t.ntrc;
     const int ib = P.b.order ? P.b.order[blockIdx.x / t.ntrc] : blockIdx.x / t.ntrc;
     if (blockIdx.x == 0 && tid == 0) *P.slow_count = 0;
-    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
-        // 0: sigma-only proposal -- the stored trace is re-used (likelihood.f90:81), so is its cached
-        // quadratic form; < 0: no evaluation at all (an invalid model from rf_eval_models_device)
-        if (itrc == 0 && tid == 0 && P.b.fwd_flag[ib] < 0) {
-            P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
-            P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
-        } else if (itrc == 0 && tid == 0) {
-            const int wk = P.b.walker_ids[ib];
-            const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * t.ntrc;
-            P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
-            P.w.prop_fwd[wk] = 0;
-        }
-        return;
-    }
+    if (item_not_evaluated(P.b, P.w, t, ib, itrc == 0 && tid == 0)) return;
     const int walker = P.b.walker_ids[ib];
     const int f = t.ray_common ? 0 : itrc;
     const int ipha = t.ipha[itrc];
@@ -2002,18 +2040,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_anyn_kernel(TraceParams P
     const int itrc = blockIdx.x % t.ntrc;
     const int ib = P.b.order ? P.b.order[blockIdx.x / t.ntrc] : blockIdx.x / t.ntrc;
     if (blockIdx.x == 0 && tid == 0) *P.slow_count = 0;
-    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
-        if (itrc == 0 && tid == 0 && P.b.fwd_flag[ib] < 0) {
-            P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
-            P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
-        } else if (itrc == 0 && tid == 0) {
-            const int wk = P.b.walker_ids[ib];
-            const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * t.ntrc;
-            P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
-            P.w.prop_fwd[wk] = 0;
-        }
-        return;
-    }
+    if (item_not_evaluated(P.b, P.w, t, ib, itrc == 0 && tid == 0)) return;
     const int walker = P.b.walker_ids[ib];
     const int f = t.ray_common ? 0 : itrc;
     const int ipha = t.ipha[itrc];
@@ -2178,19 +2205,7 @@ __global__ __launch_bounds__(TRACE_THREADS) void trace_long_kernel(LongParams Q)
         __syncthreads();                                                  // the previous unit is finished with LDS and its rows
         const int itrc = u % t.ntrc;
         const int ib = P.b.order ? P.b.order[u / t.ntrc] : u / t.ntrc;
-        if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
-            // 0: sigma-only proposal (likelihood.f90:81); < 0: no evaluation at all (see trace_kernel)
-            if (itrc == 0 && tid == 0 && P.b.fwd_flag[ib] < 0) {
-                P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
-                P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
-            } else if (itrc == 0 && tid == 0) {
-                const int wk = P.b.walker_ids[ib];
-                const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * t.ntrc;
-                P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
-                P.w.prop_fwd[wk] = 0;
-            }
-            continue;
-        }
+        if (item_not_evaluated(P.b, P.w, t, ib, itrc == 0 && tid == 0)) continue;
         const int walker = P.b.walker_ids[ib];
         const int f = t.ray_common ? 0 : itrc;
         const int ipha = t.ipha[itrc];
@@ -2390,20 +2405,7 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
     const int itrc = bid % t.ntrc;            // == forward-trace index here (nfwd == ntrc)
     const int ib = P.b.order ? P.b.order[bid / t.ntrc] : bid / t.ntrc;
     if (bid == 0 && tid == 0) *P.slow_count = 0;
-    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
-        // 0: sigma-only proposal -- the stored trace is re-used (likelihood.f90:81), so is its cached
-        // quadratic form; < 0: no evaluation at all (an invalid model from rf_eval_models_device)
-        if (itrc == 0 && tid == 0 && P.b.fwd_flag[ib] < 0) {
-            P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
-            P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
-        } else if (itrc == 0 && tid == 0) {
-            const int wk = P.b.walker_ids[ib];
-            const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * t.ntrc;
-            P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
-            P.w.prop_fwd[wk] = 0;
-        }
-        return;
-    }
+    if (item_not_evaluated(P.b, P.w, t, ib, itrc == 0 && tid == 0)) return;
     const int walker = P.b.walker_ids[ib];
     const int ipha = t.ipha[itrc];
     const bool decon = t.deconv_mode == 1;
@@ -2775,19 +2777,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
     const int itrc = bid % t.ntrc;            // == forward-trace index here (nfwd == ntrc)
     const int ib = P.b.order ? P.b.order[bid / t.ntrc] : bid / t.ntrc;
     if (bid == 0 && tid == 0) *P.slow_count = 0;
-    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
-        // 0: sigma-only proposal (likelihood.f90:81); < 0: no evaluation at all (see fused_kernel)
-        if (itrc == 0 && tid == 0 && P.b.fwd_flag[ib] < 0) {
-            P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
-            P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
-        } else if (itrc == 0 && tid == 0) {
-            const int wk = P.b.walker_ids[ib];
-            const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * t.ntrc;
-            P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * t.ntrc, t.ntrc, t.nsmp, false);
-            P.w.prop_fwd[wk] = 0;
-        }
-        return;
-    }
+    if (item_not_evaluated(P.b, P.w, t, ib, itrc == 0 && tid == 0)) return;
     const int walker = P.b.walker_ids[ib];
     const int ipha = t.ipha[itrc];
     const bool decon = t.deconv_mode == 1;
@@ -2932,19 +2922,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fusedc_kernel(FusedParams F)
     }
     const int ib = P.b.order ? P.b.order[bid] : bid;
     if (bid == 0 && tid == 0) *P.slow_count = 0;
-    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) {
-        // 0: sigma-only proposal (likelihood.f90:81); < 0: no evaluation at all (see fused_kernel)
-        if (tid == 0 && P.b.fwd_flag[ib] < 0) {
-            P.b.logl[ib] = __longlong_as_double(0x7ff8000000000000LL);
-            P.w.prop_fwd[P.b.walker_ids[ib]] = 0;
-        } else if (tid == 0) {
-            const int wk = P.b.walker_ids[ib];
-            const double *phi = P.w.phi + ((size_t)P.w.cur_slot[wk] * P.w.nslots + wk) * ntrc;
-            P.b.logl[ib] = logl_from_phi(phi, P.b.sig + (size_t)ib * ntrc, ntrc, nsmp, false);
-            P.w.prop_fwd[wk] = 0;
-        }
-        return;
-    }
+    if (item_not_evaluated(P.b, P.w, t, ib, tid == 0)) return;
     const int walker = P.b.walker_ids[ib];
     const int ipha = t.ipha[0];                   // common to every trace (check_ray, forward.f90:59-91)
     const bool decon = t.deconv_mode == 1;
@@ -3225,7 +3203,7 @@ __global__ __launch_bounds__(256) void phi_deferred_kernel(LoglParams P)
     const int it = blockIdx.x % ntrc, grp = blockIdx.x / ntrc, ib0 = grp * PHI_W;
     for (int e = tid; e < PHI_W * nsmp; e += 256) {
         const int w = e / nsmp, i = e - w * nsmp, ib = ib0 + w;
-        const bool live = ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1);
+        const bool live = ib < P.b.nb && P.w.item_state[ib] == 1;
         mis[e] = live ? P.w.misfit[((size_t)ib * ntrc + it) * P.t.mis_stride + i] : 0.0;
     }
     __syncthreads();
@@ -3288,7 +3266,7 @@ __global__ __launch_bounds__(256) void phi_deferred_kernel(LoglParams P)
     }
     __syncthreads();
     const int ib = ib0 + tid;
-    const bool mine = tid < PHI_W && ib < P.b.nb && (!P.b.fwd_flag || P.b.fwd_flag[ib] == 1);
+    const bool mine = tid < PHI_W && ib < P.b.nb && P.w.item_state[ib] == 1;
     const int walker = mine ? P.b.walker_ids[ib] : 0;
     double *phis = P.w.phi + ((size_t)(mine ? 1 - P.w.cur_slot[walker] : 0) * P.w.nslots + walker) * ntrc;
     const double phi = (red[tid & (PHI_W - 1)] + red[PHI_W + (tid & (PHI_W - 1))]) +
@@ -3494,7 +3472,7 @@ __global__ __launch_bounds__(256) void phi_gemm_finish_kernel(LoglParams P, cons
 #pragma clang fp contract(off)
     const int ib = blockIdx.x * blockDim.x + threadIdx.x;
     if (ib >= P.b.nb) return;
-    if (P.b.fwd_flag && P.b.fwd_flag[ib] != 1) return;
+    if (P.w.item_state[ib] != 1) return;
     const int ntrc = P.t.ntrc, walker = P.b.walker_ids[ib];
     double *phis = P.w.phi + ((size_t)(1 - P.w.cur_slot[walker]) * P.w.nslots + walker) * ntrc;
     for (int it = 0; it < ntrc; ++it) {
@@ -3527,6 +3505,7 @@ __global__ __launch_bounds__(256) void misfit_of_trace_kernel(DeviceTables t, Wa
     const double *obs = t.obs + (size_t)itrc * t.nsmp;
     double *dst = w.misfit + (size_t)itrc * t.mis_stride;
     for (int i = threadIdx.x; i < t.nsmp; i += 256) dst[i] = src[i] - obs[i];
+    if (itrc == 0 && threadIdx.x == 0) w.item_state[0] = 1;   // (no stage_kernel on this path: the one item is to be finished)
 }
 
 void launch_misfit_of_trace(const DeviceTables &t, const WalkerState &w, int walker, hipStream_t s)
@@ -3676,7 +3655,7 @@ __device__ __forceinline__ void order_block(int nb, const int *nlay, const int *
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
     for (int i = tid; i < nb; i += blockDim.x) {
-        const int key = (fwd_flag && fwd_flag[i] != 1) ? 0 : min(nlay[i], 255);
+        const int key = (fwd_flag && fwd_flag[i] != 1) ? 0 : max(0, min(nlay[i], 255));
         atomicAdd(&hist[key], 1);
     }
     __syncthreads();
@@ -3701,7 +3680,7 @@ __device__ __forceinline__ void order_block(int nb, const int *nlay, const int *
     }
     __syncthreads();
     for (int i = tid; i < nb; i += blockDim.x) {
-        const int key = (fwd_flag && fwd_flag[i] != 1) ? 0 : min(nlay[i], 255);
+        const int key = (fwd_flag && fwd_flag[i] != 1) ? 0 : max(0, min(nlay[i], 255));
         order[atomicAdd(&start[key], 1)] = i;
     }
 }
@@ -3749,6 +3728,14 @@ __global__ void commit_kernel(WalkerState w, int nb, const int *walker_ids, cons
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
     const int wk = walker_ids[i];
+    if (wk < 0 || wk >= w.nslots) {            // (rf_commit_device cannot check its ids on the host: refuse, report)
+        if (w.err[0] == 0) {
+            w.err[1] = i;
+            w.err[2] = wk;
+            w.err[0] = 2;
+        }
+        return;
+    }
     if (accept[i] && w.prop_fwd[wk]) w.cur_slot[wk] = 1 - w.cur_slot[wk];
     w.prop_fwd[wk] = 0;
 }

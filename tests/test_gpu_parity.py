@@ -1030,3 +1030,59 @@ def test_contexts_give_their_memory_back(oracle):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info()[0]
     assert free0 - free1 < 64 << 20, (free0, free1)      # (the allocator may keep a few pooled blocks: far below one context)
+
+
+def test_device_batch_inputs_are_validated(oracle):
+    """rf_eval_batch_device cannot look at its arrays on the host; stage_kernel (which touches every item once) checks
+    them on the device: a layer count outside [2, nlay_pad], a walker id outside the context's slots or a fwd_flag > 1
+    makes that ITEM refused -- logL = NaN, nothing of it evaluated, no out-of-bounds access -- while its neighbours in
+    the batch get bit-identical results, and the next call that checks the context's error word (rf_get_rft, rf_commit*,
+    rf_profile_read ...) fails with the item and the reason; afterwards the context works as before."""
+    import torch
+
+    from rf_inv_amd.engine import RFGPUError
+
+    rng = np.random.default_rng(77)
+    cfg = make_cfg(nfft=4096, rayps=[0.06, 0.09], ipha=[1, -1])
+    nsmp, nb, pad = 101, 600, 20
+    true = random_stack(rng, 5)
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, int(n)) for n in rng.integers(3, 18, nb)]
+    nlay, layers = pack_layers(stacks, pad)
+    sig = rng.uniform(0.01, 0.05, (nb, 2))
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=pad) as eng:
+        ids = np.arange(nb, dtype=np.int32)
+        d_logl = torch.empty(nb, dtype=torch.float64, device=dev)
+        eng.eval_batch_device(t(ids), t(nlay), t(layers), t(sig), d_logl)
+        torch.cuda.synchronize()
+        clean = d_logl.cpu().numpy()
+        assert np.all(np.isfinite(clean))
+        trace7 = eng.get_rft(7, which=1).copy()
+        for kind, item, mutate in (("nlay", 100, lambda i, n, f: n.__setitem__(100, pad + 5)),
+                                   ("nlay", 3, lambda i, n, f: n.__setitem__(3, 1)),
+                                   ("walker id", 250, lambda i, n, f: i.__setitem__(250, nb + 10)),
+                                   ("walker id", 599, lambda i, n, f: i.__setitem__(599, -3)),
+                                   ("fwd_flag", 42, lambda i, n, f: f.__setitem__(42, 2))):
+            i2, n2, f2 = ids.copy(), nlay.copy(), np.ones(nb, dtype=np.int32)
+            mutate(i2, n2, f2)
+            eng.eval_batch_device(t(i2), t(n2), t(layers), t(sig), d_logl, fwd_flag=t(f2))
+            torch.cuda.synchronize()
+            got = d_logl.cpu().numpy()
+            assert np.isnan(got[item]), (kind, item)
+            rest = np.arange(nb) != item
+            assert np.array_equal(got[rest], clean[rest]), kind          # the neighbours: bit for bit the clean batch
+            with pytest.raises(RFGPUError, match=f"batch item {item}: .*{kind}"):
+                eng.get_rft(7, which=1)
+            assert np.array_equal(eng.get_rft(7, which=1), trace7)       # reported once; the context goes on
+        # rf_commit_device checks its ids on the device too
+        bad_ids = ids.copy()
+        bad_ids[11] = 5 * nb
+        eng.commit_device(t(bad_ids), t(np.ones(nb, dtype=np.int32)))
+        torch.cuda.synchronize()
+        with pytest.raises(RFGPUError, match="walker id"):
+            eng.profile_read()
+        ll = eng.eval_batch(ids, nlay, layers, sig)
+        assert np.array_equal(ll, clean)
