@@ -50,7 +50,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector == matrix peak (datasheet)
 ALSO_NOMINAL_MS = {"c1": 0.03, "c2": 0.075, "c2d": 0.08, "c3": 0.45, "c4": 1.9, "c4common": 0.95, "c5": 13.0,
-                   "c4w20": 2.2, "c4w60": 4.0}   # ms per step
+                   "c4w20": 2.2, "c4w60": 4.0, "c4win": 1.8, "c5win": 12.5}   # ms per step
 SPEC_CLOCK_GHZ = 2.4      # the engine clock 78.6 TF is quoted at (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4e9)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 ENV_ALLOWED = {"RFGPU_BENCH_BACKEND"}   # "gloo": functional test of the N > 1 path on one GPU
@@ -91,6 +91,15 @@ WORKLOADS = {
                   desc="c4w60: the c4 shape with a 60 s time window (t_end 60 -> nsmp 1201; R^-1 11.5 MB per trace): "
                        "8192 walkers/GPU x 3 traces x nfft 4096 x <=30 layers, PT swap; quadratic forms as one "
                        "FP64-MFMA GEMM per batch (phi_gemm_kernel)"),
+    # the option a host that only ever reads samples 1 .. nsmp can set (pt_control_batched does): never the headline
+    "c4win": dict(walkers=8192, nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], k_max=30, sdep=0.0, deconv=0,
+                  temps=8, options={"trace_window": 1.0},
+                  desc="c4win: c4 with rf_set_option('trace_window', 1): only samples 1 .. nsmp of every trace are stored "
+                       "(what the likelihood and the histograms read, src/likelihood.f90:88, src/pt_mcmc.f90:273-274); "
+                       "same logL bit for bit; NOT the reference's full rft(nfft, ntrc) image"),
+    "c5win": dict(walkers=32768, nfft=4096, rayps=[0.06, 0.08, 0.10, 0.12], ipha=[1, 1, -1, -1], k_max=30, sdep=2.0,
+                  deconv=0, temps=16, options={"trace_window": 1.0},
+                  desc="c5win: c5 with rf_set_option('trace_window', 1): 0.2 GB of resident traces instead of 8.6 GB"),
     "c1": dict(walkers=1024, nfft=256, rayps=[0.06, 0.08], ipha=[1, 1], k_max=10, sdep=2.0, deconv=0, temps=1,
                desc="c1-shape: 1024 walkers/GPU x 2 P traces x nfft 256 x ocean x <=11 layers"),
 }
@@ -512,7 +521,7 @@ def main():
                   device=local_rank)
         with RFEngine(obs=np.zeros((p.ntrc, p.nsmp)), r_inv=r_inv, max_walkers=1, **kw) as e0:
             obs = np.ascontiguousarray(e0.calc_rf(nl_t, a_t, b_t, r_t, h_t)[:p.nsmp].T)
-        eng = RFEngine(obs=obs, r_inv=r_inv, max_walkers=nb, options=overrides, **kw)
+        eng = RFEngine(obs=obs, r_inv=r_inv, max_walkers=nb, options={**w.get("options", {}), **overrides}, **kw)
 
         stream = torch.cuda.Stream(device=dev)
         d_ids = torch.arange(nb, dtype=torch.int32, device=dev)
@@ -661,6 +670,7 @@ def main():
                   "bootstrap failed)", file=sys.stderr)
         plan = eng.launch_plan
         assert plan["build"] == "production" or overrides or args.lib, plan
+        assert plan["trace_window"] == bool(w.get("options", {}).get("trace_window", overrides.get("trace_window", 0)))
         assert np.all(np.isfinite(ll_gpu)), "non-finite logL in the benchmark batch"
 
         # the depths the LAST step evaluated (they are what h_logl holds and what the checker must be given)
@@ -741,7 +751,7 @@ def main():
                                  "transport": "none (one rank)" if world == 1 else
                                               "launcher's process group + rf_pt_swap_gathered_device (librfgpu's own RCCL "
                                               "communicator not formed: ranks share a GPU, or its bootstrap failed)"}),
-                       "perturb_nlay": args.perturb_nlay,
+                       "perturb_nlay": args.perturb_nlay, "workload_options": w.get("options", {}),
                        "launch_plan": plan, "overrides": overrides,
                        "lib": {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "sha256": lib_sha, "kernels_sha256": kernels_sha,
                                "default_build": args.lib is None},
@@ -797,7 +807,7 @@ def main():
         return res
 
     main_res = run(args.workload, args.steps, args.warmup, not args.no_cpu_baseline and world == 1)
-    also_list = args.also if args.also is not None else ("c2,c2d,c3,c5,c4common,c4w20,c4w60,c4stale" if world == 1 else "")
+    also_list = args.also if args.also is not None else ("c2,c2d,c3,c5,c4common,c4w20,c4w60,c4win,c5win,c4stale" if world == 1 else "")
     also = {}
     keep = ("value", "ms_per_step", "ms_per_step_median", "steps", "config", "roofline", "kernel_ms", "parity_in_bench",
             "quadratic_form_gemm")

@@ -66,6 +66,12 @@ typedef struct rf_config {
 /* replaces init_fftw (src/fftw.f90:41-48) + init_forward (src/forward.f90:47-55)
  * + init_r_inv (src/likelihood.f90:168-241) + allocation of rft/log_likelihood
  * state (src/likelihood.f90:150-151). */
+/* Device memory of a context (W = max_walkers + 1): traces 16 W ntrc nfft bytes (option "trace_window": nsmp instead of
+ * nfft); per-item constants 200 W nfwd nlay_max bytes; contexts on the split launch plan (common rays off nfft 4096,
+ * nfft 8192 and beyond, nfft not a power of two, or after rf_set_option("fused", 0)) add the spectra, 32 W nfwd (nfft/2+1)
+ * bytes, allocated here or by that rf_set_option call; long series (nfft > 8192, or > 2048 and not a power of two) add
+ * two scratch rows of 16 M bytes (M = the transform length, <= 65536) per resident block, at most 2 blocks per CU
+ * (1 GB at M = 65536 on 256 CUs); long windows (nsmp > 191) add the padded R^-1 image and misfit rows of ~8 nsmp bytes. */
 int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out);
 int rf_ctx_destroy(rf_ctx *ctx);
 const char *rf_last_error(void);
@@ -365,6 +371,13 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
  *   "block_threads"    0 by the context's capacity (default: max_walkers * ntrc blocks within three rounds of the
  *                      GPU -> 512; fixed per context, never per launch) | 256 fused_kernel | 512 fused8_kernel
  *                      (nfft 4096 on land only)
+ *   "trace_window"     0 (default: every trace is kept as the reference's rft(nfft, ntrc, chain), filled completely) | 1:
+ *                      only samples 1 .. nsmp are stored -- all the likelihood, the histograms and make_syn ever read
+ *                      (src/likelihood.f90:88, src/pt_mcmc.f90:273-274): the trace array shrinks nfft / nsmp-fold (C5:
+ *                      8.6 GB -> 0.2 GB) and the trace kernels write 40x less.  Same logL and same samples 1 .. nsmp, bit
+ *                      for bit.  rf_get_rft* then refuse n > nsmp, rf_calc_rf and rf_calc_likelihood with prop_rft
+ *                      refuse.  Switching it re-allocates the array: EVERY stored trace is dropped (set it before the
+ *                      first evaluation, or re-evaluate and commit the chains afterwards, as pt_control_batched does)
  *   "bin_cutoff"       0 (default: every bin like the reference) | tol in (0, 1): bins whose Gaussian filter
  *                      weight is below tol * flt(1) are not propagated (contexts with one
  *                      forward computation per trace only: common-ray contexts share one pass between filters
@@ -385,7 +398,8 @@ int rf_set_option(rf_ctx *ctx, const char *name, double value);
  *  [12] 1 on the long-window plan (nsmp > 191; the reference allows npts_max = 2000, src/params.f90:44): every trace
  *       kernel leaves its misfits in HBM and the quadratic forms misfit . R^-1 . misfit of the whole batch run as ONE
  *       tiled GEMM on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) followed by logL; "defer_logl" is then ignored.
- *       Fixed per context from nsmp; ms[2] of rf_profile_read is the GEMM + logL pair */
+ *       Fixed per context from nsmp; ms[2] of rf_profile_read is the GEMM + logL pair
+ *  [13] the "trace_window" option */
 int rf_get_launch_plan(const rf_ctx *ctx, int32_t *plan);
 
 /* HIP-event timing (on the streams the kernels are launched on) of the three kernels

@@ -109,6 +109,7 @@ struct rf_ctx {
                                  // (measured at the end of round 3, 8-wave vs 4-wave: two rounds +2.7 %, three +1.5 %,
                                  // four -3.8 %, six -4 %, C3's sixteen and C4's forty-eight -3..4 %)
     double bin_cutoff = 0.0;  // "bin_cutoff": opt-in filter-support cut-off (0 = off: every bin like the reference)
+    int trace_window = 0;     // "trace_window": 1 = only samples 1 .. nsmp of every trace are stored
     int n_overrides = 0;      // options set away from their defaults (echoed by rf_get_launch_plan)
     int ablate = 0;           // RFGPU_DIAGNOSTICS builds only ("ablate"): stops the kernel early, results invalid
     double *h_single_in = nullptr, *h_single_out = nullptr;   // pinned staging of the per-call drop-in
@@ -146,6 +147,7 @@ CommState *&ctx_comm(rf_ctx *c) { return c->comm; }
 }
 
 static int device_error(rf_ctx *c, const char *where);
+static int ensure_spec(rf_ctx *c);
 
 extern "C" const char *rf_last_error(void) { return g_err.c_str(); }
 extern "C" int rf_abi_version(void) { return RFGPU_ABI_VERSION; }
@@ -377,6 +379,25 @@ static int ensure_out(rf_ctx *c, int nb)
 }
 static size_t out_region(const rf_ctx *c, int region) { return (size_t)region * 2 * c->out_cap; }   // in doubles
 
+// The walkers' traces: [2][nslots][ntrc][len] -- len = nfft (the reference's rft(nfft, ntrc, nchains), filled
+// completely), or nsmp with the "trace_window" option: the samples the likelihood, the histograms and make_syn ever
+// read (src/likelihood.f90:88, src/pt_mcmc.f90:273-274).  (Re)allocated zero-filled: every stored trace is gone.
+static int alloc_traces(rf_ctx *c, int len)
+{
+    if (c->ws.rft) {
+        c->owned.erase(std::remove(c->owned.begin(), c->owned.end(), (void *)c->ws.rft), c->owned.end());
+        HIP_TRY(hipFree(c->ws.rft));
+        c->ws.rft = nullptr;
+    }
+    const size_t elems = 2 * (size_t)c->nslots * c->cfg.ntrc * (size_t)len;
+    void *p = nullptr;
+    if (dev_alloc(c, &p, sizeof(double) * elems)) return 1;
+    c->ws.rft = (double *)p;
+    c->ws.trace_len = len;
+    HIP_TRY(hipMemset(p, 0, sizeof(double) * elems));
+    return 0;
+}
+
 // Launch plan from the context's shape, then the explicit options on top.
 static void default_plan(rf_ctx *c)
 {
@@ -544,10 +565,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
 
     // walker state
     void *p;
-    const size_t rft_elems = 2 * (size_t)c->nslots * ntrc * n;
-    if (dev_alloc(c, &p, sizeof(double) * rft_elems)) return cleanup(1);
-    c->ws.rft = (double *)p;
-    if (hipMemset(p, 0, sizeof(double) * rft_elems) != hipSuccess) return cleanup(fail("hipMemset failed"));
+    c->ws.rft = nullptr;
+    if (alloc_traces(c, n)) return cleanup(1);
     if (dev_alloc(c, &p, sizeof(double) * 2 * (size_t)c->nslots * ntrc)) return cleanup(1);
     c->ws.phi = (double *)p;
     (void)hipMemset(p, 0, sizeof(double) * 2 * (size_t)c->nslots * ntrc);
@@ -683,6 +702,7 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
     c->fusedc_allowed = n == 4096 && c->ray_common && ntrc > 1 && cfg->sdep <= 0.0 &&
                         fused8_lds_bytes(lnsmp, cfg->nlay_max) <= 80 * 1024;
     default_plan(c);
+    if (!c->fused && !c->fusedc && ensure_spec(c)) return cleanup(1);
     *ctx_out = c;
     return 0;
 }
@@ -826,6 +846,18 @@ static bool use_fused8(const rf_ctx *c)
     return blocks <= (long long)c->fused8_max_rounds * 2 * c->num_cu;
 }
 
+// The split plan's intermediate, spec[nslots][nfwd][2][nh] complex128 (8.6 GB at the C5 capacity): allocated when a
+// context first NEEDS it -- at creation or at the rf_set_option call that makes the split plan the context's plan, so
+// that running out of memory surfaces at a configuration call, not in the middle of a run.
+static int ensure_spec(rf_ctx *c)
+{
+    if (c->spec) return 0;
+    void *p = nullptr;
+    if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * c->nfwd * 2 * c->nh)) return 1;
+    c->spec = (double2 *)p;
+    return 0;
+}
+
 // what follows a trace kernel that left its misfits in HBM: the quadratic forms and logL of the batch
 // (defer 1: phi_deferred_kernel, 8 items per block; defer 2, long windows: one GEMM on the FP64 matrix cores)
 static int finish_likelihood(rf_ctx *c, const BatchArgs &b, int defer, hipStream_t s)
@@ -909,11 +941,7 @@ static int run_batch(rf_ctx *c, const BatchArgs &b_in, hipStream_t s)
         if (e) (void)hipEventRecord(e, s);
         if (finish_likelihood(c, b, defer, s)) return 1;
     } else {
-        if (!c->spec) {
-            void *p = nullptr;
-            if (dev_alloc(c, &p, sizeof(double2) * (size_t)c->nslots * c->nfwd * 2 * c->nh)) return 1;
-            c->spec = (double2 *)p;
-        }
+        if (ensure_spec(c)) return 1;
         hipEvent_t e = prof_begin(c, 0, s);
         launch_spectra(c->tab, b, c->spec, pick_nsplit(c, b.nb), c->chain, c->waves_per_block, c->slow_list,
                        c->slow_count, c->ws, s);
@@ -989,15 +1017,17 @@ extern "C" int rf_get_rft(rf_ctx *c, int32_t walker, int32_t which, int32_t nout
     if (!c || !out) return fail("rf_get_rft: null argument");
     if (walker < 0 || walker >= c->nslots) return fail("rf_get_rft: walker out of range");
     if (nout < 1 || nout > c->cfg.nfft) return fail("rf_get_rft: n out of range");
+    if (nout > c->ws.trace_len) return fail("rf_get_rft: the context keeps samples 1 .. nsmp of every trace only (option trace_window)");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->stream));
     int cur = 0, pf = 0;
     HIP_TRY(hipMemcpy(&cur, c->ws.cur_slot + walker, sizeof(int), hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(&pf, c->ws.prop_fwd + walker, sizeof(int), hipMemcpyDeviceToHost));
     const int slot = (which == 1 && pf) ? 1 - cur : cur;
-    const int n = c->cfg.nfft, ntrc = c->cfg.ntrc;
-    const double *src = c->ws.rft + (((size_t)slot * c->nslots + walker) * ntrc) * (size_t)n;
-    HIP_TRY(hipMemcpy2D(out, sizeof(double) * nout, src, sizeof(double) * n, sizeof(double) * nout, ntrc,
+    const int ntrc = c->cfg.ntrc;
+    const int len = c->ws.trace_len;
+    const double *src = c->ws.rft + (((size_t)slot * c->nslots + walker) * ntrc) * (size_t)len;
+    HIP_TRY(hipMemcpy2D(out, sizeof(double) * nout, src, sizeof(double) * len, sizeof(double) * nout, ntrc,
                         hipMemcpyDeviceToHost));
     return device_error(c, "rf_get_rft");
 }
@@ -1008,6 +1038,7 @@ extern "C" int rf_get_rft_batch(rf_ctx *c, int32_t n, const int32_t *walker_ids,
     if (!c || !walker_ids || !out) return fail("rf_get_rft_batch: null argument");
     if (n <= 0) return 0;
     if (nout < 1 || nout > c->cfg.nfft) return fail("rf_get_rft_batch: n out of range");
+    if (nout > c->ws.trace_len) return fail("rf_get_rft_batch: the context keeps samples 1 .. nsmp of every trace only (option trace_window)");
     for (int i = 0; i < n; ++i)
         if (walker_ids[i] < 0 || walker_ids[i] >= c->nslots) return fail("rf_get_rft_batch: walker out of range");
     HIP_TRY(hipSetDevice(c->device));
@@ -1037,6 +1068,9 @@ extern "C" int rf_calc_likelihood(rf_ctx *c, int32_t walker, int32_t fwd_flag, i
 {
     if (!c || !sig || !prop_log_likelihood) return fail("rf_calc_likelihood: null argument");
     if (walker < 0 || walker >= c->nslots) return fail("rf_calc_likelihood: walker out of range");
+    if (prop_rft && c->ws.trace_len < c->cfg.nfft)
+        return fail("rf_calc_likelihood: prop_rft(nfft, ntrc) cannot be delivered: the context keeps samples 1 .. nsmp only "
+                    "(option trace_window); pass NULL and read the window with rf_get_rft");
     if (fwd_flag) {
         if (!alpha || !beta || !rho || !h) return fail("rf_calc_likelihood: null layer arrays");
         if (nlay < 2 || nlay > c->cfg.nlay_max) return fail("rf_calc_likelihood: nlay out of range");
@@ -1125,8 +1159,10 @@ extern "C" int rf_calc_likelihood_of_trace(rf_ctx *c, const double *rft, const d
     HIP_TRY(hipStreamSynchronize(s));
     int cur = 0;
     HIP_TRY(hipMemcpy(&cur, c->ws.cur_slot + wk, sizeof(int), hipMemcpyDeviceToHost));
-    double *dst = c->ws.rft + (((size_t)(1 - cur) * c->nslots + wk) * ntrc) * (size_t)n;
-    HIP_TRY(hipMemcpyAsync(dst, rft, sizeof(double) * (size_t)n * ntrc, hipMemcpyHostToDevice, s));
+    const int len = c->ws.trace_len;     // (nfft, or the window's nsmp samples of each trace)
+    double *dst = c->ws.rft + (((size_t)(1 - cur) * c->nslots + wk) * ntrc) * (size_t)len;
+    HIP_TRY(hipMemcpy2DAsync(dst, sizeof(double) * len, rft, sizeof(double) * n, sizeof(double) * len, ntrc,
+                             hipMemcpyHostToDevice, s));
     const int one = 1;
     HIP_TRY(hipMemcpyAsync(c->d_ids, &wk, sizeof(int), hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(c->d_fwd, &one, sizeof(int), hipMemcpyHostToDevice, s));
@@ -1603,6 +1639,11 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
         if (!integral || !(iv == 0 || iv == 256 || iv == 512))
             return fail("rf_set_option: block_threads must be 0 (by batch size), 256 or 512");
         c->block_threads = iv;
+    } else if (k == "trace_window") {
+        if (!integral || iv < 0 || iv > 1) return fail("rf_set_option: trace_window must be 0 or 1");
+        const int len = iv ? c->cfg.nsmp : c->cfg.nfft;
+        if (len != c->ws.trace_len && alloc_traces(c, len)) return 1;
+        c->trace_window = iv;
     } else if (k == "bin_cutoff") {
         if (!(value >= 0.0 && value < 1.0)) return fail("rf_set_option: bin_cutoff must be in [0, 1)");
         c->bin_cutoff = value;
@@ -1615,9 +1656,10 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
         return fail("rf_set_option: unknown option '" + k + "'");
     }
     default_plan(c);
+    if (!c->fused && !c->fusedc && ensure_spec(c)) return 1;
     c->n_overrides = (c->fused_override != -1) + (c->chain_override != -1) + (!c->lpt) + (!c->order_reuse) +
                      (c->nsplit_override != 0) + (c->waves_per_block != 4) + (c->defer_logl != -1) +
-                     (c->block_threads != 0) + (c->bin_cutoff > 0.0) + (c->ablate != 0);
+                     (c->block_threads != 0) + (c->bin_cutoff > 0.0) + (c->ablate != 0) + (c->trace_window != 0);
     return 0;
 }
 
@@ -1641,7 +1683,8 @@ extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
     plan[10] = c->block_threads;
     plan[11] = (c->fusedc || use_fused8(c)) ? 512 : 256;
     plan[12] = c->tab.phi_gemm;
-    plan[13] = plan[14] = plan[15] = 0;
+    plan[13] = c->trace_window;
+    plan[14] = plan[15] = 0;
     return 0;
 }
 

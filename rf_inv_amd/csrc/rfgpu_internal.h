@@ -51,7 +51,8 @@ struct BatchArgs {
 };
 
 struct WalkerState {
-    double *rft;      // [2][nslots][ntrc][nfft]
+    double *rft;      // [2][nslots][ntrc][trace_len]
+    int trace_len;    // samples kept of every trace: nfft, or nsmp with the "trace_window" option
     double *phi;      // [2][nslots][ntrc]
     int *cur_slot;    // [nslots] 0/1: which half holds the current trace
     int *prop_fwd;    // [nslots] last proposal ran the forward model

@@ -1776,7 +1776,8 @@ __device__ __forceinline__ bool tail_in_registers(const TraceParams &P, double2 
     for (int k = 0; k < R; ++k) {
         const unsigned i0 = (unsigned)(at0 + step * bitrev_small<LOG2R>(k)) & mask;   // 0-based sample of rft
         const double val = v[k].x * rfac;                            // forward.f90:202 (see rfac)
-        __builtin_nontemporal_store(val, &dst[i0]);   // written once, read rarely: keep it out of L2
+        // written once, read rarely: keep it out of L2.  ("trace_window": only samples 1 .. nsmp are kept, trace_len = nsmp)
+        if (i0 < (unsigned)P.w.trace_len) __builtin_nontemporal_store(val, &dst[i0]);
         if (xout) xout[i0] = val;
         if (i0 < (unsigned)nsmp) {
             const double m = val - obs[i0];                          // likelihood.f90:88
@@ -1801,7 +1802,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
     const int n = t.nfft, nsmp = t.nsmp;
     RFGPU_ABLATE_AT(1, );
     double *__restrict__ dst =
-        P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
+        P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)P.w.trace_len;
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
     double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * t.mis_stride;   // defer mode only
     double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
@@ -1850,7 +1851,7 @@ __device__ __forceinline__ void trace_tail(const TraceParams &P, double2 *a, dou
             val = -a[fft_pad(j - 1)].x;
         }
         if (!decon) val = val * rfac;                                // forward.f90:202 (see rfac)
-        dst[i - 1] = val;
+        if (i <= P.w.trace_len) dst[i - 1] = val;
         if (xout) xout[i - 1] = val;
         if (i <= nsmp) {
             const double m = val - obs[i - 1];                       // likelihood.f90:88
@@ -2718,7 +2719,7 @@ __device__ __forceinline__ void w8_fft_store(const TraceParams &P, double2 *a, d
         __syncthreads();
         fac = red[0];                                                // maxval(rx) forward.f90:201
     }
-    double *__restrict__ dst = P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
+    double *__restrict__ dst = P.w.rft + (((size_t)slot * P.w.nslots + walker) * t.ntrc + itrc) * (size_t)P.w.trace_len;
     const double *__restrict__ obs = t.obs + (size_t)itrc * nsmp;
     double *__restrict__ mis_g = P.w.misfit + ((size_t)ib * t.ntrc + itrc) * t.mis_stride;   // defer mode only
     double *xout = (P.extra_out && ib == 0) ? P.extra_out + (size_t)itrc * n : nullptr;
@@ -2730,7 +2731,7 @@ __device__ __forceinline__ void w8_fft_store(const TraceParams &P, double2 *a, d
     for (int k = 0; k < 8; ++k) {
         const unsigned i0 = (unsigned)(at0 + step * bitrev_small<3>(k)) & 4095u;      // 0-based sample of rft
         const double val = v[k].x * rfac;                            // forward.f90:202 (see rfac)
-        __builtin_nontemporal_store(val, &dst[i0]);
+        if (i0 < (unsigned)P.w.trace_len) __builtin_nontemporal_store(val, &dst[i0]);
         if (xout) xout[i0] = val;
         if (i0 < (unsigned)nsmp) {
             const double m = val - obs[i0];                          // likelihood.f90:88
@@ -3090,13 +3091,13 @@ void launch_fused(const DeviceTables &t, const BatchArgs &b, const WalkerState &
 __global__ __launch_bounds__(TRACE_THREADS) void phi_kernel(DeviceTables t, WalkerState w, int walker)
 {
     extern __shared__ double2 lds2[];
-    const int nsmp = t.nsmp, n = t.nfft;
+    const int nsmp = t.nsmp;
     double *work = reinterpret_cast<double *>(lds2);                  // [4 * nsmp]
     double *mis = work + 4 * (size_t)((nsmp + 1) & ~1);
     double *red = mis + ((nsmp + 1) & ~1);
     const int tid = threadIdx.x, itrc = blockIdx.x;
     const int slot = 1 - w.cur_slot[walker];
-    const double *src = w.rft + (((size_t)slot * w.nslots + walker) * t.ntrc + itrc) * (size_t)n;
+    const double *src = w.rft + (((size_t)slot * w.nslots + walker) * t.ntrc + itrc) * (size_t)w.trace_len;
     const double *obs = t.obs + (size_t)itrc * nsmp;
     for (int i = tid; i < nsmp; i += TRACE_THREADS) mis[i] = src[i] - obs[i];   // likelihood.f90:88
     __syncthreads();
@@ -3501,7 +3502,7 @@ __global__ __launch_bounds__(256) void misfit_of_trace_kernel(DeviceTables t, Wa
 {
     const int itrc = blockIdx.x;
     const int slot = 1 - w.cur_slot[walker];
-    const double *src = w.rft + (((size_t)slot * w.nslots + walker) * t.ntrc + itrc) * (size_t)t.nfft;
+    const double *src = w.rft + (((size_t)slot * w.nslots + walker) * t.ntrc + itrc) * (size_t)w.trace_len;
     const double *obs = t.obs + (size_t)itrc * t.nsmp;
     double *dst = w.misfit + (size_t)itrc * t.mis_stride;
     for (int i = threadIdx.x; i < t.nsmp; i += 256) dst[i] = src[i] - obs[i];
@@ -3708,7 +3709,7 @@ __global__ void gather_rft_kernel(WalkerState w, int ntrc, int nfft, int n, cons
     const int wk = walker_ids[i];
     const int cur = w.cur_slot[wk];
     const int slot = (which == 1 && w.prop_fwd[wk]) ? 1 - cur : cur;
-    const double *src = w.rft + (((size_t)slot * w.nslots + wk) * ntrc + itrc) * (size_t)nfft;
+    const double *src = w.rft + (((size_t)slot * w.nslots + wk) * ntrc + itrc) * (size_t)w.trace_len;
     double *dst = out + ((size_t)i * ntrc + itrc) * (size_t)nout;
     for (int j = threadIdx.x; j < nout; j += blockDim.x) dst[j] = src[j];
 }

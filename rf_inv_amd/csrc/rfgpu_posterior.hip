@@ -147,7 +147,7 @@ __global__ __launch_bounds__(128) void post_amp_kernel(PostConfig c, PostState s
     const int j = blockIdx.x / c.ntrc, itrc = blockIdx.x % c.ntrc;
     if (j >= *st.nsel) return;
     const int wk = b.walker_ids[st.sel[j]];
-    const double *src = w.rft + (((size_t)w.cur_slot[wk] * w.nslots + wk) * c.ntrc + itrc) * (size_t)c.nfft;
+    const double *src = w.rft + (((size_t)w.cur_slot[wk] * w.nslots + wk) * c.ntrc + itrc) * (size_t)w.trace_len;
     int *hist = st.namp + (size_t)itrc * c.nsmp * c.nbin_amp;
     int oor = 0;
     for (int it = threadIdx.x; it < c.nsmp; it += blockDim.x) {

@@ -48,6 +48,11 @@ module pt_mcmc_batched
   ! 2 (default): the chains of a rank are worked in two halves, one being evaluated on the GPU while the host judges and
   ! re-proposes the other (same trajectory: see the loop); 1: propose all, evaluate all, judge all
   integer, public :: rf_pipeline_segments = 2
+  ! .true. (default): the engine keeps only samples 1 .. nsmp of every trace while this loop runs (rf_set_option
+  ! "trace_window") -- all the likelihood and the amplitude histograms read (src/likelihood.f90:88,
+  ! src/pt_mcmc.f90:273-274); the trace kernels write nfft / nsmp times less and the resident traces shrink as much.
+  ! The chains' current traces are rebuilt by one batched evaluation when the loop starts (bit-identical values).
+  logical, public :: rf_windowed_traces = .true.
 
 contains
 
@@ -116,6 +121,28 @@ contains
        b_id(ichain) = ichain - 1            ! (constant: every iteration hands over all chains, null proposals flagged)
        b_acc(ichain) = 1
     end do
+    if (rf_windowed_traces) then
+       ! windowed trace storage: switching drops every stored trace, so the chains' current models are evaluated once
+       ! more, all at once -- the same kernels on the same inputs: the log-likelihoods must come back bit for bit
+       call rfgpu_check(rf_set_option(rf_ctx, "trace_window" // c_null_char, 1.0_c_double), "rf_set_option")
+       do ichain = 1, nchains
+          p_k(ichain) = k(ichain)
+          p_z(1:k_max-1, ichain) = z(1:k_max-1, ichain)
+          p_dvp(:, ichain) = dvp(1:k_max, ichain)
+          p_dvs(:, ichain) = dvs(1:k_max, ichain)
+          p_sig(:, ichain) = sig(1:ntrc, ichain)
+          b_fwd(ichain) = 1
+       end do
+       call rfgpu_check(rf_eval_models(rf_ctx, int(nchains, c_int32_t), b_id, b_fwd, p_k, p_z, int(k_max, c_int32_t), &
+            & p_dvp, p_dvs, p_sig, b_logl, c_null_ptr), "rf_eval_models")
+       do ichain = 1, nchains
+          if (b_logl(ichain) /= log_likelihood(ichain) .and. &
+               & (b_logl(ichain) == b_logl(ichain) .or. log_likelihood(ichain) == log_likelihood(ichain))) then   ! (NaN = NaN here)
+             write(0,*) "ERROR: pt_control_batched: chain", ichain, " re-evaluated to", b_logl(ichain), " not", log_likelihood(ichain)
+             call rfgpu_check(1_c_int, "windowed re-evaluation of the initial models")
+          end if
+       end do
+    end if
     call rfgpu_check(rf_commit(rf_ctx, int(nchains, c_int32_t), b_id, b_acc), "rf_commit")
 
     ! ------------------------------------------------------------------------------------------------------

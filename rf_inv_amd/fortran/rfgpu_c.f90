@@ -146,6 +146,13 @@ module rfgpu_c
        type(c_ptr), value :: valid          ! c_null_ptr: not wanted
      end function rf_eval_wait
 
+     integer(c_int) function rf_set_option(ctx, name, value) bind(C, name="rf_set_option")
+       import :: c_int, c_ptr, c_char, c_double
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: name(*)     ! NUL-terminated
+       real(c_double), value :: value
+     end function rf_set_option
+
      ! pinned host memory (arrays from it travel to the GPU by DMA as they are)
      integer(c_int) function rf_host_alloc(bytes, ptr) bind(C, name="rf_host_alloc")
        import :: c_int, c_ptr, c_size_t

@@ -6,7 +6,9 @@
                    little-endian, 4-byte records), i.e. exactly what read_obs (src/params.f90:422-476) reads back
   reference_noise  the "Add noise" block (src/make_syn.f90:80-115) draw for draw: sigma from ONE grnd(), nfft gauss()
                    values per series from the MT19937 stream in the reference's order, r2c -> times flt(:, itrc)
-                   -> c2r (FFTW's unnormalised pair); when the rays are common ONE white series feeds every trace
+                   -> c2r (FFTW's unnormalised pair); when the rays are common ONE white series is drawn and the
+                   loop of :90-96 is reproduced as written: trace 1 is that series through flt(:, 1), traces 2 ..
+                   are trace 1's OUTPUT through their own filter (the loop re-reads noise(:, 1) after overwriting it)
   make_syn         traces of a given layer stack + that noise -> the two SAC files per trace
   make_syn_program the whole program: sgrnd(iseed), init_model, init_likelihood (their draws come first in the
                    stream), format_model of chain 1, test_vel, noise, SAC files
@@ -62,8 +64,12 @@ def reference_noise(rng: MT19937, p: Params, flt, is_ray_common: bool):
     if is_ray_common:
         sigma[0] = rng.grnd() * (p.sig_max[0] - p.sig_min[0]) + p.sig_min[0]            # :85
         white = np.array([gauss(rng) * sigma[0] for _ in range(nfft)])[:, None]         # :86-88
+        # :90-96, literally: the loop reads its input from noise(:, 1) and writes trace itrc's result to
+        # noise(:, itrc) -- so iteration 1 REPLACES the white series by its own filtered (unnormalised: x nfft) output,
+        # and traces 2 .. ntrc are that already filtered column through their own filter: flt_t(flt_1(white)) x nfft^2
+        noise[:, 0] = white[:, 0]
         for t in range(ntrc):
-            noise[:, t] = _filter_series(white[:, 0], flt[:, t], nfft)                  # :90-96
+            noise[:, t] = _filter_series(noise[:, 0], flt[:, t], nfft)
         sigma[1:] = sigma[0]          # (the reference reports and uses noise_sigma(1) only)
     else:
         white = np.zeros((nfft, ntrc))

@@ -1086,3 +1086,64 @@ def test_device_batch_inputs_are_validated(oracle):
             eng.profile_read()
         ll = eng.eval_batch(ids, nlay, layers, sig)
         assert np.array_equal(ll, clean)
+
+
+@pytest.mark.parametrize("shape", ["land3", "common3", "ocean2", "nfft512", "long_window"])
+def test_trace_window_option(oracle, shape):
+    """rf_set_option("trace_window", 1): only samples 1 .. nsmp of every trace are stored.  logL and those samples are
+    bit-identical to the default (full rft(nfft, ntrc) image) through every kind of trace kernel, commits and sigma-only
+    proposals keep working, the host-owned-trace call too; what needs the full image is refused; switching back gives
+    the full image again."""
+    from rf_inv_amd.engine import RFGPUError
+
+    kw = {"land3": dict(nfft=4096, rayps=[0.06, 0.08, 0.1], ipha=[1, 1, -1]),
+          "common3": dict(nfft=4096, rayps=[0.07, 0.07, 0.07], ipha=[1, 1, 1], a_gus=[4.0, 2.5, 1.5]),
+          "ocean2": dict(nfft=4096, rayps=[0.06, 0.1], ipha=[1, -1], sdep=2.0),
+          "nfft512": dict(nfft=512, rayps=[0.06], ipha=[-1], deconv_mode=1),
+          "long_window": dict(nfft=4096, rayps=[0.06, 0.09], ipha=[1, -1])}[shape]
+    nsmp = 333 if shape == "long_window" else 101
+    rng = np.random.default_rng(zlib.crc32(("tw" + shape).encode()))
+    cfg = make_cfg(t_start=-1.0, **kw)
+    ocean = cfg["sdep"] > 0
+    ntrc, nfft = len(cfg["rayps"]), cfg["nfft"]
+    true = random_stack(rng, 6, ocean, cfg["sdep"])
+    obs = synth_obs(oracle, cfg, true, nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    nb = 900
+    stacks = [random_stack(rng, int(n), ocean, cfg["sdep"]) for n in rng.integers(3, 20, nb)]
+    nlay, layers = pack_layers(stacks, 22)
+    sig = rng.uniform(0.01, 0.05, (nb, ntrc))
+    ids = np.arange(nb)
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=22) as eng:
+        full = eng.eval_batch(ids, nlay, layers, sig)
+        tr_full = eng.get_rft_batch(ids[::50], which=1)                      # [*, ntrc, nfft]
+        eng.set_option("trace_window", 1)
+        assert eng.launch_plan["trace_window"]
+        win = eng.eval_batch(ids, nlay, layers, sig)
+        assert np.array_equal(win, full)
+        tr_win = eng.get_rft_batch(ids[::50], which=1, n=nsmp)
+        assert np.array_equal(tr_win, tr_full[:, :, :nsmp])
+        assert np.array_equal(eng.get_rft(150, which=1, n=nsmp).T, tr_full[3, :, :nsmp])
+        for call in (lambda: eng.get_rft(0, which=1), lambda: eng.get_rft_batch(ids[:2], which=1, n=nsmp + 1),
+                     lambda: eng.calc_rf(len(true[0]), *true),
+                     lambda: eng.calc_likelihood(0, True, int(nlay[0]), *[layers[0, r, :nlay[0]] for r in range(4)], sig[0])):
+            with pytest.raises(RFGPUError, match="trace_window|nsmp"):
+                call()
+        # accept half, then sigma-only proposals everywhere: committed walkers re-use their windowed trace
+        acc = (ids % 2).astype(np.int32)
+        eng.commit(ids, acc)
+        ff = np.zeros(nb, dtype=np.int32)
+        ll2 = eng.eval_batch(ids, nlay, layers, 2 * sig, fwd_flag=ff)
+        q = -(full + nsmp * np.log(sig).sum(axis=1))
+        # one sigma per walker scaled by 2: each trace's phi / sigma^2 term scales by 1/4
+        want = -q / 4 - nsmp * np.log(2 * sig).sum(axis=1)
+        assert np.allclose(ll2[acc == 1], want[acc == 1], rtol=1e-12, atol=1e-9)
+        # per-call drop-in without the trace, and the host-owned-trace call with a full-length host array
+        l0, none = eng.calc_likelihood(1, True, int(nlay[1]), *[layers[1, r, :nlay[1]] for r in range(4)], sig[1], want_rft=False)
+        assert l0 == full[1] and none is None
+        host_trace = np.zeros((nfft, ntrc))
+        host_trace[:nsmp] = tr_full[0, :, :nsmp].T
+        assert eng.calc_likelihood_of_trace(host_trace, sig[0]) == full[0]
+        eng.set_option("trace_window", 0)
+        again = eng.eval_batch(ids, nlay, layers, sig)
+        assert np.array_equal(again, full) and np.array_equal(eng.get_rft_batch(ids[::50], which=1), tr_full)

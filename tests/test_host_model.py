@@ -177,8 +177,10 @@ def test_make_syn_noise_consumes_the_stream_like_the_reference(oracle):
 
 def test_make_syn_noise_common_rays_share_one_white_series(oracle):
     """src/make_syn.f90:84-98: with a common ray geometry ONE sigma and ONE white series are drawn (1 + 2 nfft draws
-    in all) and every trace gets that series through its own filter: the noise spectra of two traces differ only by
-    flt(:, itrc)."""
+    in all).  The loop :90-96 takes its input from noise(:, 1) and stores trace itrc's result in noise(:, itrc): its
+    first pass overwrites the white series with trace 1's filtered, unnormalised output, which is what the later
+    passes then filter -- trace t >= 2 = flt_t(flt_1(white)) with FFTW's factor nfft twice.  Pinned here literally
+    (a restatement of those seven lines on plain arrays), not as one would have meant it."""
     from rf_inv_amd.make_syn import reference_noise
     from rf_inv_amd.mt19937 import MT19937
 
@@ -193,13 +195,19 @@ def test_make_syn_noise_common_rays_share_one_white_series(oracle):
     for _ in range(2 * p.nfft):
         g2.grnd()
     assert rng.grnd() == g2.grnd()                                           # nothing else was drawn
-    w_spec = np.fft.rfft(white[:, 0])
+    # :90-96 on plain arrays: rx <- noise(:, 1); r2c; cx *= flt(:, itrc); c2r; noise(:, itrc) <- rx
+    col = [white[:, 0].copy(), None, None]
     for t in range(3):
-        spec = np.fft.rfft(noise[:, t]) / p.nfft
-        assert np.allclose(spec, w_spec * flt[:, t], rtol=1e-10, atol=1e-13 * np.abs(w_spec * flt[:, t]).max())
+        rx = col[0].copy()
+        cx = np.fft.rfft(rx) * flt[:, t]
+        col[t] = np.fft.irfft(cx, p.nfft) * p.nfft
+    for t in range(3):
+        assert np.allclose(noise[:, t], col[t], rtol=1e-12, atol=1e-14 * np.abs(col[t]).max())
+    # trace 1: the white series through its own filter; trace 2: trace 1's output through flt(:, 2), nfft twice
+    w_spec = np.fft.rfft(white[:, 0])
     k = slice(1, 12)   # where all three filters are far from underflow
-    ratio = np.fft.rfft(noise[:, 1])[k] / np.fft.rfft(noise[:, 0])[k]
-    assert np.allclose(ratio, flt[k, 1] / flt[k, 0], rtol=1e-9)
+    assert np.allclose(np.fft.rfft(noise[:, 0])[k] / p.nfft, (w_spec * flt[:, 0])[k], rtol=1e-9)
+    assert np.allclose(np.fft.rfft(noise[:, 1])[k] / p.nfft ** 2, (w_spec * flt[:, 0] * flt[:, 1])[k], rtol=1e-9)
 
 
 def test_make_syn_file_names_are_the_ones_the_reference_creates(tmp_path):
