@@ -91,11 +91,28 @@ __device__ __forceinline__ void cdiv2(double2 a1, double2 a2, double2 b, double2
 // 51, no selects.  Smith's range reduction protects |b| beyond 1e154 or below 1e-154, which the boundary-condition
 // determinant of a walker on the fast paths (unit gauge, phases below 1e6 rad) never reaches; the generic path keeps
 // cdiv2.  Each quotient within 3 ulp of the exact one (Smith: 2.5).
+//
+// Round 4 ("one quotient"): ONE reciprocal of the determinant, w = conj(b) / |b|^2, and both numerators
+// times w -- 2 + 4 + 4 multiply-adds instead of 2 x (4 + 2) -- with 1 / |b|^2 from v_rcp_f64 and two Newton steps
+// (5 instructions, ~1 ulp) instead of the IEEE division's scale / fmas / fixup sequence (12): that sequence exists for
+// the subnormal and overflow ranges, which |b|^2 of a walker on the fast paths never reaches (see above); 0, Inf and
+// NaN still give Inf / 0 / NaN (a Newton step of an exact Inf or 0 would give NaN: the selects keep the seed).
+__device__ __forceinline__ double rcp_nr2(double x)
+{
+    const double r0 = __builtin_amdgcn_rcp(x);
+    const double e0 = fma(-x, r0, 1.0);
+    const double r1 = fma(r0, e0, r0);
+    const double e1 = fma(-x, r1, 1.0);
+    const double r2 = fma(r1, e1, r1);
+    return (e0 == e0 && fabs(r0) < HUGE_VAL) ? r2 : r0;     // x = 0, Inf, NaN: the seed is already the answer
+}
+
 __device__ __forceinline__ void cdiv2_norm(double2 a1, double2 a2, double2 b, double2 &x1, double2 &x2)
 {
-    const double t = 1.0 / fma(b.x, b.x, b.y * b.y);
-    x1 = make_double2(fma(a1.x, b.x, a1.y * b.y) * t, fma(a1.y, b.x, -(a1.x * b.y)) * t);
-    x2 = make_double2(fma(a2.x, b.x, a2.y * b.y) * t, fma(a2.y, b.x, -(a2.x * b.y)) * t);
+    const double t = rcp_nr2(fma(b.x, b.x, b.y * b.y));
+    const double wx = b.x * t, wy = -(b.y * t);             // w = conj(b) / |b|^2
+    x1 = make_double2(fma(a1.x, wx, -(a1.y * wy)), fma(a1.x, wy, a1.y * wx));
+    x2 = make_double2(fma(a2.x, wx, -(a2.y * wy)), fma(a2.x, wy, a2.y * wx));
 }
 
 // direct_arrival (forward.f90:474-519).  Its result feeds nint() (integer bookkeeping
@@ -547,7 +564,11 @@ __device__ __forceinline__ void finish_bin(const ColState<NCOL> &s, CP tail, dou
     const double2 sl42 = make_double2(t42.y, -t42.x);
     if (NCOL == 2) {
         // free surface (forward.f90:267-275)
-        const double2 denom = csub(cmul(sl31, sl42), cmul(sl32, sl41));
+        // sl31 sl42 - sl32 sl41 as two four-term chains (1 mul + 3 fma each; the products' roundings differ from
+        // csub(cmul, cmul) in the last bit -- the generic path keeps that form)
+        const double2 denom = FAST ? make_double2(fma(sl31.x, sl42.x, fma(-sl31.y, sl42.y, fma(-sl32.x, sl41.x, sl32.y * sl41.y))),
+                                                  fma(sl31.x, sl42.y, fma(sl31.y, sl42.x, fma(-sl32.x, sl41.y, -(sl32.y * sl41.x)))))
+                                   : csub(cmul(sl31, sl42), cmul(sl32, sl41));
         if (ipha >= 0)
             cdivq<FAST>(sl42, cneg(sl41), denom, ur, uz);
         else
