@@ -549,6 +549,7 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
         g.np = (nsmp + 127) / 128 * 128;
         g.nchunk = g.np / 64;
         g.pstride = c->nslots;
+        g.shape = 16;
         const std::vector<double> rg = pad_r_inv(c->r_inv, ntrc, nsmp, g.kp, g.np);
         void *q = nullptr;
         if (upload(c, rg, &g.rg) || dev_alloc(c, &q, sizeof(double) * (size_t)ntrc * g.nchunk * g.pstride)) return cleanup(1);
@@ -1639,6 +1640,9 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
         if (!integral || !(iv == 0 || iv == 256 || iv == 512))
             return fail("rf_set_option: block_threads must be 0 (by batch size), 256 or 512");
         c->block_threads = iv;
+    } else if (k == "gemm_shape") {
+        if (!integral || (iv != 4 && iv != 16)) return fail("rf_set_option: gemm_shape must be 4 or 16");
+        c->pg.shape = iv;
     } else if (k == "trace_window") {
         if (!integral || iv < 0 || iv > 1) return fail("rf_set_option: trace_window must be 0 or 1");
         const int len = iv ? c->cfg.nsmp : c->cfg.nfft;

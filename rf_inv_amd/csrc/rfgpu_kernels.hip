@@ -3374,6 +3374,15 @@ struct PhiGemmParams {
 typedef double pg_acc_t __attribute__((ext_vector_type(4)));
 typedef double pg_v2_t __attribute__((ext_vector_type(2)));
 
+// SHAPE 16: v_mfma_f64_16x16x4_f64 as described above.  SHAPE 4: v_mfma_f64_4x4x4_4b_f64, whose four 4x4x4 blocks
+// (block b = (lane >> 2) & 3; A_b[i][k] at lane i + 4 b + 16 k, B_b[k][j] at lane j + 4 b + 16 k, D_b[i][j] at lane
+// j + 4 b + 16 i: found with tools/mfma_f64_4x4_layout.hip) are used as ONE 4 x 16 x 4 product: the same A values in all
+// four blocks (an LDS broadcast read), block b taking columns 4 b .. 4 b + 3 -- so the B operand and the column of a D
+// lane are those of the 16x16x4 form (B[k = l >> 4][col l & 15], D[row l >> 4][col l & 15]) and a wave's 64 x 64 tile is
+// 16 row groups x 4 column tiles = 64 accumulators of one double.  Same k order per output element, same epilogue
+// sums: the two shapes return the same bits.  The small instruction issues four times as often at a quarter of the
+// work; on this part it sustains a higher FP64 rate (tools/mfma_overlap.hip: 75 against 47 TF on register operands).
+template <int SHAPE>
 __global__ __launch_bounds__(256, 2) void phi_gemm_kernel(PhiGemmParams G)
 {
     __shared__ double As[PG_BM * PG_LDA];
@@ -3414,11 +3423,17 @@ __global__ __launch_bounds__(256, 2) void phi_gemm_kernel(PhiGemmParams G)
         pa[i] = *ap[i];
         pb[i] = *bp[i];
     }
-    pg_acc_t acc[4][4];
+    pg_acc_t acc[4][4];          // SHAPE 16: [mt][nt], register r = row (l >> 4) + 4 r of the tile
+    double acc4[16][4];          // SHAPE 4: [row group][nt], row 4 rg + (l >> 4)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = pg_acc_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc4[rg][nt] = 0.0;
+    const int rg_live = min(16, max(0, (G.nb - mw + 3) >> 2));
 
     const int nkt = G.kp / PG_BK;
     for (int kt = 0; kt < nkt; ++kt) {
@@ -3445,9 +3460,29 @@ __global__ __launch_bounds__(256, 2) void phi_gemm_kernel(PhiGemmParams G)
         for (int kk = 0; kk < PG_BK / 4; ++kk) {
             double av[4], bv[4];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) av[mt] = As[(64 * wm + 16 * mt + l15) * PG_LDA + 4 * kk + l4];
-#pragma unroll
             for (int nt = 0; nt < 4; ++nt) bv[nt] = Bs[(4 * kk + l4) * PG_LDB + 64 * wn + 16 * nt + l15];
+            if constexpr (SHAPE == 4) {
+                double a4[16];
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) a4[rg] = As[(64 * wm + 4 * rg + (lane & 3)) * PG_LDA + 4 * kk + l4];
+                if (full) {
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            acc4[rg][nt] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[rg], bv[nt], acc4[rg][nt], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg)
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt)
+                            if (rg < rg_live && nt < nt_live)
+                                acc4[rg][nt] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[rg], bv[nt], acc4[rg][nt], 0, 0, 0);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) av[mt] = As[(64 * wm + 16 * mt + l15) * PG_LDA + 4 * kk + l4];
             if (full) {
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
@@ -3466,6 +3501,24 @@ __global__ __launch_bounds__(256, 2) void phi_gemm_kernel(PhiGemmParams G)
     }
     // ---- phi partial of the wave's 64 columns for each of its 64 rows ------------------------------------------------
     double *__restrict__ pout = G.part + ((size_t)it * G.nchunk + (nw >> 6)) * G.pstride;
+    if constexpr (SHAPE == 4) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+            const int row = mw + 4 * rg + l4;
+            const bool live = row < G.nb;
+            const double *__restrict__ mrow = Ag + (size_t)(live ? row : 0) * a_rs + nw + l15;
+            double sum = 0.0;
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                if (nt < nt_live) sum = fma(acc4[rg][nt], live ? mrow[16 * nt] : 0.0, sum);
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            sum += __shfl_xor(sum, 4, 64);
+            sum += __shfl_xor(sum, 8, 64);
+            if (l15 == 0 && live) pout[row] = sum;
+        }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -3511,7 +3564,10 @@ void launch_phi_gemm(const DeviceTables &t, const BatchArgs &b, const WalkerStat
 {
     PhiGemmParams G{w.misfit, g.rg, g.part, b.nb, t.ntrc, t.mis_stride, g.kp, g.np, g.nchunk, g.pstride};
     const unsigned nmb = (unsigned)((b.nb + PG_BM - 1) / PG_BM), nnb = (unsigned)(g.np / PG_BN);
-    hipLaunchKernelGGL(phi_gemm_kernel, dim3(nmb * nnb * (unsigned)t.ntrc), dim3(256), 0, s, G);
+    if (g.shape == 4)
+        hipLaunchKernelGGL(phi_gemm_kernel<4>, dim3(nmb * nnb * (unsigned)t.ntrc), dim3(256), 0, s, G);
+    else
+        hipLaunchKernelGGL(phi_gemm_kernel<16>, dim3(nmb * nnb * (unsigned)t.ntrc), dim3(256), 0, s, G);
     LoglParams P{t, b, w};
     hipLaunchKernelGGL(phi_gemm_finish_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P, g.part,
                        (g.kp + 63) / 64, g.nchunk, g.pstride);

@@ -29,6 +29,8 @@ for set in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
            "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA" \
            "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" \
            "SQ_INSTS_SMEM SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_BUSY_CU_CYCLES" \
+           "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" \
            "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
   use=$(filter $set)

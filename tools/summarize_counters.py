@@ -98,6 +98,17 @@ for e in doc["kernels"]:
     if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
         line += (f" wait_any={c.get('SQ_WAIT_ANY', 0) / c['SQ_WAVE_CYCLES']:.2f}"
                  f" active_valu={c.get('SQ_ACTIVE_INST_VALU', 0) / c['SQ_WAVE_CYCLES']:.2f}")
+    if c.get("SQ_INSTS_MFMA") or c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        # FP64 matrix cores (phi_gemm_kernel): MFMA wave-instructions, the pipe's busy cycles per instruction and its
+        # utilisation = busy cycles / (dispatch duration x clock x 1024 SIMDs), when the clock of the shape is known
+        line += f" mfma_insts={c.get('SQ_INSTS_MFMA', 0):.3e} mfma_busy_cycles={c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.3e}"
+        if c.get("SQ_INSTS_VALU_MFMA_MOPS_F64"):
+            line += f" mfma_mops_f64={c['SQ_INSTS_VALU_MFMA_MOPS_F64']:.3e}"
+        if c.get("SQ_INSTS_MFMA") and c.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+            line += f" busy_cycles_per_mfma={c['SQ_VALU_MFMA_BUSY_CYCLES'] / c['SQ_INSTS_MFMA']:.1f}"
+    if c.get("TCC_REQ_sum"):
+        line += (f" l2_req={c['TCC_REQ_sum']:.3e} l2_hit_rate="
+                 f"{c.get('TCC_HIT_sum', 0) / max(1.0, c.get('TCC_HIT_sum', 0) + c.get('TCC_MISS_sum', 0)):.3f}")
     if "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"]:
         line += f" lds_conflict={c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:.2f}"
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
