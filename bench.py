@@ -714,6 +714,12 @@ def main():
             # tools/summarize_counters.py): the part lowers it below the 2.4 GHz `peak` is quoted at when the fp64
             # vector ALUs are the load (HBM-bound kernels of the same pass run at 2.4).  `frac_at_clock` = frac
             # priced at that clock -- `frac` stays the spec-clock figure.
+            # the same at STEP level: the fp64 flops every kernel of a step executes / ms_per_step.  The dominant kernel's
+            # from its counters; the follow-up kernel's quadratic forms as 2 nsmp^2 + 2 nsmp per (walker, trace) -- what
+            # phi_deferred_kernel / phi_gemm_kernel execute, padding aside --; stage_kernel, the swap and the order kernels
+            # execute < 0.2 % of a step's flops and are left out (a lower bound by that much)
+            "frac_step": ((exe + nb * p.ntrc * (2.0 * p.nsmp ** 2 + 2.0 * p.nsmp) * (1.0 if prof["logl_launches"] else 0.0))
+                          / (dt / steps) / 1e12 / FP64_PEAK_TFLOPS if exe and counters_fresh else None),
             "clock_ghz": ctr.get("_clock_ghz") if ctr else None,
             "frac_at_clock": (exe / t_k / 1e12 / (FP64_PEAK_TFLOPS * ctr["_clock_ghz"] / SPEC_CLOCK_GHZ)
                               if exe and t_k and ctr.get("_clock_ghz") and counters_fresh else None),

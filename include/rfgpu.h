@@ -328,7 +328,8 @@ int rf_post_reset(rf_ctx *ctx);
  * current state.  temps (may be NULL) applies the reference's filter temp <= 1 + 1e-6 (:204)
  * on the device: chains above it are skipped.  The caller applies the iteration filter
  * (iter > nburn, mod(iter, ncorr) == 0).  _device: all pointers are device pointers and the
- * call is asynchronous on `stream`; the host variant stages and synchronises.
+ * call is asynchronous on `stream`; the host variant copies its arrays before it returns (they may be changed at once)
+ * and, like rf_commit, does not wait for the device: stream-ordered between the calls issued before and after it.
  * Departures (the reference has undefined behaviour there): histogram indices outside an
  * array are clamped to its edge bins; models beyond max_models are counted but their
  * profile rows are dropped.  Amplitudes outside [amp_min, amp_max) go to the edge bins as in

@@ -63,7 +63,7 @@ struct rf_ctx {
         size_t cap = 0, off = 0;
         hipEvent_t ev = nullptr;  // recorded after the last asynchronous use (an evaluation in flight; rf_commit returns early)
         bool pending = false;
-    } arena[RF_EVAL_MAX_IN_FLIGHT + 1];
+    } arena[RF_EVAL_MAX_IN_FLIGHT + 2];   // [.. + 1]: rf_post_record's own (it returns early too)
     struct Ticket {
         bool busy = false;
         int nb = 0;
@@ -873,12 +873,14 @@ static int finish_likelihood(rf_ctx *c, const BatchArgs &b, int defer, hipStream
     return 0;
 }
 
-// rf_commit (host arrays) returns before the device has flipped the trace slots; a *_device call on ANOTHER stream
-// that reads or writes walker state is put behind it
+// rf_commit and rf_post_record (host arrays) return before the device has done their work; a *_device call on ANOTHER
+// stream that reads or writes walker state or the accumulators is put behind them
 static int order_after_commit(rf_ctx *c, hipStream_t s)
 {
-    const rf_ctx::Arena &A = c->arena[RF_EVAL_MAX_IN_FLIGHT];
-    if (A.pending && s != c->stream) HIP_TRY(hipStreamWaitEvent(s, A.ev, 0));
+    for (int i = RF_EVAL_MAX_IN_FLIGHT; i < RF_EVAL_MAX_IN_FLIGHT + 2; ++i) {      // rf_commit's and rf_post_record's
+        const rf_ctx::Arena &A = c->arena[i];
+        if (A.pending && s != c->stream) HIP_TRY(hipStreamWaitEvent(s, A.ev, 0));
+    }
     return 0;
 }
 
@@ -1523,17 +1525,19 @@ extern "C" int rf_post_record(rf_ctx *c, int32_t n, const int32_t *walker_ids, c
     double *dz = c->d_post_in, *ddvp = dz + N * (kmax - 1), *ddvs = ddvp + N * kmax, *dsig = ddvs + N * kmax,
            *dlogl = dsig + N * ntrc, *dtemps = dlogl + N;
     int *dids = c->d_post_k, *dk = dids + n;
-    HIP_TRY(hipMemcpyAsync(dids, walker_ids, sizeof(int) * N, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dk, k, sizeof(int) * N, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dz, z, sizeof(double) * N * (kmax - 1), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ddvp, dvp, sizeof(double) * N * kmax, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(ddvs, dvs, sizeof(double) * N * kmax, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dsig, sig, sizeof(double) * N * ntrc, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(dlogl, logl, sizeof(double) * N, hipMemcpyHostToDevice, s));
-    if (temps) HIP_TRY(hipMemcpyAsync(dtemps, temps, sizeof(double) * N, hipMemcpyHostToDevice, s));
+    // Like rf_commit, a record returns nothing from the device and does not wait for it: the host arrays are copied
+    // into a pinned arena of their own before the call returns (the caller may change them at once), the transfers and
+    // kernels are stream-ordered behind everything issued before and in front of everything issued after.
+    rf_ctx::Arena &A = c->arena[RF_EVAL_MAX_IN_FLIGHT + 1];
+    if (arena_begin(A, sizeof(int) * 2 * N + sizeof(double) * N * (3 * (size_t)kmax + ntrc + 2))) return 1;
+    if (h2d(A, dids, walker_ids, sizeof(int) * N, s) || h2d(A, dk, k, sizeof(int) * N, s) ||
+        h2d(A, dz, z, sizeof(double) * N * (kmax - 1), s) || h2d(A, ddvp, dvp, sizeof(double) * N * kmax, s) ||
+        h2d(A, ddvs, dvs, sizeof(double) * N * kmax, s) || h2d(A, dsig, sig, sizeof(double) * N * ntrc, s) ||
+        h2d(A, dlogl, logl, sizeof(double) * N, s))
+        return 1;
+    if (temps && h2d(A, dtemps, temps, sizeof(double) * N, s)) return 1;
     if (rf_post_record_device(c, n, dids, dk, dz, ddvp, ddvs, dsig, dlogl, temps ? dtemps : nullptr, s)) return 1;
-    HIP_TRY(hipStreamSynchronize(s));   // the host arrays may be reused on return
-    return 0;
+    return arena_mark(A, s);
 }
 
 extern "C" int rf_post_read(rf_ctx *c, const rf_post_result *o)
