@@ -549,7 +549,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
         g.np = (nsmp + 127) / 128 * 128;
         g.nchunk = g.np / 64;
         g.pstride = c->nslots;
-        g.shape = 16;
+        g.tile = 0;
+        g.num_cu = c->num_cu;
         const std::vector<double> rg = pad_r_inv(c->r_inv, ntrc, nsmp, g.kp, g.np);
         void *q = nullptr;
         if (upload(c, rg, &g.rg) || dev_alloc(c, &q, sizeof(double) * (size_t)ntrc * g.nchunk * g.pstride)) return cleanup(1);
@@ -1644,9 +1645,9 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
         if (!integral || !(iv == 0 || iv == 256 || iv == 512))
             return fail("rf_set_option: block_threads must be 0 (by batch size), 256 or 512");
         c->block_threads = iv;
-    } else if (k == "gemm_shape") {
-        if (!integral || (iv != 4 && iv != 16)) return fail("rf_set_option: gemm_shape must be 4 or 16");
-        c->pg.shape = iv;
+    } else if (k == "gemm_tile") {
+        if (!integral || (iv != 0 && iv != 64 && iv != 128)) return fail("rf_set_option: gemm_tile must be 0 (by launch size), 64 or 128");
+        c->pg.tile = iv;
     } else if (k == "trace_window") {
         if (!integral || iv < 0 || iv > 1) return fail("rf_set_option: trace_window must be 0 or 1");
         const int len = iv ? c->cfg.nsmp : c->cfg.nfft;
@@ -1667,7 +1668,8 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     if (!c->fused && !c->fusedc && ensure_spec(c)) return 1;
     c->n_overrides = (c->fused_override != -1) + (c->chain_override != -1) + (!c->lpt) + (!c->order_reuse) +
                      (c->nsplit_override != 0) + (c->waves_per_block != 4) + (c->defer_logl != -1) +
-                     (c->block_threads != 0) + (c->bin_cutoff > 0.0) + (c->ablate != 0) + (c->trace_window != 0);
+                     (c->block_threads != 0) + (c->bin_cutoff > 0.0) + (c->ablate != 0) + (c->trace_window != 0) +
+                     (c->pg.tile != 0);
     return 0;
 }
 

@@ -3360,9 +3360,8 @@ void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w
 // (likelihood.f90:94-96).  Every step has a fixed order that does not depend on the batch: a chain evaluated alone or
 // in a full batch gets bit-identical values.
 // ---------------------------------------------------------------------------
-constexpr int PG_BM = 128, PG_BN = 128, PG_BK = 16;
+constexpr int PG_BK = 16;
 constexpr int PG_LDA = PG_BK + 1;      // doubles per LDS row of the A tile ([row][k]; odd: the fragment reads spread over the banks)
-constexpr int PG_LDB = PG_BN + 16;     // ... of the B tile ([k][col]; rows 16 doubles apart modulo the banks)
 
 struct PhiGemmParams {
     const double *mis;     // [>= nb][ntrc][ld] misfits, rows zero-padded to ld = kp
@@ -3374,124 +3373,110 @@ struct PhiGemmParams {
 typedef double pg_acc_t __attribute__((ext_vector_type(4)));
 typedef double pg_v2_t __attribute__((ext_vector_type(2)));
 
-// SHAPE 16: v_mfma_f64_16x16x4_f64 as described above.  SHAPE 4: v_mfma_f64_4x4x4_4b_f64, whose four 4x4x4 blocks
-// (block b = (lane >> 2) & 3; A_b[i][k] at lane i + 4 b + 16 k, B_b[k][j] at lane j + 4 b + 16 k, D_b[i][j] at lane
-// j + 4 b + 16 i: found with tools/mfma_f64_4x4_layout.hip) are used as ONE 4 x 16 x 4 product: the same A values in all
-// four blocks (an LDS broadcast read), block b taking columns 4 b .. 4 b + 3 -- so the B operand and the column of a D
-// lane are those of the 16x16x4 form (B[k = l >> 4][col l & 15], D[row l >> 4][col l & 15]) and a wave's 64 x 64 tile is
-// 16 row groups x 4 column tiles = 64 accumulators of one double.  Same k order per output element, same epilogue
-// sums: the two shapes return the same bits.  The small instruction issues four times as often at a quarter of the
-// work; on this part it sustains a higher FP64 rate (tools/mfma_overlap.hip: 75 against 47 TF on register operands).
-template <int SHAPE>
-__global__ __launch_bounds__(256, 2) void phi_gemm_kernel(PhiGemmParams G)
+// Two tilings of the same product, chosen by the host from the size of the launch (the values do not depend on it:
+// every output element is the same k-ordered chain of MFMAs, every 64-column partial the same sums):
+//   WN = 2: block 128 x 128, waves 2 (M) x 2 (N), wave tile 64 x 64 (MT = 4 row tiles): 16 flop per byte staged --
+//           launches of several rounds of blocks;
+//   WN = 1: block 128 x 64, waves 4 (M) x 1, wave tile 32 x 64 (MT = 2): half the work per block, four blocks per CU
+//           -- small launches (a 20 s window on 8192 walkers is 8 GFLOP: 1.5 rounds of the big blocks, whose second
+//           round is half empty), and windows whose last 128-column block would be mostly padding.
+// (A third variant on v_mfma_f64_4x4x4_4b_f64 -- its four blocks as one 4 x 16 x 4 product, same bits -- was measured
+// slower, LDS-bound: profiles/EXPERIMENTS.md; tools/mfma_f64_4x4_layout.hip has the operand layout.)
+template <int WN>
+__global__ __launch_bounds__(256, WN == 2 ? 2 : 4) void phi_gemm_kernel(PhiGemmParams G)
 {
-    __shared__ double As[PG_BM * PG_LDA];
-    __shared__ __attribute__((aligned(16))) double Bs[PG_BK * PG_LDB];
+    constexpr int BM = 128, BN = 64 * WN, WM = 4 / WN, MT = BM / WM / 16;   // MT row tiles of 16 per wave
+    constexpr int LDB = BN + 16;       // doubles per LDS row of the B tile ([k][col]; rows 16 doubles apart modulo the banks)
+    constexpr int NA = BM / 32, NB = BN / 32;                               // double2 per thread and K step: A tile, B tile
+    __shared__ double As[BM * PG_LDA];
+    __shared__ __attribute__((aligned(16))) double Bs[PG_BK * LDB];
     const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int l15 = lane & 15, l4 = lane >> 4;
     // blocks of one (trace, column block) are consecutive: they share the B tile (L2) and stream their own A tiles
-    const int nmb = (G.nb + PG_BM - 1) / PG_BM, nnb = G.np / PG_BN;
+    const int nmb = (G.nb + BM - 1) / BM, nnb = (G.kp + BN - 1) / BN;
     int bid = blockIdx.x;
     const int mblk = bid % nmb;
     bid /= nmb;
     const int nblk = bid % nnb, it = bid / nnb;
-    const int m0 = mblk * PG_BM, n0 = nblk * PG_BN;
-    const int wm = wv & 1, wn = wv >> 1;
-    const int mw = m0 + 64 * wm, nw = n0 + 64 * wn;
+    const int m0 = mblk * BM, n0 = nblk * BN;
+    const int wm = wv % WM, wn = wv / WM;
+    const int mw = m0 + 16 * MT * wm, nw = n0 + 64 * wn;
     // live 16-row / 16-column sub-tiles of this wave (wave-uniform)
-    const int mt_live = min(4, max(0, (G.nb - mw + 15) >> 4));
+    const int mt_live = min(MT, max(0, (G.nb - mw + 15) >> 4));
     const int nt_live = min(4, max(0, (G.kp - nw) >> 4));
-    const bool full = mt_live == 4 && nt_live == 4;
+    const bool full = mt_live == MT && nt_live == 4;
 
     const size_t a_rs = (size_t)G.ntrc * G.ld;                                   // doubles between the rows of two items
     const double *__restrict__ Ag = G.mis + (size_t)it * G.ld;
     const double *__restrict__ Bg = G.rg + (size_t)it * G.kp * G.np + n0;
-    // staging: A tile 128 rows x 8 double2, B tile 16 rows x 64 double2 -- four of each per thread.  Rows beyond the
-    // batch re-read its last row: their accumulators are never written anywhere.
-    const pg_v2_t *ap[4], *bp[4];
-    pg_v2_t pa[4], pb[4];
+    // staging: A tile BM rows x 8 double2, B tile 16 rows x BN / 2 double2.  Rows beyond the batch re-read its last
+    // row: their accumulators are never written anywhere.  (np, a multiple of 128, covers every column block.)
+    const pg_v2_t *ap[NA], *bp[NB];
+    pg_v2_t pa[NA], pb[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NA; ++i) {
         const int e = tid + 256 * i;
         const int row = min(m0 + (e >> 3), G.nb - 1);
         ap[i] = reinterpret_cast<const pg_v2_t *>(Ag + (size_t)row * a_rs + 2 * (e & 7));
-        bp[i] = reinterpret_cast<const pg_v2_t *>(Bg + (size_t)(e >> 6) * G.np + 2 * (e & 63));
-    }
-    const size_t b_step = (size_t)(PG_BK / 2) * G.np;      // double2 per K step of the B image
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
         pa[i] = *ap[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int e = tid + 256 * i;
+        bp[i] = reinterpret_cast<const pg_v2_t *>(Bg + (size_t)(e / (BN / 2)) * G.np + 2 * (e % (BN / 2)));
         pb[i] = *bp[i];
     }
-    pg_acc_t acc[4][4];          // SHAPE 16: [mt][nt], register r = row (l >> 4) + 4 r of the tile
-    double acc4[16][4];          // SHAPE 4: [row group][nt], row 4 rg + (l >> 4)
+    const size_t b_step = (size_t)(PG_BK / 2) * G.np;      // double2 per K step of the B image
+    pg_acc_t acc[MT][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = pg_acc_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int rg = 0; rg < 16; ++rg)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt) acc4[rg][nt] = 0.0;
-    const int rg_live = min(16, max(0, (G.nb - mw + 3) >> 2));
 
     const int nkt = G.kp / PG_BK;
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                                  // the previous step's fragments are read
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int e = tid + 256 * i;
             double *da = As + (e >> 3) * PG_LDA + 2 * (e & 7);
             da[0] = pa[i].x;
             da[1] = pa[i].y;
-            *reinterpret_cast<pg_v2_t *>(Bs + (e >> 6) * PG_LDB + 2 * (e & 63)) = pb[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int e = tid + 256 * i;
+            *reinterpret_cast<pg_v2_t *>(Bs + (e / (BN / 2)) * LDB + 2 * (e % (BN / 2))) = pb[i];
         }
         __syncthreads();
         if (kt + 1 < nkt) {                               // the next step's tiles: in flight behind this step's MFMAs
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NA; ++i) {
                 ap[i] += PG_BK / 2;
-                bp[i] += b_step;
                 pa[i] = *ap[i];
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                bp[i] += b_step;
                 pb[i] = *bp[i];
             }
         }
 #pragma unroll
         for (int kk = 0; kk < PG_BK / 4; ++kk) {
-            double av[4], bv[4];
+            double av[MT], bv[4];
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) bv[nt] = Bs[(4 * kk + l4) * PG_LDB + 64 * wn + 16 * nt + l15];
-            if constexpr (SHAPE == 4) {
-                double a4[16];
+            for (int mt = 0; mt < MT; ++mt) av[mt] = As[(16 * MT * wm + 16 * mt + l15) * PG_LDA + 4 * kk + l4];
 #pragma unroll
-                for (int rg = 0; rg < 16; ++rg) a4[rg] = As[(64 * wm + 4 * rg + (lane & 3)) * PG_LDA + 4 * kk + l4];
-                if (full) {
-#pragma unroll
-                    for (int rg = 0; rg < 16; ++rg)
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
-                            acc4[rg][nt] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[rg], bv[nt], acc4[rg][nt], 0, 0, 0);
-                } else {
-#pragma unroll
-                    for (int rg = 0; rg < 16; ++rg)
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt)
-                            if (rg < rg_live && nt < nt_live)
-                                acc4[rg][nt] = __builtin_amdgcn_mfma_f64_4x4x4f64(a4[rg], bv[nt], acc4[rg][nt], 0, 0, 0);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) av[mt] = As[(64 * wm + 16 * mt + l15) * PG_LDA + 4 * kk + l4];
+            for (int nt = 0; nt < 4; ++nt) bv[nt] = Bs[(4 * kk + l4) * LDB + 64 * wn + 16 * nt + l15];
             if (full) {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
                         acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
             } else {
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 4; ++nt)
                         if (mt < mt_live && nt < nt_live)
@@ -3499,28 +3484,10 @@ __global__ __launch_bounds__(256, 2) void phi_gemm_kernel(PhiGemmParams G)
             }
         }
     }
-    // ---- phi partial of the wave's 64 columns for each of its 64 rows ------------------------------------------------
+    // ---- phi partial of the wave's 64 columns for each of its rows -----------------------------------------------------
     double *__restrict__ pout = G.part + ((size_t)it * G.nchunk + (nw >> 6)) * G.pstride;
-    if constexpr (SHAPE == 4) {
 #pragma unroll
-        for (int rg = 0; rg < 16; ++rg) {
-            const int row = mw + 4 * rg + l4;
-            const bool live = row < G.nb;
-            const double *__restrict__ mrow = Ag + (size_t)(live ? row : 0) * a_rs + nw + l15;
-            double sum = 0.0;
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                if (nt < nt_live) sum = fma(acc4[rg][nt], live ? mrow[16 * nt] : 0.0, sum);
-            sum += __shfl_xor(sum, 1, 64);
-            sum += __shfl_xor(sum, 2, 64);
-            sum += __shfl_xor(sum, 4, 64);
-            sum += __shfl_xor(sum, 8, 64);
-            if (l15 == 0 && live) pout[row] = sum;
-        }
-        return;
-    }
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = mw + 16 * mt + l4 + 4 * r;
@@ -3563,11 +3530,15 @@ __global__ __launch_bounds__(256) void phi_gemm_finish_kernel(LoglParams P, cons
 void launch_phi_gemm(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, const PhiGemmTables &g, hipStream_t s)
 {
     PhiGemmParams G{w.misfit, g.rg, g.part, b.nb, t.ntrc, t.mis_stride, g.kp, g.np, g.nchunk, g.pstride};
-    const unsigned nmb = (unsigned)((b.nb + PG_BM - 1) / PG_BM), nnb = (unsigned)(g.np / PG_BN);
-    if (g.shape == 4)
-        hipLaunchKernelGGL(phi_gemm_kernel<4>, dim3(nmb * nnb * (unsigned)t.ntrc), dim3(256), 0, s, G);
+    // the tiling (same values either way: see the kernel): 128 x 128 blocks once they make at least `wide_rounds`
+    // rounds of the GPU's 2 x num_cu slots, 128 x 64 blocks below that
+    const unsigned nmb = (unsigned)((b.nb + 127) / 128);
+    const unsigned nnb2 = (unsigned)((g.kp + 127) / 128), nnb1 = (unsigned)((g.kp + 63) / 64);
+    const bool wide = g.tile == 128 || (g.tile == 0 && (long long)nmb * nnb2 * t.ntrc >= 3LL * 2 * g.num_cu);
+    if (wide)
+        hipLaunchKernelGGL(phi_gemm_kernel<2>, dim3(nmb * nnb2 * (unsigned)t.ntrc), dim3(256), 0, s, G);
     else
-        hipLaunchKernelGGL(phi_gemm_kernel<16>, dim3(nmb * nnb * (unsigned)t.ntrc), dim3(256), 0, s, G);
+        hipLaunchKernelGGL(phi_gemm_kernel<1>, dim3(nmb * nnb1 * (unsigned)t.ntrc), dim3(256), 0, s, G);
     LoglParams P{t, b, w};
     hipLaunchKernelGGL(phi_gemm_finish_kernel, dim3((unsigned)((b.nb + 255) / 256)), dim3(256), 0, s, P, g.part,
                        (g.kp + 63) / 64, g.nchunk, g.pstride);

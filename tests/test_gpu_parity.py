@@ -1147,3 +1147,24 @@ def test_trace_window_option(oracle, shape):
         eng.set_option("trace_window", 0)
         again = eng.eval_batch(ids, nlay, layers, sig)
         assert np.array_equal(again, full) and np.array_equal(eng.get_rft_batch(ids[::50], which=1), tr_full)
+
+
+def test_long_window_gemm_tilings_agree(oracle):
+    """phi_gemm_kernel's two block tilings (128 x 128 for launches of several rounds of blocks, 128 x 64 below; option
+    gemm_tile forces one) return the same bits -- the choice by launch size cannot make a chain's result depend on the
+    batch it is evaluated in."""
+    rng = np.random.default_rng(12)
+    nsmp, nb = 530, 333
+    cfg = make_cfg(nfft=4096, rayps=[0.06, 0.09], ipha=[1, -1], t_start=-3.0)
+    obs = synth_obs(oracle, cfg, random_stack(rng, 5), nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    nlay, layers = pack_layers([random_stack(rng, int(n)) for n in rng.integers(3, 20, nb)], 22)
+    sig = rng.uniform(0.01, 0.05, (nb, 2))
+    out = {}
+    for tile in (0, 64, 128):
+        with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=22, options={"gemm_tile": tile}) as eng:
+            out[tile] = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+            assert eng.eval_batch(np.array([7]), nlay[7:8], layers[7:8], sig[7:8])[0] == out[tile][7]
+    assert np.array_equal(out[64], out[128]) and np.array_equal(out[0], out[64])
+    ref, kap = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads(), want_kappa=True)
+    assert_logl_parity(out[0], ref, kap, "tilings")

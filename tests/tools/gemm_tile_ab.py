@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Long-window likelihood: the two MFMA shapes of phi_gemm_kernel (rf_set_option "gemm_shape" 16 | 4) give the same bits;
-their kernel times at bench.py's c4w20 / c4w60, interleaved.   usage: tests/tools/gemm_shape_ab.py [reps]"""
+"""Long-window likelihood: the two block tilings of phi_gemm_kernel (rf_set_option "gemm_tile" 128 | 64; 0 = by launch
+size) give the same bits; their kernel times at bench.py's c4w20 / c4w60, interleaved.
+usage: tests/tools/gemm_tile_ab.py [reps]"""
 import json
 import os
 import subprocess
@@ -27,24 +28,24 @@ def same_bits():
         nlay, layers = pack_layers([random_stack(rng, int(n)) for n in rng.integers(3, 20, nb)], 22)
         sig = rng.uniform(0.01, 0.05, (nb, 2))
         out = {}
-        for shape in (16, 4):
+        for shape in (128, 64):
             with RFEngine(nfft=4096, delta=cfg["delta"], t_start=cfg["t_start"], deconv_mode=0, sdep=0.0, rayps=cfg["rayps"],
                           a_gus=cfg["a_gus"], ipha=cfg["ipha"], obs=obs, nsmp=nsmp, r_inv=r_inv, max_walkers=nb, nlay_max=22,
-                          options={"gemm_shape": shape}) as eng:
+                          options={"gemm_tile": shape}) as eng:
                 out[shape] = eng.eval_batch(np.arange(nb), nlay, layers, sig)
-        assert np.array_equal(out[16], out[4]), (nsmp, np.abs(out[16] - out[4]).max())
-        print(f"nsmp {nsmp}: the two shapes agree bit for bit on {nb} walkers")
+        assert np.array_equal(out[128], out[64]), (nsmp, np.abs(out[128] - out[64]).max())
+        print(f"nsmp {nsmp}: the two tilings agree bit for bit on {nb} walkers")
 
 
 def times(reps):
     for rep in range(reps):
         for wl in ("c4w60", "c4w20"):
-            for shape in (16, 4):
+            for shape in (128, 64):
                 r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", wl, "--also", "", "--steps", "60",
-                                    "--warmup", "10", "--no-cpu-baseline", "--opt", f"gemm_shape={shape}"], capture_output=True, text=True)
+                                    "--warmup", "10", "--no-cpu-baseline", "--opt", f"gemm_tile={shape}"], capture_output=True, text=True)
                 d = json.loads(r.stdout.strip().splitlines()[-1])
                 q = d["quadratic_form_gemm"]
-                print(f"rep{rep} {wl} shape {shape:2d}: step {d['ms_per_step']:.3f} ms, fused {d['kernel_ms']['fused']:.3f}, GEMM + logL "
+                print(f"rep{rep} {wl} tile {shape:3d}: step {d['ms_per_step']:.3f} ms, fused {d['kernel_ms']['fused']:.3f}, GEMM + logL "
                       f"{q['ms']:.3f} ms = {q['achieved']:.1f} TF algorithmic; parity worst rel {d['parity_in_bench']['max_rel_dlogl']:.1e}",
                       flush=True)
 
