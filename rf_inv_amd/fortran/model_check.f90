@@ -1,0 +1,94 @@
+!=======================================================================
+! module rf_model_check -- the VERDICT of the reference's format_model
+! (src/model.f90:175-290: is the proposed model valid?) without its products.
+!
+! pt_control_batched needs that verdict on the host -- a chain's random
+! stream depends on it (an invalid model is a null proposal: no acceptance
+! uniform is drawn, src/pt_mcmc.f90:163-176) -- but nothing else of
+! format_model: the engine formats the layer stack itself, bit for bit
+! (format_model_kernel).  The reference routine costs ~0.35-0.55 us per call
+! at k_max 30 (a recursive three-array quicksort, the density polynomial of
+! every layer, five output arrays), which made the host's proposal loop the
+! bound of the whole sampler; this one sorts an index by insertion and stops
+! at the first violated rule.
+!
+! Same verdict as format_model for every input the sampler can produce:
+!   * the layer rules are the reference's expressions, in its operand order
+!     (:219-231 top layer incl. the `0.125 * alpha` thickness rule, :248-260
+!     middle layers, :276-281 half-space; nint look-ups :212,239,268);
+!   * the sort only has to ORDER the interfaces: two equal depths would make
+!     the reference's unstable quicksort decide which perturbation belongs to
+!     which layer, but they also make a layer of thickness 0 < h_min, i.e. an
+!     invalid model whatever the order.  With h_min <= 0 that argument fails
+!     and the reference routine is called instead.
+! Checked against format_model itself on millions of random and adversarial
+! proposals (tests/fortran/check_model_verdict.f90, tests/test_host_model.py).
+!=======================================================================
+module rf_model_check
+  implicit none
+  public proposal_is_valid
+  private
+
+contains
+
+  logical function proposal_is_valid(prop_k, prop_z, prop_dvp, prop_dvs) result(ok)
+    use params, only: k_max, nlay_max, sdep, z_max, h_min, vp_mode, vp_min, vp_max, vs_min, vs_max, vpvs_min, vpvs_max
+    use model, only: format_model, vp_ref, vs_ref, z_ref_min, dz_ref
+    integer, intent(in) :: prop_k
+    real(8), intent(in) :: prop_z(k_max-1), prop_dvp(k_max), prop_dvs(k_max)
+    integer :: idx(k_max), i, j, t, iz, nlay
+    real(8) :: zj, zprev, zc, a, b, thick
+    real(8) :: alpha(nlay_max), beta(nlay_max), rho(nlay_max), h(nlay_max)
+
+    if (.not. (h_min > 0.d0)) then
+       call format_model(prop_k, prop_z, prop_dvp, prop_dvs, nlay, alpha, beta, rho, h, ok)
+       return
+    end if
+
+    ! interfaces in ascending depth (insertion sort of an index: k <= 29, mostly short)
+    do i = 1, prop_k
+       t = i
+       zj = prop_z(i)
+       j = i - 1
+       do while (j >= 1)
+          if (prop_z(idx(j)) <= zj) exit
+          idx(j + 1) = idx(j)
+          j = j - 1
+       end do
+       idx(j + 1) = t
+    end do
+
+    ok = .false.
+    zprev = sdep
+    do j = 1, prop_k + 1
+       if (j <= prop_k) then
+          zj = prop_z(idx(j))
+          zc = 0.5d0 * (zj + zprev)            ! :210 (top: 0.5 (sdep + z1)), :238
+          t = idx(j)
+       else
+          zj = z_max
+          zc = 0.5d0 * (z_max + zprev)         ! :267
+          t = k_max
+       end if
+       iz = nint((zc - z_ref_min) / dz_ref) + 1
+       b = vs_ref(iz) + prop_dvs(t)
+       if (vp_mode == 1) then
+          a = vp_ref(iz) + prop_dvp(t)
+       else
+          a = vp_ref(iz)
+       end if
+       if (a < vp_min .or. a > vp_max .or. b < vs_min .or. b > vs_max .or. &
+            & a / b < vpvs_min .or. a / b > vpvs_max) return
+       if (j == 1) then
+          thick = zj - sdep
+          if (thick < 0.125 * a) return        ! :229 (not h_min)
+       else if (j <= prop_k) then
+          thick = zj - zprev
+          if (thick < h_min) return            ! :256
+       end if
+       zprev = zj
+    end do
+    ok = .true.
+  end function proposal_is_valid
+
+end module rf_model_check

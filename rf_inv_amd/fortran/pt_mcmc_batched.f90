@@ -64,6 +64,7 @@ contains
     use model
     use likelihood, only: sig, log_likelihood
     use forward, only: rf_ctx
+    use rf_model_check, only: proposal_is_valid
     use pt_mcmc
     include "mpif.h"
     logical, intent(in) :: verb
@@ -389,11 +390,9 @@ contains
          live = .not. (cand_sig(pick) < sig_min(pick) .or. cand_sig(pick) > sig_max(pick))
       end if
 
-      if (live) then
-         ! (only the verdict is used: the engine formats the model itself, bit for bit the same)
-         call format_model(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs, nlay, alpha, beta, rho, h, ok)
-         live = ok
-      end if
+      ! only format_model's VERDICT is needed here (the engine formats the model itself, bit for bit the same):
+      ! rf_model_check gives it without the sort of three arrays, the densities and the five output arrays
+      if (live) live = proposal_is_valid(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs)
       p_k(jc) = cand_k
     end subroutine draw_candidate
 

@@ -1,0 +1,84 @@
+!=======================================================================
+! proposal_is_valid (rf_inv_amd/fortran/model_check.f90) against the verdict of the
+! REFERENCE's own format_model (src/model.f90:175-290, compiled unmodified) on random and
+! adversarial proposals drawn around the params.in in the working directory:
+!   usage: check_model_verdict params.in n_random
+! Prints "check_model_verdict: <n> proposals, <valid> valid, <mismatches> mismatches".
+! Proposal kinds: the sampler's own (prior draws, one-parameter perturbations of valid models),
+! exact ties of two interface depths, thicknesses exactly at / one ulp around h_min and the
+! 0.125 * alpha rule, velocities exactly at the limits, interfaces at z_min / z_max.
+!=======================================================================
+program check_model_verdict
+  use params
+  use mt19937
+  use model
+  use math, only: gauss
+  use rf_model_check
+  implicit none
+  character(clen_max) :: param_file, arg
+  integer :: n, i, kk, j, kind_, nvalid, nbad, nlay, pick
+  logical :: ok_ref, ok_new
+  real(8) :: pz(200), pvp(200), pvs(200), alpha(nlay_max), beta(nlay_max), rho(nlay_max), h(nlay_max), u
+
+  param_file = "params.in"
+  n = 1000000
+  if (command_argument_count() > 0) call get_command_argument(1, param_file)
+  if (command_argument_count() > 1) then
+     call get_command_argument(2, arg)
+     read(arg, *) n
+  end if
+  call get_params(.false., param_file)
+  call sgrnd(iseed)
+  call read_ref_model(.false.)
+  nvalid = 0
+  nbad = 0
+  do i = 1, n
+     pz = 0.d0; pvp = 0.d0; pvs = 0.d0
+     kk = k_min + int(grnd() * (k_max - k_min))
+     do j = 1, kk
+        pz(j) = z_min + grnd() * (z_max - z_min)
+        pvs(j) = gauss() * dvs_prior * 0.3d0
+        pvp(j) = gauss() * dvp_prior * 0.3d0
+     end do
+     pvs(k_max) = gauss() * dvs_prior * 0.3d0
+     pvp(k_max) = gauss() * dvp_prior * 0.3d0
+     kind_ = mod(i, 8)
+     pick = 1 + int(grnd() * kk)
+     select case (kind_)
+     case (1)                       ! two interfaces at exactly the same depth
+        if (kk >= 2) pz(pick) = pz(1 + mod(pick, kk))
+     case (2)                       ! a middle layer exactly h_min thick, or one ulp thinner / thicker
+        if (kk >= 2) then
+           u = pz(1 + mod(pick, kk)) + h_min
+           if (mod(i / 8, 3) == 1) u = nearest(u, 1.d0)
+           if (mod(i / 8, 3) == 2) u = nearest(u, -1.d0)
+           pz(pick) = u
+        end if
+     case (3)                       ! the shallowest interface around the 0.125 * alpha rule
+        u = sdep + 0.125d0 * vp_ref(1)
+        if (mod(i / 8, 3) == 1) u = nearest(u, 1.d0)
+        if (mod(i / 8, 3) == 2) u = nearest(u, -1.d0)
+        pz(pick) = u
+     case (4)                       ! a velocity exactly at a limit
+        if (mod(i / 8, 2) == 0) then
+           pvs(pick) = vs_max - vs_ref(1)
+        else
+           pvs(pick) = vs_min - vs_ref(1)
+        end if
+     case (5)                       ! interfaces at the ends of the depth range
+        pz(pick) = merge(z_min, z_max, mod(i / 8, 2) == 0)
+     case (6)                       ! large perturbations: the ratio and range rules
+        pvs(pick) = gauss() * 2.d0
+        pvp(pick) = gauss() * 1.d0
+     case default                   ! the sampler's own kind of proposal
+     end select
+     call format_model(kk, pz(1:k_max-1), pvp(1:k_max), pvs(1:k_max), nlay, alpha, beta, rho, h, ok_ref)
+     ok_new = proposal_is_valid(kk, pz(1:k_max-1), pvp(1:k_max), pvs(1:k_max))
+     if (ok_ref) nvalid = nvalid + 1
+     if (ok_ref .neqv. ok_new) then
+        nbad = nbad + 1
+        if (nbad <= 5) write(*,*) "MISMATCH kind", kind_, " k", kk, " reference", ok_ref, " ours", ok_new
+     end if
+  end do
+  write(*,'(A,I0,A,I0,A,I0,A)') " check_model_verdict: ", n, " proposals, ", nvalid, " valid, ", nbad, " mismatches"
+end program check_model_verdict

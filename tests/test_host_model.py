@@ -1,12 +1,15 @@
 """Host-side mirrors (rf_inv_amd.params / model / likelihood.init_r_inv) against the oracle
 and the reference's sample files.  CPU only."""
 import os
+import sys
 
 import numpy as np
 import pytest
 
 from rf_inv_amd import format_model, get_params, read_obs, read_ref_model, vp_to_rho
 from rf_inv_amd.likelihood import init_r_inv
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -217,3 +220,31 @@ def test_make_syn_file_names_are_the_ones_the_reference_creates(tmp_path):
 
     assert _names(3, False) == ("test_trace03", "test_trace03wn")
     assert _names(3, True) == ("test_trace.03", "test_trace.03wn")
+
+
+@pytest.mark.parametrize("shape", ["sample_syn", "c4"])
+def test_fast_validity_verdict_equals_the_reference_format_model(tmp_path, shape):
+    """rf_inv_amd/fortran/model_check.f90::proposal_is_valid -- what pt_control_batched asks instead of calling the
+    reference's format_model for its verdict alone (the random stream depends on it) -- against that very routine
+    (src/model.f90:175-290, compiled unmodified): 600 000 proposals of eight kinds (the sampler's own, exact ties of two
+    depths, thicknesses at and one ulp around h_min and the 0.125 alpha rule, velocities at their limits, depths at the
+    ends of the range, large perturbations), ocean / land, k_max 10 / 30: not one verdict differs."""
+    import shutil
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "check_model_verdict")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/check_model_verdict not built (no Fortran compiler / reference tree at build time)")
+    work = tmp_path / shape
+    if shape == "sample_syn":
+        shutil.copytree(os.path.join(ROOT, "tests", "golden", "sample_syn"), work)
+        os.makedirs(work / "rslt", exist_ok=True)
+    else:
+        subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "shape_run.py"), "c4", "16", str(work)], check=True,
+                       capture_output=True, timeout=300)
+    r = subprocess.run([exe, "params.in", "600000"], cwd=work, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [x for x in r.stdout.splitlines() if "check_model_verdict:" in x][-1].split()
+    n, valid, bad = int(line[1]), int(line[3]), int(line[5])
+    assert n == 600000 and bad == 0, r.stdout
+    assert 0.1 * n < valid < 0.9 * n        # both verdicts well represented
