@@ -372,8 +372,8 @@ int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
  *   "block_threads"    0 by the context's capacity (default: max_walkers * ntrc blocks within three rounds of the
  *                      GPU -> 512; fixed per context, never per launch) | 256 fused_kernel | 512 fused8_kernel
  *                      (nfft 4096 on land only)
- *   "gemm_tile"        0 by launch size (default) | 128 | 64: the block tile of the long-window plan's GEMM (plan[12]):
- *                      128 x 128 (launches of >= 3 rounds of blocks) or 128 x 64 walkers x columns; same values
+ *   "gemm_tile"        0 (default) = 64 | 128: the block tile of the long-window plan's GEMM (plan[12]): 128 x 64
+ *                      (walkers x columns, four blocks per CU) or 128 x 128 (two); same values
  *   "trace_window"     0 (default: every trace is kept as the reference's rft(nfft, ntrc, chain), filled completely) | 1:
  *                      only samples 1 .. nsmp are stored -- all the likelihood, the histograms and make_syn ever read
  *                      (src/likelihood.f90:88, src/pt_mcmc.f90:273-274): the trace array shrinks nfft / nsmp-fold (C5:

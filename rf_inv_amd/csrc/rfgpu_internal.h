@@ -37,7 +37,7 @@ struct PhiGemmTables {
     const double *rg;       // [ntrc][kp][np] R^-1(i, j) at [i][j], zero-padded: kp = nsmp rounded up to 16, np to 128
     double *part;           // [ntrc][nchunk][pstride] per 64-column chunk partial sums of misfit . R^-1 . misfit
     int kp, np, nchunk, pstride;
-    int tile;               // "gemm_tile": 0 by launch size (default) | 128: 128 x 128 blocks | 64: 128 x 64 blocks (same values)
+    int tile;               // "gemm_tile": 0 (default) / 64: 128 x 64 blocks | 128: 128 x 128 blocks (same values)
     int num_cu;
 };
 

@@ -3373,13 +3373,15 @@ struct PhiGemmParams {
 typedef double pg_acc_t __attribute__((ext_vector_type(4)));
 typedef double pg_v2_t __attribute__((ext_vector_type(2)));
 
-// Two tilings of the same product, chosen by the host from the size of the launch (the values do not depend on it:
-// every output element is the same k-ordered chain of MFMAs, every 64-column partial the same sums):
-//   WN = 2: block 128 x 128, waves 2 (M) x 2 (N), wave tile 64 x 64 (MT = 4 row tiles): 16 flop per byte staged --
-//           launches of several rounds of blocks;
-//   WN = 1: block 128 x 64, waves 4 (M) x 1, wave tile 32 x 64 (MT = 2): half the work per block, four blocks per CU
-//           -- small launches (a 20 s window on 8192 walkers is 8 GFLOP: 1.5 rounds of the big blocks, whose second
-//           round is half empty), and windows whose last 128-column block would be mostly padding.
+// Two tilings of the same product (the values do not depend on the choice: every output element is the same k-ordered
+// chain of MFMAs, every 64-column partial the same sums):
+//   WN = 1 (default): block 128 x 64, waves 4 (M) x 1, wave tile 32 x 64 (MT = 2 row tiles): 123 VGPRs, 27 KB of LDS,
+//           FOUR blocks per CU -- four waves per SIMD keep the matrix pipe fed across each other's barriers and staging,
+//           small launches spread evenly (a 20 s window on 8192 walkers is 8 GFLOP), and a window's last column block
+//           carries at most 48 columns of padding.  Measured (tests/tools/gemm_tile_ab.py, profiles/r04_gemm_tile_ab.txt):
+//           c4w60 1.17 ms = 61 TF of algorithmic flops against 1.34 ms = 53 TF for the wide tile, c4w20 0.19 against 0.21.
+//   WN = 2 ("gemm_tile" = 128): block 128 x 128, waves 2 x 2, wave tile 64 x 64 (MT = 4): 16 flop per byte staged
+//           instead of 10.7, 208 VGPRs, two blocks per CU.  The first version; kept behind the option.
 // (A third variant on v_mfma_f64_4x4x4_4b_f64 -- its four blocks as one 4 x 16 x 4 product, same bits -- was measured
 // slower, LDS-bound: profiles/EXPERIMENTS.md; tools/mfma_f64_4x4_layout.hip has the operand layout.)
 template <int WN>
@@ -3530,12 +3532,10 @@ __global__ __launch_bounds__(256) void phi_gemm_finish_kernel(LoglParams P, cons
 void launch_phi_gemm(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, const PhiGemmTables &g, hipStream_t s)
 {
     PhiGemmParams G{w.misfit, g.rg, g.part, b.nb, t.ntrc, t.mis_stride, g.kp, g.np, g.nchunk, g.pstride};
-    // the tiling (same values either way: see the kernel): 128 x 128 blocks once they make at least `wide_rounds`
-    // rounds of the GPU's 2 x num_cu slots, 128 x 64 blocks below that
+    // the tiling (same values either way: see the kernel): 128 x 64 blocks unless the option asks for 128 x 128
     const unsigned nmb = (unsigned)((b.nb + 127) / 128);
     const unsigned nnb2 = (unsigned)((g.kp + 127) / 128), nnb1 = (unsigned)((g.kp + 63) / 64);
-    const bool wide = g.tile == 128 || (g.tile == 0 && (long long)nmb * nnb2 * t.ntrc >= 3LL * 2 * g.num_cu);
-    if (wide)
+    if (g.tile == 128)
         hipLaunchKernelGGL(phi_gemm_kernel<2>, dim3(nmb * nnb2 * (unsigned)t.ntrc), dim3(256), 0, s, G);
     else
         hipLaunchKernelGGL(phi_gemm_kernel<1>, dim3(nmb * nnb1 * (unsigned)t.ntrc), dim3(256), 0, s, G);
