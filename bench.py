@@ -200,6 +200,7 @@ def committed_counters(kernel, grid_threads):
                 out["_lib_sha256"] = d.get("lib_sha256")
                 out["_kernels_sha256"] = d.get("kernels_sha256")
                 out["_clock_ghz"] = e.get("clock_ghz")
+                out["_mean_s"] = e.get("mean_s")
                 return out
     return None
 
@@ -609,7 +610,14 @@ def main():
             n_pre += 8
             torch.cuda.synchronize(dev)
             _ = [a.elapsed_time(b) for a, b in scratch]
-            if time.perf_counter() - t_pre >= args.prewarm_seconds:
+            more = time.perf_counter() - t_pre < args.prewarm_seconds
+            if world > 1:
+                # every rank must run the SAME number of steps (each carries a collective of the temperature exchange):
+                # the ranks go on while any of them wants to
+                flag = torch.tensor([1 if more else 0], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                more = int(flag.item()) != 0
+            if not more:
                 break
         scratch = []
         for i in range(warmup):
@@ -788,12 +796,33 @@ def main():
             # algorithmic flops (src/likelihood.f90:92: matmul(misfits, r_inv)); the time includes the logL kernel
             gf = 2.0 * nb * p.ntrc * float(p.nsmp) ** 2
             t_q = prof["logl_ms"] / n_l * 1e-3
+            # committed counters of the GEMM at this launch shape (128 x 64 blocks of 256 threads): MFMA wave-instructions
+            # (2048 flop each), the matrix pipe's busy cycles (64 per instruction) / (kernel time x its clock x 1024 SIMDs)
+            kp = (p.nsmp + 15) // 16 * 16
+            g_thr = 256 * ((nb + 127) // 128) * ((kp + 63) // 64) * p.ntrc
+            gc = committed_counters("rfgpu::phi_gemm_kernel", g_thr)
+            g_fresh = bool(gc) and bool(gc.get("_kernels_sha256")) and gc["_kernels_sha256"] == kernels_sha
+            mf = None
+            if gc and g_fresh and gc.get("SQ_INSTS_MFMA"):
+                mf = {"mfma_wave_instructions": gc["SQ_INSTS_MFMA"], "executed_gflop": 2048.0 * gc["SQ_INSTS_MFMA"] / 1e9,
+                      "busy_cycles_per_instruction": gc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / gc["SQ_INSTS_MFMA"],
+                      "clock_ghz": gc.get("_clock_ghz"),
+                      "pipe_busy_frac_in_counter_pass": (gc.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 /
+                                                         (gc["_clock_ghz"] * 1e9 * gc["_mean_s"])
+                                                         if gc.get("_clock_ghz") and gc.get("_mean_s") else None),
+                      "hbm_mb": ((2048.0 * gc["FETCH_SIZE"] + 1024.0 * gc["WRITE_SIZE"]) / 1e6
+                                 if "FETCH_SIZE" in gc and "WRITE_SIZE" in gc else None),
+                      "l2_hit_rate": (gc["TCC_HIT_sum"] / (gc["TCC_HIT_sum"] + gc["TCC_MISS_sum"])
+                                      if gc.get("TCC_HIT_sum") is not None and gc.get("TCC_MISS_sum") else None),
+                      "file": gc["_file"]}
             res["quadratic_form_gemm"] = {
                 "kernel": "rfgpu::phi_gemm_kernel + phi_gemm_finish_kernel", "bound": "fp64_mfma", "unit": "TFLOP/s",
                 "peak": FP64_PEAK_TFLOPS, "gflop_per_launch": gf / 1e9, "ms": 1e3 * t_q,
-                "achieved": gf / t_q / 1e12, "frac": gf / t_q / 1e12 / FP64_PEAK_TFLOPS,
-                "note": "v_mfma_f64_16x16x4_f64 alone reaches 47 TF on this part (tools/mfma_overlap.hip, "
-                        "profiles/r03_mfma_overlap.txt); R^-1 streamed once per 128 walkers"}
+                "achieved": gf / t_q / 1e12, "frac": gf / t_q / 1e12 / FP64_PEAK_TFLOPS, "grid_threads": g_thr,
+                "mfma": mf,
+                "note": "algorithmic flops 2 nb ntrc nsmp^2 over the HIP-event time of the GEMM + logL kernels; the FP64 "
+                        "matrix peak equals the vector peak (78.6 TF at 2.4 GHz: one 16x16x4 instruction per 64 cycles and "
+                        "SIMD); R^-1 is streamed once per 128 walkers"}
         if rank == 0 and (with_cpu or parity_n):
             from oracle import rf_oracle as orc
 

@@ -402,7 +402,9 @@ int rf_set_option(rf_ctx *ctx, const char *name, double value);
  *       kernel leaves its misfits in HBM and the quadratic forms misfit . R^-1 . misfit of the whole batch run as ONE
  *       tiled GEMM on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) followed by logL; "defer_logl" is then ignored.
  *       Fixed per context from nsmp; ms[2] of rf_profile_read is the GEMM + logL pair
- *  [13] the "trace_window" option */
+ *  [13] the "trace_window" option
+ *  [14] host arrays of the last rf_eval_batch / rf_eval_models(_begin) call that were copied into the context's pinned
+ *       staging area (pageable memory); 0 = all of them travelled by DMA from the caller's own pinned arrays (rf_host_alloc) */
 int rf_get_launch_plan(const rf_ctx *ctx, int32_t *plan);
 
 /* HIP-event timing (on the streams the kernels are launched on) of the three kernels

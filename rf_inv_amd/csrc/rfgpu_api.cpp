@@ -63,6 +63,7 @@ struct rf_ctx {
         size_t cap = 0, off = 0;
         hipEvent_t ev = nullptr;  // recorded after the last asynchronous use (an evaluation in flight; rf_commit returns early)
         bool pending = false;
+        int staged = 0;           // host arrays of the current call that were copied here (pageable), not DMA'd in place
     } arena[RF_EVAL_MAX_IN_FLIGHT + 2];   // [.. + 1]: rf_post_record's own (it returns early too)
     struct Ticket {
         bool busy = false;
@@ -110,6 +111,8 @@ struct rf_ctx {
                                  // four -3.8 %, six -4 %, C3's sixteen and C4's forty-eight -3..4 %)
     double bin_cutoff = 0.0;  // "bin_cutoff": opt-in filter-support cut-off (0 = off: every bin like the reference)
     int trace_window = 0;     // "trace_window": 1 = only samples 1 .. nsmp of every trace are stored
+    int last_staged = 0;      // input arrays of the last rf_eval_batch / rf_eval_models(_begin) that went through the pinned
+                              // arena (pageable memory); 0 = every one travelled by DMA from the caller's own pinned array
     int n_overrides = 0;      // options set away from their defaults (echoed by rf_get_launch_plan)
     int ablate = 0;           // RFGPU_DIAGNOSTICS builds only ("ablate"): stops the kernel early, results invalid
     double *h_single_in = nullptr, *h_single_out = nullptr;   // pinned staging of the per-call drop-in
@@ -329,6 +332,7 @@ static int arena_begin(rf_ctx::Arena &A, size_t bytes)
         A.cap = cap;
     }
     A.off = 0;
+    A.staged = 0;
     return 0;
 }
 
@@ -357,6 +361,7 @@ static int h2d(rf_ctx::Arena &A, void *dst, const void *src, size_t bytes, hipSt
         void *stage = arena_take(A, bytes);
         std::memcpy(stage, src, bytes);
         from = stage;
+        ++A.staged;
     }
     HIP_TRY(hipMemcpyAsync(dst, from, bytes, hipMemcpyHostToDevice, s));
     return 0;
@@ -1011,6 +1016,7 @@ extern "C" int rf_eval_batch(rf_ctx *c, int32_t nb, const int32_t *walker_ids, c
         b.order = c->d_order;
     }
     if (run_batch(c, b, s)) return 1;
+    c->last_staged = A.staged;
     HIP_TRY(hipStreamSynchronize(s));
     std::memcpy(logl, h_logl, sizeof(double) * nb);
     return device_error(c, "rf_eval_batch");
@@ -1295,6 +1301,7 @@ extern "C" int rf_eval_models_begin(rf_ctx *c, int32_t nb, const int32_t *walker
     c->order_next_nb = 0;
     if (run_batch(c, b, s)) return 1;
     if (arena_mark(A, s)) return 1;      // the ticket's completion event
+    c->last_staged = A.staged;
     c->ticket[slot] = rf_ctx::Ticket{true, nb, want_valid != 0};
     c->ticket_next = (slot + 1) % RF_EVAL_MAX_IN_FLIGHT;
     *ticket = slot;
@@ -1694,7 +1701,8 @@ extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
     plan[11] = (c->fusedc || use_fused8(c)) ? 512 : 256;
     plan[12] = c->tab.phi_gemm;
     plan[13] = c->trace_window;
-    plan[14] = plan[15] = 0;
+    plan[14] = c->last_staged;
+    plan[15] = 0;
     return 0;
 }
 

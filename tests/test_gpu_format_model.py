@@ -151,7 +151,18 @@ def test_eval_models_from_host_arrays(oracle, golden_dir, pinned, ldz_full):
         k, z, dvp, dvs, sig, ff = (pin(a) for a in (k, z, dvp, dvs, sig, ff))
     with RFEngine.from_params(p, r_inv=init_r_inv(p.nsmp, p.a_gus, p.delta), max_walkers=nb) as eng:
         eng.set_model(p, ref)
-        ll, ok = eng.eval_models(np.arange(nb), k, z, dvp, dvs, sig, fwd_flag=ff, want_valid=True)
+        ids_in = np.arange(nb, dtype=np.int32)
+        if pinned:
+            ids_in = pin(ids_in)
+        ll, ok = eng.eval_models(ids_in, k, z, dvp, dvs, sig, fwd_flag=ff, want_valid=True)
+        # pinned arrays go down by DMA as they are (also from an interior pointer: the second half of the batch);
+        # pageable ones through the context's arena: ids, k, fwd_flag, z, dvs, sig (dvp is not read at vp_mode 0)
+        assert eng.launch_plan["staged_host_arrays"] == (0 if pinned else 6)
+        if pinned:
+            h = nb // 2
+            half = eng.eval_models(ids_in[h:], k[h:], z[h:], dvp[h:], dvs[h:], sig[h:], fwd_flag=ff[h:])
+            assert eng.launch_plan["staged_host_arrays"] == 0
+            assert np.array_equal(half, ll[h:], equal_nan=True)
         stacks, rows = [], []
         for i in range(nb):
             if ff[i] < 0:

@@ -66,6 +66,7 @@ for (k, grid, wg), ctrs in sorted(agg.items()):
          "launches": max(n for n, _ in ctrs.values()), "counters": {c: v / n for c, (n, v) in sorted(ctrs.items())}}
     if gui.get((k, grid, wg)):
         e["clock_ghz"] = clock_ghz(gui[(k, grid, wg)])
+        e["mean_s"] = sum(t for _, t in gui[(k, grid, wg)]) / len(gui[(k, grid, wg)]) * 1e-9   # dispatch duration in that pass
     doc["kernels"].append(e)
 json.dump(doc, open(os.path.join(out, "counters.json"), "w"), indent=1)
 
