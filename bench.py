@@ -182,13 +182,17 @@ def alg_work(p, nlay, common):
     return f_spec, f_spec + f_rest, b
 
 
-def committed_counters(kernel, grid_threads):
+def committed_counters(kernel, grid_threads, long_window=False):
     """Per-launch hardware counters of `kernel` at exactly this launch shape from the newest committed
     profile (profiles/rNN_counters.json, written by tools/collect_counters.sh from separate rocprofv3
     --pmc passes over THIS script; FETCH_SIZE doubled per the gfx950 correction of
     MI355X_MICROARCH.md).  bench.py itself cannot collect PMC counters.  None when no launch of that
-    kernel and grid is in the file."""
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")), reverse=True):
+    kernel and grid is in the file.  The long-window workloads (c4w20, c4w60) launch the C4 fused kernel at C4's grid but
+    write different bytes: their counters live in files of their own (rNN_longwindow_counters.json, collected over
+    `--workload c4w60 --also c4w20`), which the other workloads' look-ups skip."""
+    files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")), reverse=True)
+             if ("longwindow" in os.path.basename(f)) == bool(long_window)]
+    for f in files:
         try:
             d = json.load(open(f))
         except Exception:
@@ -697,7 +701,7 @@ def main():
             grid_threads = bt * (nblk + (1 if (plan["lpt"] and plan["order_reuse"] and nb >= 512) else 0))
         else:
             grid_threads = None   # split path: matched by name only (nsplit decides the grid)
-        ctr = committed_counters(kname, grid_threads) if grid_threads else None
+        ctr = committed_counters(kname, grid_threads, long_window=plan["long_window_gemm"]) if grid_threads else None
         exe = executed_fp64_flops(ctr) if ctr else None
         t_k = kernel_ms * 1e-3 if kernel_ms else None
         # counters describe kernels: they are this build's if its gfx950 code objects (.hip_fatbin) are the ones they
@@ -800,7 +804,7 @@ def main():
             # (2048 flop each), the matrix pipe's busy cycles (64 per instruction) / (kernel time x its clock x 1024 SIMDs)
             kp = (p.nsmp + 15) // 16 * 16
             g_thr = 256 * ((nb + 127) // 128) * ((kp + 63) // 64) * p.ntrc
-            gc = committed_counters("rfgpu::phi_gemm_kernel", g_thr)
+            gc = committed_counters("rfgpu::phi_gemm_kernel", g_thr, long_window=True)
             g_fresh = bool(gc) and bool(gc.get("_kernels_sha256")) and gc["_kernels_sha256"] == kernels_sha
             mf = None
             if gc and g_fresh and gc.get("SQ_INSTS_MFMA"):
