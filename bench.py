@@ -718,8 +718,10 @@ def main():
             "frac": exe / t_k / 1e12 / FP64_PEAK_TFLOPS if exe and t_k and counters_fresh else None,
             "frac_with_stale_counters": (exe / t_k / 1e12 / FP64_PEAK_TFLOPS
                                          if exe and t_k and not counters_fresh else None),
+            # (the windowed-trace workloads launch the same kernel at the same grid as their full-trace twins but write
+            # 40x fewer trace bytes: the committed counters are the twins', so no traffic figure for them)
             "traffic": (2048.0 * ctr["FETCH_SIZE"] + 1024.0 * ctr["WRITE_SIZE"]) if ctr and "FETCH_SIZE" in ctr
-                       and "WRITE_SIZE" in ctr else None,
+                       and "WRITE_SIZE" in ctr and not plan["trace_window"] else None,
             "kernel": kname, "kernel_ms": kernel_ms, "grid_threads": grid_threads,
             "executed_gflop_per_launch": exe / 1e9 if exe else None,
             # shader clock this kernel ran at in the counter pass (GRBM_GUI_ACTIVE / 8 XCDs / its duration,

@@ -348,7 +348,7 @@ def test_common_ray_fused_kernel(oracle, deconv, ipha):
                 assert np.all(np.abs(ll - ref_ll) <= logl_tol(ref_ll) * allow), (fused, defer, np.abs(ll - ref_ll) / logl_tol(ref_ll))
                 for i in range(nb):
                     err = np.abs(rft[i] - ref_rft[i]).max() / np.abs(ref_rft[i]).max()
-                    assert err <= 1e-11 * allow[i], (fused, i, err)
+                    assert err <= 1e-12 * allow[i], (fused, i, err, kap[i])     # the bound every other trace check uses (kappa rule)
                 eng.commit(np.arange(nb), np.ones(nb, dtype=np.int32))
                 ff = (np.arange(nb) % 2).astype(np.int32)
                 ll2 = eng.eval_batch(np.arange(nb), nlay[::-1].copy(), layers[::-1].copy(), 2 * sig, fwd_flag=ff)
