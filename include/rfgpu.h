@@ -355,6 +355,24 @@ typedef struct rf_post_result {
 } rf_post_result;
 int rf_post_read(rf_ctx *ctx, const rf_post_result *out);
 
+/* End-of-run merge of the accumulators over the context's RCCL communicator (rf_comm_init), replacing the MPI calls
+ * at the top of output_results for the arrays kept on the device.  Both are collective and synchronise the context
+ * stream.
+ * rf_comm_post_reduce: src/mcmc_out.f90:58-71,74-79 -- mpi_reduce(SUM -> root) of nk, namp, nvpz, nvsz, nvpvsz, nz,
+ *   nsig (int32) and vp_mean, vs_mean, vpvs_mean (f64), plus amp_out_of_range -- as one group of ncclReduce IN PLACE
+ *   into the root's device accumulators: rf_post_read on the root then returns the merged arrays; other ranks keep their
+ *   own.  nmod (:52) is summed into *nmod_sum (root only; may be NULL) and NOT into the root's accumulator, whose
+ *   count goes on naming the root's own model rows.  Call it once per run.  (nprop / naccept / likelihood_hist,
+ *   :54-57,72-73, are host-module arrays: the host reduces them as before.)
+ * rf_comm_post_gather: src/mcmc_out.f90:88-93 -- mpi_gather of vs_model, vp_model (and all_likelihood, which the
+ *   reference allocates per rank, :84, but never gathers).  nmod_rank[nranks] (every rank; may be NULL) = models each
+ *   rank recorded; on the root, host arrays vp_model_all / vs_model_all [nranks][max_models][nbin_z] and
+ *   all_likelihood_all [nranks][max_models] (any may be NULL; ignored on other ranks) receive per rank block the first
+ *   min(nmod_rank[r], max_models) rows, later rows untouched (as rf_post_read). */
+int rf_comm_post_reduce(rf_ctx *ctx, int32_t root, int32_t *nmod_sum);
+int rf_comm_post_gather(rf_ctx *ctx, int32_t root, int32_t *nmod_rank, double *vp_model_all, double *vs_model_all,
+                        double *all_likelihood_all);
+
 /* ---- instrumentation ----------------------------------------------------- */
 /* Launch-plan options.  librfgpu reads NO environment variables; a knob is set here, validated,
  * and reported by rf_get_launch_plan.  Every option re-partitions or re-orders the same work:

@@ -96,6 +96,8 @@ SYMBOLS = {
     "rf_comm_destroy": (C.c_int, [_vp]),
     "rf_comm_info": (C.c_int, [_vp, ip, ip, ip]),
     "rf_comm_bcast_i32": (C.c_int, [_vp, ip, C.c_int32, C.c_int32]),
+    "rf_comm_post_reduce": (C.c_int, [_vp, C.c_int32, ip]),
+    "rf_comm_post_gather": (C.c_int, [_vp, C.c_int32, ip, dp, dp, dp]),
     "rf_pt_swap_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, dp, ip]),
     "rf_pt_swap_allgather_device": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp]),
     "rf_pt_swap_gathered_device": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -147,6 +147,12 @@ namespace rfgpu {
 hipStream_t ctx_stream(rf_ctx *c) { return c->stream; }
 int ctx_device(rf_ctx *c) { return c->device; }
 CommState *&ctx_comm(rf_ctx *c) { return c->comm; }
+bool ctx_post(rf_ctx *c, const PostConfig **q, const PostState **st)
+{
+    *q = &c->post;
+    *st = &c->pst;
+    return c->have_post;
+}
 }
 
 static int device_error(rf_ctx *c, const char *where);

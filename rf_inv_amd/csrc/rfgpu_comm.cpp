@@ -13,8 +13,10 @@
 #include <unistd.h>
 
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include <rccl/rccl.h>
 
@@ -23,6 +25,7 @@ int comm_fail(const std::string &msg);   // sets rf_last_error (rfgpu_api.cpp)
 hipStream_t ctx_stream(rf_ctx *c);
 int ctx_device(rf_ctx *c);
 CommState *&ctx_comm(rf_ctx *c);
+bool ctx_post(rf_ctx *c, const PostConfig **q, const PostState **st);   // false: no rf_post_create yet
 }
 using namespace rfgpu;
 
@@ -36,6 +39,7 @@ struct Rccl {
     decltype(&ncclGetVersion) GetVersion = nullptr;
     decltype(&ncclBroadcast) Broadcast = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclReduce) Reduce = nullptr;
     decltype(&ncclSend) Send = nullptr;
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
@@ -61,9 +65,9 @@ Rccl *rccl()
     if (!r.h) return nullptr;
 #define RF_SYM(n) r.n = reinterpret_cast<decltype(r.n)>(dlsym(r.h, "nccl" #n))
     RF_SYM(GetUniqueId); RF_SYM(CommInitRank); RF_SYM(CommDestroy); RF_SYM(GetErrorString); RF_SYM(GetVersion); RF_SYM(Broadcast);
-    RF_SYM(AllGather); RF_SYM(Send); RF_SYM(Recv); RF_SYM(GroupStart); RF_SYM(GroupEnd);
+    RF_SYM(AllGather); RF_SYM(Reduce); RF_SYM(Send); RF_SYM(Recv); RF_SYM(GroupStart); RF_SYM(GroupEnd);
 #undef RF_SYM
-    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.AllGather || !r.Send || !r.Recv ||
+    if (!r.GetUniqueId || !r.CommInitRank || !r.CommDestroy || !r.Broadcast || !r.AllGather || !r.Reduce || !r.Send || !r.Recv ||
         !r.GroupStart || !r.GroupEnd) {
         dlclose(r.h);
         r.h = nullptr;
@@ -308,4 +312,132 @@ extern "C" int rf_pt_swap_allgather_device(rf_ctx *c, int32_t nchains, int32_t n
     launch_pt_swap_gathered(npairs, d_pairs, d_log_u, g_t, g_l, nchains, s->rank, s->nranks, d_temps, nullptr, st);
     HIPC_TRY(hipGetLastError());
     return 0;
+}
+
+// ---- end-of-run merge of the posterior accumulators (last sentence) -------------------------------
+// The top of output_results (src/mcmc_out.f90:52-79) for the accumulators rf_post_* keeps on the device: its
+// mpi_reduce(SUM -> 0) of nk, namp, nvpz, nvsz, nvpvsz, nz, nsig (int32) and vp_mean, vs_mean, vpvs_mean (f64) as ONE
+// RCCL group of ncclReduce(sum) IN PLACE into the root's accumulators -- histograms go GPU to GPU, nothing is staged
+// through the hosts; rf_post_read on the root then returns the merged arrays (the other ranks' accumulators are
+// unchanged).  nmod (:52) is summed into *nmod_sum instead (root only): the root's own count stays what names its
+// model rows.  amp_out_of_range (this library's counter for the reference's warning line) is summed too.  The proposal
+// counters and likelihood_hist of :54-57,72-73 live in the host's modules and stay with the host's own reduce.
+// Collective over the communicator; ONCE per run (a second call would add the other ranks' counts again).  fp64 sums:
+// RCCL's order over ranks, like MPI's, is the library's; with two ranks it is the one possible order.
+extern "C" int rf_comm_post_reduce(rf_ctx *c, int32_t root, int32_t *nmod_sum)
+{
+    if (!c) return comm_fail("rf_comm_post_reduce: null context");
+    CommState *s = ctx_comm(c);
+    if (!s) return comm_fail("rf_comm_post_reduce: rf_comm_init has not been called");
+    if (root < 0 || root >= s->nranks) return comm_fail("rf_comm_post_reduce: root out of range");
+    const PostConfig *q;
+    const PostState *p;
+    if (!ctx_post(c, &q, &p)) return comm_fail("rf_comm_post_reduce: rf_post_create has not been called");
+    Rccl *R = rccl();
+    hipStream_t st = ctx_stream(c);
+    HIPC_TRY(hipSetDevice(ctx_device(c)));
+    const size_t nz = q->nbin_z;
+    const struct { void *ptr; size_t n; ncclDataType_t t; } items[] = {
+        {p->nk, (size_t)q->k_max, ncclInt32},
+        {p->nz, nz, ncclInt32},
+        {p->nsig, (size_t)q->ntrc * q->nbin_sig, ncclInt32},
+        {p->namp, (size_t)q->ntrc * q->nsmp * q->nbin_amp, ncclInt32},
+        {p->nvpz, (size_t)q->nbin_vp * nz, ncclInt32},
+        {p->nvsz, (size_t)q->nbin_vs * nz, ncclInt32},
+        {p->nvpvsz, (size_t)q->nbin_vpvs * nz, ncclInt32},
+        {p->vp_mean, nz, ncclDouble},
+        {p->vs_mean, nz, ncclDouble},
+        {p->vpvs_mean, nz, ncclDouble},
+        {p->amp_oor, 1, ncclInt64},
+    };
+    int32_t *d_nmod = reinterpret_cast<int32_t *>(s->d_buf), *h_nmod = reinterpret_cast<int32_t *>(s->h_buf);
+    RCCL_TRY(R->GroupStart());
+    for (const auto &it : items) RCCL_TRY(R->Reduce(it.ptr, it.ptr, it.n, it.t, ncclSum, root, s->comm, st));
+    RCCL_TRY(R->Reduce(p->nmod, d_nmod, 1, ncclInt32, ncclSum, root, s->comm, st));
+    RCCL_TRY(R->GroupEnd());
+    if (s->rank == root) HIPC_TRY(hipMemcpyAsync(h_nmod, d_nmod, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPC_TRY(hipStreamSynchronize(st));
+    if (s->rank == root && nmod_sum) *nmod_sum = h_nmod[0];
+    return 0;
+}
+
+// The two mpi_gather of src/mcmc_out.f90:88-93 (vs_model, vp_model: every rank's per-model profile rows, rank blocks in
+// rank order on rank 0), plus all_likelihood, which the reference allocates for every rank (:84) but never gathers.
+// nmod_rank[nranks] (every rank, may be NULL): the models each rank recorded.  On the root the host arrays
+// vp_model_all / vs_model_all [nranks][max_models][nbin_z] and all_likelihood_all [nranks][max_models] (any may be
+// NULL) receive, per rank block, the first min(nmod_rank[r], max_models) rows -- as rf_post_read, the later rows keep what
+// the caller put there (init_pt_mcmc's vs_model(1,:) = -999.9, src/pt_mcmc.f90:419).  Rows travel device to device (one
+// ncclSend per array and rank, the root receives into a staging block and copies it out); the other ranks' pointers
+// are ignored.  Collective; call it BEFORE rf_comm_post_reduce or after, the rows are not touched by the reduce.
+extern "C" int rf_comm_post_gather(rf_ctx *c, int32_t root, int32_t *nmod_rank, double *vp_model_all, double *vs_model_all,
+                                   double *all_likelihood_all)
+{
+    if (!c) return comm_fail("rf_comm_post_gather: null context");
+    CommState *s = ctx_comm(c);
+    if (!s) return comm_fail("rf_comm_post_gather: rf_comm_init has not been called");
+    if (root < 0 || root >= s->nranks) return comm_fail("rf_comm_post_gather: root out of range");
+    const PostConfig *q;
+    const PostState *p;
+    if (!ctx_post(c, &q, &p)) return comm_fail("rf_comm_post_gather: rf_post_create has not been called");
+    Rccl *R = rccl();
+    hipStream_t st = ctx_stream(c);
+    HIPC_TRY(hipSetDevice(ctx_device(c)));
+    const int nr = s->nranks;
+    const size_t nz = q->nbin_z, nm = (size_t)q->max_models;
+    // every rank's count first (it sizes the messages): an all-gather of one int32
+    int32_t *d_cnt = nullptr;
+    HIPC_TRY(hipMalloc((void **)&d_cnt, sizeof(int32_t) * nr));
+    std::vector<int32_t> cnt(nr);
+    auto done = [&](int rc) {
+        (void)hipFree(d_cnt);
+        return rc;
+    };
+    {
+        ncclResult_t r_ = R->AllGather(p->nmod, d_cnt, 1, ncclInt32, s->comm, st);
+        if (r_ != ncclSuccess) return done(comm_fail("rf_comm_post_gather: ncclAllGather failed"));
+        if (hipMemcpyAsync(cnt.data(), d_cnt, sizeof(int32_t) * nr, hipMemcpyDeviceToHost, st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return done(comm_fail("rf_comm_post_gather: reading the counts failed"));
+    }
+    if (nmod_rank) std::memcpy(nmod_rank, cnt.data(), sizeof(int32_t) * nr);
+    auto rows_of = [&](int r) { return std::min((size_t)std::max(cnt[r], 0), nm); };
+    const struct { const double *dev; double *host; size_t width; } arr[3] = {
+        {p->vp_model, vp_model_all, nz}, {p->vs_model, vs_model_all, nz}, {p->all_likelihood, all_likelihood_all, 1}};
+    if (s->rank != root) {
+        // (the root may not want an array: every rank still sends all three, the message pattern does not depend on the
+        // root's pointers, which this rank cannot see)
+        const size_t rows = rows_of(s->rank);
+        for (const auto &a : arr) {
+            ncclResult_t r_ = R->Send(a.dev, rows * a.width, ncclDouble, root, s->comm, st);
+            if (r_ != ncclSuccess) return done(comm_fail("rf_comm_post_gather: ncclSend failed"));
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) return done(comm_fail("rf_comm_post_gather: stream synchronisation failed"));
+        return done(0);
+    }
+    size_t most = 0;
+    for (int r = 0; r < nr; ++r) most = std::max(most, rows_of(r));
+    double *d_stage = nullptr;
+    if (most && hipMalloc((void **)&d_stage, sizeof(double) * most * nz) != hipSuccess)
+        return done(comm_fail("rf_comm_post_gather: staging allocation failed"));
+    auto done2 = [&](int rc) {
+        if (d_stage) (void)hipFree(d_stage);
+        return done(rc);
+    };
+    for (int r = 0; r < nr; ++r) {
+        const size_t rows = rows_of(r);
+        for (const auto &a : arr) {
+            const double *src = a.dev;
+            if (r != root) {
+                ncclResult_t r_ = R->Recv(d_stage, rows * a.width, ncclDouble, r, s->comm, st);
+                if (r_ != ncclSuccess) return done2(comm_fail("rf_comm_post_gather: ncclRecv failed"));
+                src = d_stage;
+            }
+            if (a.host && rows &&
+                hipMemcpyAsync(a.host + (size_t)r * nm * a.width, src, sizeof(double) * rows * a.width, hipMemcpyDeviceToHost, st) != hipSuccess)
+                return done2(comm_fail("rf_comm_post_gather: copy to the host failed"));
+            // (the staging block is reused by the next message)
+            if (hipStreamSynchronize(st) != hipSuccess) return done2(comm_fail("rf_comm_post_gather: stream synchronisation failed"));
+        }
+    }
+    return done2(0);
 }

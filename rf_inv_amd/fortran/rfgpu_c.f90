@@ -257,6 +257,23 @@ module rfgpu_c
        integer(c_int32_t), value :: n, root
      end function rf_comm_bcast_i32
 
+     ! end-of-run merge of the device accumulators (src/mcmc_out.f90:52-93) over the RCCL communicator
+     integer(c_int) function rf_comm_post_reduce(ctx, root, nmod_sum) bind(C, name="rf_comm_post_reduce")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: root
+       integer(c_int32_t), intent(out) :: nmod_sum
+     end function rf_comm_post_reduce
+
+     integer(c_int) function rf_comm_post_gather(ctx, root, nmod_rank, vp_model_all, vs_model_all, all_likelihood_all) &
+          & bind(C, name="rf_comm_post_gather")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: root
+       integer(c_int32_t), intent(out) :: nmod_rank(*)
+       type(c_ptr), value :: vp_model_all, vs_model_all, all_likelihood_all   ! c_loc of the root's arrays, or c_null_ptr
+     end function rf_comm_post_gather
+
      integer(c_int) function rf_pt_swap_exchange(ctx, peer, judge, temp, logl, log_u, new_temp, accepted) &
           & bind(C, name="rf_pt_swap_exchange")
        import :: c_int, c_ptr, c_int32_t, c_double

@@ -39,6 +39,7 @@ class PosteriorResult:
     vs_model: np.ndarray
     all_likelihood: np.ndarray
     amp_out_of_range: int = 0
+    nmod_rank: np.ndarray | None = None   # merge_over_comm: models recorded by each rank
 
 
 class Posterior:
@@ -126,6 +127,35 @@ class Posterior:
         e = self.engine
         e._chk(e._lib.rf_post_read(e._ctx, C.byref(out)))
         r.nmod, r.amp_out_of_range = int(nmod.value), int(oor.value)
+        return r
+
+
+    def merge_over_comm(self, root=0, with_models=True) -> PosteriorResult:
+        """The merge at the top of output_results (src/mcmc_out.f90:52-93) over the engine's RCCL communicator
+        (engine.comm_init): rf_comm_post_gather (the model rows, rank blocks in rank order) + rf_comm_post_reduce
+        (histograms and mean sums, ncclReduce in place into the root's device accumulators).  Collective; once per
+        run.  Returns the merged result on `root`, this rank's own (unmerged) result elsewhere."""
+        e, p, nm = self.engine, self.p, self.max_models
+        info = e.comm_info(version=False)
+        rank, nranks = info["rank"], info["nranks"]
+        counts = np.zeros(nranks, dtype=np.int32)
+        keep = with_models and nm > 0
+        if rank == root and keep:
+            vp = np.zeros((nranks * nm, p.nbin_z))
+            vs = np.zeros((nranks * nm, p.nbin_z))
+            vs[:, 0] = -999.9                    # unused slots as init_pt_mcmc leaves them (src/pt_mcmc.f90:419)
+            al = np.zeros(nranks * nm)
+            e._chk(e._lib.rf_comm_post_gather(e._ctx, int(root), _iptr(counts), _dptr(vp), _dptr(vs), _dptr(al)))
+        else:
+            e._chk(e._lib.rf_comm_post_gather(e._ctx, int(root), _iptr(counts), None, None, None))
+        total = C.c_int32(0)
+        e._chk(e._lib.rf_comm_post_reduce(e._ctx, int(root), C.byref(total)))
+        r = self.read(with_models=with_models and rank != root)
+        if rank == root:
+            r.nmod = int(total.value)
+            if keep:
+                r.vp_model, r.vs_model, r.all_likelihood = vp, vs, al
+        r.nmod_rank = counts
         return r
 
 

@@ -1,12 +1,14 @@
-// rccl_double.cpp -- TEST DOUBLE of the eleven RCCL entry points rfgpu_comm.cpp binds.  Test infrastructure only:
+// rccl_double.cpp -- TEST DOUBLE of the twelve RCCL entry points rfgpu_comm.cpp binds.  Test infrastructure only:
 // the product loads the real librccl.so.1; tests/test_pt_swap.py points librfgpu at this file with
 // rf_comm_set_library so that TWO RANKS ON ONE GPU -- which real RCCL refuses -- drive rf_comm_init,
-// rf_comm_bcast_i32, rf_pt_swap_exchange and rf_pt_swap_allgather_device with nranks = 2 through the C ABI.
+// rf_comm_bcast_i32, rf_pt_swap_exchange, rf_pt_swap_allgather_device and rf_comm_post_reduce / _gather with nranks = 2
+// through the C ABI.
 //
 // Data moves through a file in /dev/shm named after the unique id: a collective synchronises its stream, copies its
 // contribution device -> shared memory, waits for the other ranks, copies their contributions back to the device.
 // Same call semantics as RCCL at the level librfgpu relies on: results are in place for later work on the stream;
-// all-gather lays rank blocks out in rank order; sends and receives of one group do not deadlock.  Every wait gives
+// all-gather lays rank blocks out in rank order; reduce sums in rank order into the root's buffer only (send == recv
+// allowed); sends and receives of one group do not deadlock (a long message moves in BOX-sized pieces).  Every wait gives
 // up after 120 s with an error instead of hanging a test.
 //   hipcc -shared -fPIC -o librccl_double.so tests/c/rccl_double.cpp
 #include <hip/hip_runtime_api.h>
@@ -25,7 +27,7 @@
 namespace {
 constexpr int MAXR = 8;
 constexpr size_t SLOT = 1u << 20;   // bytes one rank may contribute to a collective
-constexpr size_t BOX = 256;         // bytes of one point-to-point message
+constexpr size_t BOX = 1u << 14;    // bytes of one piece of a point-to-point message
 
 struct Shm {
     volatile long posted[MAXR], readn[MAXR];                  // collectives: op number a rank has posted / finished reading
@@ -42,7 +44,7 @@ struct Comm {
 };
 
 struct Op {
-    int kind;   // 0 all-gather, 1 broadcast, 2 send, 3 recv
+    int kind;   // 0 all-gather, 1 broadcast, 2 send, 3 recv, 4 reduce(sum) to `peer`
     const void *send;
     void *recv;
     size_t count;
@@ -53,7 +55,7 @@ struct Op {
 };
 thread_local int g_depth = 0;
 thread_local int g_nq = 0;
-thread_local Op g_q[16];
+thread_local Op g_q[32];
 
 size_t type_bytes(ncclDataType_t t)
 {
@@ -90,14 +92,14 @@ ncclResult_t run(const Op &o)
     Comm *c = o.comm;
     Shm *s = c->shm;
     const size_t bytes = o.count * type_bytes(o.type);
-    if (o.kind <= 1) {
+    if (o.kind <= 1 || o.kind == 4) {
         if (bytes > SLOT) return ncclInvalidArgument;
         const long n = ++c->seq;
         // nobody still reads what this rank posted for the previous collective
         if (!wait_for([&] { for (int r = 0; r < c->nranks; ++r) if (s->readn[r] < n - 1) return false; return true; }))
             return ncclSystemError;
         if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
-        if (o.kind == 0 || c->rank == o.peer)
+        if (o.kind != 1 || c->rank == o.peer)
             if (hipMemcpy(s->coll[c->rank], o.send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
         __sync_synchronize();
         s->posted[c->rank] = n;
@@ -107,6 +109,19 @@ ncclResult_t run(const Op &o)
             for (int r = 0; r < c->nranks; ++r)
                 if (hipMemcpy((char *)o.recv + (size_t)r * bytes, s->coll[r], bytes, hipMemcpyHostToDevice) != hipSuccess)
                     return ncclUnhandledCudaError;
+        } else if (o.kind == 4) {
+            if (c->rank == o.peer) {
+                static thread_local char acc[SLOT];
+                std::memset(acc, 0, bytes);
+                for (int r = 0; r < c->nranks; ++r)
+                    for (size_t i = 0; i < o.count; ++i) {
+                        if (o.type == ncclInt32) reinterpret_cast<int *>(acc)[i] += reinterpret_cast<const int *>(s->coll[r])[i];
+                        else if (o.type == ncclInt64) reinterpret_cast<long long *>(acc)[i] += reinterpret_cast<const long long *>(s->coll[r])[i];
+                        else if (o.type == ncclFloat64) reinterpret_cast<double *>(acc)[i] += reinterpret_cast<const double *>(s->coll[r])[i];
+                        else return ncclInvalidArgument;
+                    }
+                if (hipMemcpy(o.recv, acc, bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+            }
         } else if (hipMemcpy(o.recv, s->coll[o.peer], bytes, hipMemcpyHostToDevice) != hipSuccess) {
             return ncclUnhandledCudaError;
         }
@@ -114,28 +129,38 @@ ncclResult_t run(const Op &o)
         s->readn[c->rank] = n;
         return ncclSuccess;
     }
-    if (bytes > BOX || o.peer < 0 || o.peer >= c->nranks) return ncclInvalidArgument;
+    if (o.peer < 0 || o.peer >= c->nranks) return ncclInvalidArgument;
     if (o.kind == 2) {
         const int me = c->rank, to = o.peer;
-        if (!wait_for([&] { return s->p_read[me][to] == s->p_posted[me][to]; })) return ncclSystemError;
         if (hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
-        if (hipMemcpy(s->box[me][to], o.send, bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
-        __sync_synchronize();
-        s->p_posted[me][to] = s->p_posted[me][to] + 1;
+        // (a message within one piece only fills the mailbox -- what lets a group send and then receive; a longer one
+        // waits for the receiver piece by piece: such sends are issued one-way)
+        for (size_t off = 0; off < bytes || off == 0; off += BOX) {
+            const size_t n = bytes - off < BOX ? bytes - off : BOX;
+            if (!wait_for([&] { return s->p_read[me][to] == s->p_posted[me][to]; })) return ncclSystemError;
+            if (n && hipMemcpy(s->box[me][to], (const char *)o.send + off, n, hipMemcpyDeviceToHost) != hipSuccess)
+                return ncclUnhandledCudaError;
+            __sync_synchronize();
+            s->p_posted[me][to] = s->p_posted[me][to] + 1;
+        }
         return ncclSuccess;
     }
     const int from = o.peer, me = c->rank;
-    if (!wait_for([&] { return s->p_posted[from][me] > s->p_read[from][me]; })) return ncclSystemError;
-    if (hipMemcpy(o.recv, s->box[from][me], bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
-    __sync_synchronize();
-    s->p_read[from][me] = s->p_read[from][me] + 1;
+    for (size_t off = 0; off < bytes || off == 0; off += BOX) {
+        const size_t n = bytes - off < BOX ? bytes - off : BOX;
+        if (!wait_for([&] { return s->p_posted[from][me] > s->p_read[from][me]; })) return ncclSystemError;
+        if (n && hipMemcpy((char *)o.recv + off, s->box[from][me], n, hipMemcpyHostToDevice) != hipSuccess)
+            return ncclUnhandledCudaError;
+        __sync_synchronize();
+        s->p_read[from][me] = s->p_read[from][me] + 1;
+    }
     return ncclSuccess;
 }
 
 ncclResult_t submit(const Op &o)
 {
     if (g_depth == 0) return run(o);
-    if (g_nq >= 16) return ncclInternalError;
+    if (g_nq >= 32) return ncclInternalError;
     g_q[g_nq++] = o;
     return ncclSuccess;
 }
@@ -235,6 +260,14 @@ ncclResult_t ncclBroadcast(const void *sendbuff, void *recvbuff, size_t count, n
     Comm *c = reinterpret_cast<Comm *>(comm);
     if (root < 0 || root >= c->nranks) return ncclInvalidArgument;
     return submit(Op{1, sendbuff, recvbuff, count, datatype, root, c, stream});
+}
+
+ncclResult_t ncclReduce(const void *sendbuff, void *recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, int root,
+                        ncclComm_t comm, hipStream_t stream)
+{
+    Comm *c = reinterpret_cast<Comm *>(comm);
+    if (root < 0 || root >= c->nranks || op != ncclSum) return ncclInvalidArgument;
+    return submit(Op{4, sendbuff, recvbuff, count, datatype, root, c, stream});
 }
 
 ncclResult_t ncclSend(const void *sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm,

@@ -268,3 +268,83 @@ def test_two_rank_python_main_equals_two_rank_reference_run(golden_dir, tmp_path
     outs = [pr.communicate(timeout=900)[0] for pr in procs]
     assert all(pr.returncode == 0 for pr in procs), "\n".join(outs)
     _compare_result_dirs(our_dir / "rslt", ref_dir / "rslt", nburn + niter, sigma_solved=False)
+
+
+def _run_post_merge(tmp_path, world, devices, rccl_library=None):
+    sys_path_tools = os.path.join(ROOT, "tests", "tools")
+    import sys
+
+    sys.path.insert(0, sys_path_tools)
+    import post_merge_worker as wk
+
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(sys_path_tools, "post_merge_worker.py"), str(r), str(world),
+                               str(tmp_path), str(devices[r])] + ([rccl_library] if rccl_library else []), env=env, cwd=ROOT)
+             for r in range(world)]
+    for q in procs:
+        assert q.wait(timeout=600) == 0
+    own = [np.load(tmp_path / f"own_{r}.npz") for r in range(world)]
+    merged = [np.load(tmp_path / f"merged_{r}.npz") for r in range(world)]
+    after = [np.load(tmp_path / f"after_{r}.npz") for r in range(world)]
+    nm = wk.MAX_MODELS
+    counts = np.array([int(o["nmod"]) for o in own])
+    assert len(set(counts)) == world and counts[-1] > nm > counts[0]         # ragged, one rank overflowing
+    m0 = merged[0]
+    assert int(m0["nmod"]) == counts.sum()                                    # mpi_reduce of nmod, src/mcmc_out.f90:52
+    assert np.array_equal(m0["nmod_rank"], counts)
+    assert int(m0["amp_out_of_range"]) == sum(int(o["amp_out_of_range"]) for o in own) > 0
+    for f in INT_FIELDS:                                                      # :58-71
+        want = sum(o[f].astype(np.int64) for o in own)
+        assert np.array_equal(m0[f], want), f
+        assert want.any()
+    for f in ("vp_mean", "vs_mean", "vpvs_mean"):                             # :74-79 (rank order; exact for 2 ranks)
+        want = np.zeros_like(own[0][f])
+        for o in own:
+            want = want + o[f]
+        assert np.allclose(m0[f], want, rtol=4e-16, atol=0), f
+        if world == 2:
+            assert np.array_equal(m0[f], want), f
+    # :88-93 -- rank blocks of max_models rows in rank order; unused rows as init_pt_mcmc leaves them
+    for f, width in (("vp_model", 37), ("vs_model", 37), ("all_likelihood", None)):
+        got = m0[f]
+        assert got.shape[0] == world * nm
+        for r in range(world):
+            rows = min(counts[r], nm)
+            blk = got[r * nm:(r + 1) * nm]
+            assert np.array_equal(blk[:rows], own[r][f][:rows]), (f, r)
+            rest = blk[rows:]
+            if f == "vs_model":
+                assert np.all(rest[:, 0] == -999.9) and not rest[:, 1:].any()
+            else:
+                assert not rest.any()
+    # the root's device accumulators hold the sums (its model rows and count stay its own); other ranks are untouched
+    for f in INT_FIELDS + ("vp_mean", "vs_mean", "vpvs_mean"):
+        assert np.array_equal(after[0][f], m0[f]), f
+    assert int(after[0]["nmod"]) == counts[0]
+    assert np.array_equal(after[0]["vp_model"], own[0]["vp_model"])
+    for r in range(1, world):
+        for f in own[r].files:
+            assert np.array_equal(after[r][f], own[r][f]), (r, f)
+            if f != "nmod_rank":
+                assert np.array_equal(merged[r][f], own[r][f]), (r, f)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_posterior_merge_over_the_communicator(tmp_path, world):
+    """rf_comm_post_reduce / rf_comm_post_gather (the mpi_reduce / mpi_gather block of src/mcmc_out.f90:52-93 on the
+    device accumulators) with several ranks on the box's one GPU over tests/c/rccl_double.cpp (real RCCL refuses two
+    ranks on one device): the merged result on the root is the sum / rank-ordered concatenation of what the ranks held."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib = str(tmp_path / "librccl_double.so")
+    subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-o", lib, os.path.join(ROOT, "tests", "c", "rccl_double.cpp")],
+                   check=True, capture_output=True, timeout=300)
+    _run_post_merge(tmp_path, world, [0] * world, rccl_library=lib)
+
+
+def test_posterior_merge_between_two_gpus(tmp_path):
+    """The same over real RCCL: needs two GPUs."""
+    import torch
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
+    _run_post_merge(tmp_path, 2, [0, 1])

@@ -245,7 +245,7 @@ def test_rccl_exchange_between_two_gpus(tmp_path):
 def test_cross_rank_entry_points_with_several_ranks_on_one_gpu(tmp_path, world):
     """rf_comm_init, rf_comm_bcast_i32, rf_pt_swap_exchange and rf_pt_swap_allgather_device with nranks > 1 on a
     ONE-GPU box: the ranks share device 0 and librfgpu is pointed (rf_comm_set_library) at tests/c/rccl_double.cpp,
-    a host-staged stand-in for the eleven nccl* calls -- real RCCL refuses two ranks on one device.  Everything
+    a host-staged stand-in for the twelve nccl* calls -- real RCCL refuses two ranks on one device.  Everything
     above those calls (rank -> walker block mapping, the grouped send/receive and the decision both ranks form from
     it, the gathered layout the swap kernel indexes, the in-place temperature update) is the code a multi-GPU run
     executes."""

@@ -10,7 +10,7 @@ librfgpu's RCCL entry points exactly like the Fortran host does (rf_inv_amd/fort
 usage: rccl_two_rank_worker.py RANK WORLD OUT_DIR [DEVICE [RCCL_LIBRARY]]
 DEVICE: the GPU of this rank (default: RANK).  RCCL_LIBRARY: rf_comm_set_library -- the one-GPU variant of the test
 runs both ranks on device 0 over tests/c/rccl_double.cpp, a host-staged test double (real RCCL refuses two ranks on
-one device); everything of librfgpu above the eleven nccl* calls is the code a multi-GPU run executes.
+one device); everything of librfgpu above the twelve nccl* calls is the code a multi-GPU run executes.
 Writes OUT_DIR/p2p_RANK.npy and OUT_DIR/allgather_RANK.npy: the temperature history [steps + 1, nchains]."""
 import os
 import sys
