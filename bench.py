@@ -821,14 +821,23 @@ def main():
                       "l2_hit_rate": (gc["TCC_HIT_sum"] / (gc["TCC_HIT_sum"] + gc["TCC_MISS_sum"])
                                       if gc.get("TCC_HIT_sum") is not None and gc.get("TCC_MISS_sum") else None),
                       "file": gc["_file"]}
+            # what the kernel multiplies: with the triangular image ("gemm_triangle", default) column chunk c of 64 runs
+            # rows 0 .. 64 (c + 1) - 1 only; the full product runs all kp rows for every chunk
+            tri = bool(plan.get("gemm_triangle"))
+            nchunk = (kp + 63) // 64
+            rows = sum(min(kp, 64 * (c + 1)) if tri else kp for c in range(nchunk))
+            gf_run = 2.0 * nb * p.ntrc * 64.0 * rows
             res["quadratic_form_gemm"] = {
                 "kernel": "rfgpu::phi_gemm_kernel + phi_gemm_finish_kernel", "bound": "fp64_mfma", "unit": "TFLOP/s",
-                "peak": FP64_PEAK_TFLOPS, "gflop_per_launch": gf / 1e9, "ms": 1e3 * t_q,
-                "achieved": gf / t_q / 1e12, "frac": gf / t_q / 1e12 / FP64_PEAK_TFLOPS, "grid_threads": g_thr,
+                "peak": FP64_PEAK_TFLOPS, "triangle": tri, "gflop_per_launch": gf_run / 1e9, "ms": 1e3 * t_q,
+                "achieved": gf_run / t_q / 1e12, "frac": gf_run / t_q / 1e12 / FP64_PEAK_TFLOPS, "grid_threads": g_thr,
+                "algorithmic": {"gflop_per_launch": gf / 1e9, "tflops": gf / t_q / 1e12,
+                                "ratio_to_peak": gf / t_q / 1e12 / FP64_PEAK_TFLOPS},
                 "mfma": mf,
-                "note": "algorithmic flops 2 nb ntrc nsmp^2 over the HIP-event time of the GEMM + logL kernels; the FP64 "
-                        "matrix peak equals the vector peak (78.6 TF at 2.4 GHz: one 16x16x4 instruction per 64 cycles and "
-                        "SIMD); R^-1 is streamed once per 128 walkers"}
+                "note": "achieved / frac: the multiply-adds the kernel runs (triangle: 2 nb ntrc 64 sum_c min(kp, 64 (c + 1)), "
+                        "about half of the reference's matmul(misfits, r_inv) = 2 nb ntrc nsmp^2, which is `algorithmic`) over "
+                        "the HIP-event time of the GEMM + logL kernels; the FP64 matrix peak equals the vector peak (78.6 TF at "
+                        "2.4 GHz: one 16x16x4 instruction per 64 cycles and SIMD); R^-1 is streamed once per 128 walkers"}
         if rank == 0 and (with_cpu or parity_n):
             from oracle import rf_oracle as orc
 

@@ -392,6 +392,10 @@ int rf_comm_post_gather(rf_ctx *ctx, int32_t root, int32_t *nmod_rank, double *v
  *                      (nfft 4096 on land only)
  *   "gemm_tile"        0 (default) = 64 | 128: the block tile of the long-window plan's GEMM (plan[12]): 128 x 64
  *                      (walkers x columns, four blocks per CU) or 128 x 128 (two); same values
+ *   "gemm_triangle"    1 (default): the long-window GEMM runs on the quadratic form's upper triangle T(i, j) = R^-1(i, j)
+ *                      + R^-1(j, i) (i < j), R^-1(j, j), 0 below -- m R m^T = sum_j m_j sum_{i<=j} m_i T(i, j) for ANY R, half
+ *                      the multiply-adds | 0: the full product m . R^-1 in the reference's row order.  Results agree to
+ *                      rounding (both within the parity tolerance of the oracle), not bit for bit.
  *   "trace_window"     0 (default: every trace is kept as the reference's rft(nfft, ntrc, chain), filled completely) | 1:
  *                      only samples 1 .. nsmp are stored -- all the likelihood, the histograms and make_syn ever read
  *                      (src/likelihood.f90:88, src/pt_mcmc.f90:273-274): the trace array shrinks nfft / nsmp-fold (C5:
@@ -416,7 +420,7 @@ int rf_set_option(rf_ctx *ctx, const char *name, double value);
  *  [7] 1 when a bin cut-off is active            [8] number of options away from their defaults
  *  [9] 0 production build | 1 RFGPU_DIAGNOSTICS build | 2 diagnostics build with "ablate" set (results invalid)
  *  [10] the "block_threads" option (0 = by capacity)   [11] threads per block of the context's fused kernel
- *  [12] 1 on the long-window plan (nsmp > 191; the reference allows npts_max = 2000, src/params.f90:44): every trace
+ *  [12] 0 | 2 (1 with "gemm_triangle" = 0) on the long-window plan (nsmp > 191; the reference allows npts_max = 2000, src/params.f90:44): every trace
  *       kernel leaves its misfits in HBM and the quadratic forms misfit . R^-1 . misfit of the whole batch run as ONE
  *       tiled GEMM on the FP64 matrix cores (v_mfma_f64_16x16x4_f64) followed by logL; "defer_logl" is then ignored.
  *       Fixed per context from nsmp; ms[2] of rf_profile_read is the GEMM + logL pair

@@ -285,6 +285,22 @@ static std::vector<double> pad_r_inv(const std::vector<double> &r, int ntrc, int
     return out;
 }
 
+// The same quadratic form through its upper triangle: m R m^T = sum_j m_j sum_{i <= j} m_i T(i, j) with T(i, j) =
+// R(i, j) + R(j, i) above the diagonal, R(j, j) on it, 0 below -- exact for ANY R (only the symmetric part of a matrix
+// enters its quadratic form), so nothing is assumed about how symmetric the SVD left r_inv.  Column block c of the
+// product then needs rows 0 .. 64 (c + 1) - 1 only: half the multiply-adds and half the matrix traffic.
+static std::vector<double> triangle_r_inv(const std::vector<double> &rg, int ntrc, int kp, int np)
+{
+    std::vector<double> out(rg.size(), 0.0);
+    for (int t = 0; t < ntrc; ++t) {
+        const double *r = rg.data() + (size_t)t * kp * np;
+        double *o = out.data() + (size_t)t * kp * np;
+        for (int i = 0; i < kp; ++i)
+            for (int j = i; j < kp; ++j) o[(size_t)i * np + j] = i == j ? r[(size_t)i * np + i] : r[(size_t)i * np + j] + r[(size_t)j * np + i];
+    }
+    return out;
+}
+
 static int ensure_stage(rf_ctx *c, int nb, int pad)
 {
     if (nb <= c->stage_nb && pad <= c->stage_pad) return 0;
@@ -561,10 +577,12 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
         g.nchunk = g.np / 64;
         g.pstride = c->nslots;
         g.tile = 0;
+        g.triangle = 1;
         g.num_cu = c->num_cu;
         const std::vector<double> rg = pad_r_inv(c->r_inv, ntrc, nsmp, g.kp, g.np);
+        const std::vector<double> rt = triangle_r_inv(rg, ntrc, g.kp, g.np);
         void *q = nullptr;
-        if (upload(c, rg, &g.rg) || dev_alloc(c, &q, sizeof(double) * (size_t)ntrc * g.nchunk * g.pstride)) return cleanup(1);
+        if (upload(c, rg, &g.rg) || upload(c, rt, &g.rt) || dev_alloc(c, &q, sizeof(double) * (size_t)ntrc * g.nchunk * g.pstride)) return cleanup(1);
         g.part = (double *)q;
     }
     if (upload(c, c->flt, &T.flt) || upload(c, obs, &T.obs) || upload(c, r_inv_t, &T.r_inv_t) ||
@@ -1661,6 +1679,9 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     } else if (k == "gemm_tile") {
         if (!integral || (iv != 0 && iv != 64 && iv != 128)) return fail("rf_set_option: gemm_tile must be 0 (by launch size), 64 or 128");
         c->pg.tile = iv;
+    } else if (k == "gemm_triangle") {
+        if (!integral || iv < 0 || iv > 1) return fail("rf_set_option: gemm_triangle must be 0 or 1");
+        c->pg.triangle = iv;
     } else if (k == "trace_window") {
         if (!integral || iv < 0 || iv > 1) return fail("rf_set_option: trace_window must be 0 or 1");
         const int len = iv ? c->cfg.nsmp : c->cfg.nfft;
@@ -1705,7 +1726,7 @@ extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
 #endif
     plan[10] = c->block_threads;
     plan[11] = (c->fusedc || use_fused8(c)) ? 512 : 256;
-    plan[12] = c->tab.phi_gemm;
+    plan[12] = c->tab.phi_gemm ? (c->pg.triangle ? 2 : 1) : 0;
     plan[13] = c->trace_window;
     plan[14] = c->last_staged;
     plan[15] = 0;

@@ -35,8 +35,10 @@ struct DeviceTables {
 // tables of the long-window plan (phi_gemm_kernel)
 struct PhiGemmTables {
     const double *rg;       // [ntrc][kp][np] R^-1(i, j) at [i][j], zero-padded: kp = nsmp rounded up to 16, np to 128
+    const double *rt;       // the same quadratic form's upper triangle: R^-1(i, j) + R^-1(j, i) for i < j, the diagonal, 0 below
     double *part;           // [ntrc][nchunk][pstride] per 64-column chunk partial sums of misfit . R^-1 . misfit
     int kp, np, nchunk, pstride;
+    int triangle;           // "gemm_triangle": 1 (default) the triangular image and half the K loop | 0 the full product
     int tile;               // "gemm_tile": 0 (default) / 64: 128 x 64 blocks | 128: 128 x 128 blocks (same values)
     int num_cu;
 };

@@ -3343,8 +3343,13 @@ void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w
 // byte.  Beyond what phi_deferred_kernel's LDS holds (nsmp > 191) the quadratic forms of a batch are instead ONE GEMM
 //     Phi1[nb x nsmp] = M_t[nb x nsmp] . R^-1_t[nsmp x nsmp]      per trace t, then  phi = rowsum(Phi1 o M_t)
 // on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), the only dense contraction of the path.
-// R^-1 is NOT assumed symmetric (it is only to ~1e-10): the sum runs over its row index exactly as in
-// the reference's row-vector x matrix product.
+// R^-1 is NOT assumed symmetric (it is only to ~1e-10).  By default the product runs on the quadratic
+// form's UPPER TRIANGLE T (triangle_r_inv, rfgpu_api.cpp: T(i, j) = R^-1(i, j) + R^-1(j, i) above the diagonal, the
+// diagonal, 0 below): m R m^T = sum_j m_j sum_{i <= j} m_i T(i, j) holds for any matrix -- only its symmetric part
+// enters the form -- and column block c then needs rows 0 .. 64 (c + 1) - 1 only: half the multiply-adds, half the
+// matrix traffic (c4w60: GEMM 1.16 -> see profiles/EXPERIMENTS.md).  The rounding differs from the reference's
+// row-vector x matrix product the way any other summation order does (checked against the oracle at every window in
+// the tests).  "gemm_triangle" = 0 runs the full product on R^-1 itself, row index ascending as in the reference.
 //
 // Tiling: a 256-thread block owns 128 walkers x 128 columns; its four waves 64 x 64 each (4 x 4 MFMA tiles, 16
 // accumulators of 4 doubles per lane).  K advances in steps of 16 through LDS: the A tile (128 misfit rows x 16) and
@@ -3365,9 +3370,10 @@ constexpr int PG_LDA = PG_BK + 1;      // doubles per LDS row of the A tile ([ro
 
 struct PhiGemmParams {
     const double *mis;     // [>= nb][ntrc][ld] misfits, rows zero-padded to ld = kp
-    const double *rg;      // [ntrc][kp][np]
+    const double *rg;      // [ntrc][kp][np]: R^-1, or its quadratic form's upper triangle (tri)
     double *part;          // [ntrc][nchunk][pstride]
     int nb, ntrc, ld, kp, np, nchunk, pstride;
+    int tri;               // rg is upper triangular: column block n0 needs rows 0 .. n0 + BN - 1 only
 };
 
 typedef double pg_acc_t __attribute__((ext_vector_type(4)));
@@ -3399,7 +3405,8 @@ __global__ __launch_bounds__(256, WN == 2 ? 2 : 4) void phi_gemm_kernel(PhiGemmP
     int bid = blockIdx.x;
     const int mblk = bid % nmb;
     bid /= nmb;
-    const int nblk = bid % nnb, it = bid / nnb;
+    // (triangular image: the column blocks with the long K loops first, the short ones fill in behind them)
+    const int nblk = G.tri ? nnb - 1 - bid % nnb : bid % nnb, it = bid / nnb;
     const int m0 = mblk * BM, n0 = nblk * BN;
     const int wm = wv % WM, wn = wv / WM;
     const int mw = m0 + 16 * MT * wm, nw = n0 + 64 * wn;
@@ -3435,7 +3442,9 @@ __global__ __launch_bounds__(256, WN == 2 ? 2 : 4) void phi_gemm_kernel(PhiGemmP
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = pg_acc_t{0.0, 0.0, 0.0, 0.0};
 
-    const int nkt = G.kp / PG_BK;
+    // Triangular image: rows beyond the block's last column are zero.  (A 128-wide block runs its left 64 columns
+    // through 64 rows of zeros: acc + m * 0 leaves every accumulator as it is, so both tilings still give the same bits.)
+    const int nkt = (G.tri ? min(G.kp, n0 + BN) : G.kp) / PG_BK;
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                                  // the previous step's fragments are read
 #pragma unroll
@@ -3531,7 +3540,7 @@ __global__ __launch_bounds__(256) void phi_gemm_finish_kernel(LoglParams P, cons
 
 void launch_phi_gemm(const DeviceTables &t, const BatchArgs &b, const WalkerState &w, const PhiGemmTables &g, hipStream_t s)
 {
-    PhiGemmParams G{w.misfit, g.rg, g.part, b.nb, t.ntrc, t.mis_stride, g.kp, g.np, g.nchunk, g.pstride};
+    PhiGemmParams G{w.misfit, g.triangle ? g.rt : g.rg, g.part, b.nb, t.ntrc, t.mis_stride, g.kp, g.np, g.nchunk, g.pstride, g.triangle};
     // the tiling (same values either way: see the kernel): 128 x 64 blocks unless the option asks for 128 x 128
     const unsigned nmb = (unsigned)((b.nb + 127) / 128);
     const unsigned nnb2 = (unsigned)((g.kp + 127) / 128), nnb1 = (unsigned)((g.kp + 63) / 64);

@@ -367,7 +367,8 @@ class RFEngine:
                 "bin_cutoff": bool(plan[7]), "overrides": plan[8],
                 "build": ("production", "diagnostics", "diagnostics+ablate")[plan[9]],
                 "block_threads_option": plan[10], "block_threads_full_batch": plan[11],
-                "long_window_gemm": bool(plan[12]), "trace_window": bool(plan[13]), "staged_host_arrays": plan[14]}
+                "long_window_gemm": bool(plan[12]), "gemm_triangle": plan[12] == 2,
+                "trace_window": bool(plan[13]), "staged_host_arrays": plan[14]}
 
     def profile_enable(self, on=True):
         """on: False / True (every batch) / k > 1 (every k-th batch is timed)."""

@@ -1150,9 +1150,9 @@ def test_trace_window_option(oracle, shape):
 
 
 def test_long_window_gemm_tilings_agree(oracle):
-    """phi_gemm_kernel's two block tilings (128 x 128 for launches of several rounds of blocks, 128 x 64 below; option
-    gemm_tile forces one) return the same bits -- the choice by launch size cannot make a chain's result depend on the
-    batch it is evaluated in."""
+    """phi_gemm_kernel's two block tilings (option gemm_tile) return the same bits -- on the quadratic form's upper
+    triangle (the default) and on the full product ("gemm_triangle" = 0) -- and a chain evaluated alone gets the bits it
+    gets in the batch.  The two forms differ from each other by rounding only and both meet the oracle."""
     rng = np.random.default_rng(12)
     nsmp, nb = 530, 333
     cfg = make_cfg(nfft=4096, rayps=[0.06, 0.09], ipha=[1, -1], t_start=-3.0)
@@ -1160,11 +1160,41 @@ def test_long_window_gemm_tilings_agree(oracle):
     r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
     nlay, layers = pack_layers([random_stack(rng, int(n)) for n in rng.integers(3, 20, nb)], 22)
     sig = rng.uniform(0.01, 0.05, (nb, 2))
-    out = {}
-    for tile in (0, 64, 128):
-        with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=22, options={"gemm_tile": tile}) as eng:
-            out[tile] = eng.eval_batch(np.arange(nb), nlay, layers, sig)
-            assert eng.eval_batch(np.array([7]), nlay[7:8], layers[7:8], sig[7:8])[0] == out[tile][7]
-    assert np.array_equal(out[64], out[128]) and np.array_equal(out[0], out[64])
     ref, kap = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads(), want_kappa=True)
-    assert_logl_parity(out[0], ref, kap, "tilings")
+    form = {}
+    for tri in (1, 0):
+        out = {}
+        for tile in (0, 64, 128):
+            with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=22,
+                         options={"gemm_tile": tile, "gemm_triangle": tri}) as eng:
+                assert eng.launch_plan["long_window_gemm"] and eng.launch_plan["gemm_triangle"] == bool(tri)
+                out[tile] = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+                assert eng.eval_batch(np.array([7]), nlay[7:8], layers[7:8], sig[7:8])[0] == out[tile][7]
+        assert np.array_equal(out[64], out[128]) and np.array_equal(out[0], out[64])
+        assert_logl_parity(out[0], ref, kap, f"tilings, triangle {tri}")
+        form[tri] = out[0]
+    assert not np.array_equal(form[0], form[1])                      # two summation orders ...
+    assert np.median(np.abs(form[0] - form[1]) / np.abs(form[0])) < 1e-13   # ... of the same sums (each within the oracle's tolerance above)
+
+
+def test_long_window_triangle_with_an_asymmetric_matrix(oracle):
+    """The triangular form assumes nothing about R^-1: with a deliberately NON-symmetric matrix (what a caller's own
+    r_inv may be; the reference's product is defined for any matrix, src/likelihood.f90:92-93) both forms still return
+    the reference's misfit . R^-1 . misfit."""
+    rng = np.random.default_rng(21)
+    nsmp, nb = 333, 150
+    cfg = make_cfg(nfft=2048, rayps=[0.07], ipha=[1], t_start=-2.0)
+    obs = synth_obs(oracle, cfg, random_stack(rng, 4), nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    skew = rng.normal(0, 1, (nsmp, nsmp))
+    r_inv = r_inv + 0.05 * np.abs(r_inv).max() * (skew - skew.T)[None]   # antisymmetric part: no effect on the form ...
+    r_inv[0] += 0.01 * np.abs(r_inv).max() * np.triu(rng.normal(0, 1, (nsmp, nsmp)), 1)   # ... and a lopsided part that has one
+    nlay, layers = pack_layers([random_stack(rng, int(n)) for n in rng.integers(3, 12, nb)], 14)
+    sig = rng.uniform(0.01, 0.05, (nb, 1))
+    ref, kap = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads(), want_kappa=True)
+    for tri in (1, 0):
+        with _engine(cfg, obs, nsmp, r_inv, max_walkers=nb, nlay_max=14, options={"gemm_triangle": tri}) as eng:
+            got = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+        # (the antisymmetric part cancels in exact arithmetic only; its rounding -- eps |m| |A| |m| -- stays far inside
+        # the tolerance: |A| is 5 % of |R|)
+        assert_logl_parity(got, ref, kap, f"asymmetric matrix, triangle {tri}")
