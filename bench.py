@@ -182,6 +182,17 @@ def alg_work(p, nlay, common):
     return f_spec, f_spec + f_rest, b
 
 
+def quad_flops_run(nsmp, plan):
+    """Multiply-add flops the likelihood's quadratic form executes per (walker, trace): 2 nsmp^2 (quad_form /
+    phi_deferred_kernel: the reference's matmul); on the long-window plan the GEMM's K loop per 64-column chunk c --
+    rows 0 .. 64 (c + 1) - 1 of the triangular image ("gemm_triangle", default), all kp rows of the full one."""
+    if not plan.get("long_window_gemm"):
+        return 2.0 * nsmp ** 2
+    kp = (nsmp + 15) // 16 * 16
+    rows = sum(min(kp, 64 * (c + 1)) if plan.get("gemm_triangle") else kp for c in range((kp + 63) // 64))
+    return 2.0 * 64.0 * rows
+
+
 def committed_counters(kernel, grid_threads, long_window=False):
     """Per-launch hardware counters of `kernel` at exactly this launch shape from the newest committed
     profile (profiles/rNN_counters.json, written by tools/collect_counters.sh from separate rocprofv3
@@ -729,10 +740,10 @@ def main():
             # vector ALUs are the load (HBM-bound kernels of the same pass run at 2.4).  `frac_at_clock` = frac
             # priced at that clock -- `frac` stays the spec-clock figure.
             # the same at STEP level: the fp64 flops every kernel of a step executes / ms_per_step.  The dominant kernel's
-            # from its counters; the follow-up kernel's quadratic forms as 2 nsmp^2 + 2 nsmp per (walker, trace) -- what
-            # phi_deferred_kernel / phi_gemm_kernel execute, padding aside --; stage_kernel, the swap and the order kernels
+            # from its counters; the follow-up kernel's quadratic forms as quad_flops_run + 2 nsmp per (walker, trace) -- what
+            # phi_deferred_kernel / phi_gemm_kernel execute (the latter on the form's upper triangle) --; stage_kernel, the swap and the order kernels
             # execute < 0.2 % of a step's flops and are left out (a lower bound by that much)
-            "frac_step": ((exe + nb * p.ntrc * (2.0 * p.nsmp ** 2 + 2.0 * p.nsmp) * (1.0 if prof["logl_launches"] else 0.0))
+            "frac_step": ((exe + nb * p.ntrc * (quad_flops_run(p.nsmp, plan) + 2.0 * p.nsmp) * (1.0 if prof["logl_launches"] else 0.0))
                           / (dt / steps) / 1e12 / FP64_PEAK_TFLOPS if exe and counters_fresh else None),
             "clock_ghz": ctr.get("_clock_ghz") if ctr else None,
             "frac_at_clock": (exe / t_k / 1e12 / (FP64_PEAK_TFLOPS * ctr["_clock_ghz"] / SPEC_CLOCK_GHZ)
@@ -824,9 +835,7 @@ def main():
             # what the kernel multiplies: with the triangular image ("gemm_triangle", default) column chunk c of 64 runs
             # rows 0 .. 64 (c + 1) - 1 only; the full product runs all kp rows for every chunk
             tri = bool(plan.get("gemm_triangle"))
-            nchunk = (kp + 63) // 64
-            rows = sum(min(kp, 64 * (c + 1)) if tri else kp for c in range(nchunk))
-            gf_run = 2.0 * nb * p.ntrc * 64.0 * rows
+            gf_run = nb * p.ntrc * quad_flops_run(p.nsmp, plan)
             res["quadratic_form_gemm"] = {
                 "kernel": "rfgpu::phi_gemm_kernel + phi_gemm_finish_kernel", "bound": "fp64_mfma", "unit": "TFLOP/s",
                 "peak": FP64_PEAK_TFLOPS, "triangle": tri, "gflop_per_launch": gf_run / 1e9, "ms": 1e3 * t_q,

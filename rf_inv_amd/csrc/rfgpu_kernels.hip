@@ -3347,7 +3347,7 @@ void launch_logl(const DeviceTables &t, const BatchArgs &b, const WalkerState &w
 // form's UPPER TRIANGLE T (triangle_r_inv, rfgpu_api.cpp: T(i, j) = R^-1(i, j) + R^-1(j, i) above the diagonal, the
 // diagonal, 0 below): m R m^T = sum_j m_j sum_{i <= j} m_i T(i, j) holds for any matrix -- only its symmetric part
 // enters the form -- and column block c then needs rows 0 .. 64 (c + 1) - 1 only: half the multiply-adds, half the
-// matrix traffic (c4w60: GEMM 1.16 -> see profiles/EXPERIMENTS.md).  The rounding differs from the reference's
+// matrix traffic (c4w60: GEMM + logL 1.17 -> 0.68 ms, profiles/EXPERIMENTS.md).  The rounding differs from the reference's
 // row-vector x matrix product the way any other summation order does (checked against the oracle at every window in
 // the tests).  "gemm_triangle" = 0 runs the full product on R^-1 itself, row index ascending as in the reference.
 //
@@ -3385,7 +3385,7 @@ typedef double pg_v2_t __attribute__((ext_vector_type(2)));
 //           FOUR blocks per CU -- four waves per SIMD keep the matrix pipe fed across each other's barriers and staging,
 //           small launches spread evenly (a 20 s window on 8192 walkers is 8 GFLOP), and a window's last column block
 //           carries at most 48 columns of padding.  Measured (tests/tools/gemm_tile_ab.py, profiles/r04_gemm_tile_ab.txt):
-//           c4w60 1.17 ms = 61 TF of algorithmic flops against 1.34 ms = 53 TF for the wide tile, c4w20 0.19 against 0.21.
+//           full product: c4w60 1.17 ms against 1.34 ms for the wide tile, c4w20 0.19 against 0.21; triangle: 0.67 against 0.78.
 //   WN = 2 ("gemm_tile" = 128): block 128 x 128, waves 2 x 2, wave tile 64 x 64 (MT = 4): 16 flop per byte staged
 //           instead of 10.7, 208 VGPRs, two blocks per CU.  The first version; kept behind the option.
 // (A third variant on v_mfma_f64_4x4x4_4b_f64 -- its four blocks as one 4 x 16 x 4 product, same bits -- was measured
