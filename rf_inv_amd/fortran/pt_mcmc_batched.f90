@@ -68,7 +68,7 @@ contains
     use pt_mcmc
     include "mpif.h"
     logical, intent(in) :: verb
-    integer :: nproc, rank, ierr, it, n_tot_iter, n_all, ichain, nb, i
+    integer :: nproc, rank, ierr, it, n_tot_iter, n_all, ichain, nb, i, j
     integer :: itype, nlay, cand_k
     logical :: live, yn
     real(8) :: alpha(nlay_max), beta(nlay_max), rho(nlay_max), h(nlay_max)
@@ -76,6 +76,11 @@ contains
     ! per-chain proposals of the current iteration.  The arrays the engine reads live in pinned host memory
     ! (rf_host_alloc): they travel to the GPU by DMA as the proposal step left them.
     integer, allocatable :: p_type(:)
+    ! column jc of p_z / p_dvp / p_dvs equals the chain's state except in rows p_lo(jc) .. p_hi(jc) (none: 1 .. 0), p_sig
+    ! except where p_sigd(jc): a proposal touches one interface (a death: those from the removed one on), so the
+    ! candidate is built, undone and adopted by copying that range instead of 3 k_max + ntrc numbers each time
+    integer, allocatable :: p_lo(:), p_hi(:)
+    logical, allocatable :: p_sigd(:)
     logical, allocatable :: p_live(:), p_acc(:)
     real(8), allocatable :: p_lp(:), p_logr(:)
     integer(c_int32_t), pointer, contiguous :: p_k(:), b_id(:), b_fwd(:)
@@ -104,6 +109,7 @@ contains
     t_cold = 1.d0 + 1.0e-6
 
     allocate(p_type(nchains), p_live(nchains), p_acc(nchains), p_lp(nchains), p_logr(nchains), b_acc(nchains))
+    allocate(p_lo(nchains), p_hi(nchains), p_sigd(nchains))
     call pinned_i32(pin(1), p_k, nchains)
     call pinned_i32(pin(2), b_id, nchains)
     call pinned_i32(pin(3), b_fwd, nchains)
@@ -122,18 +128,22 @@ contains
        b_id(ichain) = ichain - 1            ! (constant: every iteration hands over all chains, null proposals flagged)
        b_acc(ichain) = 1
     end do
+    ! the proposal columns start as copies of the chains' states (draw_candidate keeps them that way)
+    do ichain = 1, nchains
+       p_k(ichain) = k(ichain)
+       p_z(1:k_max-1, ichain) = z(1:k_max-1, ichain)
+       p_dvp(:, ichain) = dvp(1:k_max, ichain)
+       p_dvs(:, ichain) = dvs(1:k_max, ichain)
+       p_sig(:, ichain) = sig(1:ntrc, ichain)
+       p_lo(ichain) = 1
+       p_hi(ichain) = 0
+       p_sigd(ichain) = .false.
+       b_fwd(ichain) = 1
+    end do
     if (rf_windowed_traces) then
        ! windowed trace storage: switching drops every stored trace, so the chains' current models are evaluated once
        ! more, all at once -- the same kernels on the same inputs: the log-likelihoods must come back bit for bit
        call rfgpu_check(rf_set_option(rf_ctx, "trace_window" // c_null_char, 1.0_c_double), "rf_set_option")
-       do ichain = 1, nchains
-          p_k(ichain) = k(ichain)
-          p_z(1:k_max-1, ichain) = z(1:k_max-1, ichain)
-          p_dvp(:, ichain) = dvp(1:k_max, ichain)
-          p_dvs(:, ichain) = dvs(1:k_max, ichain)
-          p_sig(:, ichain) = sig(1:ntrc, ichain)
-          b_fwd(ichain) = 1
-       end do
        call rfgpu_check(rf_eval_models(rf_ctx, int(nchains, c_int32_t), b_id, b_fwd, p_k, p_z, int(k_max, c_int32_t), &
             & p_dvp, p_dvs, p_sig, b_logl, c_null_ptr), "rf_eval_models")
        do ichain = 1, nchains
@@ -192,11 +202,17 @@ contains
                 if (yn) then
                    b_acc(ichain) = 1
                    log_likelihood(ichain) = b_logl(ichain)
+                   ! the candidate becomes the state: it differs from it in rows p_lo .. p_hi only
                    k(ichain) = p_k(ichain)
-                   dvp(1:k_max, ichain) = p_dvp(1:k_max, ichain)
-                   dvs(1:k_max, ichain) = p_dvs(1:k_max, ichain)
-                   z(1:k_max-1, ichain) = p_z(1:k_max-1, ichain)
-                   sig(1:ntrc, ichain) = p_sig(1:ntrc, ichain)
+                   i = p_lo(ichain)
+                   j = p_hi(ichain)
+                   if (j >= i) then
+                      dvp(i:j, ichain) = p_dvp(i:j, ichain)
+                      dvs(i:j, ichain) = p_dvs(i:j, ichain)
+                      j = min(j, k_max - 1)
+                      if (j >= i) z(i:j, ichain) = p_z(i:j, ichain)
+                   end if
+                   if (p_sigd(ichain)) sig(1:ntrc, ichain) = p_sig(1:ntrc, ichain)
                 end if
                 p_acc(ichain) = yn
              end do
@@ -323,7 +339,7 @@ contains
     ! so the stream position after this call is the reference's.
     subroutine draw_candidate(jc)
       integer, intent(in) :: jc
-      integer :: pick
+      integer :: pick, ulo, uhi
       logical :: ok
 
       ! the candidate is built in place, in column jc of the pinned proposal arrays
@@ -331,10 +347,20 @@ contains
 
       cand_z => p_z(:, jc);  cand_dvp => p_dvp(:, jc);  cand_dvs => p_dvs(:, jc);  cand_sig => p_sig(:, jc)
       cand_k = k(jc)
-      cand_dvp(:) = dvp(1:k_max, jc)
-      cand_dvs(:) = dvs(1:k_max, jc)
-      cand_z(1:k_max-1) = z(1:k_max-1, jc)
-      cand_sig(:) = sig(1:ntrc, jc)
+      ! the column back to the chain's state: only the rows the previous candidate touched can differ (after an
+      ! acceptance they do not either)
+      ulo = p_lo(jc)
+      uhi = p_hi(jc)
+      if (uhi >= ulo) then
+         cand_dvp(ulo:uhi) = dvp(ulo:uhi, jc)
+         cand_dvs(ulo:uhi) = dvs(ulo:uhi, jc)
+         uhi = min(uhi, k_max - 1)
+         if (uhi >= ulo) cand_z(ulo:uhi) = z(ulo:uhi, jc)
+      end if
+      if (p_sigd(jc)) cand_sig(:) = sig(1:ntrc, jc)
+      p_lo(jc) = 1
+      p_hi(jc) = 0
+      p_sigd(jc) = .false.
       lpr = 0.d0
       live = .true.
 
@@ -353,6 +379,8 @@ contains
                cand_dvs(cand_k) = gauss() * dvs_prior
             end select
             cand_z(cand_k) = z_min + grnd() * (z_max - z_min)
+            p_lo(jc) = cand_k
+            p_hi(jc) = cand_k
          end if
       else if (itype == itype_death) then
          ! remove interface `pick`: close the gap, clear the vacated slot
@@ -368,15 +396,21 @@ contains
             cand_dvp(cand_k + 1) = 0.d0
             cand_dvs(cand_k + 1) = 0.d0
             cand_z(cand_k + 1) = 0.d0
+            p_lo(jc) = pick
+            p_hi(jc) = cand_k + 1
          end if
       else if (itype == itype_z) then
          pick = int(grnd() * cand_k) + 1
          cand_z(pick) = cand_z(pick) + gauss() * dev_z
+         p_lo(jc) = pick
+         p_hi(jc) = pick
          live = .not. (cand_z(pick) < z_min .or. cand_z(pick) > z_max)
       else if (itype == itype_dvs .or. itype == itype_dvp) then
          ! velocity perturbation of one layer (the last index addresses the half-space slot)
          pick = int(grnd() * (cand_k + 1)) + 1
          if (pick == cand_k + 1) pick = k_max
+         p_lo(jc) = pick
+         p_hi(jc) = pick
          if (itype == itype_dvs) then
             cand_dvs(pick) = cand_dvs(pick) + gauss() * dev_dvs
             lpr = log_prior_ratio(cand_dvs(pick), dvs(pick, jc), dvs_prior, prior_mode)
@@ -387,6 +421,7 @@ contains
       else if (itype == itype_sig) then
          pick = isig_trc(int(grnd() * nsig_trc) + 1)
          cand_sig(pick) = cand_sig(pick) + gauss() * dev_sig
+         p_sigd(jc) = .true.
          live = .not. (cand_sig(pick) < sig_min(pick) .or. cand_sig(pick) > sig_max(pick))
       end if
 
