@@ -408,6 +408,7 @@ extern "C" int rf_comm_post_gather(rf_ctx *c, int32_t root, int32_t *nmod_rank, 
         // root's pointers, which this rank cannot see)
         const size_t rows = rows_of(s->rank);
         for (const auto &a : arr) {
+            if (!rows) break;              // (nothing recorded: the root, which has the counts too, posts no receive)
             ncclResult_t r_ = R->Send(a.dev, rows * a.width, ncclDouble, root, s->comm, st);
             if (r_ != ncclSuccess) return done(comm_fail("rf_comm_post_gather: ncclSend failed"));
         }
@@ -427,7 +428,7 @@ extern "C" int rf_comm_post_gather(rf_ctx *c, int32_t root, int32_t *nmod_rank, 
         const size_t rows = rows_of(r);
         for (const auto &a : arr) {
             const double *src = a.dev;
-            if (r != root) {
+            if (r != root && rows) {
                 ncclResult_t r_ = R->Recv(d_stage, rows * a.width, ncclDouble, r, s->comm, st);
                 if (r_ != ncclSuccess) return done2(comm_fail("rf_comm_post_gather: ncclRecv failed"));
                 src = d_stage;

@@ -289,6 +289,7 @@ def _run_post_merge(tmp_path, world, devices, rccl_library=None):
     nm = wk.MAX_MODELS
     counts = np.array([int(o["nmod"]) for o in own])
     assert len(set(counts)) == world and counts[-1] > nm > counts[0]         # ragged, one rank overflowing
+    assert (world == 3) == (counts.min() == 0)                                # three ranks: one has nothing to send
     m0 = merged[0]
     assert int(m0["nmod"]) == counts.sum()                                    # mpi_reduce of nmod, src/mcmc_out.f90:52
     assert np.array_equal(m0["nmod_rank"], counts)
