@@ -236,6 +236,12 @@ int rf_eval_wait(rf_ctx *ctx, int32_t ticket, double *logl, int32_t *valid);
  * area (one host memcpy per array and call: ~1 KB per chain at k_max 30).  Optional; any host memory works. */
 int rf_host_alloc(size_t bytes, void **ptr);
 int rf_host_free(void *ptr);
+/* The same for host ranks that SHARE a GPU: POSIX shared memory mapped by every rank of the node (same `name`, which
+ * starts with '/'; exactly one rank passes create != 0 and returns before the others call -- the host's barrier) and
+ * registered with the GPU in the rank whose context reads / writes it (gpu != 0), so that one rank can hand the
+ * proposals of all of them to its context in ONE call, by DMA.  rf_host_free_shared unmaps (the creator also unlinks). */
+int rf_host_alloc_shared(const char *name, size_t bytes, int32_t create, int32_t gpu, void **ptr);
+int rf_host_free_shared(void *ptr);
 
 /* ---- parallel tempering ------------------------------------------------ */
 /* judge_pt (src/pt_mcmc.f90:580-595) for npairs DISJOINT chain pairs: swap
@@ -318,7 +324,14 @@ typedef struct rf_post_config {
                              int(nchains*niter/ncorr), :407-409); 0 = do not keep per-model profiles */
 } rf_post_config;
 int rf_post_create(rf_ctx *ctx, const rf_post_config *cfg);
-int rf_post_reset(rf_ctx *ctx);
+int rf_post_reset(rf_ctx *ctx);                 /* every set */
+/* Accumulator SETS: a context that evaluates the chains of several host ranks (ranks sharing a GPU) keeps one set of
+ * accumulators per rank, so that each rank ends with the arrays it would have filled alone and the reference's
+ * output_results (src/mcmc_out.f90:52-93) reduces and gathers them unchanged.  rf_post_sets(n) before rf_post_create
+ * (default 1); rf_post_select(i) names the set that the following rf_post_record* / rf_post_read / rf_comm_post_*
+ * calls address (stream-ordered like the calls themselves). */
+int rf_post_sets(rf_ctx *ctx, int32_t nsets);
+int rf_post_select(rf_ctx *ctx, int32_t set);
 
 /* Record n chains, in order, exactly as n consecutive passes through src/pt_mcmc.f90:204-286
  * would (the fp64 sums vp_mean / vs_mean / vpvs_mean -- and the ocean-layer ASSIGNMENTS

@@ -409,3 +409,23 @@ def host_alloc(shape, dtype=np.float64):
     arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
     weakref.finalize(buf, lib.rf_host_free, ptr)
     return arr
+
+
+def host_alloc_shared(name, shape, dtype=np.float64, create=False, gpu=False):
+    """A numpy array in POSIX shared memory mapped by every process that passes the same `name` ('/...'), registered
+    with the GPU in the process that passes gpu=True (rf_host_alloc_shared): ranks that share a GPU write their
+    proposals into slices of it and one of them hands the whole array to its context.  Exactly one process creates;
+    the others call after it has returned.  Unmapped (the creator also unlinks) with the array."""
+    import weakref
+
+    lib = _lib.load()
+    dt = np.dtype(dtype)
+    n = int(np.prod(shape))
+    nbytes = max(8, n * dt.itemsize)
+    ptr = C.c_void_p()
+    if lib.rf_host_alloc_shared(name.encode(), nbytes, int(bool(create)), int(bool(gpu)), C.byref(ptr)):
+        raise RFGPUError(lib.rf_last_error().decode())
+    buf = (C.c_char * nbytes).from_address(ptr.value)
+    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
+    weakref.finalize(buf, lib.rf_host_free_shared, ptr)
+    return arr

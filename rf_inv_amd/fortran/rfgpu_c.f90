@@ -160,6 +160,20 @@ module rfgpu_c
        type(c_ptr), intent(out) :: ptr
      end function rf_host_alloc
 
+     ! host memory shared by the ranks of a node (POSIX shared memory), registered with the GPU where gpu /= 0
+     integer(c_int) function rf_host_alloc_shared(name, bytes, create, gpu, ptr) bind(C, name="rf_host_alloc_shared")
+       import :: c_int, c_size_t, c_ptr, c_char, c_int32_t
+       character(kind=c_char), intent(in) :: name(*)
+       integer(c_size_t), value :: bytes
+       integer(c_int32_t), value :: create, gpu
+       type(c_ptr), intent(out) :: ptr
+     end function rf_host_alloc_shared
+
+     integer(c_int) function rf_host_free_shared(ptr) bind(C, name="rf_host_free_shared")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ptr
+     end function rf_host_free_shared
+
      integer(c_int) function rf_host_free(ptr) bind(C, name="rf_host_free")
        import :: c_int, c_ptr
        type(c_ptr), value :: ptr
@@ -198,6 +212,18 @@ module rfgpu_c
        type(c_ptr), value :: ctx
        type(rf_post_config), intent(in) :: cfg
      end function rf_post_create
+
+     integer(c_int) function rf_post_sets(ctx, nsets) bind(C, name="rf_post_sets")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: nsets
+     end function rf_post_sets
+
+     integer(c_int) function rf_post_select(ctx, set) bind(C, name="rf_post_select")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: set
+     end function rf_post_select
 
      integer(c_int) function rf_post_reset(ctx) bind(C, name="rf_post_reset")
        import :: c_int, c_ptr

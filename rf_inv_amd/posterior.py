@@ -45,9 +45,13 @@ class PosteriorResult:
 class Posterior:
     """Device-resident accumulators of one engine context (one rank)."""
 
-    def __init__(self, engine: RFEngine, p: Params, max_models: int | None = None):
-        """Needs engine.set_model(p, ref) first (the V-z profile runs format_model)."""
+    def __init__(self, engine: RFEngine, p: Params, max_models: int | None = None, nsets: int = 1):
+        """Needs engine.set_model(p, ref) first (the V-z profile runs format_model).  nsets > 1: one set of
+        accumulators per host rank the context serves (rf_post_sets); select(i) names the set that record / read use."""
         self.engine, self.p = engine, p
+        self.nsets = int(nsets)
+        if self.nsets != 1:
+            engine._chk(engine._lib.rf_post_sets(engine._ctx, self.nsets))
         if max_models is None:
             max_models = int(p.nchains * p.niter / p.ncorr)                      # :407-409
         self.max_models = int(max_models)
@@ -58,6 +62,9 @@ class Posterior:
                                 int(p.nbin_amp), float(p.amp_min), float(p.amp_max), float(p.z_min),
                                 _dptr(self._smin), _dptr(self._smax), _iptr(self._smode), self.max_models)
         engine._chk(engine._lib.rf_post_create(engine._ctx, C.byref(cfg)))
+
+    def select(self, i):
+        self.engine._chk(self.engine._lib.rf_post_select(self.engine._ctx, int(i)))
 
     def reset(self):
         self.engine._chk(self.engine._lib.rf_post_reset(self.engine._ctx))
