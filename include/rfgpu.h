@@ -242,6 +242,10 @@ int rf_host_free(void *ptr);
  * proposals of all of them to its context in ONE call, by DMA.  rf_host_free_shared unmaps (the creator also unlinks). */
 int rf_host_alloc_shared(const char *name, size_t bytes, int32_t create, int32_t gpu, void **ptr);
 int rf_host_free_shared(void *ptr);
+/* This process will issue no more GPU work: give its queues back (hipDeviceReset).  Every context of the process must
+ * have been destroyed.  For host ranks of a GPU group other than its first: many processes holding idle queues on one
+ * GPU make the hardware scheduler time-slice them, and the rank that launches waits for its turn. */
+int rf_release_gpu(void);
 
 /* ---- parallel tempering ------------------------------------------------ */
 /* judge_pt (src/pt_mcmc.f90:580-595) for npairs DISJOINT chain pairs: swap

@@ -345,15 +345,19 @@ static bool is_pinned_host(const void *p)
     return a.type == hipMemoryTypeHost;
 }
 
-// Start of a host-pointer call: waits for an earlier asynchronous user of the arena, makes room for `bytes`, rewinds.
+// Start of a host-pointer call: makes room for `bytes`, rewinds.  An earlier asynchronous user of the arena (its copies
+// may still be queued behind running kernels) is waited for only when this call really writes into the arena -- the
+// first arena_take: a call whose arrays are all pinned transfers them in place and never touches it (a GPU group's
+// first rank records the posterior of every rank of the group back to back: each call used to wait for the previous
+// one's copies, i.e. for the evaluation running in front of them).
 static int arena_begin(rf_ctx::Arena &A, size_t bytes)
 {
-    if (A.pending) {
-        HIP_TRY(hipEventSynchronize(A.ev));
-        A.pending = false;
-    }
     bytes += 8 * 256;                  // alignment slack of up to eight takes
     if (bytes > A.cap) {
+        if (A.pending) {
+            HIP_TRY(hipEventSynchronize(A.ev));
+            A.pending = false;
+        }
         if (A.p) HIP_TRY(hipHostFree(A.p));
         A.p = nullptr;
         A.cap = 0;
@@ -368,6 +372,10 @@ static int arena_begin(rf_ctx::Arena &A, size_t bytes)
 
 static void *arena_take(rf_ctx::Arena &A, size_t bytes)
 {
+    if (A.pending) {
+        (void)hipEventSynchronize(A.ev);
+        A.pending = false;
+    }
     const size_t at = (A.off + 255) & ~(size_t)255;
     A.off = at + bytes;
     return A.p + at;                   // (arena_begin sized the arena for every take of the call)
@@ -1426,6 +1434,16 @@ extern "C" int rf_host_alloc_shared(const char *name, size_t bytes, int32_t crea
     }
     g_shared.push_back(SharedBlock{m, bytes, name, create != 0, reg});
     *ptr = m;
+    return 0;
+}
+
+// A process that will issue no more GPU work gives its queues back (hipDeviceReset): host ranks whose chains are
+// evaluated by another rank's context (a GPU group) call it after destroying their own context -- with many processes
+// holding idle queues on one GPU the hardware scheduler starts to time-slice them, and the one rank that does launch
+// waits for its turn.
+extern "C" int rf_release_gpu(void)
+{
+    HIP_TRY(hipDeviceReset());
     return 0;
 }
 

@@ -3573,7 +3573,7 @@ void launch_misfit_of_trace(const DeviceTables &t, const WalkerState &w, int wal
 
 // ---------------------------------------------------------------------------
 // format_model on the device (reference src/model.f90:175-290 with vp_to_rho :298-314 and
-// the 3-array quick_sort of src/sort.f90:34-68): one thread per walker turns
+// the 3-array quick_sort of src/sort.f90:34-68): one wave per walker turns
 // (k, z, dVp, dVs) into the layer stack (alpha, beta, rho, h).  All of it is bookkeeping
 // that must be bit-exact -- the same unstable quicksort (ties keep the reference's
 // permutation), nint() table look-ups, no FMA contraction, single-precision literals.
@@ -3630,37 +3630,87 @@ __device__ void quick_sort3_dev(double *a, double *b, double *c, int n)
 
 __device__ __forceinline__ int f_nint_dev(double x) { return (int)(x >= 0.0 ? floor(x + 0.5) : -floor(0.5 - x)); }
 
-__global__ __launch_bounds__(128) void format_model_kernel(FormatParams P)
+// One WAVE per walker (until round 4: one thread, whose quicksort walked three arrays in global scratch -- 350 us for any
+// batch at k_max 30, a third of the C4 evaluation's stream time once the sampler's proposals went down unformatted).
+// The interfaces sit in LDS; lane i ranks interface i by counting the shallower ones and scatters it to its place:
+// with distinct depths the sorted order is unique, so this IS the reference quicksort's result.  Equal depths -- where
+// the unstable quicksort's permutation decides which perturbation belongs to which layer -- are detected (a wave
+// vote) and such a walker is sorted by lane 0 with the reference's algorithm itself.  Then one lane per layer: table
+// look-up, velocities, density, thickness, the validity rules; the verdict is a wave vote.
+constexpr int FM_WAVES = 4;     // walkers per block
+
+__global__ __launch_bounds__(64 * FM_WAVES) void format_model_kernel(FormatParams P)
 {
 #pragma clang fp contract(off)
-    const int ib = blockIdx.x * blockDim.x + threadIdx.x;
-    if (ib >= P.nb) return;
+    extern __shared__ double fm_lds[];             // [FM_WAVES][6][kmax]: z, dVp, dVs as given | sorted
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ib = blockIdx.x * FM_WAVES + wv;
+    if (ib >= P.nb) return;                        // (wave-uniform: no barrier below, waves work alone)
     const ModelConfig &m = P.m;
     const int kmax = m.k_max, k = P.k[ib];
     const int fwd = P.fwd_in ? P.fwd_in[ib] : 1;
     if (fwd != 1) {          // sigma-only (or skipped) item: no model to format
-        P.nlay[ib] = 2;
-        P.flag[ib] = fwd;
-        if (P.valid) P.valid[ib] = 1;
+        if (lane == 0) {
+            P.nlay[ib] = 2;
+            P.flag[ib] = fwd;
+            if (P.valid) P.valid[ib] = 1;
+        }
         return;
     }
-    double *tz = P.scratch + (size_t)ib * 3 * kmax, *tvp = tz + kmax, *tvs = tvp + kmax;
-    const int ldz = P.ldz > 0 ? P.ldz : kmax - 1;   // (the batched Fortran host keeps z(k_max, nchains))
-    for (int i = 0; i < kmax - 1; ++i) tz[i] = P.z[(size_t)ib * ldz + i];
-    for (int i = 0; i < kmax; ++i) {
-        tvp[i] = P.dvp[(size_t)ib * kmax + i];
-        tvs[i] = P.dvs[(size_t)ib * kmax + i];
+    if (k < 1 || k >= kmax) {   // (the host entry points refuse such a batch; a device array may hold anything)
+        if (lane == 0) {
+            P.nlay[ib] = 2;
+            P.flag[ib] = -1;
+            if (P.valid) P.valid[ib] = 0;
+        }
+        return;
     }
-    quick_sort3_dev(tz, tvp, tvs, k);                                        // :197-198
+    double *uz = fm_lds + (size_t)wv * 6 * kmax, *uvp = uz + kmax, *uvs = uvp + kmax;
+    double *tz = uvs + kmax, *tvp = tz + kmax, *tvs = tvp + kmax;
+    const int ldz = P.ldz > 0 ? P.ldz : kmax - 1;   // (the batched Fortran host keeps z(k_max, nchains))
+    for (int i = lane; i < kmax; i += 64) {
+        uz[i] = i < kmax - 1 ? P.z[(size_t)ib * ldz + i] : 0.0;
+        uvp[i] = P.dvp[(size_t)ib * kmax + i];
+        uvs[i] = P.dvs[(size_t)ib * kmax + i];
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- sort the first k interfaces by depth (:197-198) ----------------------------------------------------
+    bool tie = false;
+    for (int i = lane; i < k; i += 64) {
+        const double zi = uz[i];
+        int rank = 0;
+        for (int j2 = 0; j2 < k; ++j2) {
+            const double zj = uz[j2];
+            rank += zj < zi;
+            tie |= (zj == zi) & (j2 != i);
+        }
+        tz[rank] = zi;
+        tvp[rank] = uvp[i];
+        tvs[rank] = uvs[i];
+    }
+    if (__any(tie)) {
+        // equal depths: the reference's quicksort itself, on the arrays as given (lane 0)
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            for (int i = 0; i < k; ++i) { tz[i] = uz[i]; tvp[i] = uvp[i]; tvs[i] = uvs[i]; }
+            quick_sort3_dev(tz, tvp, tvs, k);
+        }
+    }
+    // (entries beyond k keep their places: only the half-space's perturbations, index kmax - 1, are read)
+    for (int i = lane; i < kmax; i += 64)
+        if (i >= k) { tvp[i] = uvp[i]; tvs[i] = uvs[i]; }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    // ---- one lane per layer ------------------------------------------------------------------------------------
     const int pad = P.nlay_pad;
     double *A = P.layers + (size_t)ib * 4 * pad, *B = A + pad, *R = B + pad, *H = R + pad;
-    bool ok = true;
-    int i = 0;
-    if (m.sdep > 0.0) {                                                      // :201-207
-        A[i] = 1.5; B[i] = -999.0; R[i] = 1.0; H[i] = m.sdep;
-        ++i;
+    const int i0 = m.sdep > 0.0 ? 1 : 0;
+    if (i0 && lane == 0) {                                                  // :201-207
+        A[0] = 1.5; B[0] = -999.0; R[0] = 1.0; H[0] = m.sdep;
     }
-    for (int j = 1; j <= k + 1; ++j) {
+    bool ok = true;
+    for (int j = 1 + lane; j <= k + 1; j += 64) {
         // j = 1: top layer (:210-231), 2..k: middle layers (:235-262), k+1: half-space (:265-282)
         double zc, thick;
         int idx;
@@ -3683,19 +3733,23 @@ __global__ __launch_bounds__(128) void format_model_kernel(FormatParams P)
         if (a < m.vp_min || a > m.vp_max || b < m.vs_min || b > m.vs_max || a / b < m.vpvs_min ||
             a / b > m.vpvs_max)
             ok = false;
+        const int i = i0 + j - 1;
         A[i] = a; B[i] = b; R[i] = vp_to_rho_dev(a); H[i] = thick;
         if (j == 1 && thick < (double)0.125f * a) ok = false;                // :229 (not h_min)
         if (j > 1 && j <= k && thick < m.h_min) ok = false;                  // :256
-        ++i;
     }
-    P.nlay[ib] = i;
-    P.flag[ib] = ok ? 1 : -1;
-    if (P.valid) P.valid[ib] = ok ? 1 : 0;
+    ok = __all(ok);
+    if (lane == 0) {
+        P.nlay[ib] = i0 + k + 1;
+        P.flag[ib] = ok ? 1 : -1;
+        if (P.valid) P.valid[ib] = ok ? 1 : 0;
+    }
 }
 
 void launch_format_model(const FormatParams &P, hipStream_t s)
 {
-    hipLaunchKernelGGL(format_model_kernel, dim3((unsigned)((P.nb + 127) / 128)), dim3(128), 0, s, P);
+    const size_t lds = sizeof(double) * FM_WAVES * 6 * (size_t)P.m.k_max;
+    hipLaunchKernelGGL(format_model_kernel, dim3((unsigned)((P.nb + FM_WAVES - 1) / FM_WAVES)), dim3(64 * FM_WAVES), lds, s, P);
 }
 
 // ---------------------------------------------------------------------------

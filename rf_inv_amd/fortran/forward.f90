@@ -24,19 +24,18 @@ module forward
   ! HIP device ordinal; a host that runs several MPI ranks per node sets it
   ! (e.g. rank modulo GPUs per node) before init_forward.
   integer, public :: rf_device = 0
+  ! the tables a context is created from (what init_forward copied out of module params)
+  integer(c_int32_t), allocatable, target, save, private :: ipha_c(:)
+  real(c_double), allocatable, target, save, private :: rayps_c(:), a_gus_c(:), obs_c(:,:)
 
-  public init_forward, calc_rf
+  public init_forward, calc_rf, rfgpu_new_context
 
 contains
 
   !---------------------------------------------------------------------
   subroutine init_forward(verb)
-    use params, only: nfft, ntrc, nsmp, deconv_mode, delta, t_start, sdep, &
-         & rayps, a_gus, ipha, obs, npts_max, nchains, k_max
+    use params, only: nfft, ntrc, rayps, a_gus, ipha, obs, npts_max, nchains
     logical, intent(in) :: verb
-    type(rf_config) :: cfg
-    integer(c_int32_t), allocatable, target, save :: ipha_c(:)
-    real(c_double), allocatable, target, save :: rayps_c(:), a_gus_c(:), obs_c(:,:)
     integer(c_int32_t) :: flag
     integer :: nh
 
@@ -46,23 +45,7 @@ contains
     a_gus_c = a_gus
     obs_c = obs
 
-    cfg%nfft = nfft
-    cfg%ntrc = ntrc
-    cfg%nsmp = nsmp
-    cfg%deconv_mode = deconv_mode
-    cfg%delta = delta
-    cfg%t_start = t_start
-    cfg%sdep = sdep
-    cfg%rayps = c_loc(rayps_c)
-    cfg%a_gus = c_loc(a_gus_c)
-    cfg%ipha = c_loc(ipha_c)
-    cfg%obs = c_loc(obs_c)
-    cfg%ldobs = npts_max
-    cfg%r_inv = c_null_ptr          ! library default; init_likelihood may override
-    cfg%max_walkers = nchains
-    cfg%nlay_max = k_max + 2        ! ocean + k_max - 1 interfaces + half-space
-    cfg%device = rf_device
-    call rfgpu_check(rf_ctx_create(cfg, rf_ctx), "rf_ctx_create")
+    call rfgpu_new_context(nchains, rf_ctx)
 
     nh = nfft / 2 + 1
     allocate(flt(nh, ntrc))
@@ -82,6 +65,34 @@ contains
        write(*,*)
     end if
   end subroutine init_forward
+
+  !---------------------------------------------------------------------
+  ! Another engine context on the same tables with room for max_walkers chains: a rank that evaluates the chains of
+  ! every rank sharing its GPU (pt_control_batched) needs one for all of them.  (After init_forward.)
+  subroutine rfgpu_new_context(max_walkers, ctx)
+    use params, only: nfft, ntrc, nsmp, deconv_mode, delta, t_start, sdep, npts_max, k_max
+    integer, intent(in) :: max_walkers
+    type(c_ptr), intent(out) :: ctx
+    type(rf_config) :: cfg
+
+    cfg%nfft = nfft
+    cfg%ntrc = ntrc
+    cfg%nsmp = nsmp
+    cfg%deconv_mode = deconv_mode
+    cfg%delta = delta
+    cfg%t_start = t_start
+    cfg%sdep = sdep
+    cfg%rayps = c_loc(rayps_c)
+    cfg%a_gus = c_loc(a_gus_c)
+    cfg%ipha = c_loc(ipha_c)
+    cfg%obs = c_loc(obs_c)
+    cfg%ldobs = npts_max
+    cfg%r_inv = c_null_ptr          ! library default; init_likelihood may override
+    cfg%max_walkers = max_walkers
+    cfg%nlay_max = k_max + 2        ! ocean + k_max - 1 interfaces + half-space
+    cfg%device = rf_device
+    call rfgpu_check(rf_ctx_create(cfg, ctx), "rf_ctx_create")
+  end subroutine rfgpu_new_context
 
   !---------------------------------------------------------------------
   ! n, ntrc and rayps are part of the reference's interface; like every call site of the

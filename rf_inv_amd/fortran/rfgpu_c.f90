@@ -74,6 +74,12 @@ module rfgpu_c
        integer(c_int32_t), intent(out) :: flag
      end function rf_get_is_ray_common
 
+     integer(c_int) function rf_get_r_inv(ctx, r_inv) bind(C, name="rf_get_r_inv")
+       import :: c_int, c_ptr, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: r_inv(*)
+     end function rf_get_r_inv
+
      integer(c_int) function rf_set_r_inv(ctx, r_inv) bind(C, name="rf_set_r_inv")
        import :: c_int, c_ptr, c_double
        type(c_ptr), value :: ctx
@@ -169,6 +175,10 @@ module rfgpu_c
        type(c_ptr), intent(out) :: ptr
      end function rf_host_alloc_shared
 
+     integer(c_int) function rf_release_gpu() bind(C, name="rf_release_gpu")
+       import :: c_int
+     end function rf_release_gpu
+
      integer(c_int) function rf_host_free_shared(ptr) bind(C, name="rf_host_free_shared")
        import :: c_int, c_ptr
        type(c_ptr), value :: ptr
@@ -212,6 +222,20 @@ module rfgpu_c
        type(c_ptr), value :: ctx
        type(rf_post_config), intent(in) :: cfg
      end function rf_post_create
+
+     integer(c_int) function rf_profile_enable(ctx, on) bind(C, name="rf_profile_enable")
+       import :: c_int, c_ptr, c_int32_t
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), value :: on
+     end function rf_profile_enable
+
+     integer(c_int) function rf_profile_read(ctx, ms, launches, reset) bind(C, name="rf_profile_read")
+       import :: c_int, c_ptr, c_int32_t, c_int64_t, c_double
+       type(c_ptr), value :: ctx
+       real(c_double), intent(out) :: ms(3)
+       integer(c_int64_t), intent(out) :: launches(4)
+       integer(c_int32_t), value :: reset
+     end function rf_profile_read
 
      integer(c_int) function rf_post_sets(ctx, nsets) bind(C, name="rf_post_sets")
        import :: c_int, c_ptr, c_int32_t
@@ -322,6 +346,7 @@ contains
   ! Print-finalize-stop, the reference's convention for fatal errors
   ! (e.g. /root/reference/src/likelihood.f90:206-210).
   subroutine rfgpu_check(ierr, where)
+    include "mpif.h"
     integer(c_int), intent(in) :: ierr
     character(*), intent(in) :: where
     character(kind=c_char), pointer :: msg(:)
@@ -338,7 +363,8 @@ contains
        end do
     end if
     write(0, *)
-    call mpi_finalize(ierr2)
+    ! (abort, not finalize: the other ranks may be waiting for this one in a barrier or a collective)
+    call mpi_abort(MPI_COMM_WORLD, 1, ierr2)
     stop
   end subroutine rfgpu_check
 

@@ -165,30 +165,35 @@ def test_fortran_batched_sampler_equals_reference_sampler(golden_dir, tmp_path):
 
 
 @pytest.mark.gpu
-def test_fortran_batched_sampler_two_mpi_ranks(golden_dir, tmp_path):
-    """Two MPI ranks (both on the one GPU of the test box): the cross-rank temperature exchange of
-    pt_control_batched (send/recv of (T, logL) and the returned temperature) against the
-    reference's pt_control, rank by rank."""
+@pytest.mark.parametrize("nranks", [2, 3])
+def test_fortran_batched_sampler_several_mpi_ranks(golden_dir, tmp_path, nranks):
+    """Several MPI ranks (all on the one GPU of the test box) against the reference's pt_control, rank by rank and
+    result file by result file: the cross-rank temperature exchange of pt_control_batched (mode 1, the default: every
+    rank launches for itself), and -- mode 3, rf_share_gpu -- the GPU group: the ranks write their proposals into
+    shared memory and the group's first rank evaluates the chains of all of them on one context, one launch per
+    pipeline segment (rf_host_alloc_shared, rf_post_sets).  Same trajectories, same files."""
     mpiexec = "/opt/conda/bin/mpiexec"
     if not os.path.exists(RFINV) or not os.path.exists(mpiexec):
         pytest.skip("drive_rfinv or mpiexec not available")
-    dumps = []
-    for mode in ("0", "1"):
+    dumps = {}
+    for mode in ("0", "1", "3"):
         work = tmp_path / f"mpi{mode}"
         shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
         os.makedirs(work / "rslt")
-        r = subprocess.run([mpiexec, "-np", "2", RFINV, "params.in", "40", "160", mode, "out"], cwd=work,
+        r = subprocess.run([mpiexec, "-np", str(nranks), RFINV, "params.in", "40", "160", mode, "out"], cwd=work,
                            env=dict(os.environ), capture_output=True, text=True, timeout=900)
         if r.returncode != 0 and ("hydra" in r.stderr.lower() or "unable" in r.stderr.lower()):
             pytest.skip("mpiexec cannot start processes here: " + r.stderr[-200:])
-        assert r.returncode == 0 and r.stdout.count("drive_rfinv: ok") == 2, r.stdout + r.stderr
-        dumps.append([open(work / f"rfinv_dump_{k}.txt").read() for k in (0, 1)])
-    assert dumps[0][0] == dumps[1][0] and dumps[0][1] == dumps[1][1]
-    for name in RESULT_FILES:       # output_results' mpi_reduce / mpi_gather over the two ranks' accumulators
-        assert open(tmp_path / "mpi0" / "rslt" / name).read() == open(tmp_path / "mpi1" / "rslt" / name).read(), name
-    assert dumps[0][0] != dumps[0][1]          # the two ranks run different chains (seed depends on rank)
+        assert r.returncode == 0 and r.stdout.count("drive_rfinv: ok") == nranks, r.stdout + r.stderr
+        assert ("GPU groups:" in r.stderr) == (mode == "3"), r.stderr
+        dumps[mode] = [open(work / f"rfinv_dump_{k}.txt").read() for k in range(nranks)]
+    for mode in ("1", "3"):
+        assert dumps[mode] == dumps["0"], mode
+        for name in RESULT_FILES:   # output_results' mpi_reduce / mpi_gather over the ranks' accumulators
+            assert open(tmp_path / "mpi0" / "rslt" / name).read() == open(tmp_path / f"mpi{mode}" / "rslt" / name).read(), (mode, name)
+    assert dumps["0"][0] != dumps["0"][1]      # the ranks run different chains (seed depends on rank)
     # temperatures moved between ranks at least once: rank 0 started with [1, tempered...]
-    t0 = [float(x) for x in dumps[0][0].split()[-5:]]
+    t0 = [float(x) for x in dumps["0"][0].split()[-5:]]
     assert len(t0) == 5 and all(x >= 1.0 for x in t0)
 
 

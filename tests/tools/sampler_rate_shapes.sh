@@ -34,6 +34,10 @@ for line in open(sys.argv[1]):
         ph = [float(x) for x in line.split()[-5:]]
         print("    rank 0, ms per iteration: propose %.3f  eval %.3f  accept+commit %.3f  record %.3f  swap %.3f"
               % tuple(1e3 * x / nit for x in ph))
+    if "group seconds" in line:
+        ph = [float(x) for x in line.split()[-6:]]
+        print("    rank 0, within eval, ms per iteration: wait for the GPU %.3f  barrier after it %.3f  barrier before the engine calls %.3f  commit %.3f  record %.3f  begin %.3f"
+              % tuple(1e3 * x / nit for x in ph))
 PY
   rm -rf $W
 done
