@@ -57,24 +57,31 @@ __global__ __launch_bounds__(1024) void post_select_kernel(int n, const double *
     }
 }
 
-// (2) one thread per recorded model: counters (:208-231) and the model's depth-profile row
-// (the layer walk of :243-270, values only; the accumulation happens in post_accum_kernel).
-__global__ __launch_bounds__(128) void post_rows_kernel(PostConfig c, PostState st, PostBatch b)
+// (2) one WAVE per recorded model: counters (:208-231) and the model's depth-profile row (the layer walk of :243-270,
+// values only; the accumulation happens in post_accum_kernel).  Lanes own depth bins: each walks the layers with the
+// reference's running depth (the same sequence of additions) and keeps the LAST layer that covers its bin -- what the
+// reference's in-order overwrites leave.  (Until round 4 one thread per model wrote its row bin by bin: 180 us a call.)
+constexpr int PR_WAVES = 4;
+
+__global__ __launch_bounds__(64 * PR_WAVES) void post_rows_kernel(PostConfig c, PostState st, PostBatch b)
 {
 #pragma clang fp contract(off)
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * PR_WAVES + (threadIdx.x >> 6);
     if (j >= *st.nsel) return;
     const int i = st.sel[j];
     const long long imod = (long long)st.nmod[1] + j;           // 0-based nmod of this model
-    if (imod < c.max_models) st.all_likelihood[imod] = b.logl[i];   // :210
     const int k = b.k[i];
-    atomicAdd(&st.nk[clamp_bin(k, c.k_max) - 1], 1);                  // :213
-    for (int t = 0; t < c.ntrc; ++t)                                  // :216-223
+    if (lane == 0) {
+        if (imod < c.max_models) st.all_likelihood[imod] = b.logl[i];   // :210
+        atomicAdd(&st.nk[clamp_bin(k, c.k_max) - 1], 1);                  // :213
+    }
+    for (int t = lane; t < c.ntrc; t += 64)                           // :216-223
         if (c.sig_mode[t] == 1) {
             const int ibin = f_int((b.sig[(size_t)i * c.ntrc + t] - c.sig_min[t]) / c.dbin_sig[t]) + 1;
             atomicAdd(&st.nsig[(size_t)t * c.nbin_sig + clamp_bin(ibin, c.nbin_sig) - 1], 1);
         }
-    for (int il = 0; il < k - 1; ++il) {                              // :226-229
+    for (int il = lane; il < k - 1; il += 64) {                       // :226-229
         const int ibin = f_int((b.z[(size_t)i * (c.k_max - 1) + il] - c.z_min) / c.dbin_z) + 1;
         atomicAdd(&st.nz[clamp_bin(ibin, c.nbin_z) - 1], 1);
     }
@@ -82,21 +89,34 @@ __global__ __launch_bounds__(128) void post_rows_kernel(PostConfig c, PostState 
     const int nl = b.nlay[i];
     const double *A = b.layers + (size_t)i * 4 * b.nlay_pad, *B = A + b.nlay_pad, *H = A + 3 * (size_t)b.nlay_pad;
     double *ra = st.row_a + (size_t)j * c.nbin_z, *rb = st.row_b + (size_t)j * c.nbin_z;
-    for (int iz = 0; iz < c.nbin_z; ++iz) ra[iz] = __builtin_nan("");   // not covered
-    double tmpz = 0.0;
-    for (int il = 0; il < nl; ++il) {
-        const int iz1 = f_int(tmpz / c.dbin_z) + 1;
-        const int iz2 = il < nl - 1 ? f_int((tmpz + H[il]) / c.dbin_z) + 1 : c.nbin_z + 1;
-        const int lo = iz1 < 1 ? 1 : iz1, hi = iz2 - 1 > c.nbin_z ? c.nbin_z : iz2 - 1;
-        for (int iz = lo; iz <= hi; ++iz) {
-            ra[iz - 1] = A[il];
-            rb[iz - 1] = B[il];
+    for (int iz0 = 0; iz0 < c.nbin_z; iz0 += 64) {
+        const int iz = iz0 + lane + 1;                               // 1-based depth bin of this lane
+        double va = __builtin_nan(""), vb = 0.0;                     // not covered
+        double tmpz = 0.0;
+        for (int il = 0; il < nl; ++il) {
+            const double h = H[il];
+            const int iz1 = f_int(tmpz / c.dbin_z) + 1;
+            const int iz2 = il < nl - 1 ? f_int((tmpz + h) / c.dbin_z) + 1 : c.nbin_z + 1;
+            const int lo = iz1 < 1 ? 1 : iz1, hi = iz2 - 1 > c.nbin_z ? c.nbin_z : iz2 - 1;
+            if (iz >= lo && iz <= hi) {
+                va = A[il];
+                vb = B[il];
+            }
+            tmpz = tmpz + h;
         }
-        tmpz = tmpz + H[il];
+        if (iz <= c.nbin_z) {
+            ra[iz - 1] = va;
+            if (va == va) rb[iz - 1] = vb;
+        }
     }
 }
 
-// (3) one thread per depth bin walks the batch in chain order (:243-270 accumulation part)
+// (3) one thread per depth bin walks the batch in chain order (:243-270 accumulation part).  The rows of PA_AHEAD
+// models are requested together (the loop was a chain of one load's latency per model), the histogram cells take
+// atomics without a return value (integer counts commute; nothing waits for them), the three running sums and the
+// ocean-layer assignments stay strictly in chain order.
+constexpr int PA_AHEAD = 8;
+
 __global__ __launch_bounds__(64) void post_accum_kernel(PostConfig c, PostState st)
 {
 #pragma clang fp contract(off)
@@ -105,33 +125,45 @@ __global__ __launch_bounds__(64) void post_accum_kernel(PostConfig c, PostState 
     const int nsel = *st.nsel;
     const long long base = st.nmod[1];
     double vp_mean = st.vp_mean[iz], vs_mean = st.vs_mean[iz], vpvs_mean = st.vpvs_mean[iz];
-    for (int j = 0; j < nsel; ++j) {
-        const double a = st.row_a[(size_t)j * c.nbin_z + iz];
-        if (a != a) continue;
-        const double bt = st.row_b[(size_t)j * c.nbin_z + iz];
-        const int ivp = clamp_bin(f_int((a - c.vp_min) / c.dbin_vp) + 1, c.nbin_vp);
-        int ivs = f_int((bt - c.vs_min) / c.dbin_vs) + 1;
-        ivs = clamp_bin(ivs, c.nbin_vs);                     // max(1, ivs) :253 (+ upper edge)
-        int ivpvs = f_int(((a / bt) - c.vpvs_min) / c.dbin_vpvs) + 1;
-        ivpvs = clamp_bin(ivpvs, c.nbin_vpvs);               // :255-256
-        st.nvpz[(size_t)(ivp - 1) * c.nbin_z + iz] += 1;
-        st.nvsz[(size_t)(ivs - 1) * c.nbin_z + iz] += 1;
-        st.nvpvsz[(size_t)(ivpvs - 1) * c.nbin_z + iz] += 1;
-        vp_mean = vp_mean + a;
-        double vs_row;
-        if (bt > 0.0) {
-            vpvs_mean = vpvs_mean + a / bt;
-            vs_mean = vs_mean + bt;
-            vs_row = bt;
-        } else {                                             // ocean layer: assignments (:263-264)
-            vpvs_mean = c.vpvs_min;
-            vs_mean = c.vs_min;
-            vs_row = c.vs_min;
+    for (int j0 = 0; j0 < nsel; j0 += PA_AHEAD) {
+        double av[PA_AHEAD], bv[PA_AHEAD];
+#pragma unroll
+        for (int u = 0; u < PA_AHEAD; ++u) {
+            const int j = j0 + u < nsel ? j0 + u : nsel - 1;
+            av[u] = st.row_a[(size_t)j * c.nbin_z + iz];
+            bv[u] = st.row_b[(size_t)j * c.nbin_z + iz];     // (never read where the bin is not covered)
         }
-        const long long imod = base + j;
-        if (imod < c.max_models) {
-            st.vp_model[(size_t)imod * c.nbin_z + iz] = a;
-            st.vs_model[(size_t)imod * c.nbin_z + iz] = vs_row;
+#pragma unroll
+        for (int u = 0; u < PA_AHEAD; ++u) {
+            const int j = j0 + u;
+            if (j >= nsel) break;
+            const double a = av[u];
+            if (a != a) continue;
+            const double bt = bv[u];
+            const int ivp = clamp_bin(f_int((a - c.vp_min) / c.dbin_vp) + 1, c.nbin_vp);
+            int ivs = f_int((bt - c.vs_min) / c.dbin_vs) + 1;
+            ivs = clamp_bin(ivs, c.nbin_vs);                     // max(1, ivs) :253 (+ upper edge)
+            int ivpvs = f_int(((a / bt) - c.vpvs_min) / c.dbin_vpvs) + 1;
+            ivpvs = clamp_bin(ivpvs, c.nbin_vpvs);               // :255-256
+            atomicAdd(&st.nvpz[(size_t)(ivp - 1) * c.nbin_z + iz], 1);
+            atomicAdd(&st.nvsz[(size_t)(ivs - 1) * c.nbin_z + iz], 1);
+            atomicAdd(&st.nvpvsz[(size_t)(ivpvs - 1) * c.nbin_z + iz], 1);
+            vp_mean = vp_mean + a;
+            double vs_row;
+            if (bt > 0.0) {
+                vpvs_mean = vpvs_mean + a / bt;
+                vs_mean = vs_mean + bt;
+                vs_row = bt;
+            } else {                                             // ocean layer: assignments (:263-264)
+                vpvs_mean = c.vpvs_min;
+                vs_mean = c.vs_min;
+                vs_row = c.vs_min;
+            }
+            const long long imod = base + j;
+            if (imod < c.max_models) {
+                st.vp_model[(size_t)imod * c.nbin_z + iz] = a;
+                st.vs_model[(size_t)imod * c.nbin_z + iz] = vs_row;
+            }
         }
     }
     st.vp_mean[iz] = vp_mean;
@@ -188,7 +220,7 @@ void launch_post_record(const PostConfig &c, const PostState &st, const PostBatc
                         hipStream_t s)
 {
     hipLaunchKernelGGL(post_select_kernel, dim3(1), dim3(1024), 0, s, b.n, b.temps, st);
-    hipLaunchKernelGGL(post_rows_kernel, dim3((unsigned)((b.n + 127) / 128)), dim3(128), 0, s, c, st, b);
+    hipLaunchKernelGGL(post_rows_kernel, dim3((unsigned)((b.n + PR_WAVES - 1) / PR_WAVES)), dim3(64 * PR_WAVES), 0, s, c, st, b);
     hipLaunchKernelGGL(post_accum_kernel, dim3((unsigned)((c.nbin_z + 63) / 64)), dim3(64), 0, s, c, st);
     hipLaunchKernelGGL(post_amp_kernel, dim3((unsigned)(b.n * c.ntrc)), dim3(128), 0, s, c, st, b, w);
     hipLaunchKernelGGL(post_finish_kernel, dim3(1), dim3(1), 0, s, st);
