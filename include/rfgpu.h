@@ -345,8 +345,10 @@ int rf_post_select(rf_ctx *ctx, int32_t set);
  * current state.  temps (may be NULL) applies the reference's filter temp <= 1 + 1e-6 (:204)
  * on the device: chains above it are skipped.  The caller applies the iteration filter
  * (iter > nburn, mod(iter, ncorr) == 0).  _device: all pointers are device pointers and the
- * call is asynchronous on `stream`; the host variant copies its arrays before it returns (they may be changed at once)
- * and, like rf_commit, does not wait for the device: stream-ordered between the calls issued before and after it.
+ * call is asynchronous on `stream`; the host variant copies pageable arrays before it returns (they may be changed at
+ * once; arrays in PINNED memory -- rf_host_alloc, rf_host_alloc_shared -- are read by DMA in place after it returns:
+ * leave them alone until a later call on the context has waited for work issued after it, e.g. rf_eval_wait) and, like
+ * rf_commit, does not wait for the device: stream-ordered between the calls issued before and after it.
  * Departures (the reference has undefined behaviour there): histogram indices outside an
  * array are clamped to its edge bins; models beyond max_models are counted but their
  * profile rows are dropped.  Amplitudes outside [amp_min, amp_max) go to the edge bins as in

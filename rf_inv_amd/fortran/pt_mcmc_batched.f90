@@ -62,7 +62,7 @@ module pt_mcmc_batched
   ! random stream, state and posterior accumulators: same trajectories, same result files).  .false. (default): every
   ! rank launches for itself.  Measured (profiles/r04_sampler_rate_shapes.txt): the group loses -- one stream runs a
   ! segment's copies, format_model, stage and commit kernels one after the other, where independent ranks' streams
-  ! overlap them with each other's main kernels (C4 shape, 4 ranks: 4.5 M against 4.7 M steps/s; C3: 10.6 M against 13.1 M).
+  ! overlap them with each other's main kernels (C4 shape, 4 ranks: 4.5 M against 4.8 M steps/s; C3: 12.0 M against 13.7 M).
   logical, public :: rf_share_gpu = .false.
 
   ! .true.: HIP-event times of the loop's kernels (rf_profile_enable on the evaluating context): totals in
