@@ -48,9 +48,11 @@ module pt_mcmc_batched
   ! ... and, within phase 2, of a GPU group's steps on this rank: 1 rf_eval_wait (first rank), 2 the barrier after it,
   ! 3 the barrier before the engine calls, 4 / 5 / 6 the engine calls: rf_commit, rf_post_record, rf_eval_models_begin (first rank)
   real(8), public :: rf_group_seconds(6) = 0.d0
-  ! 2 (default): the chains of a rank are worked in two halves, one being evaluated on the GPU while the host judges and
-  ! re-proposes the other (same trajectory: see the loop); 1: propose all, evaluate all, judge all
-  integer, public :: rf_pipeline_segments = 2
+  ! 2: the chains of a rank are worked in two halves, one being evaluated on the GPU while the host judges and
+  ! re-proposes the other (same trajectory: see the loop); 1: propose all, evaluate all, judge all; 0 (default): 2 when
+  ! a half is at least 1024 chains, else 1 -- below that two small launches per iteration cost the GPU more than the
+  ! overlap returns (8 ranks x 1024 chains on one GPU, C4 shape: 4.9 M steps/s with 1 segment against 4.0 M with 2)
+  integer, public :: rf_pipeline_segments = 0
   ! .true. (default): the engine keeps only samples 1 .. nsmp of every trace while this loop runs (rf_set_option
   ! "trace_window") -- all the likelihood and the amplitude histograms read (src/likelihood.f90:88,
   ! src/pt_mcmc.f90:273-274); the trace kernels write nfft / nsmp times less and the resident traces shrink as much.
@@ -150,7 +152,9 @@ contains
     n_all = nproc * nchains
     n_tot_iter = nburn + niter
     t_cold = 1.d0 + 1.0e-6
-    nseg = max(1, min(rf_pipeline_segments, 2, nchains))
+    nseg = rf_pipeline_segments
+    if (nseg <= 0) nseg = merge(2, 1, nchains >= 2048)
+    nseg = max(1, min(nseg, 2, nchains))
     do i = 1, nseg
        seg_lo(i) = (i - 1) * nchains / nseg + 1
        seg_hi(i) = i * nchains / nseg

@@ -5,7 +5,8 @@
 # one rank's proposal loop on the host overlaps another rank's kernels).
 #   usage: tests/tools/sampler_rate_shapes.sh <c3|c4|c4w20> <total chains> <iterations> ["1 2 4"] [driver mode]
 #          driver mode 1: pt_control_batched with its two-segment pipeline (default); 2: without it; 3: mode 1 with GPU
-#          groups (rf_share_gpu: the first rank of a GPU evaluates the chains of all its ranks); 0: the reference's own
+#          groups (rf_share_gpu: the first rank of a GPU evaluates the chains of all its ranks); 4: one or two segments by
+#          the chain count (pt_control_batched's default); 0: the reference's own
 #          pt_control on the per-call drop-in.  RFINV_TIME_KERNELS=1: HIP-event kernel totals of the loop are printed too
 # The driver times its own loop (mpi_wtime around pt_control*, barriers on both sides); a short warm-up run comes
 # first so that the timed one does not pay the image's first page-in.  (ref: the loop timed is src/pt_mcmc.f90:488-571)
