@@ -23,7 +23,9 @@ Workloads (BASELINE.json configs):
 
 At N = 1 the default run also measures c2, c2d, c3, c5 (BASELINE's 32768 walkers/GPU), c4common, c4w20 and c4w60
 briefly into "also", plus the c4 shape with walker depths that change every step (`--perturb-nlay`: the dispatch order the
-previous launch prepared is then one proposal stale, as in a real chain).
+previous launch prepared is then one proposal stale, as in a real chain).  `c4host` (any `<name>host`): the c4 walkers
+handed over every step as (k, z, dVp, dVs, sigma) in pinned HOST arrays through rf_eval_models + rf_commit -- the boundary
+the batched sampler uses, PCIe included; reported in "also", never as the headline.
 
 `--gpus N` without a launcher (WORLD_SIZE unset) starts N rank processes itself -- before anything touches a GPU,
 one per device, rendezvous on 127.0.0.1 -- relays rank 0's JSON line and exits non-zero if any rank fails or
@@ -127,7 +129,7 @@ def make_params(w):
     return p
 
 
-def draw_walkers(p, ref, first_id, count, seed=12345678):
+def draw_walkers(p, ref, first_id, count, seed=12345678, return_models=False):
     """Walker models from the init_model prior (reference src/model.f90:66-95) conditioned on
     validity, with k uniform in [k_min, k_max), from a counter-based RNG
     keyed by seed + global walker id.  init_model rejects whole models, which makes deep
@@ -140,6 +142,8 @@ def draw_walkers(p, ref, first_id, count, seed=12345678):
     pad = p.k_max + 2
     layers = np.ones((count, 4, pad))
     nlay = np.zeros(count, dtype=np.int32)
+    m_k = np.zeros(count, dtype=np.int32)
+    m_z, m_dvp, m_dvs = np.zeros((count, p.k_max)), np.zeros((count, p.k_max)), np.zeros((count, p.k_max))
     vs0, vp0 = float(ref.vs_ref[0]), float(ref.vp_ref[0])
     assert np.all(ref.vs_ref == vs0) and np.all(ref.vp_ref == vp0) and p.vp_mode == 0
 
@@ -166,7 +170,69 @@ def draw_walkers(p, ref, first_id, count, seed=12345678):
         assert ok
         nlay[i] = nl
         layers[i, 0, :nl], layers[i, 1, :nl], layers[i, 2, :nl], layers[i, 3, :nl] = a, b, r, h
+        m_k[i] = k
+        m_z[i, :z.size], m_dvp[i], m_dvs[i] = z, dvp, dvs
+    if return_models:
+        return nlay, layers, (m_k, m_z, m_dvp, m_dvs)
     return nlay, layers
+
+
+def run_host_boundary(workload, steps, device):
+    """The boundary as the batched sampler uses it (rf_eval_models + rf_commit, include/rfgpu.h): the same walkers as
+    `workload`, handed over as (k, z, dVp, dVs, sigma) in PINNED host arrays every step -- H2D by DMA, format_model on the
+    device, the kernels of the resident path, logL back into host memory -- i.e. the PCIe-inclusive rate (DESIGN.md
+    section 6).  No temperature swap: a host that hands models over owns the temperatures.  Never the headline."""
+    import time
+
+    import torch
+
+    from rf_inv_amd import RFEngine, format_model, read_ref_model
+    from rf_inv_amd.engine import host_alloc
+    from rf_inv_amd.likelihood import init_r_inv
+
+    w = dict(WORKLOADS[workload])
+    p = make_params(w)
+    ref = read_ref_model(os.path.join(ROOT, "tests", "golden", "sample_syn", "model", "sample.velmod"))
+    nb = w["walkers"]
+    nlay, layers, (m_k, m_z, m_dvp, m_dvs) = draw_walkers(p, ref, 0, nb, return_models=True)
+    sig = np.full((nb, p.ntrc), 0.01)
+    r_inv = init_r_inv(p.nsmp, p.a_gus, p.delta)
+    zt = np.zeros(max(p.k_max - 1, 1)); dvt = np.zeros(p.k_max); dst = np.zeros(p.k_max)
+    zt[:3] = [3.1 + p.sdep, 7.7 + p.sdep, 14.2 + p.sdep]; dst[:3] = [-0.6, 0.2, 0.5]; dst[p.k_max - 1] = 0.9
+    nl_t, a_t, b_t, r_t, h_t, ok = format_model(p, ref, 3, zt, dvt, dst)
+    kw = dict(nfft=p.nfft, delta=p.delta, t_start=p.t_start, deconv_mode=p.deconv_mode, sdep=p.sdep, rayps=p.rayps,
+              a_gus=p.a_gus, ipha=p.ipha, nsmp=p.nsmp, nlay_max=p.k_max + 2, device=device)
+    with RFEngine(obs=np.zeros((p.ntrc, p.nsmp)), r_inv=r_inv, max_walkers=1, **kw) as e0:
+        obs = np.ascontiguousarray(e0.calc_rf(nl_t, a_t, b_t, r_t, h_t)[:p.nsmp].T)
+
+    def pin(a):
+        b = host_alloc(a.shape, a.dtype)
+        b[...] = a
+        return b
+
+    with RFEngine(obs=obs, r_inv=r_inv, max_walkers=nb, **kw) as eng:
+        eng.set_model(p, ref)
+        ids, k, z, dvp, dvs, sg = (pin(a) for a in (np.arange(nb, dtype=np.int32), m_k, m_z, m_dvp, m_dvs, sig))
+        acc = np.zeros(nb, dtype=np.int32)
+        acc[::2] = 1
+        want = eng.eval_batch(np.arange(nb), nlay, layers, sig)            # the resident path's values on these walkers
+        for _ in range(5):
+            ll = eng.eval_models(ids, k, z, dvp, dvs, sg)
+            eng.commit(ids, acc)
+        assert eng.launch_plan["staged_host_arrays"] == 0
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            ll = eng.eval_models(ids, k, z, dvp, dvs, sg)
+            eng.commit(ids, acc)
+        dt = time.perf_counter() - t0
+        bytes_in = ids.nbytes + k.nbytes + z.nbytes + dvs.nbytes + sg.nbytes + (dvp.nbytes if p.vp_mode == 1 else 0)
+        return {"value": nb * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                "config": {"workload": w["desc"].replace(", PT swap on the device", "").replace(", PT swap", "") + " -- handed over every step as (k, z, dVp, dVs, sigma) in pinned HOST arrays "
+                           "(rf_eval_models + rf_commit): DMA, format_model on the device, logL into host memory; no swap",
+                           "walkers_per_gpu": nb, "host_bytes_in_per_step": int(bytes_in), "host_bytes_out_per_step": 8 * nb,
+                           "pcie_inclusive": True},
+                "same_logl_as_the_resident_path": bool(np.array_equal(ll, want))}
 
 
 def alg_work(p, nlay, common):
@@ -438,7 +504,8 @@ def main():
                          "reference's one pair per iteration via send/recv")
     ap.add_argument("--also", default=None,
                     help="comma list of extra workloads measured briefly into 'also' (default at N = 1: "
-                         "c2,c2d,c3,c5,c4common,c4w20,c4w60,c4stale; '' for none)")
+                         "c2,c2d,c3,c5,c4common,c4w20,c4w60,c4win,c5win,c4stale,c4host; '' for none; <name>host = that workload "
+                         "handed over from pinned host arrays every step, the PCIe-inclusive boundary)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
                     help="untimed steps run for at least this long before --warmup (clock ramp; independent of --warmup)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
@@ -866,11 +933,15 @@ def main():
         return res
 
     main_res = run(args.workload, args.steps, args.warmup, not args.no_cpu_baseline and world == 1)
-    also_list = args.also if args.also is not None else ("c2,c2d,c3,c5,c4common,c4w20,c4w60,c4win,c5win,c4stale" if world == 1 else "")
+    also_list = args.also if args.also is not None else ("c2,c2d,c3,c5,c4common,c4w20,c4w60,c4win,c5win,c4stale,c4host" if world == 1 else "")
     also = {}
     keep = ("value", "ms_per_step", "ms_per_step_median", "steps", "config", "roofline", "kernel_ms", "parity_in_bench",
             "quadratic_form_gemm")
     for wl in [x for x in also_list.split(",") if x and x != args.workload]:
+        if wl.endswith("host"):
+            # the PCIe-inclusive boundary of the batched sampler (never the headline)
+            also[wl] = run_host_boundary(wl[:-4], max(20, min(200, args.steps)), local_rank)
+            continue
         if wl == "c4stale":
             # the c4 shape with 30 % of the walkers changing depth every step: the order the previous launch
             # prepared is one proposal stale (order_reuse, the default), against a fresh order_kernel per launch
