@@ -26,7 +26,7 @@
 !=======================================================================
 module rf_model_check
   implicit none
-  public proposal_is_valid
+  public proposal_is_valid, velocity_move_is_valid
   private
 
 contains
@@ -90,5 +90,73 @@ contains
     end do
     ok = .true.
   end function proposal_is_valid
+
+  !---------------------------------------------------------------------
+  ! The verdict for a proposal that changes ONE velocity perturbation (dVs or dVp of slot `pick`: an interface
+  ! 1 .. prop_k, or k_max = the half-space) of a model that is VALID without the change -- a chain's current model
+  ! always is.  format_model's rules are per layer (src/model.f90:219-231, :248-260, :276-281) and every other
+  ! layer keeps its depth, thickness and velocities, so only the layer that owns the slot is examined: its place in
+  ! depth order and the interface above it come from one pass over the depths -- no sort, no other layer's
+  ! look-ups.  Same expressions, in the same operand order, as proposal_is_valid for that layer.  (With h_min <= 0,
+  ! where two interfaces may coincide and the reference's unstable sort decides which perturbation belongs to which
+  ! layer, the full check is used.)
+  logical function velocity_move_is_valid(prop_k, prop_z, prop_dvp, prop_dvs, pick) result(ok)
+    use params, only: k_max, sdep, z_max, h_min, vp_mode, vp_min, vp_max, vs_min, vs_max, vpvs_min, vpvs_max
+    use model, only: vp_ref, vs_ref, z_ref_min, dz_ref
+    integer, intent(in) :: prop_k, pick
+    real(8), intent(in) :: prop_z(k_max-1), prop_dvp(k_max), prop_dvs(k_max)
+    integer :: i, iz
+    logical :: top
+    real(8) :: zj, zprev, zc, a, b
+
+    if (.not. (h_min > 0.d0)) then
+       ok = proposal_is_valid(prop_k, prop_z, prop_dvp, prop_dvs)
+       return
+    end if
+    ok = .false.
+    zprev = sdep
+    top = .true.
+    if (pick <= prop_k) then
+       ! the interface just above this one (the deepest of the shallower ones), or the surface / sea floor
+       zj = prop_z(pick)
+       do i = 1, prop_k
+          if (prop_z(i) < zj) then
+             if (top) then
+                zprev = prop_z(i)
+                top = .false.
+             else
+                zprev = max(zprev, prop_z(i))
+             end if
+          end if
+       end do
+       zc = 0.5d0 * (zj + zprev)
+    else
+       ! the half-space: below the deepest interface
+       do i = 1, prop_k
+          if (top) then
+             zprev = prop_z(i)
+             top = .false.
+          else
+             zprev = max(zprev, prop_z(i))
+          end if
+       end do
+       zj = z_max
+       zc = 0.5d0 * (z_max + zprev)
+       top = .false.
+    end if
+    iz = nint((zc - z_ref_min) / dz_ref) + 1
+    b = vs_ref(iz) + prop_dvs(pick)
+    if (vp_mode == 1) then
+       a = vp_ref(iz) + prop_dvp(pick)
+    else
+       a = vp_ref(iz)
+    end if
+    if (a < vp_min .or. a > vp_max .or. b < vs_min .or. b > vs_max .or. &
+         & a / b < vpvs_min .or. a / b > vpvs_max) return
+    if (top) then
+       if (zj - sdep < 0.125 * a) return        ! :229: the top layer's thickness rule depends on its velocity
+    end if
+    ok = .true.
+  end function velocity_move_is_valid
 
 end module rf_model_check

@@ -90,7 +90,7 @@ contains
     use model
     use likelihood, only: sig, log_likelihood
     use forward, only: rf_ctx, rfgpu_new_context
-    use rf_model_check, only: proposal_is_valid
+    use rf_model_check, only: proposal_is_valid, velocity_move_is_valid
     use pt_mcmc
     include "mpif.h"
     logical, intent(in) :: verb
@@ -687,8 +687,18 @@ contains
       end if
 
       ! only format_model's VERDICT is needed here (the engine formats the model itself, bit for bit the same):
-      ! rf_model_check gives it without the sort of three arrays, the densities and the five output arrays
-      if (live) live = proposal_is_valid(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs)
+      ! rf_model_check gives it without the sort of three arrays, the densities and the five output arrays -- and,
+      ! the chain's current model being valid, a noise-level move needs no look at the model at all (it is unchanged)
+      ! and a velocity move a look at the one layer it changes
+      if (live) then
+         if (itype == itype_sig) then
+            continue
+         else if (itype == itype_dvs .or. itype == itype_dvp) then
+            live = velocity_move_is_valid(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs, pick)
+         else
+            live = proposal_is_valid(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs)
+         end if
+      end if
       ck(jc) = cand_k
     end subroutine draw_candidate
 

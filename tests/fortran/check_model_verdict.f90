@@ -16,9 +16,9 @@ program check_model_verdict
   use rf_model_check
   implicit none
   character(clen_max) :: param_file, arg
-  integer :: n, i, kk, j, kind_, nvalid, nbad, nlay, pick
+  integer :: n, i, kk, j, kind_, nvalid, nbad, nlay, pick, nmove
   logical :: ok_ref, ok_new
-  real(8) :: pz(200), pvp(200), pvs(200), alpha(nlay_max), beta(nlay_max), rho(nlay_max), h(nlay_max), u
+  real(8) :: pz(200), pvp(200), pvs(200), alpha(nlay_max), beta(nlay_max), rho(nlay_max), h(nlay_max), u, v
 
   param_file = "params.in"
   n = 1000000
@@ -81,4 +81,60 @@ program check_model_verdict
      end if
   end do
   write(*,'(A,I0,A,I0,A,I0,A)') " check_model_verdict: ", n, " proposals, ", nvalid, " valid, ", nbad, " mismatches"
+
+  ! ---- velocity_move_is_valid: a VALID model + a change of one velocity perturbation (what a dVs / dVp move of the
+  ! sampler is), against the reference's format_model on the changed model.  Moves: the sampler's small steps, steps
+  ! that land exactly on / one ulp beyond a velocity limit, large ones (ratio rules), the half-space slot, the top
+  ! layer (whose thickness rule depends on its velocity when vp_mode = 1).
+  nvalid = 0
+  nbad = 0
+  nmove = 0
+  do i = 1, n
+     pz = 0.d0; pvp = 0.d0; pvs = 0.d0
+     kk = k_min + int(grnd() * (k_max - k_min))
+     do j = 1, kk
+        pz(j) = z_min + grnd() * (z_max - z_min)
+        pvs(j) = gauss() * dvs_prior * 0.2d0
+        pvp(j) = gauss() * dvp_prior * 0.2d0
+     end do
+     pvs(k_max) = gauss() * dvs_prior * 0.2d0
+     pvp(k_max) = gauss() * dvp_prior * 0.2d0
+     call format_model(kk, pz(1:k_max-1), pvp(1:k_max), pvs(1:k_max), nlay, alpha, beta, rho, h, ok_ref)
+     if (.not. ok_ref) cycle                      ! the chain's current model is always valid
+     do j = 1, 4
+        pick = 1 + int(grnd() * (kk + 1))
+        if (pick == kk + 1) pick = k_max
+        u = pvs(pick)
+        v = pvp(pick)
+        select case (mod(i + j, 6))
+        case (0)
+           pvs(pick) = pvs(pick) + gauss() * dev_dvs
+        case (1)
+           pvp(pick) = pvp(pick) + gauss() * dev_dvp
+        case (2)
+           pvs(pick) = pvs(pick) + gauss() * 1.5d0
+        case (3)
+           pvp(pick) = pvp(pick) + gauss() * 1.0d0
+        case (4)                                  ! exactly at / one ulp beyond a limit of Vs
+           pvs(pick) = merge(vs_max, vs_min, mod(i, 2) == 0) - vs_ref(1)
+           if (mod(i / 2, 3) == 1) pvs(pick) = nearest(pvs(pick), 1.d0)
+           if (mod(i / 2, 3) == 2) pvs(pick) = nearest(pvs(pick), -1.d0)
+        case default                              ! the Vp / Vs ratio at its limits
+           pvs(pick) = vp_ref(1) / merge(vpvs_max, vpvs_min, mod(i, 2) == 0) - vs_ref(1)
+           if (mod(i / 2, 3) == 1) pvs(pick) = nearest(pvs(pick), 1.d0)
+           if (mod(i / 2, 3) == 2) pvs(pick) = nearest(pvs(pick), -1.d0)
+        end select
+        call format_model(kk, pz(1:k_max-1), pvp(1:k_max), pvs(1:k_max), nlay, alpha, beta, rho, h, ok_ref)
+        ok_new = velocity_move_is_valid(kk, pz(1:k_max-1), pvp(1:k_max), pvs(1:k_max), pick)
+        nmove = nmove + 1
+        if (ok_ref) nvalid = nvalid + 1
+        if (ok_ref .neqv. ok_new) then
+           nbad = nbad + 1
+           if (nbad <= 5) write(*,*) "MOVE MISMATCH k", kk, " pick", pick, " reference", ok_ref, " ours", ok_new
+        end if
+        pvs(pick) = u                             ! back to the valid model
+        pvp(pick) = v
+     end do
+  end do
+  write(*,'(A,I0,A,I0,A,I0,A)') " check_model_verdict: ", nmove, " velocity moves, ", nvalid, " valid, ", nbad, " mismatches"
 end program check_model_verdict

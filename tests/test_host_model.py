@@ -222,13 +222,15 @@ def test_make_syn_file_names_are_the_ones_the_reference_creates(tmp_path):
     assert _names(3, True) == ("test_trace.03", "test_trace.03wn")
 
 
-@pytest.mark.parametrize("shape", ["sample_syn", "c4"])
+@pytest.mark.parametrize("shape", ["sample_syn", "c4", "c4vp"])
 def test_fast_validity_verdict_equals_the_reference_format_model(tmp_path, shape):
-    """rf_inv_amd/fortran/model_check.f90::proposal_is_valid -- what pt_control_batched asks instead of calling the
-    reference's format_model for its verdict alone (the random stream depends on it) -- against that very routine
-    (src/model.f90:175-290, compiled unmodified): 600 000 proposals of eight kinds (the sampler's own, exact ties of two
-    depths, thicknesses at and one ulp around h_min and the 0.125 alpha rule, velocities at their limits, depths at the
-    ends of the range, large perturbations), ocean / land, k_max 10 / 30: not one verdict differs."""
+    """rf_inv_amd/fortran/model_check.f90 -- what pt_control_batched asks instead of calling the reference's
+    format_model for its verdict alone (the random stream depends on it) -- against that very routine
+    (src/model.f90:175-290, compiled unmodified).  proposal_is_valid: 600 000 proposals of eight kinds (the sampler's
+    own, exact ties of two depths, thicknesses at and one ulp around h_min and the 0.125 alpha rule, velocities at
+    their limits, depths at the ends of the range, large perturbations); velocity_move_is_valid (one layer examined):
+    valid models + a change of one dVs / dVp (small, large, exactly at and one ulp beyond the Vs and Vp/Vs limits, the
+    half-space slot, the top layer).  Ocean / land, k_max 10 / 30, Vp fixed / solved for (c4vp): not one verdict differs."""
     import shutil
     import subprocess
 
@@ -242,9 +244,17 @@ def test_fast_validity_verdict_equals_the_reference_format_model(tmp_path, shape
     else:
         subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "shape_run.py"), "c4", "16", str(work)], check=True,
                        capture_output=True, timeout=300)
-    r = subprocess.run([exe, "params.in", "600000"], cwd=work, capture_output=True, text=True, timeout=600)
+        if shape == "c4vp":                    # vp_mode 1: the line after the velocity file's name
+            lines = open(work / "params.in").read().splitlines()
+            at = [i for i, x in enumerate(lines) if "sample.velmod" in x][0]
+            assert lines[at + 1].strip() == "0"
+            lines[at + 1] = "1"
+            open(work / "params.in", "w").write("\n".join(lines) + "\n")
+    r = subprocess.run([exe, "params.in", "600000"], cwd=work, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
-    line = [x for x in r.stdout.splitlines() if "check_model_verdict:" in x][-1].split()
-    n, valid, bad = int(line[1]), int(line[3]), int(line[5])
+    full, moves = [x.split() for x in r.stdout.splitlines() if "check_model_verdict:" in x][-2:]
+    n, valid, bad = int(full[1]), int(full[3]), int(full[5])
     assert n == 600000 and bad == 0, r.stdout
     assert 0.1 * n < valid < 0.9 * n        # both verdicts well represented
+    assert moves[2] == "velocity" and int(moves[1]) > 50000 and int(moves[6]) == 0, r.stdout
+    assert 0.1 * int(moves[1]) < int(moves[4]) < 0.95 * int(moves[1])
