@@ -26,7 +26,7 @@
 !=======================================================================
 module rf_model_check
   implicit none
-  public proposal_is_valid, velocity_move_is_valid
+  public proposal_is_valid, velocity_move_is_valid, interface_move_is_valid, interface_removal_is_valid
   private
 
 contains
@@ -158,5 +158,146 @@ contains
     end if
     ok = .true.
   end function velocity_move_is_valid
+
+  !---------------------------------------------------------------------
+  ! The rules of ONE layer -- the one whose bottom is the interface at depth zj (or z_max: the half-space) with the
+  ! interface zprev above it (sdep for the top layer) and the perturbations of slot islot -- exactly as
+  ! proposal_is_valid evaluates them (src/model.f90:210-231 top, :238-260 middle, :267-281 half-space).
+  logical function layer_is_valid(zj, zprev, islot, top, halfspace, prop_dvp, prop_dvs) result(ok)
+    use params, only: k_max, sdep, h_min, vp_mode, vp_min, vp_max, vs_min, vs_max, vpvs_min, vpvs_max
+    use model, only: vp_ref, vs_ref, z_ref_min, dz_ref
+    real(8), intent(in) :: zj, zprev, prop_dvp(k_max), prop_dvs(k_max)
+    integer, intent(in) :: islot
+    logical, intent(in) :: top, halfspace
+    integer :: iz
+    real(8) :: zc, a, b, thick
+
+    ok = .false.
+    zc = 0.5d0 * (zj + zprev)
+    iz = nint((zc - z_ref_min) / dz_ref) + 1
+    b = vs_ref(iz) + prop_dvs(islot)
+    if (vp_mode == 1) then
+       a = vp_ref(iz) + prop_dvp(islot)
+    else
+       a = vp_ref(iz)
+    end if
+    if (a < vp_min .or. a > vp_max .or. b < vs_min .or. b > vs_max .or. &
+         & a / b < vpvs_min .or. a / b > vpvs_max) return
+    if (top) then
+       thick = zj - sdep
+       if (thick < 0.125 * a) return
+    else if (.not. halfspace) then
+       thick = zj - zprev
+       if (thick < h_min) return
+    end if
+    ok = .true.
+  end function layer_is_valid
+
+  !---------------------------------------------------------------------
+  ! The verdict for a proposal that MOVES interface `pick` of a valid model from z_old to prop_z(pick) (moved), or
+  ! ADDS interface `pick` = prop_k at prop_z(pick) (.not. moved: a birth).  Without the interface the model is valid and
+  ! every layer that does not touch the new depth keeps its depth range, owner and velocities; two layers do: the one
+  ! above the new depth (owned by the interface itself) and the one below it (owned by the next interface down, or the
+  ! half-space), whose centre and thickness change.  A move that passes another interface changes which perturbation
+  ! belongs to which layer further away: such a proposal (and h_min <= 0) takes the full check.
+  logical function interface_move_is_valid(prop_k, prop_z, prop_dvp, prop_dvs, pick, z_old, moved) result(ok)
+    use params, only: k_max, sdep, z_max, h_min
+    integer, intent(in) :: prop_k, pick
+    real(8), intent(in) :: prop_z(k_max-1), prop_dvp(k_max), prop_dvs(k_max), z_old
+    logical, intent(in) :: moved
+    integer :: i, inext, nbefore_new, nbefore_old
+    real(8) :: znew, zi, zprev, znext
+
+    if (.not. (h_min > 0.d0)) then
+       ok = proposal_is_valid(prop_k, prop_z, prop_dvp, prop_dvs)
+       return
+    end if
+    ok = .false.
+    znew = prop_z(pick)
+    zprev = sdep
+    inext = 0
+    znext = z_max
+    nbefore_new = 0
+    nbefore_old = 0
+    do i = 1, prop_k
+       if (i == pick) cycle
+       zi = prop_z(i)
+       if (zi < znew) then
+          if (nbefore_new == 0) then
+             zprev = zi
+          else
+             zprev = max(zprev, zi)
+          end if
+          nbefore_new = nbefore_new + 1
+       else if (zi > znew) then
+          if (inext == 0) then
+             inext = i
+             znext = zi
+          else if (zi < znext) then
+             inext = i
+             znext = zi
+          end if
+       else
+          return                        ! two interfaces at one depth: a layer of thickness 0 < h_min
+       end if
+       if (moved .and. zi < z_old) nbefore_old = nbefore_old + 1
+    end do
+    if (moved .and. nbefore_old /= nbefore_new) then
+       ok = proposal_is_valid(prop_k, prop_z, prop_dvp, prop_dvs)
+       return
+    end if
+    ! the layer above the new depth, then the one below it (in the reference's order: the shallower layer first)
+    if (.not. layer_is_valid(znew, zprev, pick, nbefore_new == 0, .false., prop_dvp, prop_dvs)) return
+    if (inext > 0) then
+       ok = layer_is_valid(znext, znew, inext, .false., .false., prop_dvp, prop_dvs)
+    else
+       ok = layer_is_valid(z_max, znew, k_max, .false., .true., prop_dvp, prop_dvs)
+    end if
+  end function interface_move_is_valid
+
+  !---------------------------------------------------------------------
+  ! The verdict for a proposal that REMOVES the interface that was at z_removed from a valid model (a death: the
+  ! arrays passed are the ones after the removal).  The layer it bounded merges with the one below, which now reaches
+  ! up to the interface above: only that layer -- owned by the next interface down, or the half-space -- changes.
+  logical function interface_removal_is_valid(prop_k, prop_z, prop_dvp, prop_dvs, z_removed) result(ok)
+    use params, only: k_max, sdep, z_max, h_min
+    integer, intent(in) :: prop_k
+    real(8), intent(in) :: prop_z(k_max-1), prop_dvp(k_max), prop_dvs(k_max), z_removed
+    integer :: i, inext, nbefore
+    real(8) :: zi, zprev, znext
+
+    if (.not. (h_min > 0.d0)) then
+       ok = proposal_is_valid(prop_k, prop_z, prop_dvp, prop_dvs)
+       return
+    end if
+    zprev = sdep
+    inext = 0
+    znext = z_max
+    nbefore = 0
+    do i = 1, prop_k
+       zi = prop_z(i)
+       if (zi < z_removed) then
+          if (nbefore == 0) then
+             zprev = zi
+          else
+             zprev = max(zprev, zi)
+          end if
+          nbefore = nbefore + 1
+       else
+          if (inext == 0) then
+             inext = i
+             znext = zi
+          else if (zi < znext) then
+             inext = i
+             znext = zi
+          end if
+       end if
+    end do
+    if (inext > 0) then
+       ok = layer_is_valid(znext, zprev, inext, nbefore == 0, .false., prop_dvp, prop_dvs)
+    else
+       ok = layer_is_valid(z_max, zprev, k_max, .false., .true., prop_dvp, prop_dvs)
+    end if
+  end function interface_removal_is_valid
 
 end module rf_model_check

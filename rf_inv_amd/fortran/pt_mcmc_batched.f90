@@ -90,7 +90,7 @@ contains
     use model
     use likelihood, only: sig, log_likelihood
     use forward, only: rf_ctx, rfgpu_new_context
-    use rf_model_check, only: proposal_is_valid, velocity_move_is_valid
+    use rf_model_check, only: proposal_is_valid, velocity_move_is_valid, interface_move_is_valid, interface_removal_is_valid
     use pt_mcmc
     include "mpif.h"
     logical, intent(in) :: verb
@@ -689,12 +689,18 @@ contains
       ! only format_model's VERDICT is needed here (the engine formats the model itself, bit for bit the same):
       ! rf_model_check gives it without the sort of three arrays, the densities and the five output arrays -- and,
       ! the chain's current model being valid, a noise-level move needs no look at the model at all (it is unchanged)
-      ! and a velocity move a look at the one layer it changes
+      ! and any other move a look at the one or two layers it changes
       if (live) then
          if (itype == itype_sig) then
             continue
          else if (itype == itype_dvs .or. itype == itype_dvp) then
             live = velocity_move_is_valid(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs, pick)
+         else if (itype == itype_z) then
+            live = interface_move_is_valid(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs, pick, z(pick, jc), .true.)
+         else if (itype == itype_birth) then
+            live = interface_move_is_valid(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs, cand_k, 0.d0, .false.)
+         else if (itype == itype_death) then
+            live = interface_removal_is_valid(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs, z(pick, jc))
          else
             live = proposal_is_valid(cand_k, cand_z(1:k_max-1), cand_dvp, cand_dvs)
          end if

@@ -16,9 +16,10 @@ program check_model_verdict
   use rf_model_check
   implicit none
   character(clen_max) :: param_file, arg
-  integer :: n, i, kk, j, kind_, nvalid, nbad, nlay, pick, nmove
+  integer :: n, i, kk, j, kind_, nvalid, nbad, nlay, pick, nmove, other
   logical :: ok_ref, ok_new
   real(8) :: pz(200), pvp(200), pvs(200), alpha(nlay_max), beta(nlay_max), rho(nlay_max), h(nlay_max), u, v
+  real(8) :: qz(200), qvp(200), qvs(200)
 
   param_file = "params.in"
   n = 1000000
@@ -137,4 +138,91 @@ program check_model_verdict
      end do
   end do
   write(*,'(A,I0,A,I0,A,I0,A)') " check_model_verdict: ", nmove, " velocity moves, ", nvalid, " valid, ", nbad, " mismatches"
+
+  ! ---- interface_move_is_valid / interface_removal_is_valid: a VALID model + a depth move, a birth or a death, against
+  ! the reference's format_model on the changed model.  Depth moves: the sampler's small steps, large ones (the
+  ! interface passes others), landings exactly at / one ulp around h_min from a neighbour and the 0.125 alpha rule,
+  ! exact ties.  Births: anywhere, at h_min (+- one ulp) from an existing interface, on top of one.  Deaths: any.
+  nvalid = 0
+  nbad = 0
+  nmove = 0
+  do i = 1, n
+     pz = 0.d0; pvp = 0.d0; pvs = 0.d0
+     kk = max(k_min, 1) + int(grnd() * (k_max - 1 - max(k_min, 1)))       ! room for a birth: kk + 1 < k_max
+     do j = 1, kk
+        pz(j) = z_min + grnd() * (z_max - z_min)
+        pvs(j) = gauss() * dvs_prior * 0.2d0
+        pvp(j) = gauss() * dvp_prior * 0.2d0
+     end do
+     pvs(k_max) = gauss() * dvs_prior * 0.2d0
+     pvp(k_max) = gauss() * dvp_prior * 0.2d0
+     call format_model(kk, pz(1:k_max-1), pvp(1:k_max), pvs(1:k_max), nlay, alpha, beta, rho, h, ok_ref)
+     if (.not. ok_ref) cycle
+     do j = 1, 6
+        qz = pz; qvp = pvp; qvs = pvs
+        kind_ = mod(i + j, 12)
+        pick = 1 + int(grnd() * kk)
+        other = 1 + mod(pick + int(grnd() * max(kk - 1, 1)), kk)
+        if (kind_ <= 5) then
+           ! a depth move of interface pick
+           select case (kind_)
+           case (0, 1)
+              qz(pick) = pz(pick) + gauss() * dev_z
+           case (2)
+              qz(pick) = pz(pick) + gauss() * 8.d0
+           case (3)
+              u = pz(other) + merge(h_min, -h_min, mod(i, 2) == 0)
+              if (mod(i / 2, 3) == 1) u = nearest(u, 1.d0)
+              if (mod(i / 2, 3) == 2) u = nearest(u, -1.d0)
+              qz(pick) = u
+           case (4)
+              u = sdep + 0.125d0 * vp_ref(1)
+              if (mod(i / 2, 3) == 1) u = nearest(u, 1.d0)
+              if (mod(i / 2, 3) == 2) u = nearest(u, -1.d0)
+              qz(pick) = u
+           case default
+              if (kk >= 2) qz(pick) = pz(other)
+           end select
+           if (qz(pick) < z_min .or. qz(pick) > z_max) cycle          ! (the sampler drops such a proposal before the verdict)
+           call format_model(kk, qz(1:k_max-1), qvp(1:k_max), qvs(1:k_max), nlay, alpha, beta, rho, h, ok_ref)
+           ok_new = interface_move_is_valid(kk, qz(1:k_max-1), qvp(1:k_max), qvs(1:k_max), pick, pz(pick), .true.)
+        else if (kind_ <= 9) then
+           ! a birth: interface kk + 1
+           select case (kind_)
+           case (6, 7)
+              u = z_min + grnd() * (z_max - z_min)
+           case (8)
+              u = pz(pick) + merge(h_min, -h_min, mod(i, 2) == 0)
+              if (mod(i / 2, 3) == 1) u = nearest(u, 1.d0)
+              if (mod(i / 2, 3) == 2) u = nearest(u, -1.d0)
+           case default
+              u = pz(pick)
+           end select
+           if (u < z_min .or. u > z_max) cycle
+           qz(kk + 1) = u
+           qvs(kk + 1) = gauss() * dvs_prior * merge(0.2d0, 1.d0, mod(i, 3) /= 0)
+           qvp(kk + 1) = gauss() * dvp_prior * merge(0.2d0, 1.d0, mod(i, 3) /= 0)
+           call format_model(kk + 1, qz(1:k_max-1), qvp(1:k_max), qvs(1:k_max), nlay, alpha, beta, rho, h, ok_ref)
+           ok_new = interface_move_is_valid(kk + 1, qz(1:k_max-1), qvp(1:k_max), qvs(1:k_max), kk + 1, 0.d0, .false.)
+        else
+           ! a death of interface pick (the sampler's shift, src/pt_mcmc.f90:108-124)
+           if (kk - 1 < max(k_min, 1)) cycle
+           if (pick < kk) then
+              qz(pick:kk-1) = pz(pick+1:kk)
+              qvp(pick:kk-1) = pvp(pick+1:kk)
+              qvs(pick:kk-1) = pvs(pick+1:kk)
+           end if
+           qz(kk) = 0.d0; qvp(kk) = 0.d0; qvs(kk) = 0.d0
+           call format_model(kk - 1, qz(1:k_max-1), qvp(1:k_max), qvs(1:k_max), nlay, alpha, beta, rho, h, ok_ref)
+           ok_new = interface_removal_is_valid(kk - 1, qz(1:k_max-1), qvp(1:k_max), qvs(1:k_max), pz(pick))
+        end if
+        nmove = nmove + 1
+        if (ok_ref) nvalid = nvalid + 1
+        if (ok_ref .neqv. ok_new) then
+           nbad = nbad + 1
+           if (nbad <= 8) write(*,*) "INTERFACE MISMATCH kind", kind_, " k", kk, " pick", pick, " reference", ok_ref, " ours", ok_new
+        end if
+     end do
+  end do
+  write(*,'(A,I0,A,I0,A,I0,A)') " check_model_verdict: ", nmove, " interface moves, ", nvalid, " valid, ", nbad, " mismatches"
 end program check_model_verdict

@@ -230,7 +230,9 @@ def test_fast_validity_verdict_equals_the_reference_format_model(tmp_path, shape
     own, exact ties of two depths, thicknesses at and one ulp around h_min and the 0.125 alpha rule, velocities at
     their limits, depths at the ends of the range, large perturbations); velocity_move_is_valid (one layer examined):
     valid models + a change of one dVs / dVp (small, large, exactly at and one ulp beyond the Vs and Vp/Vs limits, the
-    half-space slot, the top layer).  Ocean / land, k_max 10 / 30, Vp fixed / solved for (c4vp): not one verdict differs."""
+    half-space slot, the top layer); interface_move_is_valid / interface_removal_is_valid (two layers / one): valid
+    models + a depth move (small, passing other interfaces, at h_min +- one ulp from a neighbour, at the 0.125 alpha
+    rule, exact ties), a birth (anywhere, at h_min +- one ulp from an interface, on top of one) or a death.  Ocean / land, k_max 10 / 30, Vp fixed / solved for (c4vp): not one verdict differs."""
     import shutil
     import subprocess
 
@@ -252,9 +254,11 @@ def test_fast_validity_verdict_equals_the_reference_format_model(tmp_path, shape
             open(work / "params.in", "w").write("\n".join(lines) + "\n")
     r = subprocess.run([exe, "params.in", "600000"], cwd=work, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout + r.stderr
-    full, moves = [x.split() for x in r.stdout.splitlines() if "check_model_verdict:" in x][-2:]
+    full, moves, ifaces = [x.split() for x in r.stdout.splitlines() if "check_model_verdict:" in x][-3:]
     n, valid, bad = int(full[1]), int(full[3]), int(full[5])
     assert n == 600000 and bad == 0, r.stdout
     assert 0.1 * n < valid < 0.9 * n        # both verdicts well represented
     assert moves[2] == "velocity" and int(moves[1]) > 50000 and int(moves[6]) == 0, r.stdout
     assert 0.1 * int(moves[1]) < int(moves[4]) < 0.95 * int(moves[1])
+    assert ifaces[2] == "interface" and int(ifaces[1]) > 50000 and int(ifaces[6]) == 0, r.stdout
+    assert 0.1 * int(ifaces[1]) < int(ifaces[4]) < 0.95 * int(ifaces[1])
