@@ -411,6 +411,11 @@ int rf_comm_post_gather(rf_ctx *ctx, int32_t root, int32_t *nmod_rank, double *v
  *                      (nfft 4096 on land only)
  *   "gemm_tile"        0 (default) = 64 | 128: the block tile of the long-window plan's GEMM (plan[12]): 128 x 64
  *                      (walkers x columns, four blocks per CU) or 128 x 128 (two); same values
+ *   "copy_stream"      0 (default) | 1: rf_eval_models_begin transfers its host arrays on a stream of the context's own,
+ *                      so that they run under the kernels of the evaluation before it (a sampler's two pipeline
+ *                      segments: one rank at the C4 shape 4.8 -> 5.2 M steps/s).  For a process that has the GPU to
+ *                      ITSELF: with several processes on one GPU the extra queue per process makes the hardware
+ *                      scheduler time-slice them (4 ranks: 5.0 -> 3.3 M).  pt_control_batched sets it accordingly.
  *   "gemm_triangle"    1 (default): the long-window GEMM runs on the quadratic form's upper triangle T(i, j) = R^-1(i, j)
  *                      + R^-1(j, i) (i < j), R^-1(j, j), 0 below -- m R m^T = sum_j m_j sum_{i<=j} m_i T(i, j) for ANY R, half
  *                      the multiply-adds | 0: the full product m . R^-1 in the reference's row order.  Results agree to

@@ -79,7 +79,18 @@ struct rf_ctx {
     int ticket_next = 0;
     double *h_out = nullptr, *d_out = nullptr;   // [RF_EVAL_MAX_IN_FLIGHT + 1][2][out_cap]: logL | valid (as int) per region; host pointer and its device alias
     int out_cap = 0;
-    // device images of the proposals of rf_eval_models: k | z(ldz = k_max) | dvp | dvs
+    // rf_eval_models_begin: one set of device input arrays per evaluation that can be in flight, filled on a stream of
+    // its own -- the transfers of one evaluation run under the kernels of the one before it (two pipeline segments of a
+    // sampler: ~85 us of DMA and gaps per 4096-chain segment at the C4 shape no longer sit between the kernels)
+    struct SlotIn {
+        int *ids = nullptr, *fwd = nullptr, *k = nullptr;
+        double *z = nullptr, *dvp = nullptr, *dvs = nullptr, *sig = nullptr;
+        int cap = 0;
+        hipEvent_t copied = nullptr;
+    } slot_in[RF_EVAL_MAX_IN_FLIGHT];
+    hipStream_t copy_stream = nullptr;
+    bool use_copy_stream = false;     // "copy_stream"
+    // device images of the proposals of rf_eval_models_device / rf_format_models_device: k | z(ldz = k_max) | dvp | dvs
     int *d_m_k = nullptr;
     double *d_m_z = nullptr, *d_m_dvp = nullptr, *d_m_dvs = nullptr;
     // device format_model (row f-2): model tables + per-batch outputs
@@ -774,6 +785,9 @@ extern "C" int rf_ctx_destroy(rf_ctx *c)
         (void)hipEventDestroy(q.e0);
         (void)hipEventDestroy(q.e1);
     }
+    for (auto &q : c->slot_in)
+        if (q.copied) (void)hipEventDestroy(q.copied);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return pending;
@@ -1321,21 +1335,43 @@ extern "C" int rf_eval_models_begin(rf_ctx *c, int32_t nb, const int32_t *walker
     if (ensure_stage(c, nb, 2) || ensure_out(c, nb)) return 1;
     hipStream_t s = c->stream;
     const size_t N = (size_t)nb;
+    // the slot's own device inputs (its previous evaluation has been waited for: nothing reads them any more)
+    rf_ctx::SlotIn &I = c->slot_in[slot];
+    if (nb > I.cap) {
+        const size_t cap = (size_t)std::max(nb, c->nslots);
+        void *p = nullptr;
+        if (dev_alloc(c, &p, sizeof(int) * 3 * cap)) return 1;
+        I.ids = (int *)p; I.fwd = I.ids + cap; I.k = I.fwd + cap;
+        if (dev_alloc(c, &p, sizeof(double) * cap * (3 * (size_t)kmax + ntrc))) return 1;
+        I.z = (double *)p; I.dvp = I.z + cap * kmax; I.dvs = I.dvp + cap * kmax; I.sig = I.dvs + cap * kmax;
+        I.cap = (int)cap;
+    }
+    // "copy_stream": the transfers on a stream of their own (a process that has the GPU to itself), or in line
+    hipStream_t cs = s;
+    if (c->use_copy_stream) {
+        if (!c->copy_stream) HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (!I.copied) HIP_TRY(hipEventCreateWithFlags(&I.copied, hipEventDisableTiming));
+        cs = c->copy_stream;
+    }
     rf_ctx::Arena &A = c->arena[slot];
     if (arena_begin(A, sizeof(int) * 3 * N + sizeof(double) * N * (ldz + 2 * (size_t)kmax + ntrc))) return 1;
-    if (h2d(A, c->d_ids, walker_ids, sizeof(int) * N, s) || h2d(A, c->d_m_k, k, sizeof(int) * N, s)) return 1;
-    if (fwd_flag && h2d(A, c->d_fwd, fwd_flag, sizeof(int) * N, s)) return 1;
-    if (h2d(A, c->d_m_z, z, sizeof(double) * N * ldz, s) || h2d(A, c->d_m_dvs, dvs, sizeof(double) * N * kmax, s) ||
-        h2d(A, c->d_sig, sig, sizeof(double) * N * ntrc, s))
+    if (h2d(A, I.ids, walker_ids, sizeof(int) * N, cs) || h2d(A, I.k, k, sizeof(int) * N, cs)) return 1;
+    if (fwd_flag && h2d(A, I.fwd, fwd_flag, sizeof(int) * N, cs)) return 1;
+    if (h2d(A, I.z, z, sizeof(double) * N * ldz, cs) || h2d(A, I.dvs, dvs, sizeof(double) * N * kmax, cs) ||
+        h2d(A, I.sig, sig, sizeof(double) * N * ntrc, cs))
         return 1;
     // (dVp enters format_model only when it is solved for, src/model.f90:216-217)
-    if (c->model.vp_mode == 1 && h2d(A, c->d_m_dvp, dvp, sizeof(double) * N * kmax, s)) return 1;
+    if (c->model.vp_mode == 1 && h2d(A, I.dvp, dvp, sizeof(double) * N * kmax, cs)) return 1;
+    if (cs != s) {
+        HIP_TRY(hipEventRecord(I.copied, cs));
+        HIP_TRY(hipStreamWaitEvent(s, I.copied, 0));
+    }
     double *d_logl = c->d_out + out_region(c, slot);
     int *d_valid = reinterpret_cast<int *>(d_logl + c->out_cap);
-    FormatParams P{c->model, nb, c->fm_pad, c->d_m_k, c->d_m_z, c->d_m_dvp, c->d_m_dvs, fwd_flag ? c->d_fwd : nullptr,
+    FormatParams P{c->model, nb, c->fm_pad, I.k, I.z, I.dvp, I.dvs, fwd_flag ? I.fwd : nullptr,
                    c->d_fm_nlay, c->d_fm_layers, c->d_fm_flag, want_valid ? d_valid : nullptr, c->d_fm_scratch, ldz};
     launch_format_model(P, s);
-    BatchArgs b{nb, c->fm_pad, c->d_ids, c->d_fm_flag, c->d_fm_nlay, c->d_fm_layers, c->d_sig, d_logl, nullptr};
+    BatchArgs b{nb, c->fm_pad, I.ids, c->d_fm_flag, c->d_fm_nlay, c->d_fm_layers, I.sig, d_logl, nullptr};
     // (consecutive evaluations of a context may be different sets of chains -- the halves of pt_control_batched's
     // pipeline: the dispatch order the previous launch prepared is not this batch's)
     c->order_next_nb = 0;
@@ -1800,6 +1836,9 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     } else if (k == "gemm_tile") {
         if (!integral || (iv != 0 && iv != 64 && iv != 128)) return fail("rf_set_option: gemm_tile must be 0 (by launch size), 64 or 128");
         c->pg.tile = iv;
+    } else if (k == "copy_stream") {
+        if (!integral || iv < 0 || iv > 1) return fail("rf_set_option: copy_stream must be 0 or 1");
+        c->use_copy_stream = iv != 0;
     } else if (k == "gemm_triangle") {
         if (!integral || iv < 0 || iv > 1) return fail("rf_set_option: gemm_triangle must be 0 or 1");
         c->pg.triangle = iv;

@@ -140,7 +140,7 @@ contains
     real(8) :: sw_logu
     ! ranks that share a GPU: the group, its communicator, this rank's place in it, and the context that evaluates
     ! the chains of all of them (the group's first rank owns it)
-    logical :: shared, leader
+    logical :: shared, leader, alone_on_gpu
     integer :: g_size, g_rank, g_first, node_comm, n_node
     type(c_ptr) :: gctx
     character(len=40) :: shm_tag
@@ -231,6 +231,12 @@ contains
     ! windowed trace storage (switching drops every stored trace) and in a GPU group (the group's context has seen
     ! none of the chains) the current models are evaluated once more, all at once -- the same kernels on the same
     ! inputs: the log-likelihoods must come back bit for bit.
+    ! a rank that has its GPU to itself lets the engine transfer a segment's proposals under the other segment's
+    ! kernels (a stream of their own); ranks sharing a GPU do not: one more queue per process and the hardware
+    ! scheduler time-slices them (a GPU group's first rank launches alone, but its context is shared work)
+    if (leader .and. alone_on_gpu) then
+       call rfgpu_check(rf_set_option(gctx, "copy_stream" // c_null_char, 1.0_c_double), "rf_set_option")
+    end if
     if (leader .and. rf_windowed_traces) then
        call rfgpu_check(rf_set_option(gctx, "trace_window" // c_null_char, 1.0_c_double), "rf_set_option")
     end if
@@ -488,7 +494,8 @@ contains
       g_rank = 0
       g_first = rank
       node_comm = MPI_COMM_NULL
-      if (nproc < 2 .or. .not. rf_share_gpu) return
+      alone_on_gpu = .true.
+      if (nproc < 2) return
       call rfgpu_check(rf_comm_device_key(rf_ctx, my_key), "rf_comm_device_key")
       allocate(keys(nproc))
       call mpi_allgather(my_key, 1, MPI_INTEGER8, keys, 1, MPI_INTEGER8, MPI_COMM_WORLD, ierr)
@@ -500,6 +507,12 @@ contains
          if (ia - 1 < rank) g_rank = g_rank + 1
          g_size = g_size + 1
       end do
+      alone_on_gpu = g_size == 1
+      if (.not. rf_share_gpu) then
+         g_size = 1
+         g_rank = 0
+         g_first = rank
+      end if
       shared = g_size > 1
       leader = g_rank == 0
       if (.not. shared) return

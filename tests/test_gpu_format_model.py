@@ -240,3 +240,56 @@ def test_eval_models_from_shared_host_memory(oracle, golden_dir, tmp_path):
         part = eng.eval_models(sh["ids"][h:], sh["k"][h:], sh["z"][h:], sh["dvp"][h:], sh["dvs"][h:], sh["sig"][h:])
         assert eng.launch_plan["staged_host_arrays"] == 0 and np.array_equal(part, want[h:], equal_nan=True)
     del sh
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+def test_copy_stream_option_same_results_with_evaluations_in_flight(oracle, golden_dir, pinned):
+    """rf_set_option("copy_stream", 1): rf_eval_models_begin transfers a batch's host arrays on a stream of the
+    context's own, under the kernels of the evaluation before it.  Three evaluations in flight (different halves of the
+    chains, as the sampler's pipeline issues them; pageable arrays go through the slot's arena), commits in between:
+    the same bits as in line."""
+    import ctypes as C
+
+    from rf_inv_amd import RFEngine, read_ref_model
+    from rf_inv_amd.engine import _dptr, _iptr, host_alloc
+    from rf_inv_amd.likelihood import init_r_inv
+
+    p, ref, mcfg = _setup(golden_dir, 0.0, 0, 12)
+    ref = read_ref_model(os.path.join(p.base_dir, p.vel_file))
+    rng = np.random.default_rng(23)
+    nb = 600
+    k, z, dvp, dvs = _proposals(rng, p, nb)
+    sig = rng.uniform(0.01, 0.03, (nb, p.ntrc))
+    ids = np.arange(nb, dtype=np.int32)
+    arrs = [ids, k, z, dvp, dvs, sig]
+    if pinned:
+        def pin(a):
+            b = host_alloc(a.shape, a.dtype)
+            b[...] = a
+            return b
+        arrs = [pin(a) for a in arrs]
+    ids, k, z, dvp, dvs, sig = arrs
+    parts = [slice(0, 200), slice(200, 400), slice(400, 600)]
+    out = {}
+    for on in (0, 1):
+        with RFEngine.from_params(p, r_inv=init_r_inv(p.nsmp, p.a_gus, p.delta), max_walkers=nb) as eng:
+            eng.set_option("copy_stream", on)
+            eng.set_model(p, ref)
+            L = eng._lib
+            res = np.full((2, nb), np.nan)
+            for rep in range(2):                       # the second round re-uses the slots and their device arrays
+                tk = []
+                for sl in parts:
+                    t = C.c_int32(-1)
+                    eng._chk(L.rf_eval_models_begin(eng._ctx, 200, _iptr(ids[sl]), None, _iptr(k[sl]), _dptr(z[sl]),
+                                                    int(z.shape[1]), _dptr(dvp[sl]), _dptr(dvs[sl]), _dptr(sig[sl]), 0,
+                                                    C.byref(t)))
+                    tk.append(t)
+                for sl, t in zip(parts, tk):
+                    buf = np.empty(200)
+                    eng._chk(L.rf_eval_wait(eng._ctx, t, _dptr(buf), None))
+                    res[rep, sl] = buf
+                eng.commit(ids, (np.arange(nb) % 2).astype(np.int32))
+            assert np.array_equal(res[0], res[1], equal_nan=True)
+            out[on] = res[0]
+    assert np.array_equal(out[0], out[1], equal_nan=True) and np.isfinite(out[0]).sum() > 30
