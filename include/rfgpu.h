@@ -241,6 +241,7 @@ int rf_host_free(void *ptr);
  * registered with the GPU in the rank whose context reads / writes it (gpu != 0), so that one rank can hand the
  * proposals of all of them to its context in ONE call, by DMA.  rf_host_free_shared unmaps (the creator also unlinks). */
 int rf_host_alloc_shared(const char *name, size_t bytes, int32_t create, int32_t gpu, void **ptr);
+int rf_host_unlink_shared(void *ptr);   /* creator, once every rank has mapped the block: the name goes, the mappings stay */
 int rf_host_free_shared(void *ptr);
 /* This process will issue no more GPU work: give its queues back (hipDeviceReset).  Every context of the process must
  * have been destroyed.  For host ranks of a GPU group other than its first: many processes holding idle queues on one

@@ -88,6 +88,7 @@ SYMBOLS = {
     "rf_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "rf_host_free": (C.c_int, [_vp]),
     "rf_host_alloc_shared": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp)]),
+    "rf_host_unlink_shared": (C.c_int, [_vp]),
     "rf_host_free_shared": (C.c_int, [_vp]),
     "rf_release_gpu": (C.c_int, []),
     "rf_pt_swap_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),

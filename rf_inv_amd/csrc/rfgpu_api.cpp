@@ -1483,6 +1483,21 @@ extern "C" int rf_release_gpu(void)
     return 0;
 }
 
+// Once every process has mapped the block its NAME can go (the mappings stay until they are unmapped): a job that dies
+// afterwards leaves nothing behind in /dev/shm.  Called by the creator after the host's barrier.
+extern "C" int rf_host_unlink_shared(void *ptr)
+{
+    for (auto &b : g_shared) {
+        if (b.p != ptr) continue;
+        if (b.creator) {
+            shm_unlink(b.name.c_str());
+            b.creator = false;
+        }
+        return 0;
+    }
+    return fail("rf_host_unlink_shared: not a pointer of rf_host_alloc_shared");
+}
+
 extern "C" int rf_host_free_shared(void *ptr)
 {
     for (size_t i = 0; i < g_shared.size(); ++i) {

@@ -559,6 +559,9 @@ contains
          call group_barrier()
          if (.not. leader) call rfgpu_check(rf_host_alloc_shared(trim(name) // c_null_char, max(bytes, 8_c_size_t), &
               & 0_c_int32_t, 0_c_int32_t, handle), "rf_host_alloc_shared")
+         ! every rank has it mapped: the name can go (nothing is left in /dev/shm if the job dies later)
+         call group_barrier()
+         if (leader) call rfgpu_check(rf_host_unlink_shared(handle), "rf_host_unlink_shared")
       end if
       pin(npin) = handle
     end subroutine host_block

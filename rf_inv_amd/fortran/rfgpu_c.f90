@@ -179,6 +179,11 @@ module rfgpu_c
        import :: c_int
      end function rf_release_gpu
 
+     integer(c_int) function rf_host_unlink_shared(ptr) bind(C, name="rf_host_unlink_shared")
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ptr
+     end function rf_host_unlink_shared
+
      integer(c_int) function rf_host_free_shared(ptr) bind(C, name="rf_host_free_shared")
        import :: c_int, c_ptr
        type(c_ptr), value :: ptr
