@@ -32,7 +32,9 @@ one per device, rendezvous on 127.0.0.1 -- relays rank 0's JSON line and exits n
 fewer than N devices are visible.  Under torchrun (WORLD_SIZE set) it must equal --gpus.  With N > 1 the swap
 step runs through librfgpu's own RCCL communicator (rf_comm_init / rf_pt_swap_allgather_device, include/rfgpu.h);
 torch.distributed is only the launcher's process group (rendezvous, barrier, max-over-ranks of the time).
-Prints ONE JSON line on rank 0.  Refuses to run with RFGPU_* variables in the environment
+Rank 0 prints ONE compact JSON line (< 4 KB: the contract's keys, `roofline`, `cpu_baseline`, the `also` rates) as the
+LAST line of stdout; the full record -- launch plan, every `also` workload with its own roofline -- goes to
+`bench_detail.json` (`--detail-file`) and to stderr.  Refuses to run with RFGPU_* variables in the environment
 (the library reads none; a stray one must not be mistaken for a setting) -- non-default
 launch plans are explicit `--opt name=value` flags and are echoed in `config`.
 """
@@ -374,6 +376,8 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
             continue
     base = {"value": n / dt, "unit": "evals/s", "cores": cores, "kind": "port",
             "per_core": n / dt / cores, "single_core": n1 / dt1, "ref_ratio": ratio,
+            "sample_short": f"{n} evals: this workload's walkers cycled, oracle/rf_oracle.c -O3, {cores} OpenMP threads, "
+                            f"{dt:.1f} s wall",
             "sample": f"{n} evals = the rank's walker set cycled ({nb} walkers, mean {float(nlay.mean()):.1f} layers), "
                       f"oracle/rf_oracle.c (gcc {' '.join(orc.FAST_FLAGS)}, OpenMP x{cores} threads = physical cores, "
                       f"{dt:.1f} s wall); single-core rate on {n1} evals"}
@@ -460,6 +464,68 @@ def spawn_ranks(n, argv):
     return rc or 0
 
 
+METRIC = "forward+likelihood evals/sec (whole node)"
+HEADLINE_MAX_BYTES = 4096
+
+
+def _sig(x, digits=6):
+    """Numbers of the headline rounded to `digits` significant digits (the side file keeps them in full)."""
+    if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
+        return x
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if math.isfinite(x) else None
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def headline_line(full, detail_file):
+    """The ONE line the driver parses: the contract's keys + `roofline` + `cpu_baseline`, nothing that repeats (launch
+    plan, notes, per-workload records live in `detail_file`).  Always shorter than HEADLINE_MAX_BYTES -- round 4's line
+    carried eleven `also` records (34.8 KB) and the driver could not parse it (tests/test_bench_line.py)."""
+    pick = lambda d, keys: {k: d.get(k) for k in keys if d is not None and k in d}
+    cfg = full.get("config", {})
+    roof = full.get("roofline") or {}
+    hbm = full.get("roofline_hbm") or {}
+    cpu = full.get("cpu_baseline")
+    par = full.get("parity_in_bench")
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                     "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    rccl = cfg.get("rccl") or {}
+    line["config"] = dict(pick(cfg, ("workload", "walkers_per_gpu", "nfft", "ntrc", "nsmp", "k_max", "mean_nlay",
+                                     "temperatures", "pt_swap", "parallelism")),
+                          rccl={k: (v[:160] if isinstance(v, str) else v) for k, v in
+                                pick(rccl, ("ranks", "version", "transport", "control_plane", "init_s", "library")).items()},
+                          lib_sha256=(cfg.get("lib") or {}).get("sha256", "")[:16],
+                          overrides=cfg.get("overrides") or {})
+    line["roofline"] = dict(pick(roof, ("bound", "unit", "peak", "achieved", "frac", "traffic", "kernel", "kernel_ms",
+                                        "clock_ghz", "frac_at_clock", "frac_step", "frac_with_stale_counters")),
+                            algorithmic_bytes=full.get("alg_bytes_per_step"),
+                            counters_file=(roof.get("counters") or {}).get("file"))
+    line["roofline_hbm"] = pick(hbm, ("bound", "unit", "peak", "achieved", "frac"))
+    if cpu:
+        line["cpu_baseline"] = dict(pick(cpu, ("value", "unit", "cores", "kind", "per_core")),
+                                    sample=cpu.get("sample_short") or (cpu.get("sample") or "")[:120])
+    if par:
+        line["parity_in_bench"] = pick(par, ("n", "max_abs_dlogl", "max_rel_dlogl", "within_tolerance",
+                                             "n_used_kappa_allowance"))
+    for k in ("swap_replay_ok", "cross_rank_swaps"):
+        if k in full:
+            line[k] = full[k]
+    if full.get("also"):
+        line["also"] = {k: v.get("value") for k, v in full["also"].items()}     # evals/s only; records in detail_file
+    line["detail_file"] = detail_file
+    s = json.dumps(_sig(line), separators=(",", ":"))
+    if len(s) >= HEADLINE_MAX_BYTES:                      # cannot happen with the keys above; never print a long line
+        line.pop("also", None)
+        line["config"].pop("overrides", None)
+        s = json.dumps(_sig(line), separators=(",", ":"))
+    assert len(s) < HEADLINE_MAX_BYTES, len(s)
+    return s
+
+
 KAPPA_MIN, KAPPA_SCALE = 100.0, 10.0      # the conditioning rule of tests/test_gpu_configs.py
 
 
@@ -518,6 +584,14 @@ def main():
     ap.add_argument("--copy-logl", action="store_true", help="always read logL back with an async copy")
     ap.add_argument("--dump-state", default=None, metavar="PATH.npz",
                     help="rank 0 writes every rank's final temperatures and logL (tests replay the swap schedule)")
+    ap.add_argument("--control-plane", default="gloo", choices=["gloo", "nccl"],
+                    help="N > 1: the launcher's process group (rendezvous, barrier, max of the time; NOT the temperature "
+                         "exchange, which is librfgpu's RCCL communicator): gloo on the host (default), or torch's RCCL group")
+    ap.add_argument("--comm-init-timeout", type=float, default=120.0, metavar="SECONDS",
+                    help="N > 1: a rank whose RCCL bootstrap (rf_comm_init) takes longer exits with code 4")
+    ap.add_argument("--detail-file", default=None, metavar="PATH.json",
+                    help="where rank 0 writes the full record (default bench_detail.json next to this script); stdout "
+                         "carries one compact line")
     ap.add_argument("--perturb-nlay", type=float, default=0.0, metavar="FRAC",
                     help="every step a fresh FRAC of the walkers evaluates its model one layer shallower (a birth / "
                          "death proposal changes nlay by one, pt_mcmc.f90:88-160): the dispatch order the previous "
@@ -557,20 +631,31 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    backend = os.environ.get("RFGPU_BENCH_BACKEND", "nccl")
+    # Two planes.  DATA: the temperature exchange of every step runs over librfgpu's own RCCL communicator (xGMI), one
+    # GPU per rank.  CONTROL: rendezvous, the 128-byte RCCL id, barrier and max-over-ranks of the time go over the
+    # launcher's process group -- gloo by default (host side, TCP on the loopback interface): the device then carries ONE
+    # communicator, librfgpu's (`--control-plane nccl` puts torch's RCCL group there as well).
+    # RFGPU_BENCH_BACKEND=gloo (functional tests on a one-GPU box): the ranks may share a GPU.
+    shared = os.environ.get("RFGPU_BENCH_BACKEND", "nccl") != "nccl"
+    backend = "gloo" if shared else args.control_plane
     if world > 1:
+        import datetime
+
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: never resolve the container's host name
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    if backend == "nccl" and world > torch.cuda.device_count():
+    if not shared and world > torch.cuda.device_count():
         raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s): one GPU per rank")
-    if backend != "nccl":
+    if shared:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -579,6 +664,8 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
+
+    comm_boot_s = [None]
 
     def run(workload, steps, warmup, with_cpu, parity_n=64):
         from rf_inv_amd import RFEngine, format_model, read_ref_model
@@ -615,7 +702,24 @@ def main():
         h_logl = torch.empty(nb, dtype=torch.float64).pin_memory()
         # N > 1: the temperature exchange runs over librfgpu's own RCCL communicator (one GPU per rank); ranks
         # that share a GPU (functional test) keep the launcher's process group as the transport
-        over_rccl = open_exchange(eng, dist, shared_gpu_ok=bool(args.rccl_library)) if world > 1 else False
+        over_rccl = False
+        if world > 1:
+            # ncclCommInitRank is collective and cannot be interrupted: a rank stuck in it for --comm-init-timeout
+            # seconds says so and leaves (exit code 4; the launcher takes the other ranks down) -- never a silent hang
+            import threading
+
+            def _stuck():
+                print(f"bench.py: rank {rank}: librfgpu's RCCL bootstrap (rf_comm_init, {world} ranks) did not finish "
+                      f"within {args.comm_init_timeout:.0f} s: giving up (exit code 4)", file=sys.stderr, flush=True)
+                os._exit(4)
+
+            dog = threading.Timer(args.comm_init_timeout, _stuck)
+            dog.daemon = True
+            dog.start()
+            t_boot = time.perf_counter()
+            over_rccl = open_exchange(eng, dist, shared_gpu_ok=bool(args.rccl_library))
+            dog.cancel()
+            comm_boot_s[0] = time.perf_counter() - t_boot
         swap = (PTSwap(eng, nb, w["temps"], dev, seed=1234, t_high=15.0, mode=args.swap, rccl=over_rccl)
                 if w["temps"] > 1 else None)
         # --perturb-nlay: NV pre-built depth vectors cycled through, so that the timed loop does nothing extra
@@ -841,14 +945,16 @@ def main():
                        "logl_readback": "kernel writes pinned host memory" if zero_copy else "device buffer + async copy",
                        "temperatures": w["temps"], "parallelism": f"walkers sharded x{world}",
                        "pt_swap": (f"{args.swap}, {swap.k} pair(s)/step" if swap is not None else "none"),
+                       # transport: "rccl_allgather" = librfgpu's RCCL group, 2 x ncclAllGather + 1 kernel per step
+                       # (rf_pt_swap_allgather_device); "process_group" = the launcher's process group gathers,
+                       # rf_pt_swap_gathered_device judges (librfgpu's communicator not formed: ranks share a GPU, or its
+                       # bootstrap failed); "none" = one rank
                        "rccl": ({"ranks": eng.comm_info()["nranks"], "version": eng.comm_info()["rccl_version"],
-                                 "transport": "librfgpu RCCL group: 2 x ncclAllGather + 1 kernel per step "
-                                              "(rf_pt_swap_allgather_device)",
+                                 "transport": "rccl_allgather", "control_plane": backend, "init_s": comm_boot_s[0],
                                  **({"library": args.rccl_library} if args.rccl_library else {})} if over_rccl else
                                 {"ranks": 0, "version": eng.comm_info()["rccl_version"],
-                                 "transport": "none (one rank)" if world == 1 else
-                                              "launcher's process group + rf_pt_swap_gathered_device (librfgpu's own RCCL "
-                                              "communicator not formed: ranks share a GPU, or its bootstrap failed)"}),
+                                 "transport": "none" if world == 1 else "process_group",
+                                 **({"control_plane": backend} if world > 1 else {})}),
                        "perturb_nlay": args.perturb_nlay, "workload_options": w.get("options", {}),
                        "launch_plan": plan, "overrides": overrides,
                        "lib": {"path": os.path.relpath(_lib.LIB_PATH, ROOT), "sha256": lib_sha, "kernels_sha256": kernels_sha,
@@ -870,6 +976,7 @@ def main():
                                {"spectra": kernel_ms, "trace": prof["trace_ms"] / n_l}),
                               **({"quadratic_form_logl": prof["logl_ms"] / n_l} if prof["logl_launches"] else {})),
             "alg_gflop_per_step": float(f_tot.sum()) / 1e9,
+            "alg_bytes_per_step": float(b_alg.sum()),
         }
         if swap_check is not None:
             res["swap_replay_ok"] = swap_check["ok"]
@@ -963,14 +1070,26 @@ def main():
         r = run(wl, n_also, max(5, min(20, args.warmup)), False)
         also[wl] = {k: r[k] for k in keep if k in r}
     if rank == 0:
-        out = {"metric": "forward+likelihood evals/sec (whole node)", "value": main_res["value"], "unit": "evals/s",
+        out = {"metric": METRIC, "value": main_res["value"], "unit": "evals/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
                "data": "synthetic"}
         out.update({k: v for k, v in main_res.items() if k not in ("value", "ms_per_step")})
         if also:
             out["also"] = also
-        print(json.dumps(out))
+        # the full record (launch plan, every `also` workload with its roofline, notes) goes to a side file and to
+        # stderr; stdout gets ONE compact line (< 4 KB), the last thing this process prints there
+        detail = args.detail_file or os.path.join(ROOT, "bench_detail.json")
+        try:
+            with open(detail, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:
+            print(f"bench.py: could not write {detail}: {e}", file=sys.stderr)
+            detail = None
+        print("bench.py detail: " + json.dumps(out), file=sys.stderr)
+        sys.stderr.flush()
+        print(headline_line(out, os.path.relpath(detail, ROOT) if detail else None))
+        sys.stdout.flush()
     failed = rank == 0 and main_res.get("swap_replay_ok") is False
     if failed:
         print("bench.py: the final temperatures do NOT equal the serial replay of the swap schedule: the temperature "

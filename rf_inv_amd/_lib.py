@@ -87,10 +87,6 @@ SYMBOLS = {
     "rf_eval_wait": (C.c_int, [_vp, C.c_int32, dp, ip]),
     "rf_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "rf_host_free": (C.c_int, [_vp]),
-    "rf_host_alloc_shared": (C.c_int, [C.c_char_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(_vp)]),
-    "rf_host_unlink_shared": (C.c_int, [_vp]),
-    "rf_host_free_shared": (C.c_int, [_vp]),
-    "rf_release_gpu": (C.c_int, []),
     "rf_pt_swap_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_comm_device_key": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "rf_comm_probe": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
@@ -100,6 +96,7 @@ SYMBOLS = {
     "rf_comm_destroy": (C.c_int, [_vp]),
     "rf_comm_info": (C.c_int, [_vp, ip, ip, ip]),
     "rf_comm_bcast_i32": (C.c_int, [_vp, ip, C.c_int32, C.c_int32]),
+    "rf_comm_set_option": (C.c_int, [_vp, C.c_char_p, C.c_double]),
     "rf_comm_post_reduce": (C.c_int, [_vp, C.c_int32, ip]),
     "rf_comm_post_gather": (C.c_int, [_vp, C.c_int32, ip, dp, dp, dp]),
     "rf_pt_swap_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, dp, ip]),
@@ -107,8 +104,6 @@ SYMBOLS = {
     "rf_pt_swap_gathered_device": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_post_create": (C.c_int, [_vp, C.POINTER(RFPostConfig)]),
     "rf_post_reset": (C.c_int, [_vp]),
-    "rf_post_sets": (C.c_int, [_vp, C.c_int32]),
-    "rf_post_select": (C.c_int, [_vp, C.c_int32]),
     "rf_post_record": (C.c_int, [_vp, C.c_int32, ip, ip, dp, dp, dp, dp, dp, dp]),
     "rf_post_record_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "rf_post_read": (C.c_int, [_vp, C.POINTER(RFPostResult)]),

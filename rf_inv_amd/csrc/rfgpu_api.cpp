@@ -1,14 +1,10 @@
-// rfgpu_api.cpp -- host side of the C ABI declared in include/rfgpu.h.
+// rfgpu_api.cpp -- host side of the C ABI declared in include/rfgpu.h and rfgpu_ext.h.
 // Context management, init-time tables (filter, twiddles, R^-1), staging of host
 // buffers and kernel launches.  No CPU fallback: every evaluation runs the gfx950
 // kernels of rfgpu_kernels.hip.
 #include "rfgpu_internal.h"
-#include "../../include/rfgpu.h"
+#include "../../include/rfgpu_ext.h"
 
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
 
 #include <algorithm>
 #include <cerrno>
@@ -108,9 +104,7 @@ struct rf_ctx {
     // posterior accumulators (row f-3)
     bool have_post = false;
     PostConfig post{};
-    PostState pst{};                  // the SELECTED accumulator set (rf_post_select): what record / read address
-    std::vector<PostState> post_sets; // [post_nsets] one set of accumulators per host rank served by this context
-    int post_nsets = 1, post_sel = 0; // rf_post_sets (before rf_post_create) / rf_post_select
+    PostState pst{};                  // the accumulators rf_post_record* / rf_post_read / rf_comm_post_* address
     std::vector<std::pair<void *, size_t>> post_zero;   // accumulators cleared by rf_post_reset
     int *d_post_nlay = nullptr, *d_post_flag = nullptr, *d_post_k = nullptr;
     double *d_post_layers = nullptr, *d_post_scratch = nullptr;
@@ -1209,7 +1203,14 @@ extern "C" int rf_set_r_inv(rf_ctx *c, const double *r_inv)
     if (c->tab.phi_gemm) {
         const std::vector<double> rg = pad_r_inv(c->r_inv, c->cfg.ntrc, c->cfg.nsmp, c->pg.kp, c->pg.np);
         HIP_TRY(hipMemcpy(const_cast<double *>(c->pg.rg), rg.data(), sizeof(double) * rg.size(), hipMemcpyHostToDevice));
+        // the triangular image is what the default plan ("gemm_triangle" 1) multiplies: it follows the new matrix too
+        const std::vector<double> rt = triangle_r_inv(rg, c->cfg.ntrc, c->pg.kp, c->pg.np);
+        HIP_TRY(hipMemcpy(const_cast<double *>(c->pg.rt), rt.data(), sizeof(double) * rt.size(), hipMemcpyHostToDevice));
     }
+    // The cached quadratic forms of the stored traces (what a sigma-only proposal re-uses, src/likelihood.f90:81) belong
+    // to the OLD matrix: they become NaN, so that such a proposal fails loudly until the chain has been re-evaluated and
+    // committed (set the matrix before the first evaluation, as the Fortran shim does).
+    HIP_TRY(hipMemset(c->ws.phi, 0xFF, sizeof(double) * 2 * (size_t)c->nslots * (size_t)c->cfg.ntrc));
     return 0;
 }
 
@@ -1426,92 +1427,6 @@ extern "C" int rf_host_free(void *ptr)
     return 0;
 }
 
-// Host memory SHARED between the processes of a node (POSIX shared memory) and, in the process that drives the GPU,
-// registered with it so that the host-pointer calls transfer it by DMA like rf_host_alloc memory.  For host ranks that
-// share one GPU: each writes its proposals into its slice, ONE of them hands the whole array to its context -- one
-// full-size launch per iteration instead of one small launch per rank (rf_inv_amd/fortran/pt_mcmc_batched.f90).
-// name: "/something" unique to the job (every rank passes the same); create != 0 in exactly one process, which must
-// return before the others call (the host's barrier); gpu != 0 in the process whose context will read / write it.
-namespace {
-struct SharedBlock {
-    void *p;
-    size_t bytes;
-    std::string name;
-    bool creator, registered;
-};
-std::vector<SharedBlock> g_shared;
-}
-
-extern "C" int rf_host_alloc_shared(const char *name, size_t bytes, int32_t create, int32_t gpu, void **ptr)
-{
-    if (!name || name[0] != '/' || !ptr) return fail("rf_host_alloc_shared: name must start with '/', ptr must not be null");
-    *ptr = nullptr;
-    if (!bytes) bytes = 8;
-    const int fd = create ? shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600) : shm_open(name, O_RDWR, 0600);
-    if (fd < 0) return fail(std::string("rf_host_alloc_shared: shm_open(") + name + "): " + std::strerror(errno));
-    if (create && ftruncate(fd, (off_t)bytes) != 0) {
-        const std::string why = std::strerror(errno);
-        close(fd);
-        shm_unlink(name);
-        return fail("rf_host_alloc_shared: ftruncate: " + why);
-    }
-    void *m = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-    close(fd);
-    if (m == MAP_FAILED) {
-        if (create) shm_unlink(name);
-        return fail(std::string("rf_host_alloc_shared: mmap: ") + std::strerror(errno));
-    }
-    bool reg = false;
-    if (gpu) {
-        // (zero-fill first: registration pins the pages, which must exist)
-        if (create) std::memset(m, 0, bytes);
-        reg = hipHostRegister(m, bytes, hipHostRegisterDefault) == hipSuccess;
-        if (!reg) (void)hipGetLastError();   // not fatal: the calls then stage this memory through the pinned arena
-    }
-    g_shared.push_back(SharedBlock{m, bytes, name, create != 0, reg});
-    *ptr = m;
-    return 0;
-}
-
-// A process that will issue no more GPU work gives its queues back (hipDeviceReset): host ranks whose chains are
-// evaluated by another rank's context (a GPU group) call it after destroying their own context -- with many processes
-// holding idle queues on one GPU the hardware scheduler starts to time-slice them, and the one rank that does launch
-// waits for its turn.
-extern "C" int rf_release_gpu(void)
-{
-    HIP_TRY(hipDeviceReset());
-    return 0;
-}
-
-// Once every process has mapped the block its NAME can go (the mappings stay until they are unmapped): a job that dies
-// afterwards leaves nothing behind in /dev/shm.  Called by the creator after the host's barrier.
-extern "C" int rf_host_unlink_shared(void *ptr)
-{
-    for (auto &b : g_shared) {
-        if (b.p != ptr) continue;
-        if (b.creator) {
-            shm_unlink(b.name.c_str());
-            b.creator = false;
-        }
-        return 0;
-    }
-    return fail("rf_host_unlink_shared: not a pointer of rf_host_alloc_shared");
-}
-
-extern "C" int rf_host_free_shared(void *ptr)
-{
-    for (size_t i = 0; i < g_shared.size(); ++i) {
-        if (g_shared[i].p != ptr) continue;
-        const SharedBlock b = g_shared[i];
-        g_shared.erase(g_shared.begin() + (long)i);
-        if (b.registered) (void)hipHostUnregister(b.p);
-        munmap(b.p, b.bytes);
-        if (b.creator) shm_unlink(b.name.c_str());
-        return 0;
-    }
-    return fail("rf_host_free_shared: not a pointer of rf_host_alloc_shared");
-}
-
 extern "C" int rf_commit_device(rf_ctx *c, int32_t nb, const int32_t *d_walker_ids, const int32_t *d_accept,
                                 void *stream)
 {
@@ -1594,31 +1509,9 @@ extern "C" int rf_post_reset(rf_ctx *c)
     if (!c || !c->have_post) return fail("rf_post_reset: rf_post_create has not been called");
     HIP_TRY(hipSetDevice(c->device));
     for (auto &z : c->post_zero) HIP_TRY(hipMemsetAsync(z.first, 0, z.second, c->stream));
-    for (const PostState &a : c->post_sets) launch_post_mark_unused(c->post, a, c->stream);
+    launch_post_mark_unused(c->post, c->pst, c->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(c->stream));
-    return 0;
-}
-
-// Several accumulator sets in one context: a context that evaluates the chains of several host ranks (ranks sharing a
-// GPU hand their proposals to one of them, rf_inv_amd/fortran/pt_mcmc_batched.f90) keeps each rank's histograms, mean
-// sums and model rows apart, so that every rank ends the run with exactly the arrays it would have filled alone and
-// the reference's output_results reduces and gathers them as ever (src/mcmc_out.f90:52-93).
-extern "C" int rf_post_sets(rf_ctx *c, int32_t nsets)
-{
-    if (!c) return fail("rf_post_sets: null context");
-    if (c->have_post) return fail("rf_post_sets: must come before rf_post_create");
-    if (nsets < 1 || nsets > 4096) return fail("rf_post_sets: nsets must be 1 .. 4096");
-    c->post_nsets = nsets;
-    return 0;
-}
-
-extern "C" int rf_post_select(rf_ctx *c, int32_t set)
-{
-    if (!c || !c->have_post) return fail("rf_post_select: rf_post_create has not been called");
-    if (set < 0 || set >= c->post_nsets) return fail("rf_post_select: set out of range");
-    c->post_sel = set;
-    c->pst = c->post_sets[(size_t)set];
     return 0;
 }
 
@@ -1652,11 +1545,11 @@ extern "C" int rf_post_create(rf_ctx *c, const rf_post_config *p)
     for (int t = 0; t < ntrc; ++t) dsig[t] = (p->sig_max[t] - p->sig_min[t]) / p->nbin_sig;
     if (upload(c, smin, &q.sig_min) || upload(c, dsig, &q.dbin_sig) || upload(c, smode, &q.sig_mode)) return 1;
 
-    c->post_sets.assign((size_t)c->post_nsets, PostState{});
-    PostState &st = c->post_sets[0];
+    c->pst = PostState{};
+    PostState &st = c->pst;
     const size_t nm = (size_t)std::max<int64_t>(p->max_models, 1);
-    // the accumulators: one set per host rank this context serves (rf_post_sets; 1 by default)
-    for (PostState &a : c->post_sets) {
+    {
+        PostState &a = st;
         if (post_alloc(c, &a.nmod, 2, true) || post_alloc(c, &a.nk, kmax, true) ||
             post_alloc(c, &a.nz, q.nbin_z, true) || post_alloc(c, &a.nsig, (size_t)ntrc * q.nbin_sig, true) ||
             post_alloc(c, &a.namp, (size_t)ntrc * nsmp * q.nbin_amp, true) ||
@@ -1669,7 +1562,7 @@ extern "C" int rf_post_create(rf_ctx *c, const rf_post_config *p)
             post_alloc(c, &a.amp_oor, 1, true))
             return 1;
     }
-    // scratch of a record call: shared by the sets (calls are stream-ordered)
+    // scratch of a record call
     if (post_alloc(c, &st.sel, c->nslots, false) ||
         post_alloc(c, &st.nsel, 1, true) || post_alloc(c, &st.row_a, (size_t)c->nslots * q.nbin_z, false) ||
         post_alloc(c, &st.row_b, (size_t)c->nslots * q.nbin_z, false) ||
@@ -1679,11 +1572,6 @@ extern "C" int rf_post_create(rf_ctx *c, const rf_post_config *p)
         post_alloc(c, &c->d_post_scratch, (size_t)c->nslots * 3 * kmax, false) ||
         post_alloc(c, &c->d_post_in, (size_t)c->nslots * (3 * (size_t)kmax + ntrc + 2), false))
         return 1;
-    for (PostState &a : c->post_sets) {
-        a.sel = st.sel; a.nsel = st.nsel; a.row_a = st.row_a; a.row_b = st.row_b;
-    }
-    c->post_sel = 0;
-    c->pst = c->post_sets[0];
     c->have_post = true;
     return rf_post_reset(c);
 }
@@ -1729,8 +1617,10 @@ extern "C" int rf_post_record(rf_ctx *c, int32_t n, const int32_t *walker_ids, c
     double *dz = c->d_post_in, *ddvp = dz + N * (kmax - 1), *ddvs = ddvp + N * kmax, *dsig = ddvs + N * kmax,
            *dlogl = dsig + N * ntrc, *dtemps = dlogl + N;
     int *dids = c->d_post_k, *dk = dids + n;
-    // Like rf_commit, a record returns nothing from the device and does not wait for it: the host arrays are copied
-    // into a pinned arena of their own before the call returns (the caller may change them at once), the transfers and
+    // Like rf_commit, a record returns nothing from the device and does not wait for it: PAGEABLE host arrays are
+    // copied into a pinned arena of their own before the call returns (the caller may change them at once); arrays in
+    // pinned memory (rf_host_alloc) are read by DMA in place AFTER it returns and must stay untouched until a later call
+    // on the context has waited for work issued behind this one (rf_eval_wait, rf_post_read ...).  The transfers and
     // kernels are stream-ordered behind everything issued before and in front of everything issued after.
     rf_ctx::Arena &A = c->arena[RF_EVAL_MAX_IN_FLIGHT + 1];
     if (arena_begin(A, sizeof(int) * 2 * N + sizeof(double) * N * (3 * (size_t)kmax + ntrc + 2))) return 1;
@@ -1878,7 +1768,7 @@ extern "C" int rf_set_option(rf_ctx *c, const char *name, double value)
     c->n_overrides = (c->fused_override != -1) + (c->chain_override != -1) + (!c->lpt) + (!c->order_reuse) +
                      (c->nsplit_override != 0) + (c->waves_per_block != 4) + (c->defer_logl != -1) +
                      (c->block_threads != 0) + (c->bin_cutoff > 0.0) + (c->ablate != 0) + (c->trace_window != 0) +
-                     (c->pg.tile != 0);
+                     (c->pg.tile != 0) + (c->tab.phi_gemm && c->pg.triangle != 1) + (c->use_copy_stream ? 1 : 0);
     return 0;
 }
 
@@ -1904,7 +1794,7 @@ extern "C" int rf_get_launch_plan(const rf_ctx *c, int32_t *plan)
     plan[12] = c->tab.phi_gemm ? (c->pg.triangle ? 2 : 1) : 0;
     plan[13] = c->trace_window;
     plan[14] = c->last_staged;
-    plan[15] = 0;
+    plan[15] = c->use_copy_stream ? 1 : 0;
     return 0;
 }
 

@@ -7,7 +7,7 @@
 // ONE grouped RCCL call.  RCCL is loaded at run time (dlopen of librccl.so.1 -- inside a PyTorch process that is
 // the RCCL torch already loaded); librfgpu has no link-time dependency on it and single-GPU users never touch it.
 #include "rfgpu_internal.h"
-#include "../../include/rfgpu.h"
+#include "../../include/rfgpu_ext.h"
 
 #include <dlfcn.h>
 #include <unistd.h>
@@ -84,6 +84,12 @@ struct rfgpu::CommState {
     double *h_buf = nullptr;     // pinned mirror
     double *d_gather = nullptr;  // [2][nranks * nchains]: every rank's T, then every rank's logL, by global walker id
     size_t gather_doubles = 0;
+    // The host-value exchanges (rf_comm_bcast_i32, rf_pt_swap_exchange) run on a stream of the communicator's own: what
+    // they carry are host scalars with no ordering against the evaluation stream, and a sampler calls them while a
+    // segment's kernels are in flight there (pt_control_batched: the pair is drawn right after rf_eval_models_begin) --
+    // on the evaluation stream the host would wait for the whole iteration's kernels before its 16 bytes moved.
+    hipStream_t stream = nullptr;
+    bool sequential_reduce = false;   // rf_comm_set_option("sequential_reduce")
 };
 
 #define RCCL_TRY(expr)                                                                                     \
@@ -175,8 +181,11 @@ extern "C" int rf_comm_init(rf_ctx *c, const uint8_t *id, int32_t rank, int32_t 
                          " (one rank per GPU is required: RCCL refuses two ranks on one device)");
     }
     if (hipMalloc((void **)&s->d_buf, sizeof(double) * 8) != hipSuccess ||
-        hipHostMalloc((void **)&s->h_buf, sizeof(double) * 8, hipHostMallocDefault) != hipSuccess) {
+        hipHostMalloc((void **)&s->h_buf, sizeof(double) * 8, hipHostMallocDefault) != hipSuccess ||
+        hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         R->CommDestroy(s->comm);
+        if (s->d_buf) (void)hipFree(s->d_buf);
+        if (s->h_buf) (void)hipHostFree(s->h_buf);
         delete s;
         return comm_fail("rf_comm_init: staging allocation failed");
     }
@@ -191,8 +200,10 @@ extern "C" int rf_comm_destroy(rf_ctx *c)
     if (!s) return 0;
     (void)hipSetDevice(ctx_device(c));
     (void)hipStreamSynchronize(ctx_stream(c));
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
     Rccl *R = rccl();
     if (R && s->comm) R->CommDestroy(s->comm);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
     if (s->d_buf) (void)hipFree(s->d_buf);
     if (s->h_buf) (void)hipHostFree(s->h_buf);
     if (s->d_gather) (void)hipFree(s->d_gather);
@@ -210,7 +221,7 @@ extern "C" int rf_comm_bcast_i32(rf_ctx *c, int32_t *buf, int32_t n, int32_t roo
     if (n < 1 || n > 8) return comm_fail("rf_comm_bcast_i32: n must be 1 .. 8");
     if (root < 0 || root >= s->nranks) return comm_fail("rf_comm_bcast_i32: root out of range");
     Rccl *R = rccl();
-    hipStream_t st = ctx_stream(c);
+    hipStream_t st = s->stream;
     HIPC_TRY(hipSetDevice(ctx_device(c)));
     int32_t *hb = reinterpret_cast<int32_t *>(s->h_buf), *db = reinterpret_cast<int32_t *>(s->d_buf);
     if (s->rank == root) {
@@ -237,7 +248,7 @@ extern "C" int rf_pt_swap_exchange(rf_ctx *c, int32_t peer, int32_t judge, doubl
     if (!s) return comm_fail("rf_pt_swap_exchange: rf_comm_init has not been called");
     if (peer < 0 || peer >= s->nranks) return comm_fail("rf_pt_swap_exchange: peer out of range");
     Rccl *R = rccl();
-    hipStream_t st = ctx_stream(c);
+    hipStream_t st = s->stream;
     HIPC_TRY(hipSetDevice(ctx_device(c)));
     s->h_buf[0] = temp;
     s->h_buf[1] = logl;
@@ -276,6 +287,22 @@ extern "C" int rf_comm_info(rf_ctx *c, int32_t *rank, int32_t *nranks, int32_t *
         if (R && R->GetVersion && R->GetVersion(&v) == ncclSuccess) *rccl_version = v;
     }
     return 0;
+}
+
+// Options of the context's communicator (after rf_comm_init).  "sequential_reduce" 0 (default) | 1: rf_comm_post_reduce
+// issues its twelve ncclReduce calls one by one instead of as one group.
+extern "C" int rf_comm_set_option(rf_ctx *c, const char *name, double value)
+{
+    if (!c || !name) return comm_fail("rf_comm_set_option: null argument");
+    CommState *s = ctx_comm(c);
+    if (!s) return comm_fail("rf_comm_set_option: rf_comm_init has not been called");
+    const std::string k(name);
+    if (k == "sequential_reduce") {
+        if (value != 0.0 && value != 1.0) return comm_fail("rf_comm_set_option: sequential_reduce must be 0 or 1");
+        s->sequential_reduce = value != 0.0;
+        return 0;
+    }
+    return comm_fail("rf_comm_set_option: unknown option '" + k + "'");
 }
 
 // Throughput form: K DISJOINT pairs per iteration over global walker ids (rank * nchains + chain,
@@ -350,11 +377,15 @@ extern "C" int rf_comm_post_reduce(rf_ctx *c, int32_t root, int32_t *nmod_sum)
         {p->vpvs_mean, nz, ncclDouble},
         {p->amp_oor, 1, ncclInt64},
     };
+    // (d_buf / h_buf also serve the host-value exchanges on the communicator's stream: those are synchronous, so
+    // nothing of theirs is in flight here)
     int32_t *d_nmod = reinterpret_cast<int32_t *>(s->d_buf), *h_nmod = reinterpret_cast<int32_t *>(s->h_buf);
-    RCCL_TRY(R->GroupStart());
+    // one group of twelve reductions (one launch); rf_comm_set_option("sequential_reduce", 1): twelve plain calls, one
+    // after the other on the stream -- the same sums, for an RCCL build that mishandles in-place reductions in a group
+    if (!s->sequential_reduce) RCCL_TRY(R->GroupStart());
     for (const auto &it : items) RCCL_TRY(R->Reduce(it.ptr, it.ptr, it.n, it.t, ncclSum, root, s->comm, st));
     RCCL_TRY(R->Reduce(p->nmod, d_nmod, 1, ncclInt32, ncclSum, root, s->comm, st));
-    RCCL_TRY(R->GroupEnd());
+    if (!s->sequential_reduce) RCCL_TRY(R->GroupEnd());
     if (s->rank == root) HIPC_TRY(hipMemcpyAsync(h_nmod, d_nmod, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPC_TRY(hipStreamSynchronize(st));
     if (s->rank == root && nmod_sum) *nmod_sum = h_nmod[0];

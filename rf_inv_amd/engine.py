@@ -319,6 +319,10 @@ class RFEngine:
         return {"rank": r.value, "nranks": n.value,
                 "rccl_version": f"{ver // 10000}.{ver // 100 % 100}.{ver % 100}" if ver else None}
 
+    def comm_set_option(self, name: str, value: float):
+        """Options of the context's communicator (rf_comm_set_option): "sequential_reduce" 0 | 1."""
+        self._chk(self._lib.rf_comm_set_option(self._ctx, name.encode(), float(value)))
+
     def comm_destroy(self):
         self._chk(self._lib.rf_comm_destroy(self._ctx))
 
@@ -368,7 +372,7 @@ class RFEngine:
                 "build": ("production", "diagnostics", "diagnostics+ablate")[plan[9]],
                 "block_threads_option": plan[10], "block_threads_full_batch": plan[11],
                 "long_window_gemm": bool(plan[12]), "gemm_triangle": plan[12] == 2,
-                "trace_window": bool(plan[13]), "staged_host_arrays": plan[14]}
+                "trace_window": bool(plan[13]), "staged_host_arrays": plan[14], "copy_stream": bool(plan[15])}
 
     def profile_enable(self, on=True):
         """on: False / True (every batch) / k > 1 (every k-th batch is timed)."""
@@ -408,24 +412,4 @@ def host_alloc(shape, dtype=np.float64):
     buf = (C.c_char * max(1, n * dt.itemsize)).from_address(ptr.value)
     arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
     weakref.finalize(buf, lib.rf_host_free, ptr)
-    return arr
-
-
-def host_alloc_shared(name, shape, dtype=np.float64, create=False, gpu=False):
-    """A numpy array in POSIX shared memory mapped by every process that passes the same `name` ('/...'), registered
-    with the GPU in the process that passes gpu=True (rf_host_alloc_shared): ranks that share a GPU write their
-    proposals into slices of it and one of them hands the whole array to its context.  Exactly one process creates;
-    the others call after it has returned.  Unmapped (the creator also unlinks) with the array."""
-    import weakref
-
-    lib = _lib.load()
-    dt = np.dtype(dtype)
-    n = int(np.prod(shape))
-    nbytes = max(8, n * dt.itemsize)
-    ptr = C.c_void_p()
-    if lib.rf_host_alloc_shared(name.encode(), nbytes, int(bool(create)), int(bool(gpu)), C.byref(ptr)):
-        raise RFGPUError(lib.rf_last_error().decode())
-    buf = (C.c_char * nbytes).from_address(ptr.value)
-    arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
-    weakref.finalize(buf, lib.rf_host_free_shared, ptr)
     return arr

@@ -28,7 +28,7 @@ module forward
   integer(c_int32_t), allocatable, target, save, private :: ipha_c(:)
   real(c_double), allocatable, target, save, private :: rayps_c(:), a_gus_c(:), obs_c(:,:)
 
-  public init_forward, calc_rf, rfgpu_new_context
+  public init_forward, calc_rf
 
 contains
 

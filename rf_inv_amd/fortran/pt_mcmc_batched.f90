@@ -45,9 +45,8 @@ module pt_mcmc_batched
   ! ... and of the iteration loop as a whole (first proposal to the last swap decision; set-up -- device tables, pinned
   ! arrays, the exchange's bootstrap -- and the read-back of the posterior accumulators excluded)
   real(8), public :: rf_loop_seconds = 0.d0
-  ! ... and, within phase 2, of a GPU group's steps on this rank: 1 rf_eval_wait (first rank), 2 the barrier after it,
-  ! 3 the barrier before the engine calls, 4 / 5 / 6 the engine calls: rf_commit, rf_post_record, rf_eval_models_begin (first rank)
-  real(8), public :: rf_group_seconds(6) = 0.d0
+  ! ... and, within phases 2 / 3, of the engine calls: 1 rf_eval_wait, 2 rf_commit, 3 rf_post_record, 4 rf_eval_models_begin
+  real(8), public :: rf_call_seconds(4) = 0.d0
   ! 2: the chains of a rank are worked in two halves, one being evaluated on the GPU while the host judges and
   ! re-proposes the other (same trajectory: see the loop); 1: propose all, evaluate all, judge all; 0 (default): 2 when
   ! a half is at least 1024 chains, else 1 -- below that two small launches per iteration cost the GPU more than the
@@ -58,27 +57,11 @@ module pt_mcmc_batched
   ! src/pt_mcmc.f90:273-274); the trace kernels write nfft / nsmp times less and the resident traces shrink as much.
   ! The chains' current traces are rebuilt by one batched evaluation when the loop starts (bit-identical values).
   logical, public :: rf_windowed_traces = .true.
-  ! .true.: ranks that drive the same GPU form a group whose first rank evaluates the chains of all of them on ONE
-  ! context -- one full-size launch per pipeline segment and iteration instead of one small launch per rank (the
-  ! proposals travel through shared memory registered with the GPU, rf_host_alloc_shared; every rank keeps its own
-  ! random stream, state and posterior accumulators: same trajectories, same result files).  .false. (default): every
-  ! rank launches for itself.  Measured (profiles/r04_sampler_rate_shapes.txt): the group loses -- one stream runs a
-  ! segment's copies, format_model, stage and commit kernels one after the other, where independent ranks' streams
-  ! overlap them with each other's main kernels (C4 shape, 4 ranks: 4.5 M against 4.8 M steps/s; C3: 12.0 M against 13.7 M).
-  logical, public :: rf_share_gpu = .false.
-
   ! .true.: HIP-event times of the loop's kernels (rf_profile_enable on the evaluating context): totals in
   ! rf_kernel_ms (main kernel(s), trace kernel, likelihood kernel), batches and launches in rf_kernel_launches
   logical, public :: rf_time_kernels = .false.
   real(c_double), public :: rf_kernel_ms(3) = 0.d0
   integer(c_int64_t), public :: rf_kernel_launches(4) = 0
-  ! a GPU group's other ranks give their own queues back once the group's context has their chains (rf_release_gpu)
-  logical, public :: rf_group_release_gpu = .true.
-  interface
-     integer(c_int) function c_getpid() bind(C, name="getpid")
-       import :: c_int
-     end function c_getpid
-  end interface
 
 contains
 
@@ -89,7 +72,7 @@ contains
     use prior, only: laplace, log_prior_ratio
     use model
     use likelihood, only: sig, log_likelihood
-    use forward, only: rf_ctx, rfgpu_new_context
+    use forward, only: rf_ctx
     use rf_model_check, only: proposal_is_valid, velocity_move_is_valid, interface_move_is_valid, interface_removal_is_valid
     use pt_mcmc
     include "mpif.h"
@@ -100,10 +83,8 @@ contains
     real(8) :: alpha(nlay_max), beta(nlay_max), rho(nlay_max), h(nlay_max)
     real(8) :: lpr, r, del_s, t_cold
     ! Per-chain proposals of the current iteration, one set of arrays per pipeline segment.  The arrays the engine
-    ! reads live in pinned host memory (rf_host_alloc) and travel to the GPU by DMA as the proposal step left them --
-    ! or, when several ranks share a GPU, in shared memory registered with the GPU by ONE of them (rf_host_alloc_shared):
-    ! sg(s) are the arrays of segment s for every rank of the GPU group, rank after rank; my(s) this rank's columns of
-    ! them, indexed by chain.  Without sharing the two coincide.
+    ! reads live in pinned host memory (rf_host_alloc) and travel to the GPU by DMA as the proposal step left them:
+    ! sg(s) are the arrays of segment s as the engine takes them (1 .. seg_n(s)); my(s) the same memory indexed by chain.
     type seg_arrays
        integer(c_int32_t), pointer :: id(:) => null(), fwd(:) => null(), k(:) => null(), acc(:) => null()
        real(c_double), pointer :: z(:,:) => null(), dvp(:,:) => null(), dvs(:,:) => null(), sig(:,:) => null()
@@ -121,32 +102,24 @@ contains
     logical, allocatable :: p_live(:), p_acc(:)
     real(8), allocatable :: p_lp(:), p_logr(:)
     type(c_ptr) :: pin(32)
-    logical :: pin_shared(32)
     integer :: npin
-    ! device-side posterior accumulation: what a record call hands over (the module arrays themselves, or -- ranks
-    ! sharing a GPU -- every rank's copy of them in shared memory, rank after rank)
-    integer(c_int32_t), pointer :: rec_id(:) => null(), rec_k(:) => null()
-    real(c_double), pointer :: rec_z(:,:) => null(), rec_dvp(:,:) => null(), rec_dvs(:,:) => null(), rec_sig(:,:) => null()
-    real(c_double), pointer :: rec_logl(:) => null(), rec_temps(:) => null()
+    ! device-side posterior accumulation: a record call hands over the module arrays themselves, plus these two
+    integer(c_int32_t), pointer :: rec_id(:) => null()
+    real(c_double), pointer :: rec_temps(:) => null()
     logical :: record_now, record_pending
     ! temperature exchange between ranks: RCCL (one GPU per rank) or MPI (ranks sharing a GPU)
     logical :: over_rccl
-    real(8) :: tick(6)
+    real(8) :: tick(5)
     ! the pipeline: segments of the chains, the evaluation in flight for each, the swap proposal drawn but not yet decided
     integer :: nseg, iseg, lo, hi, seg_lo(2), seg_hi(2), seg_n(2)
     integer(c_int32_t) :: seg_ticket(2)
     logical :: seg_busy(2), swap_drawn, launch
     integer(c_int32_t) :: sw_pick(2)
     real(8) :: sw_logu
-    ! ranks that share a GPU: the group, its communicator, this rank's place in it, and the context that evaluates
-    ! the chains of all of them (the group's first rank owns it)
-    logical :: shared, leader, alone_on_gpu
-    integer :: g_size, g_rank, g_first, node_comm, n_node
-    type(c_ptr) :: gctx
-    character(len=40) :: shm_tag
+    logical :: alone_on_gpu      ! no other rank of this run drives this rank's GPU
 
     rf_phase_seconds = 0.d0
-    rf_group_seconds = 0.d0
+    rf_call_seconds = 0.d0
     call mpi_comm_size(MPI_COMM_WORLD, nproc, ierr)
     call mpi_comm_rank(MPI_COMM_WORLD, rank, ierr)
     n_all = nproc * nchains
@@ -161,26 +134,23 @@ contains
        seg_n(i) = seg_hi(i) - seg_lo(i) + 1
     end do
 
-    call find_gpu_group()
-    n_node = nchains * g_size
-    gctx = rf_ctx
-    if (shared .and. leader) call create_group_context()
+    call count_ranks_on_my_gpu()
 
     allocate(p_type(nchains), p_live(nchains), p_acc(nchains), p_lp(nchains), p_logr(nchains))
     allocate(p_lo(nchains), p_hi(nchains), p_sigd(nchains))
     npin = 0
     do i = 1, nseg
-       call host_i32(sg(i)%id, seg_n(i) * g_size, "id", i)
-       call host_i32(sg(i)%fwd, seg_n(i) * g_size, "fw", i)
-       call host_i32(sg(i)%k, seg_n(i) * g_size, "k", i)
-       call host_i32(sg(i)%acc, seg_n(i) * g_size, "ac", i)
-       call host_f64_2d(sg(i)%z, k_max, seg_n(i) * g_size, "z", i)
-       call host_f64_2d(sg(i)%dvp, k_max, seg_n(i) * g_size, "vp", i)
-       call host_f64_2d(sg(i)%dvs, k_max, seg_n(i) * g_size, "vs", i)
-       call host_f64_2d(sg(i)%sig, ntrc, seg_n(i) * g_size, "sg", i)
-       call host_f64_1d(sg(i)%logl, seg_n(i) * g_size, "ll", i)
-       ! this rank's columns, indexed by chain
-       j = g_rank * seg_n(i)
+       call host_i32(sg(i)%id, seg_n(i))
+       call host_i32(sg(i)%fwd, seg_n(i))
+       call host_i32(sg(i)%k, seg_n(i))
+       call host_i32(sg(i)%acc, seg_n(i))
+       call host_f64_2d(sg(i)%z, k_max, seg_n(i))
+       call host_f64_2d(sg(i)%dvp, k_max, seg_n(i))
+       call host_f64_2d(sg(i)%dvs, k_max, seg_n(i))
+       call host_f64_2d(sg(i)%sig, ntrc, seg_n(i))
+       call host_f64_1d(sg(i)%logl, seg_n(i))
+       ! the same columns, indexed by chain
+       j = 0
        my(i)%id(seg_lo(i):) => sg(i)%id(j+1:j+seg_n(i))
        my(i)%fwd(seg_lo(i):) => sg(i)%fwd(j+1:j+seg_n(i))
        my(i)%k(seg_lo(i):) => sg(i)%k(j+1:j+seg_n(i))
@@ -191,29 +161,17 @@ contains
        my(i)%sig(1:, seg_lo(i):) => sg(i)%sig(:, j+1:j+seg_n(i))
        my(i)%logl(seg_lo(i):) => sg(i)%logl(j+1:j+seg_n(i))
     end do
-    if (shared) then
-       call host_i32(rec_id, n_node, "ri", 0)
-       call host_i32(rec_k, n_node, "rk", 0)
-       call host_f64_2d(rec_z, k_max - 1, n_node, "rz", 0)
-       call host_f64_2d(rec_dvp, k_max, n_node, "rp", 0)
-       call host_f64_2d(rec_dvs, k_max, n_node, "rs", 0)
-       call host_f64_2d(rec_sig, ntrc, n_node, "rg", 0)
-       call host_f64_1d(rec_logl, n_node, "rl", 0)
-       call host_f64_1d(rec_temps, n_node, "rt", 0)
-    else
-       allocate(rec_id(nchains), rec_temps(nchains))
-    end if
+    allocate(rec_id(nchains), rec_temps(nchains))
     do ichain = 1, nchains
-       rec_id(g_rank * nchains + ichain) = g_rank * nchains + ichain - 1
+       rec_id(ichain) = ichain - 1
     end do
-    if (leader) call setup_device_posterior()
+    call setup_device_posterior()
     call open_temperature_exchange()
 
-    ! the proposal columns start as copies of the chains' states (draw_candidate keeps them that way); walker ids
-    ! within the context: this rank's chains after those of the group's ranks before it
+    ! the proposal columns start as copies of the chains' states (draw_candidate keeps them that way)
     do iseg = 1, nseg
        do ichain = seg_lo(iseg), seg_hi(iseg)
-          my(iseg)%id(ichain) = g_rank * nchains + ichain - 1
+          my(iseg)%id(ichain) = ichain - 1
           my(iseg)%k(ichain) = k(ichain)
           my(iseg)%z(:, ichain) = 0.d0
           my(iseg)%z(1:k_max-1, ichain) = z(1:k_max-1, ichain)
@@ -227,51 +185,35 @@ contains
           p_sigd(ichain) = .false.
        end do
     end do
-    ! The first evaluation of every chain (init_likelihood, on the rank's own context) is its current trace.  With
-    ! windowed trace storage (switching drops every stored trace) and in a GPU group (the group's context has seen
-    ! none of the chains) the current models are evaluated once more, all at once -- the same kernels on the same
-    ! inputs: the log-likelihoods must come back bit for bit.
-    ! a rank that has its GPU to itself lets the engine transfer a segment's proposals under the other segment's
+    ! The first evaluation of every chain (init_likelihood) is its current trace.  With windowed trace storage
+    ! (switching drops every stored trace) the current models are evaluated once more, all at once -- the same kernels
+    ! on the same inputs: the log-likelihoods must come back bit for bit.
+    ! A rank that has its GPU to itself lets the engine transfer a segment's proposals under the other segment's
     ! kernels (a stream of their own); ranks sharing a GPU do not: one more queue per process and the hardware
-    ! scheduler time-slices them (a GPU group's first rank launches alone, but its context is shared work)
-    if (leader .and. alone_on_gpu) then
-       call rfgpu_check(rf_set_option(gctx, "copy_stream" // c_null_char, 1.0_c_double), "rf_set_option")
+    ! scheduler time-slices them.
+    if (alone_on_gpu) then
+       call rfgpu_check(rf_set_option(rf_ctx, "copy_stream" // c_null_char, 1.0_c_double), "rf_set_option")
     end if
-    if (leader .and. rf_windowed_traces) then
-       call rfgpu_check(rf_set_option(gctx, "trace_window" // c_null_char, 1.0_c_double), "rf_set_option")
-    end if
-    if (shared .or. rf_windowed_traces) then
-       call group_barrier()
-       if (leader) then
-          do iseg = 1, nseg
-             call rfgpu_check(rf_eval_models(gctx, int(seg_n(iseg) * g_size, c_int32_t), sg(iseg)%id, sg(iseg)%fwd, &
-                  & sg(iseg)%k, sg(iseg)%z, int(k_max, c_int32_t), sg(iseg)%dvp, sg(iseg)%dvs, sg(iseg)%sig, &
-                  & sg(iseg)%logl, c_null_ptr), "rf_eval_models")
-          end do
-       end if
-       call group_barrier()
+    if (rf_windowed_traces) then
+       call rfgpu_check(rf_set_option(rf_ctx, "trace_window" // c_null_char, 1.0_c_double), "rf_set_option")
+       do iseg = 1, nseg
+          call rfgpu_check(rf_eval_models(rf_ctx, int(seg_n(iseg), c_int32_t), sg(iseg)%id, sg(iseg)%fwd, &
+               & sg(iseg)%k, sg(iseg)%z, int(k_max, c_int32_t), sg(iseg)%dvp, sg(iseg)%dvs, sg(iseg)%sig, &
+               & sg(iseg)%logl, c_null_ptr), "rf_eval_models")
+       end do
        do iseg = 1, nseg
           do ichain = seg_lo(iseg), seg_hi(iseg)
              r = my(iseg)%logl(ichain)
              if (r /= log_likelihood(ichain) .and. (r == r .or. log_likelihood(ichain) == log_likelihood(ichain))) then   ! (NaN = NaN here)
-                ! A context picks its kernels from its capacity, and two plans agree to rounding, not bit for bit (the
-                ! group's context holds g_size times the chains of the rank's own): inside the parity tolerance the
-                ! group's value is the chain's from here on -- every later value comes from the same kernels.
-                if (shared .and. abs(r - log_likelihood(ichain)) <= max(1.0d-9, 1.0d-12 * abs(r))) then
-                   log_likelihood(ichain) = r
-                else
-                   write(0,*) "ERROR: pt_control_batched: chain", ichain, " re-evaluated to", r, " not", log_likelihood(ichain)
-                   call rfgpu_check(1_c_int, "re-evaluation of the initial models")
-                end if
+                write(0,*) "ERROR: pt_control_batched: chain", ichain, " re-evaluated to", r, " not", log_likelihood(ichain)
+                call rfgpu_check(1_c_int, "re-evaluation of the initial models")
              end if
           end do
        end do
     end if
-    if (leader) then
-       do iseg = 1, nseg
-          call rfgpu_check(rf_commit(gctx, int(seg_n(iseg) * g_size, c_int32_t), sg(iseg)%id, sg(iseg)%acc), "rf_commit")
-       end do
-    end if
+    do iseg = 1, nseg
+       call rfgpu_check(rf_commit(rf_ctx, int(seg_n(iseg), c_int32_t), sg(iseg)%id, sg(iseg)%acc), "rf_commit")
+    end do
 
     ! ------------------------------------------------------------------------------------------------------
     ! The loop, software-pipelined over nseg segments of the chains (rf_pipeline_segments; 1 = no overlap).
@@ -287,22 +229,11 @@ contains
     ! after its previous proposal has been judged; an iteration's acceptance tests see the temperatures left by
     ! the previous iteration's swap and its swap sees every chain's state after that iteration.  The trajectory
     ! is the reference's.
-    ! Ranks that share a GPU (a GPU group) run the same slots in step: each writes its columns of the shared arrays,
-    ! the group's first rank makes the engine calls for all of them -- ONE full-size launch per segment instead
-    ! of one small launch per rank -- and two barriers of the group per slot order the two: after the wait (every
-    ! rank reads its results) and before the engine calls (every rank's flags and proposals are in place).
     ! ------------------------------------------------------------------------------------------------------
     seg_busy = .false.
     swap_drawn = .false.
     record_pending = .false.
-    ! a rank whose chains the group's first rank evaluates needs its own context no longer (nothing after the loop
-    ! touches the GPU either: output_results is host code)
-    if (shared .and. .not. leader .and. rf_group_release_gpu .and. .not. over_rccl) then
-       call rfgpu_check(rf_ctx_destroy(rf_ctx), "rf_ctx_destroy")
-       rf_ctx = c_null_ptr
-       call rfgpu_check(rf_release_gpu(), "rf_release_gpu")
-    end if
-    if (leader .and. rf_time_kernels) call rfgpu_check(rf_profile_enable(gctx, 1_c_int32_t), "rf_profile_enable")
+    if (rf_time_kernels) call rfgpu_check(rf_profile_enable(rf_ctx, 1_c_int32_t), "rf_profile_enable")
     call mpi_barrier(MPI_COMM_WORLD, ierr)
     rf_loop_seconds = mpi_wtime()
 
@@ -319,11 +250,8 @@ contains
           tick(1) = mpi_wtime()
           if (it > 1) then
              if (seg_busy(iseg)) then
-                if (leader) call rfgpu_check(rf_eval_wait(gctx, seg_ticket(iseg), sg(iseg)%logl, c_null_ptr), "rf_eval_wait")
-                tick(6) = mpi_wtime()
-                call group_barrier()
-                rf_group_seconds(1) = rf_group_seconds(1) + (tick(6) - tick(1))
-                rf_group_seconds(2) = rf_group_seconds(2) + (mpi_wtime() - tick(6))
+                call rfgpu_check(rf_eval_wait(rf_ctx, seg_ticket(iseg), sg(iseg)%logl, c_null_ptr), "rf_eval_wait")
+                rf_call_seconds(1) = rf_call_seconds(1) + (mpi_wtime() - tick(1))
              end if
              tick(2) = mpi_wtime()
              do ichain = lo, hi
@@ -367,16 +295,7 @@ contains
                    ! and reads their current traces where the evaluation left them.  The temperatures are
                    ! those BEFORE this iteration's swap (src/pt_mcmc.f90:204); the call itself follows the
                    ! segment's commit below.
-                   j = g_rank * nchains
-                   rec_temps(j+1:j+nchains) = temps(1:nchains)
-                   if (shared) then
-                      rec_k(j+1:j+nchains) = k(1:nchains)
-                      rec_z(:, j+1:j+nchains) = z(1:k_max-1, 1:nchains)
-                      rec_dvp(:, j+1:j+nchains) = dvp(1:k_max, 1:nchains)
-                      rec_dvs(:, j+1:j+nchains) = dvs(1:k_max, 1:nchains)
-                      rec_sig(:, j+1:j+nchains) = sig(1:ntrc, 1:nchains)
-                      rec_logl(j+1:j+nchains) = log_likelihood(1:nchains)
-                   end if
+                   rec_temps(1:nchains) = temps(1:nchains)
                    record_pending = .true.
                 end if
                 tick(4) = mpi_wtime()
@@ -415,33 +334,30 @@ contains
           end if
           tick(2) = mpi_wtime()
           !----------------------------------------------------------------
-          ! c. the engine calls of the slot (the group's first rank, for every rank of the group): commit of the
-          !    segment's decisions, [posterior records], format_model + forward + likelihood of its new proposals --
-          !    enqueued, collected at this segment's next slot
+          ! c. the engine calls of the slot: commit of the segment's decisions, [posterior records], format_model +
+          !    forward + likelihood of its new proposals -- enqueued, collected at this segment's next slot
           !----------------------------------------------------------------
-          if (shared) call group_barrier()
-          tick(6) = mpi_wtime()
-          rf_group_seconds(3) = rf_group_seconds(3) + (tick(6) - tick(2))
-          launch = it <= n_tot_iter .and. (shared .or. nb > 0)
-          if (leader) then
-             if (it > 1 .and. seg_busy(iseg)) then
-                call rfgpu_check(rf_commit(gctx, int(seg_n(iseg) * g_size, c_int32_t), sg(iseg)%id, sg(iseg)%acc), "rf_commit")
-             end if
-             tick(4) = mpi_wtime()
-             rf_group_seconds(4) = rf_group_seconds(4) + (tick(4) - tick(6))
-             if (record_pending .and. iseg == nseg) call record_posterior()
-             tick(5) = mpi_wtime()
-             rf_group_seconds(5) = rf_group_seconds(5) + (tick(5) - tick(4))
-             if (launch) then
-                call rfgpu_check(rf_eval_models_begin(gctx, int(seg_n(iseg) * g_size, c_int32_t), sg(iseg)%id, sg(iseg)%fwd, &
-                     & sg(iseg)%k, sg(iseg)%z, int(k_max, c_int32_t), sg(iseg)%dvp, sg(iseg)%dvs, sg(iseg)%sig, &
-                     & 0_c_int32_t, seg_ticket(iseg)), "rf_eval_models_begin")
-             end if
+          launch = it <= n_tot_iter .and. nb > 0
+          if (it > 1 .and. seg_busy(iseg)) then
+             call rfgpu_check(rf_commit(rf_ctx, int(seg_n(iseg), c_int32_t), sg(iseg)%id, sg(iseg)%acc), "rf_commit")
+          end if
+          tick(4) = mpi_wtime()
+          rf_call_seconds(2) = rf_call_seconds(2) + (tick(4) - tick(2))
+          if (record_pending .and. iseg == nseg) then
+             call rfgpu_check(rf_post_record(rf_ctx, int(nchains, c_int32_t), rec_id, k, z, dvp, dvs, sig, &
+                  & log_likelihood, c_loc(rec_temps)), "rf_post_record")
+          end if
+          tick(5) = mpi_wtime()
+          rf_call_seconds(3) = rf_call_seconds(3) + (tick(5) - tick(4))
+          if (launch) then
+             call rfgpu_check(rf_eval_models_begin(rf_ctx, int(seg_n(iseg), c_int32_t), sg(iseg)%id, sg(iseg)%fwd, &
+                  & sg(iseg)%k, sg(iseg)%z, int(k_max, c_int32_t), sg(iseg)%dvp, sg(iseg)%dvs, sg(iseg)%sig, &
+                  & 0_c_int32_t, seg_ticket(iseg)), "rf_eval_models_begin")
           end if
           if (iseg == nseg) record_pending = .false.
           seg_busy(iseg) = launch
           tick(3) = mpi_wtime()
-          if (leader) rf_group_seconds(6) = rf_group_seconds(6) + (tick(3) - tick(5))
+          rf_call_seconds(4) = rf_call_seconds(4) + (tick(3) - tick(5))
           rf_phase_seconds(1) = rf_phase_seconds(1) + (tick(2) - tick(1))
           rf_phase_seconds(2) = rf_phase_seconds(2) + (tick(3) - tick(2))
           !----------------------------------------------------------------
@@ -457,158 +373,66 @@ contains
 
     call mpi_barrier(MPI_COMM_WORLD, ierr)
     rf_loop_seconds = mpi_wtime() - rf_loop_seconds
-    if (leader .and. rf_time_kernels) then
-       call rfgpu_check(rf_profile_read(gctx, rf_kernel_ms, rf_kernel_launches, 1_c_int32_t), "rf_profile_read")
-       call rfgpu_check(rf_profile_enable(gctx, 0_c_int32_t), "rf_profile_enable")
+    if (rf_time_kernels) then
+       call rfgpu_check(rf_profile_read(rf_ctx, rf_kernel_ms, rf_kernel_launches, 1_c_int32_t), "rf_profile_read")
+       call rfgpu_check(rf_profile_enable(rf_ctx, 0_c_int32_t), "rf_profile_enable")
     end if
     if (over_rccl) call rfgpu_check(rf_comm_destroy(rf_ctx), "rf_comm_destroy")
-    call fetch_device_posterior()
-    if (shared .and. leader) call rfgpu_check(rf_ctx_destroy(gctx), "rf_ctx_destroy")
-    call group_barrier()
+    call read_device_posterior()
     do i = 1, npin
-       if (pin_shared(i)) then
-          call rfgpu_check(rf_host_free_shared(pin(i)), "rf_host_free_shared")
-       else
-          call rfgpu_check(rf_host_free(pin(i)), "rf_host_free")
-       end if
+       call rfgpu_check(rf_host_free(pin(i)), "rf_host_free")
     end do
-    if (.not. shared) deallocate(rec_id, rec_temps)
-    if (shared) call mpi_comm_free(node_comm, ierr)
+    deallocate(rec_id, rec_temps)
 
   contains
 
     ! ------------------------------------------------------------------------------------------------
-    ! Which ranks drive the same GPU as this one (rf_comm_device_key: host + boot id + PCI address)?  More than one:
-    ! with rf_share_gpu they form a GPU group, whose first rank evaluates the chains of all of them on one context;
-    ! otherwise (default) every rank keeps launching for itself.
+    ! Does another rank of this run drive the same GPU (rf_comm_device_key: host + boot id + PCI address)?
     ! ------------------------------------------------------------------------------------------------
-    subroutine find_gpu_group()
+    subroutine count_ranks_on_my_gpu()
       integer(c_int64_t) :: my_key
       integer(c_int64_t), allocatable :: keys(:)
-      integer :: ia, token(2)
-      integer(c_int) :: pid
 
-      shared = .false.
-      leader = .true.
-      g_size = 1
-      g_rank = 0
-      g_first = rank
-      node_comm = MPI_COMM_NULL
       alone_on_gpu = .true.
       if (nproc < 2) return
       call rfgpu_check(rf_comm_device_key(rf_ctx, my_key), "rf_comm_device_key")
       allocate(keys(nproc))
       call mpi_allgather(my_key, 1, MPI_INTEGER8, keys, 1, MPI_INTEGER8, MPI_COMM_WORLD, ierr)
-      g_size = 0
-      g_first = -1
-      do ia = 1, nproc
-         if (keys(ia) /= my_key) cycle
-         if (g_first < 0) g_first = ia - 1
-         if (ia - 1 < rank) g_rank = g_rank + 1
-         g_size = g_size + 1
-      end do
-      alone_on_gpu = g_size == 1
-      if (.not. rf_share_gpu) then
-         g_size = 1
-         g_rank = 0
-         g_first = rank
-      end if
-      shared = g_size > 1
-      leader = g_rank == 0
-      if (.not. shared) return
-      call mpi_comm_split(MPI_COMM_WORLD, g_first, rank, node_comm, ierr)
-      ! a name for the group's shared-memory blocks that no other job on the node uses
-      pid = c_getpid()
-      token = [int(pid), int(mod(mpi_wtime() * 1.0d3, 1.0d9))]
-      call mpi_bcast(token, 2, MPI_INTEGER4, 0, node_comm, ierr)
-      write(shm_tag, '(A,I0,A,I0,A,I0)') "/rfgpu_", token(1), "_", token(2), "_", g_first
-      if (rank == 0) write(0,'(A,I0,A)') " GPU groups: ranks that share a GPU hand their proposals to the group's first rank (", &
-           & g_size, " ranks on rank 0's GPU)"
-    end subroutine find_gpu_group
+      alone_on_gpu = count(keys == my_key) == 1
+    end subroutine count_ranks_on_my_gpu
 
-    subroutine group_barrier()
-      if (shared) call mpi_barrier(node_comm, ierr)
-    end subroutine group_barrier
-
-    ! the context that holds the chains of every rank of the group: same tables, same pseudo-inverse
-    subroutine create_group_context()
-      real(c_double), allocatable :: rinv(:)
-      call rfgpu_new_context(n_node, gctx)
-      allocate(rinv(nsmp * nsmp * ntrc))
-      call rfgpu_check(rf_get_r_inv(rf_ctx, rinv), "rf_get_r_inv")
-      call rfgpu_check(rf_set_r_inv(gctx, rinv), "rf_set_r_inv")
-    end subroutine create_group_context
-
-    ! Host arrays the engine reads or writes: pinned (rf_host_alloc), or -- in a GPU group -- shared by the group's
-    ! ranks and registered with the GPU by its first rank (created there, opened by the others after a barrier).
-    subroutine host_block(bytes, tag, iseg_tag, handle)
+    ! Host arrays the engine reads or writes: pinned (rf_host_alloc)
+    subroutine host_block(bytes, handle)
       integer(c_size_t), intent(in) :: bytes
-      character(*), intent(in) :: tag
-      integer, intent(in) :: iseg_tag
       type(c_ptr), intent(out) :: handle
-      character(len=64) :: name
-
       npin = npin + 1
-      pin_shared(npin) = shared
-      if (.not. shared) then
-         call rfgpu_check(rf_host_alloc(max(bytes, 8_c_size_t), handle), "rf_host_alloc")
-      else
-         write(name, '(A,A,A,I0)') trim(shm_tag), "_", tag, iseg_tag
-         if (leader) call rfgpu_check(rf_host_alloc_shared(trim(name) // c_null_char, max(bytes, 8_c_size_t), 1_c_int32_t, &
-              & 1_c_int32_t, handle), "rf_host_alloc_shared")
-         call group_barrier()
-         if (.not. leader) call rfgpu_check(rf_host_alloc_shared(trim(name) // c_null_char, max(bytes, 8_c_size_t), &
-              & 0_c_int32_t, 0_c_int32_t, handle), "rf_host_alloc_shared")
-         ! every rank has it mapped: the name can go (nothing is left in /dev/shm if the job dies later)
-         call group_barrier()
-         if (leader) call rfgpu_check(rf_host_unlink_shared(handle), "rf_host_unlink_shared")
-      end if
+      call rfgpu_check(rf_host_alloc(max(bytes, 8_c_size_t), handle), "rf_host_alloc")
       pin(npin) = handle
     end subroutine host_block
 
-    subroutine host_i32(a, n, tag, iseg_tag)
+    subroutine host_i32(a, n)
       integer(c_int32_t), pointer, intent(out) :: a(:)
-      integer, intent(in) :: n, iseg_tag
-      character(*), intent(in) :: tag
+      integer, intent(in) :: n
       type(c_ptr) :: handle
-      call host_block(int(4, c_size_t) * int(max(n, 1), c_size_t), tag, iseg_tag, handle)
+      call host_block(int(4, c_size_t) * int(max(n, 1), c_size_t), handle)
       call c_f_pointer(handle, a, [n])
     end subroutine host_i32
 
-    subroutine host_f64_1d(a, n, tag, iseg_tag)
+    subroutine host_f64_1d(a, n)
       real(c_double), pointer, intent(out) :: a(:)
-      integer, intent(in) :: n, iseg_tag
-      character(*), intent(in) :: tag
+      integer, intent(in) :: n
       type(c_ptr) :: handle
-      call host_block(int(8, c_size_t) * int(max(n, 1), c_size_t), tag, iseg_tag, handle)
+      call host_block(int(8, c_size_t) * int(max(n, 1), c_size_t), handle)
       call c_f_pointer(handle, a, [n])
     end subroutine host_f64_1d
 
-    subroutine host_f64_2d(a, m, n, tag, iseg_tag)
+    subroutine host_f64_2d(a, m, n)
       real(c_double), pointer, intent(out) :: a(:,:)
-      integer, intent(in) :: m, n, iseg_tag
-      character(*), intent(in) :: tag
+      integer, intent(in) :: m, n
       type(c_ptr) :: handle
-      call host_block(int(8, c_size_t) * int(max(m * n, 1), c_size_t), tag, iseg_tag, handle)
+      call host_block(int(8, c_size_t) * int(max(m * n, 1), c_size_t), handle)
       call c_f_pointer(handle, a, [m, n])
     end subroutine host_f64_2d
-
-    ! rf_post_record for every rank of the group, each into its own set of accumulators (rf_post_select): a rank ends
-    ! the run with exactly the arrays it would have filled alone
-    subroutine record_posterior()
-      integer :: ig, o
-      if (.not. shared) then
-         call rfgpu_check(rf_post_record(gctx, int(nchains, c_int32_t), rec_id, k, z, dvp, dvs, sig, &
-              & log_likelihood, c_loc(rec_temps)), "rf_post_record")
-         return
-      end if
-      do ig = 0, g_size - 1
-         o = ig * nchains + 1
-         call rfgpu_check(rf_post_select(gctx, int(ig, c_int32_t)), "rf_post_select")
-         call rfgpu_check(rf_post_record(gctx, int(nchains, c_int32_t), rec_id(o:), rec_k(o:), rec_z(:, o:), rec_dvp(:, o:), &
-              & rec_dvs(:, o:), rec_sig(:, o:), rec_logl(o:), c_loc(rec_temps(o))), "rf_post_record")
-      end do
-    end subroutine record_posterior
 
     ! One chain's trans-dimensional proposal.  Sets (host-associated) itype, cand_*, lpr,
     ! live and -- for live candidates -- the formatted layer stack nlay/alpha/beta/rho/h.
@@ -877,73 +701,17 @@ contains
       mc%vp_min = vp_min;  mc%vp_max = vp_max;  mc%vs_min = vs_min;  mc%vs_max = vs_max
       mc%vpvs_min = vpvs_min;  mc%vpvs_max = vpvs_max
       mc%vp_ref = c_loc(t_vp);  mc%vs_ref = c_loc(t_vs)
-      call rfgpu_check(rf_set_model(gctx, mc), "rf_set_model")
+      call rfgpu_check(rf_set_model(rf_ctx, mc), "rf_set_model")
       pc%nbin_z = nbin_z;  pc%nbin_vs = nbin_vs;  pc%nbin_vp = nbin_vp;  pc%nbin_vpvs = nbin_vpvs
       pc%nbin_sig = nbin_sig;  pc%nbin_amp = nbin_amp
       pc%amp_min = amp_min;  pc%amp_max = amp_max;  pc%z_min = z_min
       pc%sig_min = c_loc(t_smin);  pc%sig_max = c_loc(t_smax);  pc%sig_mode = c_loc(t_smode)
       pc%max_models = size(all_likelihood)
-      ! one set of accumulators per rank of the group
-      if (shared) call rfgpu_check(rf_post_sets(gctx, int(g_size, c_int32_t)), "rf_post_sets")
-      call rfgpu_check(rf_post_create(gctx, pc), "rf_post_create")
+      call rfgpu_check(rf_post_create(rf_ctx, pc), "rf_post_create")
     end subroutine setup_device_posterior
 
-    ! Device accumulators -> the arrays of module pt_mcmc that output_results reads.  In a GPU group the first rank
-    ! reads every rank's set and mails it to its owner (end of the run, once): each rank then holds exactly what it would
-    ! have accumulated alone and the reference's output_results reduces / gathers as ever (src/mcmc_out.f90:52-93).
-    subroutine fetch_device_posterior()
-      integer :: ig, st(MPI_STATUS_SIZE)
-      real(8), allocatable :: vp0(:,:), vs0(:,:), al0(:)
-
-      if (.not. shared) then
-         call read_selected_set()
-         return
-      end if
-      if (leader) then
-         ! (rows beyond a set's models keep what init_pt_mcmc put there: start every set from that state)
-         allocate(vp0, source=vp_model)
-         allocate(vs0, source=vs_model)
-         allocate(al0, source=all_likelihood)
-         do ig = g_size - 1, 0, -1
-            vp_model = vp0;  vs_model = vs0;  all_likelihood = al0
-            call rfgpu_check(rf_post_select(gctx, int(ig, c_int32_t)), "rf_post_select")
-            call read_selected_set()
-            if (ig == 0) exit
-            call mpi_send(nmod, 1, MPI_INTEGER4, ig, 901, node_comm, ierr)
-            call mpi_send(nk, size(nk), MPI_INTEGER4, ig, 902, node_comm, ierr)
-            call mpi_send(nz, size(nz), MPI_INTEGER4, ig, 903, node_comm, ierr)
-            call mpi_send(nsig, size(nsig), MPI_INTEGER4, ig, 904, node_comm, ierr)
-            call mpi_send(namp, size(namp), MPI_INTEGER4, ig, 905, node_comm, ierr)
-            call mpi_send(nvpz, size(nvpz), MPI_INTEGER4, ig, 906, node_comm, ierr)
-            call mpi_send(nvsz, size(nvsz), MPI_INTEGER4, ig, 907, node_comm, ierr)
-            call mpi_send(nvpvsz, size(nvpvsz), MPI_INTEGER4, ig, 908, node_comm, ierr)
-            call mpi_send(vp_mean, size(vp_mean), MPI_REAL8, ig, 909, node_comm, ierr)
-            call mpi_send(vs_mean, size(vs_mean), MPI_REAL8, ig, 910, node_comm, ierr)
-            call mpi_send(vpvs_mean, size(vpvs_mean), MPI_REAL8, ig, 911, node_comm, ierr)
-            call mpi_send(vp_model, size(vp_model), MPI_REAL8, ig, 912, node_comm, ierr)
-            call mpi_send(vs_model, size(vs_model), MPI_REAL8, ig, 913, node_comm, ierr)
-            call mpi_send(all_likelihood, size(all_likelihood), MPI_REAL8, ig, 914, node_comm, ierr)
-         end do
-      else
-         call mpi_recv(nmod, 1, MPI_INTEGER4, 0, 901, node_comm, st, ierr)
-         call mpi_recv(nk, size(nk), MPI_INTEGER4, 0, 902, node_comm, st, ierr)
-         call mpi_recv(nz, size(nz), MPI_INTEGER4, 0, 903, node_comm, st, ierr)
-         call mpi_recv(nsig, size(nsig), MPI_INTEGER4, 0, 904, node_comm, st, ierr)
-         call mpi_recv(namp, size(namp), MPI_INTEGER4, 0, 905, node_comm, st, ierr)
-         call mpi_recv(nvpz, size(nvpz), MPI_INTEGER4, 0, 906, node_comm, st, ierr)
-         call mpi_recv(nvsz, size(nvsz), MPI_INTEGER4, 0, 907, node_comm, st, ierr)
-         call mpi_recv(nvpvsz, size(nvpvsz), MPI_INTEGER4, 0, 908, node_comm, st, ierr)
-         call mpi_recv(vp_mean, size(vp_mean), MPI_REAL8, 0, 909, node_comm, st, ierr)
-         call mpi_recv(vs_mean, size(vs_mean), MPI_REAL8, 0, 910, node_comm, st, ierr)
-         call mpi_recv(vpvs_mean, size(vpvs_mean), MPI_REAL8, 0, 911, node_comm, st, ierr)
-         call mpi_recv(vp_model, size(vp_model), MPI_REAL8, 0, 912, node_comm, st, ierr)
-         call mpi_recv(vs_model, size(vs_model), MPI_REAL8, 0, 913, node_comm, st, ierr)
-         call mpi_recv(all_likelihood, size(all_likelihood), MPI_REAL8, 0, 914, node_comm, st, ierr)
-      end if
-    end subroutine fetch_device_posterior
-
-    ! the selected set of accumulators of the group's context -> module pt_mcmc's arrays
-    subroutine read_selected_set()
+    ! Device accumulators -> the arrays of module pt_mcmc that output_results reads
+    subroutine read_device_posterior()
       type(rf_post_result) :: pr
       integer(c_int32_t), target :: t_nmod
       integer(c_int64_t), target :: t_oor
@@ -960,7 +728,7 @@ contains
       pr%vp_mean = c_null_ptr;  pr%vs_mean = c_null_ptr;  pr%vpvs_mean = c_null_ptr
       pr%vp_model = c_null_ptr;  pr%vs_model = c_null_ptr;  pr%all_likelihood = c_null_ptr
       pr%amp_out_of_range = c_null_ptr
-      call rfgpu_check(rf_post_read(gctx, pr), "rf_post_read")
+      call rfgpu_check(rf_post_read(rf_ctx, pr), "rf_post_read")
       nm = max(1, min(int(t_nmod), size(all_likelihood)))
       allocate(t_nk(k_max), t_nz(nbin_z), t_nsig(nbin_sig, ntrc), t_namp(nbin_amp, nsmp, ntrc))
       allocate(t_nvpz(nbin_z, nbin_vp), t_nvsz(nbin_z, nbin_vs), t_nvpvsz(nbin_z, nbin_vpvs))
@@ -970,7 +738,7 @@ contains
       pr%vp_mean = c_loc(t_vpm);  pr%vs_mean = c_loc(t_vsm);  pr%vpvs_mean = c_loc(t_vpvsm)
       pr%vp_model = c_loc(t_vpmod);  pr%vs_model = c_loc(t_vsmod);  pr%all_likelihood = c_loc(t_all)
       pr%amp_out_of_range = c_loc(t_oor)
-      call rfgpu_check(rf_post_read(gctx, pr), "rf_post_read")
+      call rfgpu_check(rf_post_read(rf_ctx, pr), "rf_post_read")
       nmod = t_nmod
       nk = t_nk;  nz = t_nz;  nsig = t_nsig;  namp = t_namp
       nvpz = t_nvpz;  nvsz = t_nvsz;  nvpvsz = t_nvpvsz
@@ -982,7 +750,7 @@ contains
          all_likelihood(1:nm) = t_all(1:nm)
       end if
       if (t_oor > 0) write(0,*) "Warning: RF amp. out of range (", t_oor, " samples)"
-    end subroutine read_selected_set
+    end subroutine read_device_posterior
 
   end subroutine pt_control_batched
 

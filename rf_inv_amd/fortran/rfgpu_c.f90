@@ -166,29 +166,6 @@ module rfgpu_c
        type(c_ptr), intent(out) :: ptr
      end function rf_host_alloc
 
-     ! host memory shared by the ranks of a node (POSIX shared memory), registered with the GPU where gpu /= 0
-     integer(c_int) function rf_host_alloc_shared(name, bytes, create, gpu, ptr) bind(C, name="rf_host_alloc_shared")
-       import :: c_int, c_size_t, c_ptr, c_char, c_int32_t
-       character(kind=c_char), intent(in) :: name(*)
-       integer(c_size_t), value :: bytes
-       integer(c_int32_t), value :: create, gpu
-       type(c_ptr), intent(out) :: ptr
-     end function rf_host_alloc_shared
-
-     integer(c_int) function rf_release_gpu() bind(C, name="rf_release_gpu")
-       import :: c_int
-     end function rf_release_gpu
-
-     integer(c_int) function rf_host_unlink_shared(ptr) bind(C, name="rf_host_unlink_shared")
-       import :: c_int, c_ptr
-       type(c_ptr), value :: ptr
-     end function rf_host_unlink_shared
-
-     integer(c_int) function rf_host_free_shared(ptr) bind(C, name="rf_host_free_shared")
-       import :: c_int, c_ptr
-       type(c_ptr), value :: ptr
-     end function rf_host_free_shared
-
      integer(c_int) function rf_host_free(ptr) bind(C, name="rf_host_free")
        import :: c_int, c_ptr
        type(c_ptr), value :: ptr
@@ -241,18 +218,6 @@ module rfgpu_c
        integer(c_int64_t), intent(out) :: launches(4)
        integer(c_int32_t), value :: reset
      end function rf_profile_read
-
-     integer(c_int) function rf_post_sets(ctx, nsets) bind(C, name="rf_post_sets")
-       import :: c_int, c_ptr, c_int32_t
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), value :: nsets
-     end function rf_post_sets
-
-     integer(c_int) function rf_post_select(ctx, set) bind(C, name="rf_post_select")
-       import :: c_int, c_ptr, c_int32_t
-       type(c_ptr), value :: ctx
-       integer(c_int32_t), value :: set
-     end function rf_post_select
 
      integer(c_int) function rf_post_reset(ctx) bind(C, name="rf_post_reset")
        import :: c_int, c_ptr
@@ -311,6 +276,14 @@ module rfgpu_c
        integer(c_int32_t), intent(inout) :: buf(*)
        integer(c_int32_t), value :: n, root
      end function rf_comm_bcast_i32
+
+     ! options of the context's communicator: "sequential_reduce" 0 | 1
+     integer(c_int) function rf_comm_set_option(ctx, name, value) bind(C, name="rf_comm_set_option")
+       import :: c_int, c_ptr, c_char, c_double
+       type(c_ptr), value :: ctx
+       character(kind=c_char), intent(in) :: name(*)
+       real(c_double), value :: value
+     end function rf_comm_set_option
 
      ! end-of-run merge of the device accumulators (src/mcmc_out.f90:52-93) over the RCCL communicator
      integer(c_int) function rf_comm_post_reduce(ctx, root, nmod_sum) bind(C, name="rf_comm_post_reduce")

@@ -45,13 +45,9 @@ class PosteriorResult:
 class Posterior:
     """Device-resident accumulators of one engine context (one rank)."""
 
-    def __init__(self, engine: RFEngine, p: Params, max_models: int | None = None, nsets: int = 1):
-        """Needs engine.set_model(p, ref) first (the V-z profile runs format_model).  nsets > 1: one set of
-        accumulators per host rank the context serves (rf_post_sets); select(i) names the set that record / read use."""
+    def __init__(self, engine: RFEngine, p: Params, max_models: int | None = None):
+        """Needs engine.set_model(p, ref) first (the V-z profile runs format_model)."""
         self.engine, self.p = engine, p
-        self.nsets = int(nsets)
-        if self.nsets != 1:
-            engine._chk(engine._lib.rf_post_sets(engine._ctx, self.nsets))
         if max_models is None:
             max_models = int(p.nchains * p.niter / p.ncorr)                      # :407-409
         self.max_models = int(max_models)
@@ -63,16 +59,15 @@ class Posterior:
                                 _dptr(self._smin), _dptr(self._smax), _iptr(self._smode), self.max_models)
         engine._chk(engine._lib.rf_post_create(engine._ctx, C.byref(cfg)))
 
-    def select(self, i):
-        self.engine._chk(self.engine._lib.rf_post_select(self.engine._ctx, int(i)))
-
     def reset(self):
         self.engine._chk(self.engine._lib.rf_post_reset(self.engine._ctx))
 
     def record(self, chains, k, z, dvp, dvs, sig, logl, temps=None):
         """Record the chains `chains` (ids into the engine's walkers) in order; k[n], z[n, k_max-1],
         dvp/dvs[n, k_max], sig[n, ntrc], logl[n] are their CURRENT state.  temps[n] (optional) applies
-        the reference's temp <= 1 + 1e-6 filter on the device."""
+        the reference's temp <= 1 + 1e-6 filter on the device.  Pageable arrays are copied before the call returns;
+        arrays from host_alloc (pinned) are read by DMA after it returns: leave them alone until a later call on the
+        engine has waited for the device (read(), eval_wait ...)."""
         ids = np.ascontiguousarray(chains, dtype=np.int32)
         n = ids.size
         if n == 0:

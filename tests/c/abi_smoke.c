@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <math.h>
 #include "rfgpu.h"
+#include "rfgpu_ext.h"   /* the extensions header is plain C too */
 
 int main(void)
 {

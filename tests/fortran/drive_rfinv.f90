@@ -6,7 +6,7 @@
 ! per-iteration mean T=1 log-likelihood (what mcmc_out writes to
 ! rslt/likelihood, src/mcmc_out.f90:142) and the proposal counters.
 !   usage: drive_rfinv params.in n_burn n_iter mode [out [rccl_library]]  (mode 0: the reference's
-!          pt_control, 1: our pt_control_batched, 2: the same without its two-segment pipeline, 3: mode 1 with GPU groups (rf_share_gpu), 4: segments by the chain count (the module's default); a fifth argument makes the reference's own
+!          pt_control, 1: our pt_control_batched, 2: the same without its two-segment pipeline, 4: segments by the chain count (the module's default); a fifth argument makes the reference's own
 !          output_results (src/mcmc_out.f90, compiled unmodified) write its result files
 !          into params.in's output directory)
 !=======================================================================
@@ -60,10 +60,9 @@ program drive_rfinv
   if (mode == 0) then
      call pt_control(.false.)
   else
-     rf_pipeline_segments = 2                    ! mode 1 and 3: the two-segment pipeline whatever the chain count
+     rf_pipeline_segments = 2                    ! mode 1: the two-segment pipeline whatever the chain count
      if (mode == 2) rf_pipeline_segments = 1     ! propose all, evaluate all, judge all (no host / GPU overlap)
      if (mode == 4) rf_pipeline_segments = 0     ! the module's default: by the number of chains
-     if (mode == 3) rf_share_gpu = .true.        ! ranks that share a GPU form a group: its first rank launches for all of them
      call get_environment_variable("RFINV_TIME_KERNELS", arg)
      rf_time_kernels = len_trim(arg) > 0
      call pt_control_batched(.false.)
@@ -78,7 +77,7 @@ program drive_rfinv
        & rf_phase_seconds
   if (rank == 0 .and. mode /= 0 .and. rf_time_kernels) write(*,'(A,3F12.3,4I9)') " drive_rfinv: kernel ms (main, trace, likelihood), batches and launches ", &
        & rf_kernel_ms, rf_kernel_launches
-  if (rank == 0 .and. mode /= 0) write(*,'(A,6F10.4)') " drive_rfinv: group seconds (wait, barrier, barrier, commit, record, begin) ", rf_group_seconds
+  if (rank == 0 .and. mode /= 0) write(*,'(A,4F10.4)') " drive_rfinv: engine call seconds (wait, commit, record, begin) ", rf_call_seconds
 
   u = 79
   if (nproc == 1) then

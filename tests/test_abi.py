@@ -1,4 +1,5 @@
-"""The C-ABI library loads and exports every symbol include/rfgpu.h declares.  CPU only:
+"""The C-ABI library loads and exports every symbol include/rfgpu.h (the section-8b contract) and include/rfgpu_ext.h
+(extensions) declare.  CPU only:
 no compute entry is called (rf_compute_r_inv is a host-only helper)."""
 import ctypes as C
 import os
@@ -10,10 +11,21 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _header_functions():
-    txt = open(os.path.join(ROOT, "include", "rfgpu.h")).read()
-    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(rf_[a-z_0-9]+)\s*\(", txt)))
+def _header_functions(names=("rfgpu.h", "rfgpu_ext.h")):
+    out = set()
+    for name in names:
+        txt = open(os.path.join(ROOT, "include", name)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        out |= set(re.findall(r"\b(rf_[a-z_0-9]+)\s*\(", txt))
+    return sorted(out)
+
+
+# SURVEY.md section 8b, last row: what a C-ABI replacement must export at least
+SURVEY_8B_MINIMUM = {"rf_ctx_create", "rf_calc_rf", "rf_calc_likelihood", "rf_eval_batch", "rf_commit", "rf_get_rft",
+                     "rf_pt_swap_device", "rf_ctx_destroy"}
+# measured slower than the default and removed in round 5 (What's weak #7): must not come back unnoticed
+REMOVED = {"rf_host_alloc_shared", "rf_host_unlink_shared", "rf_host_free_shared", "rf_release_gpu", "rf_post_sets",
+           "rf_post_select"}
 
 
 def test_header_symbols_exported_and_bound():
@@ -26,7 +38,12 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, n), f"{n} declared in rfgpu.h but not exported by librfgpu.so"
         assert n in _lib.SYMBOLS, f"{n} not bound in rf_inv_amd/_lib.py"
     assert sorted(_lib.SYMBOLS) == names
-    assert lib.rf_abi_version() == 5
+    assert lib.rf_abi_version() == 6
+    contract = set(_header_functions(("rfgpu.h",)))
+    assert SURVEY_8B_MINIMUM <= contract and len(contract) <= 32
+    # the contract header stands alone: nothing of the extensions leaks into it
+    assert not any(n.startswith(("rf_post_", "rf_eval_models", "rf_host_", "rf_set_option", "rf_profile_")) for n in contract)
+    assert not (REMOVED & set(names)) and not any(hasattr(lib, n) for n in REMOVED)
 
 
 def test_config_struct_layout_matches_header():
@@ -111,7 +128,7 @@ def test_header_is_plain_c_and_a_c_host_links(tmp_path):
                            "-lm", f"-Wl,-rpath,{libdir}"])
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "abi 5 rank" in r.stdout
+    assert "abi 6 rank" in r.stdout
     assert "no context: rf_ctx_create: no HIP device" in r.stdout or "calc_rf rc 0" in r.stdout
 
 

@@ -1,0 +1,80 @@
+"""bench.py's stdout contract: ONE compact JSON line (< 4 KB) that the driver can parse, built from the full record.
+Round 4's line carried every `also` workload (34.8 KB) and came back `parsed: null` (Missing #1)."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CANNED = os.path.join(ROOT, "profiles", "r04_bench_n1.json")    # a full record as run() + main() assemble it
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def _full():
+    return json.load(open(CANNED))
+
+
+def test_headline_is_short_and_round_trips():
+    full = _full()
+    assert len(json.dumps(full)) > 30000                         # the record that broke the driver
+    s = bench.headline_line(full, "bench_detail.json")
+    assert "\n" not in s and len(s) < 4096, len(s)
+    d = json.loads(s)
+    for k in CONTRACT:
+        assert k in d, k
+    assert d["metric"] == bench.METRIC and d["unit"] == "evals/s" and d["dtype"] == "f64"
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["value"] == pytest.approx(full["value"], rel=1e-5)
+    assert d["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    # value = walkers * steps / time, on the line's own numbers
+    assert d["value"] == pytest.approx(d["n_gpus"] * d["config"]["walkers_per_gpu"] / (d["ms_per_step"] * 1e-3), rel=1e-4)
+    assert "model" not in d["config"] and d["config"]["workload"].startswith("c4")
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms"):
+        assert k in r, k
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-4) and 0.0 < r["frac"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["parity_in_bench"]["within_tolerance"] is True
+    assert set(d["also"]) == set(full["also"]) and all(isinstance(v, float) for v in d["also"].values())
+    assert d["detail_file"] == "bench_detail.json"
+
+
+def test_headline_stays_short_whatever_the_record_carries():
+    full = _full()
+    full["config"]["overrides"] = {f"option_{i}": float(i) for i in range(40)}
+    full["also"] = {f"workload_{i}": {"value": 1.0e6 + i, "config": {"x": "y" * 5000}} for i in range(60)}
+    full["cpu_baseline"]["sample"] = "s" * 10000
+    full["cpu_baseline"].pop("sample_short", None)
+    s = bench.headline_line(full, None)
+    assert len(s) < 4096
+    d = json.loads(s)
+    assert all(k in d for k in CONTRACT)
+
+
+def test_headline_of_a_multi_rank_record_keeps_the_swap_verdict():
+    full = _full()
+    full.update(n_gpus=8, swap_replay_ok=True, cross_rank_swaps=1234)
+    full["config"]["rccl"] = {"ranks": 8, "version": "2.26.6", "transport": "rccl_allgather", "control_plane": "gloo",
+                              "init_s": 3.25, "note": "n" * 3000}
+    full.pop("cpu_baseline")
+    full.pop("also")
+    d = json.loads(bench.headline_line(full, "bench_detail.json"))
+    assert d["swap_replay_ok"] is True and d["cross_rank_swaps"] == 1234
+    assert d["config"]["rccl"] == {"ranks": 8, "version": "2.26.6", "transport": "rccl_allgather", "control_plane": "gloo",
+                                   "init_s": 3.25}
+    assert "cpu_baseline" not in d and "also" not in d
+
+
+def test_nan_never_reaches_the_line():
+    full = _full()
+    full["roofline"]["frac_at_clock"] = float("nan")
+    s = bench.headline_line(full, None)
+    assert "NaN" not in s
+    assert json.loads(s)["roofline"]["frac_at_clock"] is None

@@ -75,7 +75,11 @@ def _run_config(name, expect_defer, nsample, extra_check=None, walkers=None):
         plan = eng.launch_plan
         # the DEFAULT plan is the subject: no option set, production build
         assert plan["overrides"] == 0 and plan["build"] == "production" and plan["fused"] and plan["defer_logl"] == -1
-        assert plan["chain"] == 8        # land and ocean: one 8-bin chain per wave
+        # land and ocean: one 8-bin chain per wave (fused_kernel); contexts of <= 3 rounds of blocks at nfft 4096 on land
+        # (C2) and the common-ray kernel: 512-thread blocks, 4-bin chains
+        small = plan["block_threads_full_batch"] == 512
+        assert plan["common_ray_fused"] == bool(eng.is_ray_common and ntrc > 1)
+        assert plan["chain"] == (4 if small else 8) or plan["common_ray_fused"]
         # by batch size the library defers the quadratic form + logL to the follow-up kernel(s) here
         # (rfgpu_api.cpp run_batch: >= 2 rounds of blocks with several traces, >= 4 rounds with one)
         blocks, rnd = nb * ntrc, 2 * 256
@@ -84,23 +88,29 @@ def _run_config(name, expect_defer, nsample, extra_check=None, walkers=None):
             assert plan["long_window_gemm"] and nsmp >= 192
         else:
             assert not plan["long_window_gemm"]
-            assert (blocks >= (2 if ntrc > 1 else 4) * rnd) == expect_defer
+            if not plan["common_ray_fused"]:
+                assert (blocks >= (2 if ntrc > 1 else 4) * rnd) == expect_defer
         stream = torch.cuda.Stream(device=dev)
         d_ids = torch.arange(nb, dtype=torch.int32, device=dev)
         d_nlay, d_layers = torch.from_numpy(nlay).to(dev), torch.from_numpy(layers).to(dev)
         d_sig = torch.from_numpy(sig).to(dev)
         d_logl = torch.empty(nb, dtype=torch.float64, device=dev)
-        swap = PTSwap(eng, nb, w["temps"], dev, seed=99, t_high=15.0, mode="allgather")
-        temps = init_temps(nb, max(1, nb // w["temps"]), 15.0, np.random.Generator(np.random.Philox(key=99 + 7919)))
-        sched = PairSchedule(nb, 99, swap.k)
+        tempered = w["temps"] > 1                   # (C2 / c2d: 1024 chains at T = 1, no swap step)
+        if tempered:
+            swap = PTSwap(eng, nb, w["temps"], dev, seed=99, t_high=15.0, mode="allgather")
+            temps = init_temps(nb, max(1, nb // w["temps"]), 15.0, np.random.Generator(np.random.Philox(key=99 + 7919)))
+            sched = PairSchedule(nb, 99, swap.k)
         lls = []
         for step in range(3):                       # evaluation + swap, like bench.py's step
             with torch.cuda.stream(stream):
                 eng.eval_batch_device(d_ids, d_nlay, d_layers, d_sig, d_logl, stream=stream)
-                swap.step(d_logl, stream)
+                if tempered:
+                    swap.step(d_logl, stream)
             stream.synchronize()
             ll = d_logl.cpu().numpy()
             lls.append(ll)
+            if not tempered:
+                continue
             pairs, logu = sched.draw()
             for (i1, i2), lu in zip(pairs, logu):
                 if judge_pt(temps[i1], temps[i2], ll[i1], ll[i2], lu):
@@ -109,8 +119,9 @@ def _run_config(name, expect_defer, nsample, extra_check=None, walkers=None):
         ll = lls[0]
         assert np.all(np.isfinite(ll))
         assert np.array_equal(lls[1], ll) and np.array_equal(lls[2], ll)       # deterministic; the swap moves temperatures only
-        assert np.sum(temps != init_temps(nb, max(1, nb // w["temps"]), 15.0,
-                                          np.random.Generator(np.random.Philox(key=99 + 7919)))) > 0   # swaps did happen
+        if tempered:
+            assert np.sum(temps != init_temps(nb, max(1, nb // w["temps"]), 15.0,
+                                              np.random.Generator(np.random.Philox(key=99 + 7919)))) > 0   # swaps did happen
         # (1) walkers are independent: a permuted batch gives the permuted result, bit for bit
         perm = rng.permutation(nb)
         ll_p = eng.eval_batch(np.arange(nb), nlay[perm], layers[perm], sig)
@@ -166,6 +177,24 @@ def _run_config(name, expect_defer, nsample, extra_check=None, walkers=None):
         assert np.array_equal(eng.get_rft(int(idx[j]), which=1).T, got_all[j])
         if extra_check:
             extra_check(eng, p, cfg, obs, r_inv, oracle)
+
+
+def test_c2_default_plan_full_batch():
+    """C2 = BASELINE configs[1]: 1024 chains at T = 1, one P trace, nfft 4096, <= 15 layers: two rounds of blocks --
+    fused8_kernel (512 threads, 4-bin chains), quadratic form + logL inside the block; no swap step.  Every walker
+    against the oracle + the size-independent properties."""
+    _run_config("c2", expect_defer=False, nsample=48)
+
+
+def test_c2d_default_plan_full_batch():
+    """C2 with water-level deconvolution (deconv_mode 1, forward.f90:148-153,447-470): every one of the 1024 walkers."""
+    _run_config("c2d", expect_defer=False, nsample=48)
+
+
+def test_c4common_default_plan_full_batch():
+    """C4 in single-FWD mode (three traces of ONE ray, Gaussian a 4.0 / 2.5 / 1.5; forward.f90:59-91,141): fusedc_kernel,
+    one block per walker, one propagator pass feeding three trace tails.  Every one of the 8192 walkers."""
+    _run_config("c4common", expect_defer=True, nsample=36)
 
 
 def test_c3_default_plan_full_batch():
@@ -349,7 +378,8 @@ def test_bench_two_ranks_on_one_gpu_swap_matches_serial_replay(tmp_path, launche
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == steps
     assert abs(d["value"] - 2 * nb * steps / (d["ms_per_step"] * 1e-3 * steps)) < 1e-6 * d["value"]
     assert d["config"]["parallelism"] == "walkers sharded x2"
-    assert d["config"]["rccl"]["ranks"] == 0 and "share a GPU" in d["config"]["rccl"]["transport"]
+    assert d["config"]["rccl"]["ranks"] == 0 and d["config"]["rccl"]["transport"] == "process_group"
+    assert len(line) < 4096 and line == r.stdout.splitlines()[-1]          # one compact line, the last of stdout
     assert d["swap_replay_ok"] is True and d["cross_rank_swaps"] > 0       # the run's own check of its exchange
     st = _replay_bench_state(dump, nb, ntemps, 2)
     assert int(st["swap_steps"]) == 16 + warm + steps
@@ -377,15 +407,54 @@ def test_bench_rccl_route_with_two_ranks_on_one_gpu(tmp_path):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c3", "--walkers", str(nb), "--steps",
            str(steps), "--warmup", str(warm), "--prewarm-seconds", "0", "--no-cpu-baseline", "--also", "", "--dump-state",
-           str(dump), "--rccl-library", lib]
+           str(dump), "--rccl-library", lib, "--detail-file", str(tmp_path / "detail.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert len(r.stdout.splitlines()[-1]) < 4096
+    d = json.loads(r.stdout.splitlines()[-1])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "walkers sharded x2"
     assert d["config"]["rccl"]["ranks"] == 2 and d["config"]["rccl"]["library"] == lib
-    assert "rf_pt_swap_allgather_device" in d["config"]["rccl"]["transport"]
-    assert d["swap_replay_ok"] is True and d["cross_rank_swaps"] > 0 and d["swap_replay"]["swap_steps"] == 16 + warm + steps
+    assert d["config"]["rccl"]["transport"] == "rccl_allgather" and d["config"]["rccl"]["control_plane"] == "gloo"
+    assert d["swap_replay_ok"] is True and d["cross_rank_swaps"] > 0
+    full = json.load(open(tmp_path / "detail.json"))                       # the full record of the same run
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5) and full["swap_replay"]["swap_steps"] == 16 + warm + steps
+    assert full["config"]["launch_plan"]["build"] == "production"
     st = _replay_bench_state(dump, nb, ntemps, 2)
+    assert int(st["swap_steps"]) == 16 + warm + steps
+
+
+def test_bench_eight_ranks_over_the_rccl_double(tmp_path):
+    """The command line of the driver's 8-GPU SCALE run -- `bench.py --gpus 8`, workload c4 -- as eight ranks on the one
+    GPU over the RCCL test double: gloo control plane, rf_comm_init with nranks = 8, one grouped pair of all-gathers per
+    step over eight rank blocks, the run's own replay of the swap schedule over all 8 x 1024 walkers, ONE compact line."""
+    import json
+    import shutil
+    import subprocess
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    lib = str(tmp_path / "librccl_double.so")
+    subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-o", lib, os.path.join(ROOT, "tests", "c", "rccl_double.cpp")],
+                   check=True, capture_output=True, timeout=300)
+    dump = tmp_path / "state.npz"
+    nb, ntemps, steps, warm, nr = 1024, 8, 4, 1, 8
+    env = dict(os.environ, RFGPU_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nr), "--workload", "c4", "--walkers", str(nb),
+           "--steps", str(steps), "--warmup", str(warm), "--prewarm-seconds", "0", "--dump-state", str(dump),
+           "--rccl-library", lib, "--detail-file", str(tmp_path / "detail.json")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = r.stdout.splitlines()
+    assert len(out) == 1 and len(out[0]) < 4096                 # the ranks' relay prints rank 0's line and nothing else
+    d = json.loads(out[0])
+    assert d["n_gpus"] == nr and d["config"]["parallelism"] == f"walkers sharded x{nr}" and d["scaling"] == "weak"
+    assert d["config"]["rccl"]["ranks"] == nr and d["config"]["rccl"]["transport"] == "rccl_allgather"
+    assert d["config"]["walkers_per_gpu"] == nb and d["config"]["ntrc"] == 3
+    assert d["value"] == pytest.approx(nr * nb / (d["ms_per_step"] * 1e-3), rel=1e-4)
+    assert d["swap_replay_ok"] is True and d["cross_rank_swaps"] > 0
+    assert "cpu_baseline" not in d                              # rank 0 at N = 1 only
+    st = _replay_bench_state(dump, nb, ntemps, nr)
     assert int(st["swap_steps"]) == 16 + warm + steps
 
 

@@ -195,53 +195,6 @@ def test_eval_models_from_host_arrays(oracle, golden_dir, pinned, ldz_full):
             assert abs(ll2[i] - want) <= logl_tol(want), (i, ll2[i], want)
 
 
-def test_eval_models_from_shared_host_memory(oracle, golden_dir, tmp_path):
-    """rf_host_alloc_shared: arrays in POSIX shared memory that ANOTHER process fills (what a rank sharing the GPU
-    does with its proposals) go down by DMA from the process that owns the context -- nothing staged -- and give the
-    results of ordinary arrays, bit for bit."""
-    import subprocess
-    import sys
-    import uuid
-
-    from rf_inv_amd import RFEngine, read_ref_model
-    from rf_inv_amd.engine import host_alloc_shared
-    from rf_inv_amd.likelihood import init_r_inv
-
-    p, ref, mcfg = _setup(golden_dir, 0.0, 0, 12)
-    ref = read_ref_model(os.path.join(p.base_dir, p.vel_file))
-    rng = np.random.default_rng(11)
-    nb = 300
-    k, z, dvp, dvs = _proposals(rng, p, nb)
-    sig = rng.uniform(0.01, 0.03, (nb, p.ntrc))
-    ids = np.arange(nb, dtype=np.int32)
-    src = dict(ids=ids, k=k, z=z, dvp=dvp, dvs=dvs, sig=sig)
-    np.savez(tmp_path / "src.npz", **src)
-    tag = "/rfgpu_test_" + uuid.uuid4().hex[:12]
-    with RFEngine.from_params(p, r_inv=init_r_inv(p.nsmp, p.a_gus, p.delta), max_walkers=nb) as eng:
-        eng.set_model(p, ref)
-        want = eng.eval_models(ids, k, z, dvp, dvs, sig)
-        assert eng.launch_plan["staged_host_arrays"] > 0
-        sh = {n: host_alloc_shared(f"{tag}_{n}", a.shape, a.dtype, create=True, gpu=True) for n, a in src.items()}
-        assert all(not a.any() for a in sh.values())                   # created zero-filled
-        # another process maps the same blocks and writes the proposals
-        code = ("import sys, numpy as np; sys.path.insert(0, %r)\n"
-                "from rf_inv_amd.engine import host_alloc_shared\n"
-                "d = np.load(%r)\n"
-                "for n in d.files:\n"
-                "    a = host_alloc_shared(%r + '_' + n, d[n].shape, d[n].dtype)\n"
-                "    a[...] = d[n]\n" % (ROOT, str(tmp_path / "src.npz"), tag))
-        subprocess.run([sys.executable, "-c", code], check=True, timeout=300, cwd=ROOT)
-        for n, a in src.items():
-            assert np.array_equal(sh[n], a), n
-        got = eng.eval_models(sh["ids"], sh["k"], sh["z"], sh["dvp"], sh["dvs"], sh["sig"])
-        assert eng.launch_plan["staged_host_arrays"] == 0                # DMA in place
-        assert np.array_equal(got, want, equal_nan=True)
-        h = nb // 3                                                      # a rank's slice: an interior pointer
-        part = eng.eval_models(sh["ids"][h:], sh["k"][h:], sh["z"][h:], sh["dvp"][h:], sh["dvs"][h:], sh["sig"][h:])
-        assert eng.launch_plan["staged_host_arrays"] == 0 and np.array_equal(part, want[h:], equal_nan=True)
-    del sh
-
-
 @pytest.mark.parametrize("pinned", [False, True])
 def test_copy_stream_option_same_results_with_evaluations_in_flight(oracle, golden_dir, pinned):
     """rf_set_option("copy_stream", 1): rf_eval_models_begin transfers a batch's host arrays on a stream of the

@@ -29,7 +29,7 @@ def test_library_is_the_hip_one():
     from rf_inv_amd import _lib
 
     lib = _lib.load()
-    assert lib.rf_abi_version() == 5
+    assert lib.rf_abi_version() == 6
     assert os.path.basename(_lib.LIB_PATH) == "librfgpu.so"
 
 
@@ -1198,3 +1198,46 @@ def test_long_window_triangle_with_an_asymmetric_matrix(oracle):
         # (the antisymmetric part cancels in exact arithmetic only; its rounding -- eps |m| |A| |m| -- stays far inside
         # the tolerance: |A| is 5 % of |R|)
         assert_logl_parity(got, ref, kap, f"asymmetric matrix, triangle {tri}")
+
+
+@pytest.mark.parametrize("nsmp", [101, 333])
+@pytest.mark.parametrize("triangle", [1, 0])
+def test_set_r_inv_replaces_every_image_of_the_matrix(oracle, nsmp, triangle):
+    """rf_set_r_inv after creation (a host that builds the pseudo-inverse through its own LAPACK,
+    src/likelihood.f90:183-222): every device image of the matrix follows -- the transposed one of the in-kernel
+    quadratic form (nsmp 101), the padded one and the TRIANGULAR one the long-window GEMM multiplies by default
+    (nsmp 333; round 4 left that one at the creation-time matrix: ADVICE r04) -- so logL is the new matrix's."""
+    if nsmp < 192 and triangle == 0:
+        pytest.skip("gemm_triangle only exists on the long-window plan")
+    rng = np.random.default_rng(5 + nsmp)
+    nb = 70
+    cfg = make_cfg(nfft=1024, rayps=[0.06, 0.07], ipha=[1, 1], a_gus=[4.0, 2.5])
+    obs = synth_obs(oracle, cfg, random_stack(rng, 4), nsmp)
+    r0 = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    r1 = oracle.build_r_inv(nsmp, [3.0, 5.0], DELTA)                  # another matrix altogether
+    nlay, layers = pack_layers([random_stack(rng, int(n)) for n in rng.integers(3, 10, nb)], 12)
+    sig = rng.uniform(0.01, 0.05, (nb, 2))
+    ref0, kap = oracle.eval_batch(cfg, obs, r0, nlay, layers, sig, nsmp, nthreads=oracle.max_threads(), want_kappa=True)
+    ref1 = oracle.eval_batch(cfg, obs, r1, nlay, layers, sig, nsmp, nthreads=oracle.max_threads())
+    assert np.all(np.abs(ref1 - ref0) > 1e3 * logl_tol(ref0))          # the two matrices are told apart by far
+    opts = {"gemm_triangle": triangle} if nsmp >= 192 else {}
+    with _engine(cfg, obs, nsmp, r0, max_walkers=nb, nlay_max=12, options=opts) as eng:
+        assert eng.launch_plan["long_window_gemm"] == (nsmp >= 192)
+        assert_logl_parity(eng.eval_batch(np.arange(nb), nlay, layers, sig), ref0, kap, "creation-time matrix")
+        eng.set_r_inv(r1)
+        assert np.array_equal(eng.r_inv, r1)
+        got = eng.eval_batch(np.arange(nb), nlay, layers, sig)
+        assert_logl_parity(got, ref1, kap, f"after set_r_inv, nsmp {nsmp}, triangle {triangle}")
+        # a sigma-only proposal re-uses the quadratic forms cached with the chains' CURRENT traces
+        eng.commit(np.arange(nb), np.ones(nb, dtype=np.int32))
+        ff = np.zeros(nb, dtype=np.int32)
+        ref1s = oracle.eval_batch(cfg, obs, r1, nlay, layers, 2 * sig, nsmp, nthreads=oracle.max_threads())
+        assert_logl_parity(eng.eval_batch(np.arange(nb), nlay, layers, 2 * sig, fwd_flag=ff), ref1s, kap, "sigma-only")
+        # ... which belong to the matrix they were formed with: after another set_r_inv they are void (NaN, never a
+        # silently stale value) until the chains have been evaluated and committed again
+        eng.set_r_inv(r0)
+        assert np.all(np.isnan(eng.eval_batch(np.arange(nb), nlay, layers, 2 * sig, fwd_flag=ff)))
+        assert_logl_parity(eng.eval_batch(np.arange(nb), nlay, layers, sig), ref0, kap, "and back")
+        eng.commit(np.arange(nb), np.ones(nb, dtype=np.int32))
+        ref0s = oracle.eval_batch(cfg, obs, r0, nlay, layers, 2 * sig, nsmp, nthreads=oracle.max_threads())
+        assert_logl_parity(eng.eval_batch(np.arange(nb), nlay, layers, 2 * sig, fwd_flag=ff), ref0s, kap, "sigma-only again")

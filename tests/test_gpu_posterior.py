@@ -147,62 +147,6 @@ def test_posterior_record_matches_oracle(oracle, golden_dir, sdep, vp_mode, k_ma
         assert z0.nmod == 0 and not z0.namp.any() and not z0.vp_mean.any() and np.all(z0.vs_model[:, 0] == -999.9)
 
 
-def test_posterior_sets_keep_ranks_apart(oracle, golden_dir):
-    """rf_post_sets / rf_post_select: a context that serves several host ranks keeps one set of accumulators per rank;
-    each set ends up exactly as if its rank had recorded alone (two oracles), whatever the interleaving."""
-    from oracle.posterior_oracle import PosteriorOracle
-    from rf_inv_amd import RFEngine
-    from rf_inv_amd.posterior import Posterior
-
-    p, ref, mcfg = _setup(golden_dir, 0.0, 1, 12)
-    ntrc, n = 1, 90
-    p.ntrc, p.nsmp = ntrc, 101
-    p.sig_mode, p.sig_min, p.sig_max = [1], [0.005], [0.08]
-    p.amp_min, p.amp_max, p.nbin_amp = -0.05, 0.25, 40
-    p.nbin_z, p.nbin_vs, p.nbin_vp, p.nbin_vpvs, p.nbin_sig = 31, 25, 20, 15, 11
-    p.nchains, p.niter, p.ncorr = n, 3, 1
-    nm = 200
-    rng = np.random.default_rng(77)
-    k, z, dvp, dvs = _valid_states(oracle, rng, p, mcfg, n)
-    sig = rng.uniform(0.005, 0.0799, (n, 1))
-    pad = p.k_max + 2
-    nlay, lay = _layers(oracle, mcfg, k, z, dvp, dvs, pad)
-    obs = rng.normal(0, 0.05, (ntrc, 101))
-    ids = np.arange(n, dtype=np.int32)
-    with RFEngine(nfft=256, delta=DELTA, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=[0.06], a_gus=[4.0], ipha=[1],
-                  obs=obs, nsmp=101, max_walkers=n, nlay_max=pad) as eng:
-        logl = eng.eval_batch(ids, nlay, lay, sig)
-        eng.commit(ids, np.ones(n, dtype=np.int32))
-        traces = eng.get_rft_batch(ids, 0, 101)
-        eng.set_model(p, ref)
-        post = Posterior(eng, p, max_models=nm, nsets=3)
-        kw = dict(mcfg=mcfg, ntrc=ntrc, nsmp=101, nbin_z=p.nbin_z, nbin_vs=p.nbin_vs, nbin_vp=p.nbin_vp,
-                  nbin_vpvs=p.nbin_vpvs, nbin_sig=p.nbin_sig, nbin_amp=p.nbin_amp, amp_min=p.amp_min, amp_max=p.amp_max,
-                  z_min=p.z_min, sig_min=p.sig_min, sig_max=p.sig_max, sig_mode=p.sig_mode, max_models=nm)
-        orcs = [PosteriorOracle(**kw) for _ in range(3)]
-        blocks = [slice(0, 30), slice(30, 60), slice(60, 90)]
-        for rep in range(2):                                          # interleaved: set 0, 1, 2, 0, 1, 2 (set 1 once)
-            for s, blk in enumerate(blocks):
-                if s == 1 and rep == 1:
-                    continue
-                post.select(s)
-                post.record(ids[blk], k[blk], z[blk], dvp[blk], dvs[blk], sig[blk], logl[blk])
-                for i in range(n)[blk]:
-                    orcs[s].record(int(k[i]), z[i], dvp[i], dvs[i], sig[i], logl[i], traces[i], temp=1.0)
-        for s in (2, 0, 1):
-            post.select(s)
-            res = post.read()
-            assert res.nmod == orcs[s].nmod == (30 if s == 1 else 60)
-            _compare(res, orcs[s], nm)
-        post.reset()                                                  # every set
-        for s in range(3):
-            post.select(s)
-            z0 = post.read()
-            assert z0.nmod == 0 and not z0.namp.any() and np.all(z0.vs_model[:, 0] == -999.9)
-        with pytest.raises(Exception, match="out of range"):
-            post.select(3)
-
-
 def _read_cols(path):
     return [[float(t) for t in line.split()] for line in open(path) if line.strip()]
 

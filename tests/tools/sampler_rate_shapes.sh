@@ -4,9 +4,8 @@
 # over R MPI ranks (ranks that share a GPU exchange temperatures over MPI; each has its own context and stream, so
 # one rank's proposal loop on the host overlaps another rank's kernels).
 #   usage: tests/tools/sampler_rate_shapes.sh <c3|c4|c4w20> <total chains> <iterations> ["1 2 4"] [driver mode]
-#          driver mode 1: pt_control_batched with its two-segment pipeline (default); 2: without it; 3: mode 1 with GPU
-#          groups (rf_share_gpu: the first rank of a GPU evaluates the chains of all its ranks); 4: one or two segments by
-#          the chain count (pt_control_batched's default); 0: the reference's own
+#          driver mode 1: pt_control_batched with its two-segment pipeline (default); 2: without it; 4: one or two
+#          segments by the chain count (pt_control_batched's default); 0: the reference's own
 #          pt_control on the per-call drop-in.  RFINV_TIME_KERNELS=1: HIP-event kernel totals of the loop are printed too
 # The driver times its own loop (mpi_wtime around pt_control*, barriers on both sides); a short warm-up run comes
 # first so that the timed one does not pay the image's first page-in.  (ref: the loop timed is src/pt_mcmc.f90:488-571)
@@ -36,9 +35,9 @@ for line in open(sys.argv[1]):
         ph = [float(x) for x in line.split()[-5:]]
         print("    rank 0, ms per iteration: propose %.3f  eval %.3f  accept+commit %.3f  record %.3f  swap %.3f"
               % tuple(1e3 * x / nit for x in ph))
-    if "group seconds" in line:
-        ph = [float(x) for x in line.split()[-6:]]
-        print("    rank 0, within eval, ms per iteration: wait for the GPU %.3f  barrier after it %.3f  barrier before the engine calls %.3f  commit %.3f  record %.3f  begin %.3f"
+    if "engine call seconds" in line:
+        ph = [float(x) for x in line.split()[-4:]]
+        print("    rank 0, engine calls, ms per iteration: wait for the GPU %.3f  commit %.3f  record %.3f  begin %.3f"
               % tuple(1e3 * x / nit for x in ph))
 PY
   rm -rf $W
