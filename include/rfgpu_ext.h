@@ -4,6 +4,7 @@
  * conventions, same RFGPU_ABI_VERSION.
  *   - format_model on the device and the evaluation of proposals given as (k, z, dVp, dVs)   [row f-2]
  *   - pinned host memory for those arrays
+ *   - the two transforms of the reference's `module fftw` for hosts that execute its plans themselves  [rows a12, f-4]
  *   - posterior accumulation on the device and its end-of-run merge over RCCL               [row f-3]
  *   - launch-plan options, the launch plan, HIP-event timing
  */
@@ -69,6 +70,18 @@ int rf_eval_models_begin(rf_ctx *ctx, int32_t nb, const int32_t *walker_ids, con
                          const double *z, int32_t ldz, const double *dvp, const double *dvs, const double *sig,
                          int32_t want_valid, int32_t *ticket);
 int rf_eval_wait(rf_ctx *ctx, int32_t ticket, double *logl, int32_t *valid);
+
+/* ---- the transforms of `module fftw` outside the hot path ------------------------
+ * What the reference's two FFTW plans compute when a host executes them itself -- src/make_syn.f90:91-95,107-111 filters
+ * its noise series with dfftw_execute(ifft2) (r2c), a product with flt, dfftw_execute(ifft) (c2r) -- so that the drop-in
+ * `module fftw` (rf_inv_amd/fortran/fftw.f90) needs no FFTW3.  Host pointers, synchronous, on the calling thread's
+ * current HIP device; no context.  nfft: any length 2 .. 1048576 (the transform's definition, exact-table twiddles,
+ * compensated sums: O(nfft^2 / 2), an init-time utility -- inside evaluations the c2r is part of the trace kernels).
+ *   rf_fft_c2r: the plan `ifft` of src/fftw.f90:44 -- rx(1:nfft) from cx(1:nfft/2+1) (complex128, interleaved re, im),
+ *               unnormalised, Hermitian extension implied, Im cx(1) and Im cx(nfft/2+1) ignored as FFTW's c2r does
+ *   rf_fft_r2c: the plan `ifft2` of :45 -- cx(1:nfft/2+1) from rx(1:nfft); cx beyond nfft/2+1 is not touched */
+int rf_fft_c2r(int32_t nfft, const double *cx, double *rx);
+int rf_fft_r2c(int32_t nfft, const double *rx, double *cx);
 
 /* Pinned (page-locked, device-mapped) host memory.  Host arrays handed to rf_eval_batch / rf_eval_models from such
  * memory go to the device by DMA as they are; pageable arrays are first copied into the context's own pinned staging

@@ -85,6 +85,8 @@ SYMBOLS = {
     "rf_eval_models": (C.c_int, [_vp, C.c_int32, ip, ip, ip, dp, C.c_int32, dp, dp, dp, dp, ip]),
     "rf_eval_models_begin": (C.c_int, [_vp, C.c_int32, ip, ip, ip, dp, C.c_int32, dp, dp, dp, C.c_int32, ip]),
     "rf_eval_wait": (C.c_int, [_vp, C.c_int32, dp, ip]),
+    "rf_fft_c2r": (C.c_int, [C.c_int32, dp, dp]),
+    "rf_fft_r2c": (C.c_int, [C.c_int32, dp, dp]),
     "rf_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(_vp)]),
     "rf_host_free": (C.c_int, [_vp]),
     "rf_pt_swap_device": (C.c_int, [_vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),

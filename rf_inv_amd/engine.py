@@ -413,3 +413,28 @@ def host_alloc(shape, dtype=np.float64):
     arr = np.frombuffer(buf, dtype=dt, count=n).reshape(shape)
     weakref.finalize(buf, lib.rf_host_free, ptr)
     return arr
+
+
+def fft_c2r(cx, nfft):
+    """The reference's FFTW plan `ifft` (dfftw_plan_dft_c2r_1d, src/fftw.f90:44) on the GPU: unnormalised inverse real
+    transform of cx[0 : nfft // 2 + 1] (complex128; Im of the DC and Nyquist bins ignored) -> rx[nfft] (rf_fft_c2r)."""
+    lib = _lib.load()
+    nfft = int(nfft)
+    c = np.ascontiguousarray(np.asarray(cx, dtype=np.complex128)[: nfft // 2 + 1])
+    if c.size != nfft // 2 + 1:
+        raise ValueError("cx must hold nfft // 2 + 1 bins")
+    out = np.empty(nfft)
+    if lib.rf_fft_c2r(nfft, _dptr(c.view(np.float64)), _dptr(out)):
+        raise RFGPUError(lib.rf_last_error().decode())
+    return out
+
+
+def fft_r2c(rx):
+    """The reference's FFTW plan `ifft2` (dfftw_plan_dft_r2c_1d, src/fftw.f90:45) on the GPU: rx[nfft] ->
+    cx[nfft // 2 + 1] complex128 (rf_fft_r2c)."""
+    lib = _lib.load()
+    r = np.ascontiguousarray(rx, dtype=np.float64)
+    out = np.empty(r.size // 2 + 1, dtype=np.complex128)
+    if lib.rf_fft_r2c(int(r.size), _dptr(r), _dptr(out.view(np.float64))):
+        raise RFGPUError(lib.rf_last_error().decode())
+    return out

@@ -9,7 +9,8 @@
 ! but every evaluation is delegated to librfgpu (hand-written HIP kernels for
 ! gfx950) through the C ABI of include/rfgpu.h.  Written from scratch; nothing
 ! here is taken from the reference implementation.  The host keeps using its
-! own `params` module; `fftw` is no longer needed by this module.
+! own `params` module; `fftw` is not needed by this module (a host that still says
+! `use fftw` / `call init_fftw()` gets rf_inv_amd/fortran/fftw.f90).
 !=======================================================================
 module forward
   use iso_c_binding
@@ -67,8 +68,7 @@ contains
   end subroutine init_forward
 
   !---------------------------------------------------------------------
-  ! Another engine context on the same tables with room for max_walkers chains: a rank that evaluates the chains of
-  ! every rank sharing its GPU (pt_control_batched) needs one for all of them.  (After init_forward.)
+  ! An engine context on module params' tables with room for max_walkers chains
   subroutine rfgpu_new_context(max_walkers, ctx)
     use params, only: nfft, ntrc, nsmp, deconv_mode, delta, t_start, sdep, npts_max, k_max
     integer, intent(in) :: max_walkers

@@ -159,6 +159,21 @@ module rfgpu_c
        real(c_double), value :: value
      end function rf_set_option
 
+     ! the reference's two FFTW plans executed on the GPU (rf_inv_amd/fortran/fftw.f90)
+     integer(c_int) function rf_fft_c2r(nfft, cx, rx) bind(C, name="rf_fft_c2r")
+       import :: c_int, c_int32_t, c_double, c_double_complex
+       integer(c_int32_t), value :: nfft
+       complex(c_double_complex), intent(in) :: cx(*)
+       real(c_double), intent(out) :: rx(*)
+     end function rf_fft_c2r
+
+     integer(c_int) function rf_fft_r2c(nfft, rx, cx) bind(C, name="rf_fft_r2c")
+       import :: c_int, c_int32_t, c_double, c_double_complex
+       integer(c_int32_t), value :: nfft
+       real(c_double), intent(in) :: rx(*)
+       complex(c_double_complex), intent(inout) :: cx(*)
+     end function rf_fft_r2c
+
      ! pinned host memory (arrays from it travel to the GPU by DMA as they are)
      integer(c_int) function rf_host_alloc(bytes, ptr) bind(C, name="rf_host_alloc")
        import :: c_int, c_ptr, c_size_t
@@ -330,6 +345,7 @@ contains
     character(kind=c_char), pointer :: msg(:)
     type(c_ptr) :: p
     integer :: i, ierr2
+    logical :: mpi_up
     if (ierr == 0) return
     p = rf_last_error()
     write(0, '(3a)', advance='no') "ERROR: librfgpu ", where, ": "
@@ -341,9 +357,11 @@ contains
        end do
     end if
     write(0, *)
-    ! (abort, not finalize: the other ranks may be waiting for this one in a barrier or a collective)
-    call mpi_abort(MPI_COMM_WORLD, 1, ierr2)
-    stop
+    ! (abort, not finalize: the other ranks may be waiting for this one in a barrier or a collective; a host that never
+    ! initialised MPI -- the reference's make_syn -- just stops)
+    call mpi_initialized(mpi_up, ierr2)
+    if (mpi_up) call mpi_abort(MPI_COMM_WORLD, 1, ierr2)
+    stop 1
   end subroutine rfgpu_check
 
 end module rfgpu_c

@@ -13,8 +13,10 @@
   make_syn_program the whole program: sgrnd(iseed), init_model, init_likelihood (their draws come first in the
                    stream), format_model of chain 1, test_vel, noise, SAC files
 
-The forward model runs on the GPU engine; the host FFT pair of the noise filter (numpy's pocketfft standing in for
-FFTW's r2c / c2r plans, src/fftw.f90:44-46 -- same transform definitions) is not on the hot path.
+The forward model runs on the GPU engine, and so does the transform pair of the noise filter: FFTW's r2c / c2r plans
+(src/fftw.f90:44-46) are librfgpu's rf_fft_r2c / rf_fft_c2r (include/rfgpu_ext.h) -- the same entry points the drop-in
+Fortran `module fftw` executes, so `program make_syn` of the reference linked against the drop-in modules and this
+mirror write byte-identical files.
 File names: the reference formats them with `'(A10,I2.2,A2)'` from the 11-character literal "test_trace."
 (src/make_syn.f90:120,140); A10 keeps the leftmost ten characters, so the files it actually creates are
 `test_traceNNwn` and `test_traceNN` -- no dot.  `dotted=True` writes the names the literal suggests instead.
@@ -49,8 +51,10 @@ def write_sac(path: str, samples, delta: float, t_start: float, t_end: float):
 def _filter_series(white, flt_col, nfft: int):
     """rx = white; dfftw_execute(ifft2) [r2c]; cx(1:nh) *= flt(1:nh, itrc); dfftw_execute(ifft) [c2r]
     (src/make_syn.f90:91-95 / :108-112).  Both FFTW transforms are unnormalised."""
-    spec = np.fft.rfft(white)                              # r2c: sum_j x_j exp(-2 pi i j k / n)
-    return np.fft.irfft(spec * flt_col, nfft) * nfft       # c2r: no 1/n (numpy's irfft divides by n)
+    from .engine import fft_c2r, fft_r2c
+
+    spec = fft_r2c(white)                                  # r2c: sum_j x_j exp(-2 pi i j k / n)
+    return fft_c2r(spec * flt_col, nfft)                   # c2r: unnormalised, Im of DC / Nyquist ignored
 
 
 def reference_noise(rng: MT19937, p: Params, flt, is_ray_common: bool):

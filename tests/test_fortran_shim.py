@@ -249,3 +249,102 @@ def test_fortran_batched_sampler_many_chains(golden_dir, tmp_path):
         outs.append([open(work / "rfinv_dump.txt").read()] + [open(work / "rslt" / n).read() for n in RESULT_FILES])
     assert outs[0] == outs[1]
     assert int(outs[0][0].split()[2]) == 100               # ncool
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's OWN main programs, compiled unmodified from /root/reference/src/{rf_inv,make_syn}.f90 and linked
+# with the object lists of the reference Makefile (Makefile:28-35) in which fftw, forward and likelihood are the
+# drop-in modules of rf_inv_amd/fortran (rf_inv_amd/fortran/Makefile): "no line of the host changes" as a test.
+# ---------------------------------------------------------------------------------------------------------------
+REF_RFINV = os.path.join(ROOT, "oracle", "_ref", "rf_inv")
+REF_MAKESYN = os.path.join(ROOT, "oracle", "_ref", "make_syn")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+def test_fftw_dropin_exports_the_reference_names():
+    """Static check (no GPU): module fftw keeps the reference's public names and kinds (src/fftw.f90:28-48), includes
+    no FFTW header, and the legacy entry point make_syn.f90 calls on the two plans exists."""
+    src = open(os.path.join(ROOT, "rf_inv_amd", "fortran", "fftw.f90")).read()
+    code = "\n".join(l.split("!")[0] for l in src.splitlines())
+    for name in ("module fftw", "use params, only: nfft", "complex(kind(0d0)), allocatable :: cx(:)",
+                 "real(kind(0d0)), allocatable :: rx(:)", "integer(8) :: ifft, ifft2", "subroutine init_fftw()",
+                 "subroutine dfftw_execute(plan)"):
+        assert name in code, name
+    assert "fftw3.f" not in code and "dfftw_plan" not in code
+
+
+def _sample_syn_with_iterations(golden_dir, work, nburn, niter):
+    """A copy of the shipped sample_syn directory whose params.in asks for nburn + niter iterations."""
+    shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
+    os.makedirs(work / "rslt")
+    lines = open(work / "params.in").read().split("\n")
+    i = next(j for j, l in enumerate(lines) if l.startswith("# N_BURN"))
+    assert lines[i + 1].strip() == "3000" and lines[i + 2].startswith("# N_ITER") and lines[i + 3].strip() == "8000"
+    lines[i + 1], lines[i + 3] = str(nburn), str(niter)
+    open(work / "params.in", "w").write("\n".join(lines))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_the_reference_main_program_runs_unmodified_on_the_dropin_modules(golden_dir, tmp_path, nranks):
+    """bin/rf_inv as the reference builds it -- src/rf_inv.f90 (`use fftw`, `call init_fftw()`, init_forward ...
+    pt_control, output_results: src/rf_inv.f90:28-107) with pt_mcmc.f90, mcmc_out.f90 and the host modules, all
+    unmodified -- on module fftw / forward / likelihood of rf_inv_amd/fortran: runs under mpiexec with 1 and 2 ranks,
+    writes the 12 result files, and they are byte-identical to those of the look-alike driver tests/fortran/drive_rfinv
+    (mode 0: the same pt_control) that the other tests of this file use; iteration 1 of rslt/likelihood is the value a
+    pure-reference run recorded."""
+    if not (os.path.exists(REF_RFINV) and os.path.exists(RFINV) and os.path.exists(MPIEXEC)):
+        pytest.skip("oracle/_ref/rf_inv not built (no Fortran compiler / reference tree at build time) or no mpiexec")
+    nburn, niter = 60, 240
+    runs = {}
+    for tag, cmd in (("main", [REF_RFINV, "params.in"]),
+                     ("driver", [RFINV, "params.in", str(nburn), str(niter), "0", "out"])):
+        work = tmp_path / tag
+        _sample_syn_with_iterations(golden_dir, work, nburn, niter)
+        r = subprocess.run([MPIEXEC, "-np", str(nranks)] + cmd, cwd=work, env=dict(os.environ), capture_output=True,
+                           text=True, timeout=900)
+        if r.returncode != 0 and ("hydra" in r.stderr.lower() or "unable" in r.stderr.lower()):
+            pytest.skip("mpiexec cannot start processes here: " + r.stderr[-200:])
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        runs[tag] = r
+    # the main program's own stdout: the reference's verbose init messages and iteration counter (rank 0)
+    assert "--- Reading observed data ---" in runs["main"].stdout and "Iteration" in runs["main"].stdout
+    for name in RESULT_FILES:
+        a = open(tmp_path / "main" / "rslt" / name, "rb").read()
+        assert a == open(tmp_path / "driver" / "rslt" / name, "rb").read(), name
+        assert len(a) > 0 or name == "sigma.ppd", name
+    lk = np.loadtxt(tmp_path / "main" / "rslt" / "likelihood")
+    assert lk.shape == (nburn + niter, 2) and np.array_equal(lk[:, 0], np.arange(1, nburn + niter + 1))
+    if nranks == 1:
+        assert abs(lk[0, 1] - (-1044.33907794324)) < 1e-7
+
+
+@pytest.mark.gpu
+def test_the_reference_make_syn_runs_unmodified_on_the_dropin_modules(golden_dir, tmp_path):
+    """bin/make_syn as the reference builds it (src/make_syn.f90, unmodified; Makefile:32-35): it executes the two FFTW
+    plans of module fftw itself -- dfftw_execute(ifft2), a product with flt, dfftw_execute(ifft), src/make_syn.f90:91-95,
+    107-111 -- which the drop-in module runs on the GPU (rf_fft_r2c / rf_fft_c2r).  Its files against the Python
+    mirror of the program (rf_inv_amd.make_syn.make_syn_program: same stream, same engine, same transforms): the
+    noise-free and the noisy SAC files byte for byte, test_vel value for value."""
+    if not os.path.exists(REF_MAKESYN):
+        pytest.skip("oracle/_ref/make_syn not built (no Fortran compiler / reference tree at build time)")
+    from rf_inv_amd import RFEngine, get_params, read_obs, read_ref_model
+    from rf_inv_amd.make_syn import make_syn_program
+
+    work = tmp_path / "fortran"
+    shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
+    r = subprocess.run([REF_MAKESYN, "params.in"], cwd=work, env=dict(os.environ), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Noise level of trace" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    p = get_params(os.path.join(golden_dir, "sample_syn", "params.in"))
+    read_obs(p)
+    ref = read_ref_model(os.path.join(p.base_dir, p.vel_file))
+    with RFEngine.from_params(p, max_walkers=p.nchains) as eng:
+        out = make_syn_program(p, ref, eng, str(tmp_path / "python"))
+    said = [float(l.split(":")[-1]) for l in r.stdout.splitlines() if "Noise level of trace" in l]
+    assert np.allclose(said, out["noise_sigma"], rtol=1e-12, atol=0)
+    for t in range(1, p.ntrc + 1):
+        for name in (f"test_trace{t:02d}", f"test_trace{t:02d}wn"):
+            a, b = open(work / name, "rb").read(), open(tmp_path / "python" / name, "rb").read()
+            assert len(a) == 4 * (158 + p.nsmp)
+            assert a == b, name
+    assert np.array_equal(np.loadtxt(work / "test_vel"), np.loadtxt(tmp_path / "python" / "test_vel"))

@@ -75,11 +75,10 @@ def _run_config(name, expect_defer, nsample, extra_check=None, walkers=None):
         plan = eng.launch_plan
         # the DEFAULT plan is the subject: no option set, production build
         assert plan["overrides"] == 0 and plan["build"] == "production" and plan["fused"] and plan["defer_logl"] == -1
-        # land and ocean: one 8-bin chain per wave (fused_kernel); contexts of <= 3 rounds of blocks at nfft 4096 on land
-        # (C2) and the common-ray kernel: 512-thread blocks, 4-bin chains
-        small = plan["block_threads_full_batch"] == 512
         assert plan["common_ray_fused"] == bool(eng.is_ray_common and ntrc > 1)
-        assert plan["chain"] == (4 if small else 8) or plan["common_ray_fused"]
+        assert plan["chain"] == 8 or plan["common_ray_fused"]   # the "chain" option's default, land and ocean
+        # contexts of <= 3 rounds of blocks at nfft 4096 on land (C2) and the common-ray kernel: 512-thread blocks
+        assert (plan["block_threads_full_batch"] == 512) == (plan["common_ray_fused"] or nb * ntrc <= 3 * 512)
         # by batch size the library defers the quadratic form + logL to the follow-up kernel(s) here
         # (rfgpu_api.cpp run_batch: >= 2 rounds of blocks with several traces, >= 4 rounds with one)
         blocks, rnd = nb * ntrc, 2 * 256

@@ -1241,3 +1241,34 @@ def test_set_r_inv_replaces_every_image_of_the_matrix(oracle, nsmp, triangle):
         eng.commit(np.arange(nb), np.ones(nb, dtype=np.int32))
         ref0s = oracle.eval_batch(cfg, obs, r0, nlay, layers, 2 * sig, nsmp, nthreads=oracle.max_threads())
         assert_logl_parity(eng.eval_batch(np.arange(nb), nlay, layers, 2 * sig, fwd_flag=ff), ref0s, kap, "sigma-only again")
+
+
+@pytest.mark.parametrize("nfft", [8, 9, 250, 256, 1001, 4096, 4099, 65536])
+def test_fftw_plans_on_the_gpu(oracle, nfft):
+    """rf_fft_c2r / rf_fft_r2c: the reference's two FFTW plans (src/fftw.f90:44-45) as the drop-in module fftw and
+    rf_inv_amd.make_syn execute them -- FFTW's definitions (c2r unnormalised, Hermitian extension implied, imaginary
+    parts of the DC and Nyquist bins ignored; r2c writes nfft/2 + 1 bins), any length: even, odd, prime, 2^16."""
+    from rf_inv_amd.engine import fft_c2r, fft_r2c
+
+    rng = np.random.default_rng(nfft)
+    nh = nfft // 2 + 1
+    spec = rng.normal(0, 1, nh) + 1j * rng.normal(0, 1, nh)
+    got = fft_c2r(spec, nfft)
+    clean = spec.copy()
+    clean[0] = clean[0].real
+    if nfft % 2 == 0:
+        clean[-1] = clean[-1].real
+    if nfft <= 4099:
+        want = oracle.c2r(np.concatenate([spec, np.zeros(nfft - nh)]), nfft)      # long-double O(n^2) definition
+    else:
+        want = np.fft.irfft(clean, nfft) * nfft
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= (2e-15 if nfft <= 4099 else 2e-14) * scale * max(1.0, np.log2(nfft) / 8)
+    assert np.array_equal(got, fft_c2r(clean, nfft))                               # Im of DC / Nyquist: ignored
+    x = rng.normal(0, 1, nfft)
+    back = fft_r2c(x)
+    ref = np.fft.rfft(x)
+    assert back.shape == (nh,) and np.abs(back - ref).max() <= 1e-13 * np.abs(ref).max()
+    # the pair is n times the identity on real series (what make_syn's filter relies on with flt = 1 / n ...)
+    again = fft_c2r(back, nfft)
+    assert np.abs(again - nfft * x).max() <= 1e-13 * nfft * np.abs(x).max()
