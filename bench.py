@@ -607,6 +607,13 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}: the launcher's "
                          "rank count and --gpus must agree (a line saying n_gpus = N must come from N ranks)")
 
+    # stdout carries ONE line, the last thing rank 0 says.  Libraries write there too, at the C level and at exit time
+    # (gloo: "[Gloo] Rank 0 is connected to 7 peer ranks"; RCCL's version banner, flushed when the process ends): from
+    # here on file descriptor 1 IS stderr, and the headline goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     stray = sorted(k for k in os.environ if k.startswith("RFGPU_") and k not in ENV_ALLOWED)
     if stray:
         raise SystemExit(f"bench.py: refusing to run with {stray} in the environment: librfgpu reads no environment "
@@ -1088,8 +1095,8 @@ def main():
             detail = None
         print("bench.py detail: " + json.dumps(out), file=sys.stderr)
         sys.stderr.flush()
-        print(headline_line(out, os.path.relpath(detail, ROOT) if detail else None))
         sys.stdout.flush()
+        os.write(real_stdout, (headline_line(out, os.path.relpath(detail, ROOT) if detail else None) + "\n").encode())
     failed = rank == 0 and main_res.get("swap_replay_ok") is False
     if failed:
         print("bench.py: the final temperatures do NOT equal the serial replay of the swap schedule: the temperature "

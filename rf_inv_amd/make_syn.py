@@ -48,18 +48,22 @@ def write_sac(path: str, samples, delta: float, t_start: float, t_end: float):
     rec.tofile(path)
 
 
-def _filter_series(white, flt_col, nfft: int):
+def _filter_series(white, flt_col, nfft: int, plans=None):
     """rx = white; dfftw_execute(ifft2) [r2c]; cx(1:nh) *= flt(1:nh, itrc); dfftw_execute(ifft) [c2r]
-    (src/make_syn.f90:91-95 / :108-112).  Both FFTW transforms are unnormalised."""
-    from .engine import fft_c2r, fft_r2c
+    (src/make_syn.f90:91-95 / :108-112).  Both FFTW transforms are unnormalised.  plans: (r2c(x), c2r(spec, n)), default
+    librfgpu's (GPU; there is no host fall-back -- the CPU tests of the draw order hand in a host pair)."""
+    if plans is None:
+        from .engine import fft_c2r, fft_r2c
 
-    spec = fft_r2c(white)                                  # r2c: sum_j x_j exp(-2 pi i j k / n)
-    return fft_c2r(spec * flt_col, nfft)                   # c2r: unnormalised, Im of DC / Nyquist ignored
+        plans = (fft_r2c, fft_c2r)
+    spec = plans[0](white)                                 # r2c: sum_j x_j exp(-2 pi i j k / n)
+    return plans[1](spec * flt_col, nfft)                  # c2r: unnormalised, Im of DC / Nyquist ignored
 
 
-def reference_noise(rng: MT19937, p: Params, flt, is_ray_common: bool):
+def reference_noise(rng: MT19937, p: Params, flt, is_ray_common: bool, plans=None):
     """src/make_syn.f90:80-115.  flt[nh, ntrc] (`flt` of module forward).  Returns
-    (noise[nfft, ntrc] filtered, noise_sigma[ntrc], white[nfft, ntrc or 1] before the filter)."""
+    (noise[nfft, ntrc] filtered, noise_sigma[ntrc], white[nfft, ntrc or 1] before the filter).
+    plans: see _filter_series."""
     from .mcmc import gauss
 
     nfft, ntrc = p.nfft, p.ntrc
@@ -73,14 +77,14 @@ def reference_noise(rng: MT19937, p: Params, flt, is_ray_common: bool):
         # and traces 2 .. ntrc are that already filtered column through their own filter: flt_t(flt_1(white)) x nfft^2
         noise[:, 0] = white[:, 0]
         for t in range(ntrc):
-            noise[:, t] = _filter_series(noise[:, 0], flt[:, t], nfft)
+            noise[:, t] = _filter_series(noise[:, 0], flt[:, t], nfft, plans)
         sigma[1:] = sigma[0]          # (the reference reports and uses noise_sigma(1) only)
     else:
         white = np.zeros((nfft, ntrc))
         for t in range(ntrc):
             sigma[t] = rng.grnd() * (p.sig_max[t] - p.sig_min[t]) + p.sig_min[t]        # :102-103
             white[:, t] = [gauss(rng) * sigma[t] for _ in range(nfft)]                  # :104-106
-            noise[:, t] = _filter_series(white[:, t], flt[:, t], nfft)                  # :108-112
+            noise[:, t] = _filter_series(white[:, t], flt[:, t], nfft, plans)           # :108-112
     return noise, sigma, white
 
 

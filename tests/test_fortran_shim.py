@@ -333,6 +333,7 @@ def test_the_reference_make_syn_runs_unmodified_on_the_dropin_modules(golden_dir
 
     work = tmp_path / "fortran"
     shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
+    os.makedirs(work / "rslt")          # get_params copies params.in into the output directory (src/params.f90)
     r = subprocess.run([REF_MAKESYN, "params.in"], cwd=work, env=dict(os.environ), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "Noise level of trace" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     p = get_params(os.path.join(golden_dir, "sample_syn", "params.in"))

@@ -146,6 +146,11 @@ def _noise_params(ntrc, rays_common, nfft=128):
     return p
 
 
+# FFTW's r2c / c2r definitions through numpy, for the CPU tests of reference_noise's draw order (the product executes
+# the two plans on the GPU: rf_fft_r2c / rf_fft_c2r, tests/test_gpu_parity.py::test_fftw_plans_on_the_gpu)
+HOST_PLANS = (np.fft.rfft, lambda spec, n: np.fft.irfft(spec, n) * n)
+
+
 def test_make_syn_noise_consumes_the_stream_like_the_reference(oracle):
     """src/make_syn.f90:100-115 (rays not common): per trace ONE grnd() -> sigma = grnd() * (sig_max - sig_min) +
     sig_min, then nfft gauss() values (two grnd() each) times sigma, in trace order; r2c -> flt -> c2r unnormalised.
@@ -157,7 +162,7 @@ def test_make_syn_noise_consumes_the_stream_like_the_reference(oracle):
 
     p = _noise_params(3, False)
     flt = oracle.init_filter(p.nfft, p.delta, p.a_gus).T                     # flt(nh, ntrc)
-    noise, sigma, white = reference_noise(MT19937(4321), p, flt, False)
+    noise, sigma, white = reference_noise(MT19937(4321), p, flt, False, plans=HOST_PLANS)
     g = MT19937(4321)
     for t in range(3):
         s = g.grnd() * (p.sig_max[t] - p.sig_min[t]) + p.sig_min[t]
@@ -190,7 +195,7 @@ def test_make_syn_noise_common_rays_share_one_white_series(oracle):
     p = _noise_params(3, True)
     flt = oracle.init_filter(p.nfft, p.delta, p.a_gus).T
     rng = MT19937(99)
-    noise, sigma, white = reference_noise(rng, p, flt, True)
+    noise, sigma, white = reference_noise(rng, p, flt, True, plans=HOST_PLANS)
     assert white.shape == (p.nfft, 1) and np.all(sigma == sigma[0])
     g2 = MT19937(99)
     s = g2.grnd() * (p.sig_max[0] - p.sig_min[0]) + p.sig_min[0]
