@@ -179,7 +179,7 @@ def draw_walkers(p, ref, first_id, count, seed=12345678, return_models=False):
     return nlay, layers
 
 
-def run_host_boundary(workload, steps, device):
+def run_host_boundary(workload, steps, device, prewarm_s=1.0, warmup=5):
     """The boundary as the batched sampler uses it (rf_eval_models + rf_commit, include/rfgpu.h): the same walkers as
     `workload`, handed over as (k, z, dVp, dVs, sigma) in PINNED host arrays every step -- H2D by DMA, format_model on the
     device, the kernels of the resident path, logL back into host memory -- i.e. the PCIe-inclusive rate (DESIGN.md
@@ -218,18 +218,38 @@ def run_host_boundary(workload, steps, device):
         acc = np.zeros(nb, dtype=np.int32)
         acc[::2] = 1
         want = eng.eval_batch(np.arange(nb), nlay, layers, sig)            # the resident path's values on these walkers
-        for _ in range(5):
+        # Pre-warm by TIME like the resident runs (drawing the walkers above kept the host busy for seconds with the GPU
+        # idle: its clocks are down, and five 2 ms steps do not bring them back -- the driver's r04 run of this leg, 20
+        # steps after 5 warm-ups, read 3.57 ms per step against 2.05 here after 200: profiles/r05_host_boundary_probe.txt)
+        n_pre, t_pre = 0, time.perf_counter()
+        while n_pre < warmup or time.perf_counter() - t_pre < prewarm_s:
             ll = eng.eval_models(ids, k, z, dvp, dvs, sg)
             eng.commit(ids, acc)
+            n_pre += 1
         assert eng.launch_plan["staged_host_arrays"] == 0
         torch.cuda.synchronize(device)
+        eng.profile_enable(max(1, steps // 16))
+        t_eval = t_commit = 0.0
         t0 = time.perf_counter()
         for _ in range(steps):
+            ta = time.perf_counter()
             ll = eng.eval_models(ids, k, z, dvp, dvs, sg)
+            tb = time.perf_counter()
             eng.commit(ids, acc)
+            t_eval += tb - ta
+            t_commit += time.perf_counter() - tb
         dt = time.perf_counter() - t0
+        eng.profile_enable(False)
+        prof = eng.profile_read()
+        n_l = max(prof["launches"], 1)
         bytes_in = ids.nbytes + k.nbytes + z.nbytes + dvs.nbytes + sg.nbytes + (dvp.nbytes if p.vp_mode == 1 else 0)
         return {"value": nb * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
+                "prewarm": {"seconds": prewarm_s, "steps": n_pre},
+                # host-side split of a step: the synchronous rf_eval_models call (DMA in, format_model, stage, the
+                # evaluation kernels, logL out), rf_commit (returns without waiting), and inside the former the
+                # HIP-event time of the evaluation kernels
+                "phase_ms": {"eval_models_call": 1e3 * t_eval / steps, "commit_call": 1e3 * t_commit / steps,
+                             "kernels": (prof["spectra_ms"] + prof["trace_ms"] + prof["logl_ms"]) / n_l},
                 "config": {"workload": w["desc"].replace(", PT swap on the device", "").replace(", PT swap", "") + " -- handed over every step as (k, z, dVp, dVs, sigma) in pinned HOST arrays "
                            "(rf_eval_models + rf_commit): DMA, format_model on the device, logL into host memory; no swap",
                            "walkers_per_gpu": nb, "host_bytes_in_per_step": int(bytes_in), "host_bytes_out_per_step": 8 * nb,
@@ -1054,7 +1074,8 @@ def main():
     for wl in [x for x in also_list.split(",") if x and x != args.workload]:
         if wl.endswith("host"):
             # the PCIe-inclusive boundary of the batched sampler (never the headline)
-            also[wl] = run_host_boundary(wl[:-4], max(20, min(200, args.steps)), local_rank)
+            also[wl] = run_host_boundary(wl[:-4], 200 if args.steps >= 10 else max(20, args.steps), local_rank,
+                                         prewarm_s=args.prewarm_seconds)
             continue
         if wl == "c4stale":
             # the c4 shape with 30 % of the walkers changing depth every step: the order the previous launch

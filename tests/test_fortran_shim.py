@@ -195,8 +195,10 @@ def test_fortran_batched_sampler_several_mpi_ranks(golden_dir, tmp_path, nranks)
 
 
 @pytest.mark.gpu
-def test_fortran_batched_sampler_two_mpi_ranks_over_the_rccl_entry_points(golden_dir, tmp_path):
-    """The same two ranks with the exchange on librfgpu's communicator -- the branch a one-GPU-per-rank run takes
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_fortran_batched_sampler_two_mpi_ranks_over_the_rccl_entry_points(golden_dir, tmp_path, nranks):
+    """(nranks = 8: the rank count of the driver's 8-GPU node, 40 chains in all.)
+    The same ranks with the exchange on librfgpu's communicator -- the branch a one-GPU-per-rank run takes
     (open_temperature_exchange: rf_comm_probe / rf_comm_get_unique_id / mpi_bcast of the id / rf_comm_init;
     propose_temperature_swap: rf_comm_bcast_i32 + rf_pt_swap_exchange) -- over the RCCL test double
     (tests/c/rccl_double.cpp; real RCCL refuses two ranks on the one GPU of the box): rank by rank and file by file
@@ -213,15 +215,15 @@ def test_fortran_batched_sampler_two_mpi_ranks_over_the_rccl_entry_points(golden
         work = tmp_path / f"mpi{mode}"
         shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
         os.makedirs(work / "rslt")
-        r = subprocess.run([mpiexec, "-np", "2", RFINV, "params.in", "40", "160", mode, "out"] + ([lib] if mode == "1" else []),
-                           cwd=work, env=dict(os.environ), capture_output=True, text=True, timeout=900)
+        r = subprocess.run([mpiexec, "-np", str(nranks), RFINV, "params.in", "40", "160", mode, "out"] + ([lib] if mode == "1" else []),
+                           cwd=work, env=dict(os.environ), capture_output=True, text=True, timeout=1500)
         if r.returncode != 0 and ("hydra" in r.stderr.lower() or "unable" in r.stderr.lower()):
             pytest.skip("mpiexec cannot start processes here: " + r.stderr[-200:])
-        assert r.returncode == 0 and r.stdout.count("drive_rfinv: ok") == 2, r.stdout + r.stderr
+        assert r.returncode == 0 and r.stdout.count("drive_rfinv: ok") == nranks, r.stdout + r.stderr
         if mode == "1":
-            assert "Temperature exchange: RCCL (2 ranks" in r.stderr, r.stderr[-500:]
-        dumps.append([open(work / f"rfinv_dump_{k}.txt").read() for k in (0, 1)])
-    assert dumps[0][0] == dumps[1][0] and dumps[0][1] == dumps[1][1]
+            assert f"Temperature exchange: RCCL ({nranks} ranks" in r.stderr, r.stderr[-500:]
+        dumps.append([open(work / f"rfinv_dump_{k}.txt").read() for k in range(nranks)])
+    assert dumps[0] == dumps[1]
     for name in RESULT_FILES:
         assert open(tmp_path / "mpi0" / "rslt" / name).read() == open(tmp_path / "mpi1" / "rslt" / name).read(), name
 

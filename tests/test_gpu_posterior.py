@@ -270,7 +270,7 @@ def test_two_rank_python_main_equals_two_rank_reference_run(golden_dir, tmp_path
     _compare_result_dirs(our_dir / "rslt", ref_dir / "rslt", nburn + niter, sigma_solved=False)
 
 
-def _run_post_merge(tmp_path, world, devices, rccl_library=None):
+def _run_post_merge(tmp_path, world, devices, rccl_library=None, sequential=False):
     sys_path_tools = os.path.join(ROOT, "tests", "tools")
     import sys
 
@@ -279,7 +279,8 @@ def _run_post_merge(tmp_path, world, devices, rccl_library=None):
 
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     procs = [subprocess.Popen([sys.executable, os.path.join(sys_path_tools, "post_merge_worker.py"), str(r), str(world),
-                               str(tmp_path), str(devices[r])] + ([rccl_library] if rccl_library else []), env=env, cwd=ROOT)
+                               str(tmp_path), str(devices[r]), rccl_library or "-"] + (["sequential"] if sequential else []),
+                              env=env, cwd=ROOT)
              for r in range(world)]
     for q in procs:
         assert q.wait(timeout=600) == 0
@@ -330,16 +331,17 @@ def _run_post_merge(tmp_path, world, devices, rccl_library=None):
                 assert np.array_equal(merged[r][f], own[r][f]), (r, f)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_posterior_merge_over_the_communicator(tmp_path, world):
+@pytest.mark.parametrize("world,sequential", [(2, False), (3, False), (3, True)])
+def test_posterior_merge_over_the_communicator(tmp_path, world, sequential):
     """rf_comm_post_reduce / rf_comm_post_gather (the mpi_reduce / mpi_gather block of src/mcmc_out.f90:52-93 on the
     device accumulators) with several ranks on the box's one GPU over tests/c/rccl_double.cpp (real RCCL refuses two
-    ranks on one device): the merged result on the root is the sum / rank-ordered concatenation of what the ranks held."""
+    ranks on one device): the merged result on the root is the sum / rank-ordered concatenation of what the ranks held.
+    sequential: rf_comm_set_option("sequential_reduce", 1) -- the reduce's calls one by one instead of as one group."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     lib = str(tmp_path / "librccl_double.so")
     subprocess.run([hipcc, "-shared", "-fPIC", "-O2", "-o", lib, os.path.join(ROOT, "tests", "c", "rccl_double.cpp")],
                    check=True, capture_output=True, timeout=300)
-    _run_post_merge(tmp_path, world, [0] * world, rccl_library=lib)
+    _run_post_merge(tmp_path, world, [0] * world, rccl_library=lib, sequential=sequential)
 
 
 def test_posterior_merge_between_two_gpus(tmp_path):

@@ -3,7 +3,8 @@ fresh process that evaluates and records its own chains (rf_post_record), saves 
 the end-of-run merge over the engine's communicator -- rf_comm_post_gather + rf_comm_post_reduce through
 Posterior.merge_over_comm (the top of output_results, src/mcmc_out.f90:52-93) -- and saves what it holds afterwards.
 
-usage: post_merge_worker.py RANK WORLD OUT_DIR DEVICE [RCCL_LIBRARY]
+usage: post_merge_worker.py RANK WORLD OUT_DIR DEVICE [RCCL_LIBRARY|- [sequential]]   (sequential: the reduce's twelve
+ncclReduce calls one by one instead of as one group, rf_comm_set_option "sequential_reduce")
 Writes OUT_DIR/own_RANK.npz (before the merge), merged_RANK.npz (merge_over_comm's return), after_RANK.npz (a plain read
 after the merge)."""
 import os
@@ -34,7 +35,7 @@ def main():
     from rf_inv_amd.posterior import Posterior
 
     orc.build()
-    if len(sys.argv) > 5:
+    if len(sys.argv) > 5 and sys.argv[5] != "-":
         RFEngine.comm_set_library(sys.argv[5])
     p, ref, mcfg = tp._setup(os.path.join(ROOT, "tests", "golden"), 2.0, 0, 10)
     ntrc, n = 2, NCHAINS
@@ -75,6 +76,8 @@ def main():
         assert time.time() - t0 < 120, "no RCCL id from rank 0"
         time.sleep(0.05)
     eng.comm_init(open(idf, "rb").read(), rank, world)
+    if len(sys.argv) > 6 and sys.argv[6] == "sequential":
+        eng.comm_set_option("sequential_reduce", 1)
     save(os.path.join(out, f"merged_{rank}.npz"), post.merge_over_comm(root=0))
     save(os.path.join(out, f"after_{rank}.npz"), post.read())
     eng.comm_destroy()
