@@ -230,14 +230,17 @@ def run_host_boundary(workload, steps, device, prewarm_s=1.0, warmup=5):
         torch.cuda.synchronize(device)
         eng.profile_enable(max(1, steps // 16))
         t_eval = t_commit = 0.0
+        per_step = np.zeros(steps)
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
             ta = time.perf_counter()
             ll = eng.eval_models(ids, k, z, dvp, dvs, sg)
             tb = time.perf_counter()
             eng.commit(ids, acc)
+            tc = time.perf_counter()
             t_eval += tb - ta
-            t_commit += time.perf_counter() - tb
+            t_commit += tc - tb
+            per_step[i] = tc - ta
         dt = time.perf_counter() - t0
         eng.profile_enable(False)
         prof = eng.profile_read()
@@ -245,6 +248,8 @@ def run_host_boundary(workload, steps, device, prewarm_s=1.0, warmup=5):
         bytes_in = ids.nbytes + k.nbytes + z.nbytes + dvs.nbytes + sg.nbytes + (dvp.nbytes if p.vp_mode == 1 else 0)
         return {"value": nb * steps / dt, "ms_per_step": 1e3 * dt / steps, "steps": steps,
                 "prewarm": {"seconds": prewarm_s, "steps": n_pre},
+                # (a host hiccup inside a short timed region shows as mean >> median)
+                "ms_per_step_median": 1e3 * float(np.median(per_step)), "ms_per_step_max": 1e3 * float(per_step.max()),
                 # host-side split of a step: the synchronous rf_eval_models call (DMA in, format_model, stage, the
                 # evaluation kernels, logL out), rf_commit (returns without waiting), and inside the former the
                 # HIP-event time of the evaluation kernels

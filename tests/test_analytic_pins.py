@@ -254,3 +254,43 @@ def test_hip_c4_traces_match_reflectivity_solution(block_threads):
             for t in range(3):
                 want = al.receiver_function(4096, DELTA, T_START, A_GUS, rayps[t], int(ipha[t]), 0, *st)
                 _check(got[:, t], want, (i, t))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The checker at the shapes the all-walker tests lean on it (tests/test_gpu_configs.py: C4 = 3 traces P .06 / P .08 /
+# S .10 on <= 30 layers, C5 = 4 traces P / P / S / S under 2 km of water on <= 31 layers, nfft 4096): the ORACLE
+# against the independent reflectivity solution on deep stacks, with and without deconvolution -- on the CPU, so that
+# the oracle is pinned there before any GPU comparison uses it (Next #8).
+# ---------------------------------------------------------------------------------------------------------------
+DEEP_NFFT = 4096
+DEEP_LAND = [random_stack(np.random.default_rng(404), n) for n in (2, 5, 12, 29, 30)]
+DEEP_OCEAN = [random_stack(np.random.default_rng(505), n, ocean=True, sdep=SDEP) for n in (2, 3, 9, 30, 31)]
+
+
+@pytest.mark.parametrize("dec", [0, 1])
+@pytest.mark.parametrize("ocean", [0, 1])
+def test_oracle_deep_stacks_at_the_benchmark_trace_sets(oracle, ocean, dec):
+    """C4's (land) and C5's (ocean) trace sets at nfft 4096 on stacks of 2 .. 31 layers: every trace of every stack."""
+    if ocean:
+        rayps, ipha, stacks, sdep = [0.06, 0.08, 0.10, 0.12], [1, 1, -1, -1], DEEP_OCEAN, SDEP
+    else:
+        rayps, ipha, stacks, sdep = [0.06, 0.08, 0.10], [1, 1, -1], DEEP_LAND, 0.0
+    cfg = make_cfg(nfft=DEEP_NFFT, deconv_mode=dec, t_start=T_START, rayps=rayps, a_gus=[A_GUS] * len(rayps), ipha=ipha,
+                   sdep=sdep)
+    for i, st in enumerate(stacks):
+        got = oracle.calc_rf(cfg, *st)
+        assert got.shape == (len(rayps), DEEP_NFFT)
+        for t in range(len(rayps)):
+            want = al.receiver_function(DEEP_NFFT, DELTA, T_START, A_GUS, rayps[t], ipha[t], dec, *st)
+            _check(got[t], want, ("deep", ocean, dec, len(st[0]), t))
+
+
+def test_oracle_deep_stack_benchmark_geometry(oracle):
+    """bench.py's own geometry (t_start 0, the 5 s window of 101 samples the likelihood reads): the first nsmp samples
+    of the C4 trace set on a 30-layer stack, oracle against the reflectivity solution."""
+    st = DEEP_LAND[-1]
+    cfg = make_cfg(nfft=DEEP_NFFT, deconv_mode=0, t_start=0.0, rayps=[0.06, 0.08, 0.10], a_gus=[A_GUS] * 3, ipha=[1, 1, -1])
+    got = oracle.calc_rf(cfg, *st)
+    for t, (p, ph) in enumerate(((0.06, 1), (0.08, 1), (0.10, -1))):
+        want = al.receiver_function(DEEP_NFFT, DELTA, 0.0, A_GUS, p, ph, 0, *st)
+        assert np.abs(got[t, :101] - want[:101]).max() <= 1e-11 * np.abs(want).max()

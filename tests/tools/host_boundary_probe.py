@@ -19,10 +19,18 @@ def main():
     print("host:", os.uname().nodename, "cores", bench.physical_cores(), "affinity", len(os.sched_getaffinity(0)))
     for f in sorted(glob.glob("/sys/class/drm/card*/device/numa_node")):
         print(f, open(f).read().strip())
-    for f in sorted(glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")):
-        props = dict(l.split()[:2] for l in open(f) if len(l.split()) >= 2)
-        if int(props.get("simd_count", "0")) > 0:
-            print(f, "simd_count", props["simd_count"], "location_id", props.get("location_id"), "domain", props.get("domain"))
+    try:
+        import torch
+
+        pr = torch.cuda.get_device_properties(0)
+        bus = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}"
+        print("device 0:", pr.name, "pci", bus)
+        for f in sorted(glob.glob("/sys/class/drm/card*/device")):
+            if os.path.basename(os.path.realpath(f)).startswith(bus):
+                print("  ->", f, "numa_node", open(os.path.join(f, "numa_node")).read().strip(),
+                      "local_cpulist", open(os.path.join(f, "local_cpulist")).read().strip())
+    except Exception as e:      # noqa: BLE001 (a probe: say what could not be read and go on)
+        print("device lookup failed:", e)
     try:
         print(subprocess.run(["numactl", "--hardware"], capture_output=True, text=True, timeout=20).stdout.strip())
     except (OSError, subprocess.TimeoutExpired):
@@ -38,7 +46,8 @@ def main():
                              ("pre-warmed >= 1 s", dict(prewarm_s=1.0, warmup=5))):
                 r = bench.run_host_boundary(wl, steps, 0, **kw)
                 ph = r["phase_ms"]
-                print(f"{wl}host steps {steps:5d} {name:32s}: {r['ms_per_step']:.3f} ms/step {r['value'] / 1e6:.3f} M evals/s | "
+                print(f"{wl}host steps {steps:5d} {name:32s}: {r['ms_per_step']:.3f} ms/step (median {r['ms_per_step_median']:.3f}, "
+                      f"max {r['ms_per_step_max']:.3f}) {r['value'] / 1e6:.3f} M evals/s | "
                       f"eval_models call {ph['eval_models_call']:.3f} (kernels {ph['kernels']:.3f}) commit call "
                       f"{ph['commit_call']:.3f} | pre-warm steps {r['prewarm']['steps']}", flush=True)
 
