@@ -6,7 +6,7 @@ librfgpu (include/rfgpu.h).  Every evaluation runs hand-written HIP kernels; the
 no CPU fallback -- importing works anywhere, evaluating needs a gfx950 device and
 the built rf_inv_amd/lib/librfgpu.so.
 """
-from .params import Params, get_params, read_obs, read_sac  # noqa: F401
+from .params import Params, get_params, read_obs, read_sac, write_params  # noqa: F401
 from .model import RefModel, read_ref_model, format_model, vp_to_rho  # noqa: F401
 from .engine import RFEngine, RFGPUError  # noqa: F401
 from .forward import Forward  # noqa: F401

@@ -167,6 +167,31 @@ def get_params(param_file: str, verb: bool = False) -> Params:
     return p
 
 
+def write_params(path: str, p: Params, header: str = ""):
+    """The inverse of get_params: `p` as a params.in in the reference's positional order (src/params.f90:101-388), one
+    value group per line, quoted strings where the reference's list-directed read needs them (OUT_DIR, the observation
+    files, the velocity file).  get_params(write_params(p)) == p for every field of the file."""
+    n = int(p.ntrc)
+    r = lambda x: repr(float(x))
+    L = [f"'{p.out_dir}'", str(int(p.nburn)), str(int(p.niter)), str(int(p.ncorr)), str(int(p.nchains)), str(int(p.ncool)),
+         r(p.t_high), str(int(p.iseed)), str(n)]
+    L += [r(x) for x in p.rayps[:n]] + [r(x) for x in p.a_gus[:n]] + [str(int(x)) for x in p.ipha[:n]] + [str(int(p.nfft))]
+    L += [f"'{f}'" for f in p.obs_files[:n]]
+    L += [f"{r(p.t_start)} {r(p.t_end)}", str(int(p.deconv_mode)), r(p.sdep), f"'{p.vel_file}'", str(int(p.vp_mode)),
+          f"{int(p.k_min)} {int(p.k_max)}", f"{r(p.z_min)} {r(p.z_max)}", r(p.h_min), str(int(p.prior_mode)), r(p.dvs_prior),
+          r(p.dvp_prior)]
+    L += [f"{r(p.sig_min[i])} {r(p.sig_max[i])}" for i in range(n)]
+    L += [r(p.dev_z), r(p.dev_dvs), r(p.dev_dvp), r(p.dev_sig)]
+    L += [str(int(x)) for x in (p.nbin_z, p.nbin_vs, p.nbin_vp, p.nbin_vpvs, p.nbin_sig, p.nbin_amp)]
+    L += [f"{r(p.amp_min)} {r(p.amp_max)}", f"{r(p.vp_min)} {r(p.vp_max)}", f"{r(p.vs_min)} {r(p.vs_max)}",
+          f"{r(p.vpvs_min)} {r(p.vpvs_max)}"]
+    with open(path, "w") as fh:
+        if header:
+            fh.write("".join(f"# {h}\n" for h in header.splitlines()))
+        fh.write("\n".join(L) + "\n")
+    return path
+
+
 def _nint(x: float) -> int:
     return int(np.floor(x + 0.5)) if x >= 0 else -int(np.floor(0.5 - x))
 

@@ -1272,3 +1272,28 @@ def test_fftw_plans_on_the_gpu(oracle, nfft):
     # the pair is n times the identity on real series (what make_syn's filter relies on with flt = 1 / n ...)
     again = fft_c2r(back, nfft)
     assert np.abs(again - nfft * x).max() <= 1e-13 * nfft * np.abs(x).max()
+
+
+def test_every_option_away_from_its_default_is_echoed_by_the_launch_plan(oracle):
+    """rf_get_launch_plan's override count (plan[8]) moves for EVERY rf_set_option knob set away from its default and
+    comes back with it -- a plan changed by any option must never be reported as the default plan (bench.py and the
+    full-batch tests assert `overrides == 0`; ADVICE r04: gemm_triangle and copy_stream were not counted)."""
+    rng = np.random.default_rng(8)
+    knobs = [("fused", 0, -1), ("chain", 4, -1), ("lpt", 0, 1), ("order_reuse", 0, 1), ("nsplit", 2, 0),
+             ("waves_per_block", 2, 4), ("defer_logl", 1, -1), ("block_threads", 256, 0), ("bin_cutoff", 1e-6, 0.0),
+             ("trace_window", 1, 0), ("copy_stream", 1, 0)]
+    for nsmp, extra in ((101, []), (333, [("gemm_tile", 128, 0), ("gemm_triangle", 0, 1)])):
+        cfg = make_cfg(nfft=4096, rayps=[0.06, 0.08], ipha=[1, -1])
+        obs = synth_obs(oracle, cfg, random_stack(rng, 4), nsmp)
+        with _engine(cfg, obs, nsmp, None, max_walkers=4, nlay_max=12) as eng:
+            assert eng.launch_plan["overrides"] == 0
+            for name, away, default in knobs + extra:
+                eng.set_option(name, away)
+                assert eng.launch_plan["overrides"] == 1, (nsmp, name)
+                eng.set_option(name, default)
+                assert eng.launch_plan["overrides"] == 0, (nsmp, name)
+            assert eng.launch_plan["copy_stream"] is False
+            eng.set_option("copy_stream", 1)
+            assert eng.launch_plan["copy_stream"] is True
+            with pytest.raises(Exception, match="unknown option"):
+                eng.set_option("no_such_option", 1)

@@ -267,3 +267,26 @@ def test_fast_validity_verdict_equals_the_reference_format_model(tmp_path, shape
     assert 0.1 * int(moves[1]) < int(moves[4]) < 0.95 * int(moves[1])
     assert ifaces[2] == "interface" and int(ifaces[1]) > 50000 and int(ifaces[6]) == 0, r.stdout
     assert 0.1 * int(ifaces[1]) < int(ifaces[4]) < 0.95 * int(ifaces[1])
+
+
+def test_write_params_is_the_inverse_of_get_params(golden_dir, tmp_path):
+    """rf_inv_amd.params.write_params: the shipped params.in read, written and read again -- every field of the file
+    equal -- and a modified copy (other traces, nfft, window, ocean depth, deconvolution) survives the round trip."""
+    from rf_inv_amd import get_params, write_params
+
+    def same(a, b):
+        for k, v in a.__dict__.items():
+            if k in ("obs", "base_dir", "nsmp", "delta"):
+                continue
+            w = b.__dict__[k]
+            assert (np.array_equal(v, w) if isinstance(v, np.ndarray) else v == w), k
+
+    p = get_params(os.path.join(golden_dir, "sample_syn", "params.in"))
+    q = get_params(write_params(str(tmp_path / "a.in"), p, header="round trip\nof the shipped file"))
+    same(p, q)
+    p.ntrc, p.nfft, p.deconv_mode, p.sdep, p.t_start, p.t_end = 3, 4096, 1, 0.0, -3.0, 20.0
+    p.rayps, p.a_gus, p.ipha = np.array([0.06, 0.08, 0.1]), np.array([4.0, 2.5, 1.5]), np.array([1, 1, -1], dtype=np.int32)
+    p.obs_files = ["data/a.trc", "data/b.trc", "data/c.trc"]
+    p.sig_min, p.sig_max, p.sig_mode = np.array([0.01, 0.005, 0.01]), np.array([0.01, 0.08, 0.01]), np.array([0, 1, 0], dtype=np.int32)
+    p.k_max = 30
+    same(p, get_params(write_params(str(tmp_path / "b.in"), p)))

@@ -1,0 +1,150 @@
+"""The reference's OWN forward module on the drop-in `module fftw`.
+
+oracle/_ref/ref_forward_dump = /root/reference/src/forward.f90 compiled unmodified (-O0 -ffp-contract=off, the class of
+the reference Makefile's default flags) + the reference's params.f90 + OUR module fftw (rf_inv_amd/fortran/fftw.f90),
+whose `dfftw_execute(ifft)` -- called by calc_rf itself, src/forward.f90:172,200 -- runs the c2r on the GPU as the
+transform's definition (rf_fft_c2r).  It is first of all the test of the drop-in against its real consumer.  And since
+everything but the inverse transform in those traces is the reference's own code and arithmetic -- init_filter,
+e_inverse, layer_matrix_sol / _liq, the propagator chain, land and ocean boundary conditions, P and S spectra,
+water_level_decon, direct_arrival, the shift maps, the normalisation -- the traces are known answers for branches no
+reference-held vector covers: S phase, deconvolution, sea floor, nfft 4096, common rays, 2 .. 31 layers.  The CPU
+oracle (oracle/rf_oracle.c) and the HIP path (rf_calc_rf / rf_eval_batch through the C ABI) must both reproduce them.
+
+What this is NOT: a build of the reference's whole path (likelihood.f90 needs LAPACK, which the image lacks), nor a
+reference FFT (the c2r is ours; it is checked against the long-double O(n^2) definition in
+tests/test_gpu_parity.py::test_fftw_plans_on_the_gpu).  Needs a GPU (the drop-in has no CPU transform)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import DELTA, make_cfg, pack_layers, random_stack
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_forward_dump")
+pytestmark = pytest.mark.gpu
+
+# name -> (nfft, rayps, ipha, a_gus, deconv_mode, sdep, t_start)
+CASES = {
+    "c1_ocean_2P_nfft256": (256, [0.06, 0.08], [1, 1], [4.0, 4.0], 0, 2.0, 0.0),
+    "c2_land_P": (4096, [0.06], [1], [4.0], 0, 0.0, 0.0),
+    "c2d_land_P_decon": (4096, [0.06], [1], [4.0], 1, 0.0, 0.0),
+    "c4_land_PPS": (4096, [0.06, 0.08, 0.10], [1, 1, -1], [4.0, 4.0, 4.0], 0, 0.0, 0.0),
+    "c4_land_PPS_decon_tstart": (4096, [0.06, 0.08, 0.10], [1, 1, -1], [4.0, 2.5, 4.0], 1, 0.0, -3.0),
+    "c5_ocean_PPSS": (4096, [0.06, 0.08, 0.10, 0.12], [1, 1, -1, -1], [4.0] * 4, 0, 2.0, 0.0),
+    "c5_ocean_PPSS_decon": (4096, [0.06, 0.08, 0.10, 0.12], [1, 1, -1, -1], [4.0] * 4, 1, 2.0, -1.0),
+    "c4common_land_3P_one_ray": (4096, [0.06, 0.06, 0.06], [1, 1, 1], [4.0, 2.5, 1.5], 0, 0.0, 0.0),
+    "common_ocean_3S_one_ray_nfft2048": (2048, [0.10, 0.10, 0.10], [-1, -1, -1], [4.0, 2.5, 1.5], 0, 2.0, -2.0),
+    "odd_length_nfft1000_S": (1000, [0.11], [-1], [3.0], 0, 0.0, 0.0),
+}
+
+
+def _write_run_dir(work, nfft, rayps, ipha, a_gus, deconv, sdep, t_start, t_end=5.0):
+    """The shipped params.in with this case's geometry (rf_inv_amd.params.write_params: the reference's positional
+    format) + zero SAC traces that carry delta and the window."""
+    from rf_inv_amd import get_params, write_params
+    from rf_inv_amd.make_syn import write_sac
+
+    ntrc = len(rayps)
+    os.makedirs(work / "data")
+    os.makedirs(work / "rslt")
+    nsmp = int(round((t_end - t_start) / DELTA)) + 1
+    p = get_params(os.path.join(ROOT, "tests", "golden", "sample_syn", "params.in"))
+    p.ntrc, p.nfft, p.deconv_mode, p.sdep, p.t_start, p.t_end, p.k_max = ntrc, nfft, deconv, float(sdep), t_start, t_end, 31
+    p.rayps, p.a_gus, p.ipha = np.asarray(rayps, float), np.asarray(a_gus, float), np.asarray(ipha, dtype=np.int32)
+    p.obs_files = [f"data/t{t + 1}.trc" for t in range(ntrc)]
+    p.sig_min = p.sig_max = np.full(ntrc, 0.01)
+    for f in p.obs_files:
+        write_sac(str(work / f), np.zeros(nsmp), DELTA, t_start, t_end)
+    write_params(str(work / "params.in"), p, header="written by tests/test_reference_forward.py")
+    return nsmp
+
+
+def _stacks(rng, ocean, sdep):
+    sizes = (3, 4, 7, 12, 20, 31) if ocean else (2, 3, 6, 12, 20, 30)
+    stacks = [random_stack(rng, n, ocean, sdep) for n in sizes]
+    # a soft surface layer on a fast half-space: spectra that dip below the water level (the level clips bins)
+    soft = (np.array([1.6, 6.0, 8.0]), np.array([0.2, 3.5, 4.5]), np.array([1.5, 2.7, 3.3]), np.array([0.5, 30.0, 999.0]))
+    if ocean:
+        soft = tuple(np.concatenate([[w], x]) for w, x in zip((1.5, -999.0, 1.0, sdep), soft))
+    return stacks + [soft]
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_reference_forward_code_vs_oracle_and_hip(oracle, tmp_path, name):
+    if not os.path.exists(DUMP):
+        pytest.skip("oracle/_ref/ref_forward_dump not built (no Fortran compiler / reference tree at build time)")
+    from rf_inv_amd import RFEngine
+
+    nfft, rayps, ipha, a_gus, deconv, sdep, t_start = CASES[name]
+    ntrc, ocean = len(rayps), sdep > 0
+    rng = np.random.default_rng(sum(map(ord, name)))
+    stacks = _stacks(rng, ocean, sdep)
+    work = tmp_path / "run"
+    os.makedirs(work)
+    nsmp = _write_run_dir(work, nfft, rayps, ipha, a_gus, deconv, sdep, t_start)
+    with open(work / "stacks.txt", "w") as fh:
+        fh.write(f"{len(stacks)}\n")
+        for st in stacks:
+            fh.write(f"{len(st[0])}\n")
+            for j in range(len(st[0])):
+                fh.write(" ".join(repr(float(st[r][j])) for r in range(4)) + "\n")
+    r = subprocess.run([DUMP, "params.in", "stacks.txt", "ref.bin"], cwd=work, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ref_forward_dump: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    raw = open(work / "ref.bin", "rb").read()
+    hdr = np.frombuffer(raw[:16], dtype="<i4")
+    nh = nfft // 2 + 1
+    assert tuple(hdr) == (nfft, ntrc, nh, len(stacks))
+    body = np.frombuffer(raw[16:], dtype="<f8")
+    flt_ref = body[:nh * ntrc].reshape(ntrc, nh)
+    ref = body[nh * ntrc:].reshape(len(stacks), ntrc, nfft)            # Fortran rft(nfft, ntrc) per stack
+    common = len(set(rayps)) == 1 and len(set(ipha)) == 1 and ntrc > 1
+    assert ("T" in r.stdout.split("ok")[-1]) == common                 # the reference's is_ray_common
+
+    cfg = make_cfg(nfft=nfft, deconv_mode=deconv, t_start=t_start, sdep=sdep, rayps=rayps, a_gus=a_gus, ipha=ipha)
+    # (1) the filter table, expression for expression (src/forward.f90:95-119)
+    assert np.array_equal(oracle.init_filter(nfft, DELTA, np.asarray(a_gus, float)), flt_ref)
+    # (2) the CPU oracle against the reference's own forward code
+    for i, st in enumerate(stacks):
+        got = oracle.calc_rf(cfg, *st)
+        scale = np.abs(ref[i]).max(axis=1, keepdims=True)
+        assert np.isfinite(ref[i]).all() and (scale > 0).all()
+        assert (np.abs(got - ref[i]) <= 1e-12 * scale).all(), (name, "oracle", i, (np.abs(got - ref[i]) / scale).max())
+    # (3) the HIP path through the C ABI: the batched entry on the context's default plan, and the single-call drop-in
+    nlay, layers = pack_layers(stacks, 33)
+    with RFEngine(nfft=nfft, delta=DELTA, t_start=t_start, deconv_mode=deconv, sdep=sdep, rayps=np.asarray(rayps, float),
+                  a_gus=np.asarray(a_gus, float), ipha=np.asarray(ipha, dtype=np.int32), obs=np.zeros((ntrc, nsmp)), nsmp=nsmp,
+                  max_walkers=len(stacks), nlay_max=33) as eng:
+        assert np.array_equal(eng.flt.T, flt_ref) and eng.is_ray_common == common
+        eng.eval_batch(np.arange(len(stacks)), nlay, layers, np.full((len(stacks), ntrc), 0.02))
+        for i, st in enumerate(stacks):
+            scale = np.abs(ref[i]).max(axis=1, keepdims=True)
+            got = eng.get_rft(i, which=1).T
+            assert (np.abs(got - ref[i]) <= 1e-12 * scale).all(), (name, "hip batch", i, (np.abs(got - ref[i]) / scale).max())
+        one = eng.calc_rf(len(stacks[3][0]), *stacks[3]).T
+        assert (np.abs(one - ref[3]) <= 1e-12 * np.abs(ref[3]).max(axis=1, keepdims=True)).all()
+
+
+def test_reference_forward_code_propagates_nan_like_the_hip_path(oracle, tmp_path):
+    """An evanescent layer (1/v^2 < p^2: sqrt of a negative number, src/forward.f90:396-397) makes the reference's trace
+    NaN; the HIP path must return NaN for that trace too, not trap."""
+    if not os.path.exists(DUMP):
+        pytest.skip("oracle/_ref/ref_forward_dump not built")
+    from rf_inv_amd import RFEngine
+
+    work = tmp_path / "run"
+    os.makedirs(work)
+    nsmp = _write_run_dir(work, 256, [0.06, 0.30], [1, 1], [4.0, 4.0], 0, 0.0, 0.0)
+    st = (np.array([3.0, 6.0]), np.array([1.7, 3.4]), np.array([2.3, 2.8]), np.array([2.0, 999.0]))   # p = 0.30 > 1/6
+    open(work / "stacks.txt", "w").write("1\n2\n" + "\n".join(" ".join(repr(float(st[r][j])) for r in range(4)) for j in range(2)) + "\n")
+    r = subprocess.run([DUMP, "params.in", "stacks.txt", "ref.bin"], cwd=work, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    body = np.frombuffer(open(work / "ref.bin", "rb").read()[16:], dtype="<f8")
+    ref = body[129 * 2:].reshape(2, 256)
+    assert np.isfinite(ref[0]).all() and np.isnan(ref[1]).all()
+    with RFEngine(nfft=256, delta=DELTA, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=np.array([0.06, 0.30]),
+                  a_gus=np.array([4.0, 4.0]), ipha=np.array([1, 1], dtype=np.int32), obs=np.zeros((2, nsmp)), nsmp=nsmp,
+                  max_walkers=1, nlay_max=8) as eng:
+        got = eng.calc_rf(2, *st).T
+    assert np.isnan(got[1]).all() and np.abs(got[0] - ref[0]).max() <= 1e-12 * np.abs(ref[0]).max()
