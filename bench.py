@@ -406,8 +406,73 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
             "sample": f"{n} evals = the rank's walker set cycled ({nb} walkers, mean {float(nlay.mean()):.1f} layers), "
                       f"oracle/rf_oracle.c (gcc {' '.join(orc.FAST_FLAGS)}, OpenMP x{cores} threads = physical cores, "
                       f"{dt:.1f} s wall); single-core rate on {n1} evals"}
+    # the reference's own forward code on one core of this box, next to the port's single-core rate on the same walkers
+    n24 = min(nb, 24)
+    t0 = time.perf_counter()
+    orc.eval_batch(cfg, obs, r_inv, nlay[:n24], layers[:n24], sig[:n24], p.nsmp, nthreads=1, fast=True)
+    port24 = n24 / (time.perf_counter() - t0)
+    ref_fwd = reference_forward_rate(p, nlay, layers)
+    if ref_fwd is not None:
+        ref_fwd["port_single_core_same_walkers"] = port24
+        ref_fwd["reference_over_port"] = ref_fwd["value"] / port24
+    base["reference_forward"] = ref_fwd
     nuse = min(nb, n)
     return base, ll_all[:nuse], nuse
+
+
+def reference_forward_rate(p, nlay, layers, budget_s=8.0):
+    """The reference's OWN forward code timed on one host core of this box: oracle/_ref/ref_forward_time = the
+    reference's src/forward.f90 compiled unmodified (-O2 -ffp-contract=off; rf_inv_amd/fortran/Makefile, built where
+    /root/reference exists and shipped prebuilt) with the reference's params.f90 and the drop-in module fftw, looping
+    calc_rf (src/forward.f90:123-208) over a sample of this workload's walkers.  Forward model only: the misfit
+    quadratic form of src/likelihood.f90 (< 5 % of an evaluation at nsmp 101) is not in it -- that module
+    needs LAPACK, which the image lacks -- and calc_rf's c2r goes through the drop-in (a GPU round trip of ~0.1 ms per
+    trace, counted).  Returns None when the binary is not there or fails."""
+    import copy
+    import subprocess
+    import tempfile
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_forward_time")
+    if not os.path.exists(exe):
+        return None
+    from rf_inv_amd import write_params
+    from rf_inv_amd.make_syn import write_sac
+
+    n = min(len(nlay), 24)
+    try:
+        with tempfile.TemporaryDirectory() as work:
+            os.makedirs(os.path.join(work, "data"))
+            os.makedirs(os.path.join(work, "rslt"))
+            q = copy.copy(p)
+            q.out_dir, q.obs_files = "./rslt", [f"data/t{t + 1}.trc" for t in range(p.ntrc)]
+            for f in q.obs_files:
+                write_sac(os.path.join(work, f), np.zeros(p.nsmp), p.delta, p.t_start, p.t_end)
+            write_params(os.path.join(work, "params.in"), q)
+            with open(os.path.join(work, "stacks.txt"), "w") as fh:
+                fh.write(f"{n}\n")
+                for i in range(n):
+                    fh.write(f"{int(nlay[i])}\n")
+                    for j in range(int(nlay[i])):
+                        fh.write(" ".join(repr(float(layers[i, r, j])) for r in range(4)) + "\n")
+            # one pass is timed by the dump itself being run with reps = 1 first (page-in), then sized to the budget
+            secs, evals = None, 0
+            for reps in (1, None):
+                if reps is None:
+                    reps = int(max(1, min(50, budget_s / max(secs, 1e-3))))
+                r = subprocess.run([exe, "params.in", "stacks.txt", "ref.bin", str(reps)], cwd=work, capture_output=True,
+                                   text=True, timeout=600)
+                line = [l for l in r.stdout.splitlines() if "ref_forward_dump: seconds" in l]
+                if r.returncode != 0 or not line:
+                    return None
+                tok = line[0].split()
+                secs, evals = float(tok[2]), int(tok[4])
+        return {"value": evals / secs, "unit": "forward evaluations/s", "cores": 1, "kind": "reference (forward model only)",
+                "sample": f"{evals} calc_rf calls on {n} of this workload's walkers (mean {float(np.mean(nlay[:n])):.1f} layers), "
+                          f"{secs:.1f} s; src/forward.f90 unmodified, amdflang -O2 -ffp-contract=off; c2r through the drop-in "
+                          "module fftw (GPU round trip included); the likelihood's quadratic form (src/likelihood.f90, needs "
+                          "LAPACK) not included"}
+    except (OSError, subprocess.SubprocessError, ValueError):
+        return None
 
 
 def visible_gpus():
@@ -533,6 +598,9 @@ def headline_line(full, detail_file):
     if cpu:
         line["cpu_baseline"] = dict(pick(cpu, ("value", "unit", "cores", "kind", "per_core")),
                                     sample=cpu.get("sample_short") or (cpu.get("sample") or "")[:120])
+        if cpu.get("reference_forward"):        # the reference's own forward code, one core (detail_file: what it covers)
+            line["cpu_baseline"]["reference_forward"] = pick(cpu["reference_forward"],
+                                                             ("value", "unit", "cores", "kind", "reference_over_port"))
     if par:
         line["parity_in_bench"] = pick(par, ("n", "max_abs_dlogl", "max_rel_dlogl", "within_tolerance",
                                              "n_used_kappa_allowance"))
