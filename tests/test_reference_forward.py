@@ -99,7 +99,7 @@ def test_reference_forward_code_vs_oracle_and_hip(oracle, tmp_path, name):
     body = np.frombuffer(raw[16:], dtype="<f8")
     flt_ref = body[:nh * ntrc].reshape(ntrc, nh)
     ref = body[nh * ntrc:].reshape(len(stacks), ntrc, nfft)            # Fortran rft(nfft, ntrc) per stack
-    common = len(set(rayps)) == 1 and len(set(ipha)) == 1 and ntrc > 1
+    common = len(set(rayps)) == 1 and len(set(ipha)) == 1            # check_ray (src/forward.f90:59-91): true for one trace
     assert ("T" in r.stdout.split("ok")[-1]) == common                 # the reference's is_ray_common
 
     cfg = make_cfg(nfft=nfft, deconv_mode=deconv, t_start=t_start, sdep=sdep, rayps=rayps, a_gus=a_gus, ipha=ipha)
