@@ -148,3 +148,73 @@ def test_reference_forward_code_propagates_nan_like_the_hip_path(oracle, tmp_pat
                   max_walkers=1, nlay_max=8) as eng:
         got = eng.calc_rf(2, *st).T
     assert np.isnan(got[1]).all() and np.abs(got[0] - ref[0]).max() <= 1e-12 * np.abs(ref[0]).max()
+
+
+@pytest.mark.parametrize("workload,count", [("c4", 96), ("c5", 64), ("c2d", 64), ("c4common", 48)])
+def test_benchmark_walkers_against_the_reference_forward_code(oracle, tmp_path, workload, count):
+    """bench.py's own walkers -- the first `count` models of the workload's rank-0 batch plus its deepest ones -- through
+    the reference's forward.f90 (on the drop-in module fftw), the oracle and the HIP path at the workload's geometry:
+    the full-batch tests of tests/test_gpu_configs.py compare every walker with the ORACLE; this one ties the oracle
+    and the kernels to the reference's own code on the very models those batches hold."""
+    if not os.path.exists(DUMP):
+        pytest.skip("oracle/_ref/ref_forward_dump not built")
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from rf_inv_amd import RFEngine, read_ref_model
+
+    w = dict(bench.WORKLOADS[workload])
+    p = bench.make_params(w)
+    refm = read_ref_model(os.path.join(ROOT, "tests", "golden", "sample_syn", "model", "sample.velmod"))
+    nlay, layers = bench.draw_walkers(p, refm, 0, 4 * count)
+    pick = np.unique(np.concatenate([np.arange(count), np.argsort(nlay)[-8:], np.argsort(nlay)[:4]]))
+    nlay, layers = nlay[pick], layers[pick]
+    n = len(pick)
+    work = tmp_path / "run"
+    os.makedirs(work)
+    nsmp = _write_run_dir(work, p.nfft, p.rayps, p.ipha, p.a_gus, p.deconv_mode, p.sdep, p.t_start, p.t_end)
+    assert nsmp == p.nsmp
+    with open(work / "stacks.txt", "w") as fh:
+        fh.write(f"{n}\n")
+        for i in range(n):
+            fh.write(f"{int(nlay[i])}\n")
+            for j in range(int(nlay[i])):
+                fh.write(" ".join(repr(float(layers[i, r, j])) for r in range(4)) + "\n")
+    r = subprocess.run([DUMP, "params.in", "stacks.txt", "ref.bin"], cwd=work, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ref_forward_dump: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    nh = p.nfft // 2 + 1
+    body = np.frombuffer(open(work / "ref.bin", "rb").read()[16:], dtype="<f8")
+    ref = body[nh * p.ntrc:].reshape(n, p.ntrc, p.nfft)
+    assert np.isfinite(ref).all() and nlay.max() >= (24 if w["k_max"] >= 30 else 12)
+    cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep, rayps=p.rayps,
+               a_gus=p.a_gus, ipha=p.ipha)
+    worst_o = worst_h = 0.0
+    with RFEngine(nfft=p.nfft, delta=p.delta, t_start=p.t_start, deconv_mode=p.deconv_mode, sdep=p.sdep, rayps=p.rayps,
+                  a_gus=p.a_gus, ipha=p.ipha, obs=np.zeros((p.ntrc, p.nsmp)), nsmp=p.nsmp, max_walkers=n,
+                  nlay_max=p.k_max + 2) as eng:
+        eng.eval_batch(np.arange(n), nlay, layers, np.full((n, p.ntrc), 0.01))
+        got_all = eng.get_rft_batch(np.arange(n), which=1)                   # [n, ntrc, nfft]
+    # without deconvolution every trace carries 1 / maxval(vertical trace): the conditioning rule of DESIGN.md section 5
+    # (kappa from the oracle's own vertical trace; an allowance only from kappa 100 on)
+    _, kaps = oracle.eval_batch(cfg, np.zeros((p.ntrc, p.nsmp)), oracle.build_r_inv(p.nsmp, p.a_gus, p.delta), nlay, layers,
+                                np.full((n, p.ntrc), 0.01), p.nsmp, nthreads=oracle.max_threads(), want_kappa=True)
+    for i in range(n):
+        st = tuple(layers[i, r, :nlay[i]] for r in range(4))
+        scale = np.abs(ref[i]).max(axis=1, keepdims=True)
+        kap = float(kaps[i])
+        allow = 1e-12 * max(1.0, kap / 10.0 if kap >= 100.0 else 1.0)
+        eo = (np.abs(oracle.calc_rf(cfg, *st) - ref[i]) / scale).max()
+        eh = (np.abs(got_all[i] - ref[i]) / scale).max()
+        assert eo <= allow and eh <= allow, (workload, int(pick[i]), int(nlay[i]), eo, eh, kap)
+        if kap < 100.0:
+            worst_o, worst_h = max(worst_o, eo), max(worst_h, eh)
+    print(f"{workload}: {n} walkers (nlay {int(nlay.min())} .. {int(nlay.max())}) against the reference's forward.f90: "
+          f"max |d trace| / max|trace| oracle {worst_o:.2e}, HIP {worst_h:.2e}")
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+
+        with open(os.path.join(out_dir, f"reference_forward_{workload}.json"), "w") as fh:
+            json.dump({"workload": workload, "walkers": int(n), "nlay_min": int(nlay.min()), "nlay_max": int(nlay.max()),
+                       "max_rel_trace_error_oracle": worst_o, "max_rel_trace_error_hip": worst_h}, fh)
