@@ -31,11 +31,20 @@
  *     to this file; oracle/rf_oracle.py builds it with LAPACK dgesvd through
  *     scipy exactly as src/likelihood.f90:168-222 does.
  *
- * PARITY PINNING.  The reference's own forward/likelihood modules cannot be
- * compiled in this image without writing stand-ins (FFTW3 header + library
- * and LAPACK are absent), so there is no oracle/_ref build of them.  The
- * oracle is pinned against the reference's own fixtures instead
- * (tests/test_oracle_kat.py):
+ * PARITY PINNING.  The reference's likelihood module cannot be compiled in
+ * this image (LAPACK is absent and writing a stand-in is not allowed), nor
+ * its fftw module (FFTW3 header + library are absent).  Pins:
+ *   (0) [round 5] the reference's OWN src/forward.f90, compiled unmodified
+ *       into oracle/_ref/ref_forward_dump on the PRODUCT's drop-in `module
+ *       fftw` (rf_inv_amd/fortran/fftw.f90 -- the reference's main programs
+ *       need that module anyway; its c2r is rf_fft_c2r on the GPU, the
+ *       transform's definition): tests/test_reference_forward.py (needs a
+ *       GPU) compares every trace of 10 configurations (P / S, deconvolution,
+ *       sea floor, common rays, nfft 256 .. 4096, t_start < 0) x 7 stacks of
+ *       2 .. 31 layers, and of bench.py's own C4 / C5 / c2d / c4common
+ *       walkers, with this file: agreement 7e-16 of the trace scale.  Everything
+ *       in those traces except the inverse transform is the reference's code.
+ * and, on the CPU, the reference's own fixtures (tests/test_oracle_kat.py):
  *   (1) sample_syn/true/true.velmod + sample_syn/params.in geometry (land)
  *       -> sample_syn/data/sample_{1,2}.trc, to float32 quantisation
  *       (RMS ~2e-9 / ~5e-9): pins init_filter, e_inverse, layer_matrix_sol,
@@ -55,10 +64,11 @@
  *       log-likelihood.  Provenance caveat: that number comes from the
  *       surveyor's probe build (FFT/LAPACK link shims), not from a fixture the
  *       reference ships.
- * Branches with NO reference-GENERATED known answers: S-phase traces and
- * water-level deconvolution (the reference ships no such fixture and its
- * forward module cannot be built here).  They are pinned by an INDEPENDENT
- * formulation instead (tests/analytic_layered.py, tests/test_analytic_pins.py):
+ * Branches with no reference-SHIPPED known answers: S-phase traces, water-level
+ * deconvolution, the sea floor beyond (3).  On a GPU box pin (0) covers them with
+ * the reference's own code; on the CPU (no GPU transform for the drop-in) they
+ * are pinned by an INDEPENDENT formulation (tests/analytic_layered.py,
+ * tests/test_analytic_pins.py):
  * the receiver function of a layer stack by the reflectivity method --
  * scattering matrices from numerically solved boundary conditions, Kennett's
  * addition rules, the reverberation operator; no propagator product -- plus
@@ -71,8 +81,8 @@
  * case (layer_matrix_liq and the sea-floor rows, forward.f90:276-287,
  * 424-442) -- which therefore no longer rests on (3) alone.  Also kept: an
  * independent numpy restatement (calc_seis_numpy) and the half-space
- * apparent-angle relations (tests/test_oracle_kat.py).  With respect to
- * reference OUTPUTS these two branches remain "parity unpinned".
+ * apparent-angle relations (tests/test_oracle_kat.py).  The likelihood's
+ * quadratic form + logL rest on (3) alone as far as reference OUTPUT goes.
  */
 #include <math.h>
 #include <stdlib.h>
