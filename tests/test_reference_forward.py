@@ -218,3 +218,126 @@ def test_benchmark_walkers_against_the_reference_forward_code(oracle, tmp_path, 
         with open(os.path.join(out_dir, f"reference_forward_{workload}.json"), "w") as fh:
             json.dump({"workload": workload, "walkers": int(n), "nlay_min": int(nlay.min()), "nlay_max": int(nlay.max()),
                        "max_rel_trace_error_oracle": worst_o, "max_rel_trace_error_hip": worst_h}, fh)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The reference's OWN likelihood module on top of its own forward module: oracle/_ref/ref_path_dump =
+# src/likelihood.f90 + src/forward.f90 + model / params / mt19937 ..., all compiled unmodified, on the drop-in module
+# fftw, with LAPACK's dgesvd from the Intel MKL the image ships (/opt/conda/lib).  calc_likelihood
+# (src/likelihood.f90:56-101) is then the reference's code end to end -- format_model, calc_rf, the misfit,
+# matmul(misfits, r_inv), the log-likelihood; R^-1 from init_r_inv's dgesvd -- except for the inverse transform.
+# This is the north star's criterion itself: |logL(HIP) - logL(reference)| < 1e-9 (relative 1e-12 for large |logL|).
+# ---------------------------------------------------------------------------------------------------------------
+PATH_DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_path_dump")
+
+
+@pytest.mark.parametrize("workload,count", [("c4", 64), ("c5", 40), ("c2d", 48), ("c1", 48)])
+def test_reference_likelihood_code_vs_oracle_and_hip(oracle, tmp_path, workload, count):
+    if not os.path.exists(PATH_DUMP):
+        pytest.skip("oracle/_ref/ref_path_dump not built (no Fortran compiler / reference tree / MKL at build time)")
+    import copy
+    import shutil
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from helpers import logl_tol
+    from rf_inv_amd import RFEngine, format_model, read_ref_model, write_params
+    from rf_inv_amd.make_syn import write_sac
+
+    w = dict(bench.WORKLOADS[workload])
+    p = bench.make_params(w)
+    golden = os.path.join(ROOT, "tests", "golden", "sample_syn")
+    refm = read_ref_model(os.path.join(golden, "model", "sample.velmod"))
+    nlay, layers, (m_k, m_z, m_dvp, m_dvs) = bench.draw_walkers(p, refm, 0, 3 * count, return_models=True)
+    pick = np.unique(np.concatenate([np.arange(count), np.argsort(nlay)[-6:], np.argsort(nlay)[:3]]))
+    nlay, layers, m_k, m_z, m_dvp, m_dvs = nlay[pick], layers[pick], m_k[pick], m_z[pick], m_dvp[pick], m_dvs[pick]
+    n = len(pick)
+    rng = np.random.default_rng(sum(map(ord, workload)) + 1)
+    sig = rng.uniform(0.01, 0.03, (n, p.ntrc))
+    cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep, rayps=p.rayps,
+               a_gus=p.a_gus, ipha=p.ipha)
+    # observed traces: the noise-free synthetic of bench.py's fixed 3-interface model (as tests/test_gpu_configs.py)
+    zt = np.zeros(max(p.k_max - 1, 1)); dvt = np.zeros(p.k_max); dst = np.zeros(p.k_max)
+    zt[:3] = [3.1 + p.sdep, 7.7 + p.sdep, 14.2 + p.sdep]; dst[:3] = [-0.6, 0.2, 0.5]; dst[p.k_max - 1] = 0.9
+    nl_t, a_t, b_t, r_t, h_t, ok = format_model(p, refm, 3, zt, dvt, dst)
+    assert ok
+    obs_full = oracle.calc_rf(cfg, a_t, b_t, r_t, h_t)
+
+    work = tmp_path / "run"
+    for d in ("data", "rslt", "model"):
+        os.makedirs(work / d)
+    shutil.copy(os.path.join(golden, "model", "sample.velmod"), work / "model" / "sample.velmod")
+    q = copy.copy(p)
+    q.out_dir, q.nchains, q.ncool, q.nburn, q.niter, q.dvs_prior = "./rslt", 1, 1, 0, 10, 0.3
+    q.vel_file, q.obs_files = "model/sample.velmod", [f"data/t{t + 1}.trc" for t in range(p.ntrc)]
+    for t, f in enumerate(q.obs_files):
+        write_sac(str(work / f), obs_full[t, :p.nsmp], p.delta, p.t_start, p.t_end)
+    write_params(str(work / "params.in"), q, header="written by tests/test_reference_forward.py")
+    # what the reference will read back: float32 samples
+    obs = np.stack([obs_full[t, :p.nsmp].astype(np.float32).astype(np.float64) for t in range(p.ntrc)])
+    with open(work / "models.txt", "w") as fh:
+        fh.write(f"{n}\n")
+        for i in range(n):
+            fh.write(f"{int(m_k[i])}\n")
+            for arr in (m_z[i, :max(p.k_max - 1, 1)], m_dvp[i, :p.k_max], m_dvs[i, :p.k_max], sig[i]):
+                fh.write(" ".join(repr(float(x)) for x in arr) + "\n")
+    r = subprocess.run([PATH_DUMP, "params.in", "models.txt", "ref.bin"], cwd=work, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ref_path_dump: ok" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    raw = open(work / "ref.bin", "rb").read()
+    nfft, ntrc, nsmp, n_out, m = (int(x) for x in np.frombuffer(raw[:20], dtype="<i4"))
+    assert (nfft, ntrc, nsmp, n_out) == (p.nfft, p.ntrc, p.nsmp, n)
+    body = np.frombuffer(raw[20:], dtype="<f8")
+    o = nsmp * nsmp * ntrc
+    r_inv = body[:o].reshape(ntrc, nsmp, nsmp).copy()               # r_inv[t].ravel() == Fortran r_inv(:, :, t)
+    rec = body[o:o + n * (1 + nfft * ntrc)].reshape(n, 1 + nfft * ntrc)
+    ll_ref, rft_ref = rec[:, 0].copy(), rec[:, 1:].reshape(n, ntrc, nfft)
+    prob = body[o + n * (1 + nfft * ntrc):].reshape(m, 1 + nfft * ntrc + ntrc)
+    assert np.isfinite(ll_ref).all()
+
+    # (0) the pseudo-inverse: MKL's dgesvd here, scipy's OpenBLAS dgesvd in oracle.build_r_inv -- same rank, same matrix
+    # to the rounding of two SVDs of an ill-conditioned matrix (parity is stated for identical r_inv: the dump is used below)
+    mine = oracle.build_r_inv(nsmp, p.a_gus, p.delta)
+    assert np.abs(mine - r_inv).max() <= 1e-8 * np.abs(r_inv).max()
+    # (1) the sigma-only branch on host-stored traces: the reference's misfit loop (src/likelihood.f90:87-98) against the
+    # oracle's with the dumped matrix -- this also shows that the dumped matrix IS module likelihood's private r_inv
+    for j in range(m):
+        ll_p, tr, sg = prob[j, 0], prob[j, 1:1 + nfft * ntrc].reshape(ntrc, nfft), prob[j, 1 + nfft * ntrc:]
+        want = oracle.log_likelihood(tr, obs, r_inv, sg, nsmp)
+        assert abs(want - ll_p) <= logl_tol(ll_p), (j, want, ll_p)
+    # (2) calc_likelihood(fwd_flag = .true.) on bench.py's walkers: oracle and HIP against the reference's own code
+    _, kaps = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads(), want_kappa=True)
+    ll_orc = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads())
+    ids = np.arange(n, dtype=np.int32)
+    with RFEngine(nfft=p.nfft, delta=p.delta, t_start=p.t_start, deconv_mode=p.deconv_mode, sdep=p.sdep, rayps=p.rayps,
+                  a_gus=p.a_gus, ipha=p.ipha, obs=obs, nsmp=nsmp, r_inv=r_inv, max_walkers=n, nlay_max=p.k_max + 2) as eng:
+        eng.set_model(p, refm)
+        ll_hip = eng.eval_models(ids, m_k, m_z[:, :max(p.k_max - 1, 1)], m_dvp, m_dvs, sig)       # format_model on the device too
+        ll_hip2 = eng.eval_batch(ids, nlay, layers, sig)
+        got = eng.get_rft_batch(ids, which=1)
+    assert np.array_equal(ll_hip, ll_hip2)
+    worst = {"oracle": 0.0, "hip": 0.0}
+    for name, ll in (("oracle", ll_orc), ("hip", ll_hip)):
+        d = np.abs(ll - ll_ref)
+        tol = logl_tol(ll_ref)
+        for i in np.nonzero(~(d <= tol))[0]:
+            assert kaps[i] >= 100.0 and d[i] <= tol[i] * kaps[i] / 10.0, (workload, name, int(pick[i]), ll[i], ll_ref[i], kaps[i])
+        worst[name] = float((d / tol).max())
+        assert np.sum(~(d <= tol)) <= max(1, n // 50)
+    scale = np.abs(rft_ref).max(axis=2, keepdims=True)
+    ok_tr = np.abs(got - rft_ref) <= 1e-12 * scale * np.maximum(1.0, np.where(kaps >= 100.0, kaps / 10.0, 1.0))[:, None, None]
+    assert ok_tr.all()
+    print(f"{workload}: {n} models, |logL| {np.abs(ll_ref).min():.3g} .. {np.abs(ll_ref).max():.3g}: |dlogL| / tolerance against the "
+          f"reference's calc_likelihood: oracle {worst['oracle']:.3f}, HIP {worst['hip']:.3f}; "
+          f"max |dlogL| HIP {np.abs(ll_hip - ll_ref).max():.3e}")
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+
+        with open(os.path.join(out_dir, f"reference_likelihood_{workload}.json"), "w") as fh:
+            json.dump({"workload": workload, "models": int(n), "abs_logl_min": float(np.abs(ll_ref).min()),
+                       "abs_logl_max": float(np.abs(ll_ref).max()), "worst_fraction_of_tolerance_oracle": worst["oracle"],
+                       "worst_fraction_of_tolerance_hip": worst["hip"],
+                       "max_abs_dlogl_hip": float(np.abs(ll_hip - ll_ref).max()),
+                       "max_rel_dlogl_hip": float((np.abs(ll_hip - ll_ref) / np.abs(ll_ref)).max()),
+                       "n_kappa_ge_100": int(np.sum(kaps >= 100.0))}, fh)
