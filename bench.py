@@ -406,73 +406,90 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
             "sample": f"{n} evals = the rank's walker set cycled ({nb} walkers, mean {float(nlay.mean()):.1f} layers), "
                       f"oracle/rf_oracle.c (gcc {' '.join(orc.FAST_FLAGS)}, OpenMP x{cores} threads = physical cores, "
                       f"{dt:.1f} s wall); single-core rate on {n1} evals"}
-    # the reference's own forward code on one core of this box, next to the port's single-core rate on the same walkers
+    # the reference's own forward + likelihood code on one core of this box (sigma 0.01 like `sig`), next to the port's
+    # single-core rate on the same walkers -- and its logL against the port's on them
     n24 = min(nb, 24)
     t0 = time.perf_counter()
-    orc.eval_batch(cfg, obs, r_inv, nlay[:n24], layers[:n24], sig[:n24], p.nsmp, nthreads=1, fast=True)
+    ll24 = orc.eval_batch(cfg, obs, r_inv, nlay[:n24], layers[:n24], sig[:n24], p.nsmp, nthreads=1, fast=True)
     port24 = n24 / (time.perf_counter() - t0)
-    ref_fwd = reference_forward_rate(p, nlay, layers)
-    if ref_fwd is not None:
-        ref_fwd["port_single_core_same_walkers"] = port24
-        ref_fwd["reference_over_port"] = ref_fwd["value"] / port24
-    base["reference_forward"] = ref_fwd
+    # (the reference reads its observed traces from SAC files: float32 samples -- the port is given the same here)
+    obs32 = obs.astype(np.float32).astype(np.float64)
+    ref_rec, ll_ref = reference_path_rate(p, obs32, count=n24)
+    if ref_rec is not None:
+        ll24 = orc.eval_batch(cfg, obs32, r_inv, nlay[:n24], layers[:n24], sig[:n24], p.nsmp, nthreads=1, fast=True)
+        ref_rec["port_single_core_same_walkers"] = port24
+        ref_rec["reference_over_port"] = ref_rec["value"] / port24
+        # (R^-1 here comes from scipy's dgesvd, the reference's from MKL's: two SVDs of an ill-conditioned matrix)
+        ref_rec["max_rel_dlogl_port_vs_reference"] = float(np.max(np.abs(ll24 - ll_ref) / np.abs(ll_ref)))
+    base["reference"] = ref_rec
     nuse = min(nb, n)
     return base, ll_all[:nuse], nuse
 
 
-def reference_forward_rate(p, nlay, layers, budget_s=8.0):
-    """The reference's OWN forward code timed on one host core of this box: oracle/_ref/ref_forward_time = the
-    reference's src/forward.f90 compiled unmodified (-O2 -ffp-contract=off; rf_inv_amd/fortran/Makefile, built where
-    /root/reference exists and shipped prebuilt) with the reference's params.f90 and the drop-in module fftw, looping
-    calc_rf (src/forward.f90:123-208) over a sample of this workload's walkers.  Forward model only: the misfit
-    quadratic form of src/likelihood.f90 (< 5 % of an evaluation at nsmp 101) is not in it -- that module
-    needs LAPACK, which the image lacks -- and calc_rf's c2r goes through the drop-in (a GPU round trip of ~0.1 ms per
-    trace, counted).  Returns None when the binary is not there or fails."""
+def reference_path_rate(p, obs, budget_s=8.0, count=24):
+    """The reference's OWN forward + likelihood code timed on one host core of this box: oracle/_ref/ref_path_time = the
+    reference's src/likelihood.f90 + src/forward.f90 + model / params / mt19937 / sort / math / prior, all compiled
+    unmodified (amdflang -O2 -ffp-contract=off; rf_inv_amd/fortran/Makefile, built where /root/reference exists and
+    shipped prebuilt), LAPACK's dgesvd from the Intel MKL of the image, on the drop-in module fftw -- looping
+    calc_likelihood(fwd_flag = .true.) (src/likelihood.f90:56-101: format_model, calc_rf, misfit, quadratic form, logL)
+    over the first `count` of this workload's walkers.  The one thing in it that is not the reference's: calc_rf's c2r
+    goes through the drop-in (a GPU round trip of ~0.1 ms per transform, counted in the time).
+    Returns (record or None, logL of the sample or None)."""
     import copy
+    import shutil
     import subprocess
     import tempfile
 
-    exe = os.path.join(ROOT, "oracle", "_ref", "ref_forward_time")
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_path_time")
     if not os.path.exists(exe):
-        return None
-    from rf_inv_amd import write_params
+        return None, None
+    from rf_inv_amd import read_ref_model, write_params
     from rf_inv_amd.make_syn import write_sac
 
-    n = min(len(nlay), 24)
+    golden = os.path.join(ROOT, "tests", "golden", "sample_syn")
+    ref = read_ref_model(os.path.join(golden, "model", "sample.velmod"))
+    nlay, _, (m_k, m_z, m_dvp, m_dvs) = draw_walkers(p, ref, 0, count, return_models=True)     # the rank-0 walkers again
+    n = count
     try:
         with tempfile.TemporaryDirectory() as work:
-            os.makedirs(os.path.join(work, "data"))
-            os.makedirs(os.path.join(work, "rslt"))
+            for d in ("data", "rslt", "model"):
+                os.makedirs(os.path.join(work, d))
+            shutil.copy(os.path.join(golden, "model", "sample.velmod"), os.path.join(work, "model", "sample.velmod"))
             q = copy.copy(p)
-            q.out_dir, q.obs_files = "./rslt", [f"data/t{t + 1}.trc" for t in range(p.ntrc)]
-            for f in q.obs_files:
-                write_sac(os.path.join(work, f), np.zeros(p.nsmp), p.delta, p.t_start, p.t_end)
+            q.out_dir, q.nchains, q.ncool, q.nburn, q.niter, q.dvs_prior = "./rslt", 1, 1, 0, 10, 0.3
+            q.vel_file, q.obs_files = "model/sample.velmod", [f"data/t{t + 1}.trc" for t in range(p.ntrc)]
+            for t, f in enumerate(q.obs_files):
+                write_sac(os.path.join(work, f), obs[t, :p.nsmp], p.delta, p.t_start, p.t_end)
             write_params(os.path.join(work, "params.in"), q)
-            with open(os.path.join(work, "stacks.txt"), "w") as fh:
+            with open(os.path.join(work, "models.txt"), "w") as fh:
                 fh.write(f"{n}\n")
                 for i in range(n):
-                    fh.write(f"{int(nlay[i])}\n")
-                    for j in range(int(nlay[i])):
-                        fh.write(" ".join(repr(float(layers[i, r, j])) for r in range(4)) + "\n")
-            # one pass is timed by the dump itself being run with reps = 1 first (page-in), then sized to the budget
+                    fh.write(f"{int(m_k[i])}\n")
+                    for arr in (m_z[i, :max(p.k_max - 1, 1)], m_dvp[i, :p.k_max], m_dvs[i, :p.k_max], np.full(p.ntrc, 0.01)):
+                        fh.write(" ".join(repr(float(x)) for x in arr) + "\n")
             secs, evals = None, 0
-            for reps in (1, None):
+            for reps in (1, None):       # one pass first (page-in, and its time sizes the second run to the budget)
                 if reps is None:
                     reps = int(max(1, min(50, budget_s / max(secs, 1e-3))))
-                r = subprocess.run([exe, "params.in", "stacks.txt", "ref.bin", str(reps)], cwd=work, capture_output=True,
+                r = subprocess.run([exe, "params.in", "models.txt", "ref.bin", str(reps)], cwd=work, capture_output=True,
                                    text=True, timeout=600)
-                line = [l for l in r.stdout.splitlines() if "ref_forward_dump: seconds" in l]
+                line = [l for l in r.stdout.splitlines() if "ref_path_dump: seconds" in l]
                 if r.returncode != 0 or not line:
-                    return None
+                    return None, None
                 tok = line[0].split()
                 secs, evals = float(tok[2]), int(tok[4])
-        return {"value": evals / secs, "unit": "forward evaluations/s", "cores": 1, "kind": "reference (forward model only)",
-                "sample": f"{evals} calc_rf calls on {n} of this workload's walkers (mean {float(np.mean(nlay[:n])):.1f} layers), "
-                          f"{secs:.1f} s; src/forward.f90 unmodified, amdflang -O2 -ffp-contract=off; c2r through the drop-in "
-                          "module fftw (GPU round trip included); the likelihood's quadratic form (src/likelihood.f90, needs "
-                          "LAPACK) not included"}
-    except (OSError, subprocess.SubprocessError, ValueError):
-        return None
+            raw = open(os.path.join(work, "ref.bin"), "rb").read()
+            nsmp = int(np.frombuffer(raw[8:12], dtype="<i4")[0])
+            body = np.frombuffer(raw[20:], dtype="<f8")
+            o = nsmp * nsmp * p.ntrc
+            ll = body[o:o + n * (1 + p.nfft * p.ntrc)].reshape(n, 1 + p.nfft * p.ntrc)[:, 0].copy()
+        return ({"value": evals / secs, "unit": "evals/s", "cores": 1, "kind": "reference",
+                 "sample": f"{evals} calc_likelihood(fwd_flag = .true.) calls on {n} of this workload's walkers (mean "
+                           f"{float(np.mean(nlay)):.1f} layers), {secs:.1f} s on one core; src/likelihood.f90 + src/forward.f90 + "
+                           "host modules unmodified, amdflang -O2 -ffp-contract=off, dgesvd from MKL; c2r through the drop-in "
+                           "module fftw (GPU round trips included)"}, ll)
+    except (OSError, subprocess.SubprocessError, ValueError, IndexError):
+        return None, None
 
 
 def visible_gpus():
@@ -598,9 +615,8 @@ def headline_line(full, detail_file):
     if cpu:
         line["cpu_baseline"] = dict(pick(cpu, ("value", "unit", "cores", "kind", "per_core")),
                                     sample=cpu.get("sample_short") or (cpu.get("sample") or "")[:120])
-        if cpu.get("reference_forward"):        # the reference's own forward code, one core (detail_file: what it covers)
-            line["cpu_baseline"]["reference_forward"] = pick(cpu["reference_forward"],
-                                                             ("value", "unit", "cores", "kind", "reference_over_port"))
+        if cpu.get("reference"):        # the reference's own forward + likelihood code, one core (detail_file: the sample)
+            line["cpu_baseline"]["reference"] = pick(cpu["reference"], ("value", "unit", "cores", "kind", "reference_over_port"))
     if par:
         line["parity_in_bench"] = pick(par, ("n", "max_abs_dlogl", "max_rel_dlogl", "within_tolerance",
                                              "n_used_kappa_allowance"))

@@ -5,7 +5,10 @@
 ! calc_likelihood (src/likelihood.f90:56-101) is then the reference's own code end to end -- format_model, calc_rf,
 ! calc_seis, the misfit, matmul(misfits, r_inv), the log-likelihood -- except for the inverse transform.
 ! Follows the init order of src/rf_inv.f90:69-88.
-!   usage: ref_path_dump params.in models.txt out.bin
+!   usage: ref_path_dump params.in models.txt out.bin [reps]
+!   reps > 0: after the dump, `reps` timed passes of calc_likelihood(fwd_flag = .true.) over all models on one core:
+!   prints the seconds -- the reference's own cost per forward + likelihood evaluation on this host (its c2r round
+!   trips to the GPU included)
 !   models.txt: n; then per model: k; z(1:k_max-1); dvp(1:k_max); dvs(1:k_max); sig(1:ntrc)   (list-directed)
 !   out.bin (stream): int32 nfft, ntrc, nsmp, n, m;  real64 r_inv(nsmp, nsmp, ntrc) as built below;
 !                     per model: real64 logL, rft(nfft, ntrc)          [calc_likelihood, fwd_flag = .true.]
@@ -27,7 +30,11 @@ program ref_path_dump
   implicit none
   integer, parameter :: m = 6
   character(clen_max) :: param_file, model_file, out_file
-  integer :: n, i, j, it, jt, u, v, pk, info, lw
+  integer :: n, i, j, it, jt, u, v, pk, info, lw, reps, irep
+  integer(8) :: c0, c1, crate
+  character(32) :: arg
+  integer, allocatable :: sk(:)
+  real(8), allocatable :: sz(:,:), sdvp(:,:), sdvs(:,:), ssig(:,:)
   real(8), allocatable :: pz(:), pdvp(:), pdvs(:), psig(:), prft(:,:)
   real(8), allocatable :: cov(:,:), sv(:), uu(:,:), vt(:,:), work(:), dg(:,:), pinv(:,:,:)
   real(8) :: ll, r, wq(1)
@@ -71,6 +78,7 @@ program ref_path_dump
   open(u, file = trim(model_file), status = "old")
   open(v, file = trim(out_file), status = "replace", access = "stream", form = "unformatted")
   read(u, *) n
+  allocate(sk(n), sz(k_max - 1, n), sdvp(k_max, n), sdvs(k_max, n), ssig(ntrc, n))
   write(v) int(nfft, 4), int(ntrc, 4), int(nsmp, 4), int(n, 4), int(m, 4)
   write(v) pinv
   do i = 1, n
@@ -82,8 +90,24 @@ program ref_path_dump
      call calc_likelihood(1, .true., pk, pz, pdvp, pdvs, psig, ll, prft)
      write(v) ll
      write(v) prft
+     sk(i) = pk;  sz(:, i) = pz;  sdvp(:, i) = pdvp;  sdvs(:, i) = pdvs;  ssig(:, i) = psig
   end do
   close(u)
+  reps = 0
+  if (command_argument_count() > 3) then
+     call get_command_argument(4, arg)
+     read(arg, *) reps
+  end if
+  if (reps > 0) then
+     call system_clock(c0, crate)
+     do irep = 1, reps
+        do i = 1, n
+           call calc_likelihood(1, .true., sk(i), sz(:, i), sdvp(:, i), sdvs(:, i), ssig(:, i), ll, prft)
+        end do
+     end do
+     call system_clock(c1)
+     write(*,'(A,F12.6,A,I0)') " ref_path_dump: seconds ", dble(c1 - c0) / dble(crate), " evaluations ", reps * n
+  end if
   ! sigma-only branch on traces stored by the host (src/likelihood.f90:81): obs + a deterministic wiggle
   do j = 1, m
      do jt = 1, ntrc
