@@ -44,6 +44,10 @@
  *       2 .. 31 layers, and of bench.py's own C4 / C5 / c2d / c4common
  *       walkers, with this file: agreement 7e-16 of the trace scale.  Everything
  *       in those traces except the inverse transform is the reference's code.
+ *       The same for the likelihood: oracle/_ref/ref_path_dump adds the
+ *       reference's own src/likelihood.f90 (unmodified; dgesvd from the Intel
+ *       MKL the image ships) -- calc_likelihood end to end on bench.py's
+ *       walkers: this file's logL within 0.016 of max(1e-9, 1e-12 |logL|).
  * and, on the CPU, the reference's own fixtures (tests/test_oracle_kat.py):
  *   (1) sample_syn/true/true.velmod + sample_syn/params.in geometry (land)
  *       -> sample_syn/data/sample_{1,2}.trc, to float32 quantisation
@@ -81,8 +85,8 @@
  * case (layer_matrix_liq and the sea-floor rows, forward.f90:276-287,
  * 424-442) -- which therefore no longer rests on (3) alone.  Also kept: an
  * independent numpy restatement (calc_seis_numpy) and the half-space
- * apparent-angle relations (tests/test_oracle_kat.py).  The likelihood's
- * quadratic form + logL rest on (3) alone as far as reference OUTPUT goes.
+ * apparent-angle relations (tests/test_oracle_kat.py).  On the CPU the
+ * likelihood's quadratic form + logL rest on (3); on a GPU box on (0).
  */
 #include <math.h>
 #include <stdlib.h>
