@@ -351,3 +351,49 @@ def test_the_reference_make_syn_runs_unmodified_on_the_dropin_modules(golden_dir
             assert len(a) == 4 * (158 + p.nsmp)
             assert a == b, name
     assert np.array_equal(np.loadtxt(work / "test_vel"), np.loadtxt(tmp_path / "python" / "test_vel"))
+
+
+REF_OWN = os.path.join(ROOT, "oracle", "_ref", "rf_inv_reference")
+DROPIN_LAPACK = os.path.join(ROOT, "oracle", "_ref", "rf_inv_lapack")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks", [1, 2])
+def test_dropin_run_equals_the_run_of_the_reference_on_its_own_modules(golden_dir, tmp_path, nranks):
+    """The whole program, end to end, three ways on the shipped sample_syn directory (iteration counts reduced):
+      reference : src/rf_inv.f90 + pt_mcmc + mcmc_out + model ... on the reference's OWN src/forward.f90 and
+                  src/likelihood.f90 (all unmodified; c2r through the drop-in module fftw, dgesvd from the image's MKL)
+      drop-in   : the same main program and host modules on module forward / likelihood of rf_inv_amd/fortran (the HIP
+                  kernels; R^-1 by librfgpu's own SVD)
+      drop-in + LAPACK : the drop-in built with -DRFGPU_USE_LAPACK (R^-1 by the host's dgesvd, as the reference forms it)
+    A chain's random stream depends on every accept / reject decision, i.e. on every log-likelihood: the three runs take
+    the SAME trajectory -- the eleven result files that hold models, histograms and means are byte-identical -- and
+    rslt/likelihood (the mean log-likelihood of the non-tempered chains per iteration, printed to 17 digits) agrees to
+    1e-11 relative (LAPACK variant: the kernels' rounding only; default: plus two SVDs' rounding in R^-1)."""
+    if not all(os.path.exists(x) for x in (REF_OWN, REF_RFINV, DROPIN_LAPACK, MPIEXEC)):
+        pytest.skip("oracle/_ref mains not built (no Fortran compiler / reference tree / MKL at build time) or no mpiexec")
+    nburn, niter = 60, 240
+    for tag, exe in (("reference", REF_OWN), ("dropin", REF_RFINV), ("dropin_lapack", DROPIN_LAPACK)):
+        work = tmp_path / tag
+        _sample_syn_with_iterations(golden_dir, work, nburn, niter)
+        r = subprocess.run([MPIEXEC, "-np", str(nranks), exe, "params.in"], cwd=work, env=dict(os.environ),
+                           capture_output=True, text=True, timeout=1800)
+        if r.returncode != 0 and ("hydra" in r.stderr.lower() or "unable" in r.stderr.lower()):
+            pytest.skip("mpiexec cannot start processes here: " + r.stderr[-200:])
+        assert r.returncode == 0, (tag, r.stdout[-1500:] + r.stderr[-1500:])
+    lk = {t: np.loadtxt(tmp_path / t / "rslt" / "likelihood") for t in ("reference", "dropin", "dropin_lapack")}
+    assert lk["reference"].shape == (nburn + niter, 2)
+    if nranks == 1:
+        assert abs(lk["reference"][0, 1] - (-1044.33907794324)) < 1e-7       # SURVEY.md 8c(4), a pure-reference run's record
+    for t in ("dropin", "dropin_lapack"):
+        for name in RESULT_FILES:
+            if name == "likelihood":
+                continue
+            a = open(tmp_path / "reference" / "rslt" / name, "rb").read()
+            assert a == open(tmp_path / t / "rslt" / name, "rb").read(), (t, name)
+        rel = np.abs(lk[t][:, 1] - lk["reference"][:, 1]) / np.abs(lk["reference"][:, 1])
+        assert np.array_equal(lk[t][:, 0], lk["reference"][:, 0]) and rel.max() <= 1e-11, (t, rel.max())
+    rel_lap = (np.abs(lk["dropin_lapack"][:, 1] - lk["reference"][:, 1]) / np.abs(lk["reference"][:, 1])).max()
+    rel_def = (np.abs(lk["dropin"][:, 1] - lk["reference"][:, 1]) / np.abs(lk["reference"][:, 1])).max()
+    print(f"{nranks} rank(s), {nburn + niter} iterations: max relative difference of rslt/likelihood to the reference's own run: "
+          f"drop-in + LAPACK {rel_lap:.2e}, drop-in {rel_def:.2e}")
