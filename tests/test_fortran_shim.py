@@ -358,9 +358,10 @@ DROPIN_LAPACK = os.path.join(ROOT, "oracle", "_ref", "rf_inv_lapack")
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nranks", [1, 2])
-def test_dropin_run_equals_the_run_of_the_reference_on_its_own_modules(golden_dir, tmp_path, nranks):
-    """The whole program, end to end, three ways on the shipped sample_syn directory (iteration counts reduced):
+@pytest.mark.parametrize("nranks,nburn,niter", [(1, 60, 240), (2, 60, 240), (1, 3000, 8000)])
+def test_dropin_run_equals_the_run_of_the_reference_on_its_own_modules(golden_dir, tmp_path, nranks, nburn, niter):
+    """The whole program, end to end, three ways on the shipped sample_syn directory (iteration counts reduced, and --
+    one rank -- the shipped example at its full length: 3000 + 8000 iterations x 5 chains, 55 000 evaluations):
       reference : src/rf_inv.f90 + pt_mcmc + mcmc_out + model ... on the reference's OWN src/forward.f90 and
                   src/likelihood.f90 (all unmodified; c2r through the drop-in module fftw, dgesvd from the image's MKL)
       drop-in   : the same main program and host modules on module forward / likelihood of rf_inv_amd/fortran (the HIP
@@ -372,7 +373,6 @@ def test_dropin_run_equals_the_run_of_the_reference_on_its_own_modules(golden_di
     1e-11 relative (LAPACK variant: the kernels' rounding only; default: plus two SVDs' rounding in R^-1)."""
     if not all(os.path.exists(x) for x in (REF_OWN, REF_RFINV, DROPIN_LAPACK, MPIEXEC)):
         pytest.skip("oracle/_ref mains not built (no Fortran compiler / reference tree / MKL at build time) or no mpiexec")
-    nburn, niter = 60, 240
     for tag, exe in (("reference", REF_OWN), ("dropin", REF_RFINV), ("dropin_lapack", DROPIN_LAPACK)):
         work = tmp_path / tag
         _sample_syn_with_iterations(golden_dir, work, nburn, niter)
