@@ -1297,3 +1297,37 @@ def test_every_option_away_from_its_default_is_echoed_by_the_launch_plan(oracle)
             assert eng.launch_plan["copy_stream"] is True
             with pytest.raises(Exception, match="unknown option"):
                 eng.set_option("no_such_option", 1)
+
+
+def test_several_proposals_per_chain_in_one_launch(oracle):
+    """A multiple-try host: m candidate models per chain evaluated in ONE rf_eval_batch call on
+    a context of m x nchains slots, candidate j of chain c in slot j * nchains + c; the accepted candidate's slot is
+    committed and becomes the chain's state for the next sigma-only proposal.  Same values as m separate launches on a
+    context of nchains slots, bit for bit (results depend neither on the slot nor on the launch)."""
+    rng = np.random.default_rng(77)
+    nchains, m, nsmp = 48, 4, 101
+    cfg = make_cfg(nfft=4096, rayps=[0.06], ipha=[1])
+    obs = synth_obs(oracle, cfg, random_stack(rng, 4), nsmp)
+    r_inv = oracle.build_r_inv(nsmp, cfg["a_gus"], DELTA)
+    stacks = [random_stack(rng, int(n)) for n in rng.integers(2, 15, m * nchains)]
+    nlay, layers = pack_layers(stacks, 17)
+    sig = rng.uniform(0.01, 0.05, (m * nchains, 1))
+    # one launch of m * nchains items
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=m * nchains, nlay_max=17) as big:
+        all_at_once = big.eval_batch(np.arange(m * nchains), nlay, layers, sig)
+        # the host accepts candidate pick[c] of chain c: that slot holds the chain's state from now on
+        pick = rng.integers(0, m, nchains)
+        slot = (pick * nchains + np.arange(nchains)).astype(np.int32)
+        big.commit(slot, np.ones(nchains, dtype=np.int32))
+        sig2 = 1.7 * sig[slot]
+        sigma_only = big.eval_batch(slot, nlay[slot], layers[slot], sig2, fwd_flag=np.zeros(nchains, dtype=np.int32))
+    # m launches of nchains items on a context of nchains slots
+    with _engine(cfg, obs, nsmp, r_inv, max_walkers=nchains, nlay_max=17) as small:
+        for j in range(m):
+            blk = slice(j * nchains, (j + 1) * nchains)
+            one = small.eval_batch(np.arange(nchains), nlay[blk], layers[blk], sig[blk])
+            assert np.array_equal(one, all_at_once[blk]), j
+    ref = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads())
+    assert np.all(np.abs(all_at_once - ref) <= logl_tol(ref))
+    ref2 = oracle.eval_batch(cfg, obs, r_inv, nlay[slot], layers[slot], sig2, nsmp, nthreads=oracle.max_threads())
+    assert np.all(np.abs(sigma_only - ref2) <= logl_tol(ref2))
