@@ -612,11 +612,12 @@ def headline_line(full, detail_file):
     if par:
         line["parity_in_bench"] = pick(par, ("n", "max_abs_dlogl", "max_rel_dlogl", "within_tolerance",
                                              "n_used_kappa_allowance"))
-    for k in ("swap_replay_ok", "cross_rank_swaps"):
+    for k in ("swap_replay_ok", "cross_rank_swaps", "cpu_leg_error"):
         if k in full:
             line[k] = full[k]
     if full.get("also"):
-        line["also"] = {k: v.get("value") for k, v in full["also"].items()}     # evals/s only; records in detail_file
+        line["also"] = {k: (v.get("value") if v.get("value") is not None else "failed")
+                        for k, v in full["also"].items()}     # evals/s only; records in detail_file
     line["detail_file"] = detail_file
     s = json.dumps(_sig(line), separators=(",", ":"))
     if len(s) >= HEADLINE_MAX_BYTES:                      # cannot happen with the keys above; never print a long line
@@ -1130,6 +1131,7 @@ def main():
                         "the HIP-event time of the GEMM + logL kernels; the FP64 matrix peak equals the vector peak (78.6 TF at "
                         "2.4 GHz: one 16x16x4 instruction per 64 cycles and SIMD); R^-1 is streamed once per 128 walkers"}
         if rank == 0 and (with_cpu or parity_n):
+          try:
             from oracle import rf_oracle as orc
 
             cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep,
@@ -1144,6 +1146,10 @@ def main():
                 ll_cpu = orc.eval_batch(cfg, obs, r_inv, nlay_eval[:n], layers[:n], sig[:n], p.nsmp, nthreads=nthr)   # the checker build
             res["parity_in_bench"] = parity_report(orc, cfg, obs, r_inv, nlay_eval[:n], layers[:n], sig[:n], p.nsmp,
                                                    ll_gpu[:n], ll_cpu, nthr)
+          except Exception as e:      # noqa: BLE001  (the CPU side failing must not take the measured line with it)
+            print(f"bench.py: the CPU leg (cpu_baseline / parity_in_bench) of {workload} failed: {type(e).__name__}: {e}",
+                  file=sys.stderr)
+            res["cpu_leg_error"] = f"{type(e).__name__}: {e}"[:300]
         eng.close()
         return res
 
@@ -1152,12 +1158,11 @@ def main():
     also = {}
     keep = ("value", "ms_per_step", "ms_per_step_median", "steps", "config", "roofline", "kernel_ms", "parity_in_bench",
             "quadratic_form_gemm")
-    for wl in [x for x in also_list.split(",") if x and x != args.workload]:
+    def also_run(wl):
         if wl.endswith("host"):
             # the PCIe-inclusive boundary of the batched sampler (never the headline)
-            also[wl] = run_host_boundary(wl[:-4], 200 if args.steps >= 10 else max(20, args.steps), local_rank,
-                                         prewarm_s=args.prewarm_seconds)
-            continue
+            return run_host_boundary(wl[:-4], 200 if args.steps >= 10 else max(20, args.steps), local_rank,
+                                     prewarm_s=args.prewarm_seconds)
         if wl == "c4stale":
             # the c4 shape with 30 % of the walkers changing depth every step: the order the previous launch
             # prepared is one proposal stale (order_reuse, the default), against a fresh order_kernel per launch
@@ -1168,16 +1173,25 @@ def main():
             r2 = run("c4", n_c4, max(5, min(20, args.warmup)), False, parity_n=0)
             overrides.clear(); overrides.update(sv)
             args.perturb_nlay = 0.0
-            also[wl] = {k: r[k] for k in keep if k in r}
-            also[wl]["fresh_order_every_launch"] = {"value": r2["value"], "ms_per_step": r2["ms_per_step"],
-                                                    "kernel_ms": r2["kernel_ms"]}
-            continue
+            rec = {k: r[k] for k in keep if k in r}
+            rec["fresh_order_every_launch"] = {"value": r2["value"], "ms_per_step": r2["ms_per_step"],
+                                               "kernel_ms": r2["kernel_ms"]}
+            return rec
         # long enough that one host hiccup does not show: about 0.4 s of steps for the small shapes
         n_also = max(30, min(200, args.steps))
         if args.steps >= 10:     # (the counter passes of tools/collect_counters.sh ask for 3 steps and get them)
             n_also = max(n_also, min(6000, int(400.0 / ALSO_NOMINAL_MS.get(wl, 2.0))))
         r = run(wl, n_also, max(5, min(20, args.warmup)), False)
-        also[wl] = {k: r[k] for k in keep if k in r}
+        return {k: r[k] for k in keep if k in r}
+
+    # (a side workload that fails must not take the headline with it: its record says what happened, the line is printed)
+    for wl in [x for x in also_list.split(",") if x and x != args.workload]:
+        try:
+            also[wl] = also_run(wl)
+        except Exception as e:      # noqa: BLE001
+            print(f"bench.py: side workload {wl} failed: {type(e).__name__}: {e}", file=sys.stderr)
+            also[wl] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+            args.perturb_nlay = 0.0
     if rank == 0:
         out = {"metric": METRIC, "value": main_res["value"], "unit": "evals/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": main_res["ms_per_step"],
@@ -1198,7 +1212,14 @@ def main():
         print("bench.py detail: " + json.dumps(out), file=sys.stderr)
         sys.stderr.flush()
         sys.stdout.flush()
-        os.write(real_stdout, (headline_line(out, os.path.relpath(detail, ROOT) if detail else None) + "\n").encode())
+        try:
+            line = headline_line(out, os.path.relpath(detail, ROOT) if detail else None)
+        except Exception as e:      # noqa: BLE001  (never lose a measured number to the formatter)
+            print(f"bench.py: headline formatter failed ({type(e).__name__}: {e}): printing the contract keys only", file=sys.stderr)
+            line = json.dumps({k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                       "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+                              | {"config": {"workload": (out.get("config") or {}).get("workload")}})
+        os.write(real_stdout, (line + "\n").encode())
     failed = rank == 0 and main_res.get("swap_replay_ok") is False
     if failed:
         print("bench.py: the final temperatures do NOT equal the serial replay of the swap schedule: the temperature "
