@@ -397,3 +397,26 @@ def test_dropin_run_equals_the_run_of_the_reference_on_its_own_modules(golden_di
     rel_def = (np.abs(lk["dropin"][:, 1] - lk["reference"][:, 1]) / np.abs(lk["reference"][:, 1])).max()
     print(f"{nranks} rank(s), {nburn + niter} iterations: max relative difference of rslt/likelihood to the reference's own run: "
           f"drop-in + LAPACK {rel_lap:.2e}, drop-in {rel_def:.2e}")
+
+
+@pytest.mark.gpu
+def test_make_syn_on_the_dropin_modules_equals_make_syn_on_the_reference_modules(golden_dir, tmp_path):
+    """`program make_syn` (src/make_syn.f90, unmodified) twice: on the reference's OWN forward / likelihood modules
+    (oracle/_ref/make_syn_reference) and on the drop-in modules (oracle/_ref/make_syn).  Same random stream, same model,
+    same noise: the SAC files -- float32 samples of chain 1's synthetic trace, with and without noise -- are byte-identical
+    (the CPU and the GPU traces agree to 1e-14 of their scale), test_vel line for line."""
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "make_syn_reference")
+    if not (os.path.exists(ref_exe) and os.path.exists(REF_MAKESYN)):
+        pytest.skip("oracle/_ref/make_syn_reference not built (no Fortran compiler / reference tree / MKL at build time)")
+    outs = {}
+    for tag, exe in (("reference", ref_exe), ("dropin", REF_MAKESYN)):
+        work = tmp_path / tag
+        shutil.copytree(os.path.join(golden_dir, "sample_syn"), work)
+        os.makedirs(work / "rslt")
+        r = subprocess.run([exe, "params.in"], cwd=work, env=dict(os.environ), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "Noise level of trace" in r.stdout, (tag, r.stdout[-1500:] + r.stderr[-1500:])
+        outs[tag] = [l for l in r.stdout.splitlines() if "Noise level" in l]
+    assert outs["reference"] == outs["dropin"]
+    for name in ("test_trace01", "test_trace01wn", "test_trace02", "test_trace02wn", "test_vel"):
+        a, b = open(tmp_path / "reference" / name, "rb").read(), open(tmp_path / "dropin" / name, "rb").read()
+        assert len(a) > 0 and a == b, name
