@@ -126,6 +126,34 @@ def test_reference_forward_code_vs_oracle_and_hip(oracle, tmp_path, name):
         assert (np.abs(one - ref[3]) <= 1e-12 * np.abs(ref[3]).max(axis=1, keepdims=True)).all()
 
 
+def test_the_scenario_of_the_references_own_forward_test_program(oracle, tmp_path):
+    """src/forward_test.f90 (the reference's own check program of module forward; it no longer compiles against its own
+    params.f90 -- it assigns a `bdep` that module params has commented out, src/params.f90:67 -- so it is run here through
+    params.in instead): a 20 km layer (Vp 5, Vs 2.5, rho 3) over a half-space (8, 4, 3.3; its thickness -10 is never
+    used), one S trace, p = 0.06, Gaussian a = 8, nfft 1024, t_start = -3 (src/forward_test.f90:39-56).  The reference's
+    forward.f90, the oracle and the HIP path on exactly that."""
+    if not os.path.exists(DUMP):
+        pytest.skip("oracle/_ref/ref_forward_dump not built")
+    from rf_inv_amd import RFEngine
+
+    work = tmp_path / "run"
+    os.makedirs(work)
+    nsmp = _write_run_dir(work, 1024, [0.06], [-1], [8.0], 0, 0.0, -3.0)
+    st = (np.array([5.0, 8.0]), np.array([2.5, 4.0]), np.array([3.0, 3.3]), np.array([20.0, -10.0]))
+    open(work / "stacks.txt", "w").write("1\n2\n" + "\n".join(" ".join(repr(float(st[r][j])) for r in range(4)) for j in range(2)) + "\n")
+    r = subprocess.run([DUMP, "params.in", "stacks.txt", "ref.bin"], cwd=work, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = np.frombuffer(open(work / "ref.bin", "rb").read()[16:], dtype="<f8")[513:].reshape(1, 1024)
+    assert np.isfinite(ref).all() and ref.min() == -1.0          # an S trace normalised by the vertical maximum
+    cfg = make_cfg(nfft=1024, deconv_mode=0, t_start=-3.0, rayps=[0.06], a_gus=[8.0], ipha=[-1])
+    got_o = oracle.calc_rf(cfg, *st)
+    assert np.abs(got_o - ref).max() <= 1e-12
+    with RFEngine(nfft=1024, delta=DELTA, t_start=-3.0, deconv_mode=0, sdep=0.0, rayps=np.array([0.06]), a_gus=np.array([8.0]),
+                  ipha=np.array([-1], dtype=np.int32), obs=np.zeros((1, nsmp)), nsmp=nsmp, max_walkers=1, nlay_max=4) as eng:
+        got = eng.calc_rf(2, *st).T
+    assert np.abs(got - ref).max() <= 1e-12
+
+
 def test_reference_forward_code_propagates_nan_like_the_hip_path(oracle, tmp_path):
     """An evanescent layer (1/v^2 < p^2: sqrt of a negative number, src/forward.f90:396-397) makes the reference's trace
     NaN; the HIP path must return NaN for that trace too, not trap."""
