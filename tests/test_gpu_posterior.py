@@ -351,3 +351,56 @@ def test_posterior_merge_between_two_gpus(tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs >= 2 GPUs (RCCL refuses two ranks on one device)")
     _run_post_merge(tmp_path, 2, [0, 1])
+
+
+@pytest.mark.parametrize("sequential", [False, True])
+def test_posterior_merge_entry_points_over_real_rccl_on_one_rank(oracle, golden_dir, sequential):
+    """rf_comm_post_gather + rf_comm_post_reduce against the REAL RCCL on a communicator of one rank -- all a one-GPU box
+    can form: the twelve in-place ncclReduce calls in one group (and one by one, rf_comm_set_option "sequential_reduce"),
+    the all-gather of the model counts, the root's copy-out.  With one rank the merged result is the rank's own; what this
+    pins is that RCCL accepts the calls as librfgpu issues them (the multi-rank sums are tested over the test double)."""
+    from dataclasses import fields
+
+    from rf_inv_amd import RFEngine
+    from rf_inv_amd.posterior import Posterior
+
+    p, ref, mcfg = _setup(golden_dir, 2.0, 0, 10)
+    ntrc, n, nm = 2, 40, 60
+    p.ntrc, p.nsmp = ntrc, 101
+    p.sig_mode, p.sig_min, p.sig_max = [1, 0], [0.005, 0.01], [0.08, 0.01]
+    p.amp_min, p.amp_max, p.nbin_amp = -0.05, 0.25, 40
+    p.nbin_z, p.nbin_vs, p.nbin_vp, p.nbin_vpvs, p.nbin_sig = 37, 25, 20, 15, 11
+    p.nchains, p.niter, p.ncorr = n, 2, 1
+    rng = np.random.default_rng(901)
+    k, z, dvp, dvs = _valid_states(oracle, rng, p, mcfg, n)
+    sig = np.stack([rng.uniform(0.005, 0.0799, n), np.full(n, 0.01)], axis=1).copy()
+    pad = p.k_max + 2
+    nlay, lay = _layers(oracle, mcfg, k, z, dvp, dvs, pad)
+    obs = np.random.default_rng(7).normal(0, 0.05, (ntrc, 101))
+    ids = np.arange(n, dtype=np.int32)
+    with RFEngine(nfft=256, delta=DELTA, t_start=0.0, deconv_mode=0, sdep=2.0, rayps=[0.06, 0.075], a_gus=[4.0, 3.0],
+                  ipha=[1, 1], obs=obs, nsmp=101, max_walkers=n, nlay_max=pad) as eng:
+        logl = eng.eval_batch(ids, nlay, lay, sig)
+        eng.commit(ids, np.ones(n, dtype=np.int32))
+        eng.set_model(p, ref)
+        post = Posterior(eng, p, max_models=nm)
+        post.record(ids, k, z, dvp, dvs, sig, logl)
+        own = post.read()
+        eng.comm_init(RFEngine.comm_unique_id(), 0, 1)
+        assert eng.comm_info()["nranks"] == 1 and eng.comm_info()["rccl_version"] > 0
+        if sequential:
+            eng.comm_set_option("sequential_reduce", 1)
+        with pytest.raises(Exception, match="unknown option"):
+            eng.comm_set_option("no_such_option", 1)
+        merged = post.merge_over_comm(root=0)
+        after = post.read()
+        eng.comm_destroy()
+    assert list(merged.nmod_rank) == [own.nmod] and merged.nmod == own.nmod == n
+    for f in fields(own):
+        if f.name in ("nmod_rank", "vp_model", "vs_model", "all_likelihood"):
+            continue
+        assert np.array_equal(np.asarray(getattr(merged, f.name)), np.asarray(getattr(own, f.name))), f.name
+        assert np.array_equal(np.asarray(getattr(after, f.name)), np.asarray(getattr(own, f.name))), f.name
+    rows = min(own.nmod, nm)
+    assert np.array_equal(merged.vp_model[:rows], own.vp_model[:rows]) and np.array_equal(merged.vs_model[:rows], own.vs_model[:rows])
+    assert np.array_equal(merged.all_likelihood[:rows], own.all_likelihood[:rows])
