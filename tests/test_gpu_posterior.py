@@ -387,7 +387,7 @@ def test_posterior_merge_entry_points_over_real_rccl_on_one_rank(oracle, golden_
         post.record(ids, k, z, dvp, dvs, sig, logl)
         own = post.read()
         eng.comm_init(RFEngine.comm_unique_id(), 0, 1)
-        assert eng.comm_info()["nranks"] == 1 and eng.comm_info()["rccl_version"] > 0
+        assert eng.comm_info()["nranks"] == 1 and eng.comm_info()["rccl_version"]
         if sequential:
             eng.comm_set_option("sequential_reduce", 1)
         with pytest.raises(Exception, match="unknown option"):
