@@ -259,8 +259,10 @@ def test_benchmark_walkers_against_the_reference_forward_code(oracle, tmp_path, 
 PATH_DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_path_dump")
 
 
-@pytest.mark.parametrize("workload,count", [("c4", 64), ("c5", 40), ("c2d", 48), ("c1", 48)])
+@pytest.mark.parametrize("workload,count", [("c4", 64), ("c5", 40), ("c2d", 48), ("c1", 48), ("c4w20", 24), ("c4w60", 16)])
 def test_reference_likelihood_code_vs_oracle_and_hip(oracle, tmp_path, workload, count):
+    """(c4w20 / c4w60: time windows of 401 / 1201 samples -- the reference's matmul(misfits, r_inv) with its 1201 x 1201
+    pseudo-inverse against the long-window plan, the batch's quadratic forms as one FP64-MFMA GEMM.)"""
     if not os.path.exists(PATH_DUMP):
         pytest.skip("oracle/_ref/ref_path_dump not built (no Fortran compiler / reference tree / MKL at build time)")
     import copy
