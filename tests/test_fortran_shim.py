@@ -420,3 +420,41 @@ def test_make_syn_on_the_dropin_modules_equals_make_syn_on_the_reference_modules
     for name in ("test_trace01", "test_trace01wn", "test_trace02", "test_trace02wn", "test_vel"):
         a, b = open(tmp_path / "reference" / name, "rb").read(), open(tmp_path / "dropin" / name, "rb").read()
         assert len(a) > 0 and a == b, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["c4", "c5"])
+def test_dropin_runs_equal_the_reference_run_at_the_benchmark_shapes(tmp_path, shape):
+    """End to end at the north-star geometry, not only on the shipped nfft-256 example: run directories with the shape of
+    BASELINE configs 4 and 5 (tests/tools/shape_run.py: nfft 4096; c4 = traces P .06 / P .08 / S .10, k_max 30; c5 = 2 km
+    of water, traces P / P / S / S; 8 chains, 2 of them at T = 1, 100 iterations) through
+      (a) the reference's main program on its OWN forward / likelihood modules (oracle/_ref/rf_inv_reference),
+      (b) the same main program on the drop-in modules (oracle/_ref/rf_inv_lapack: per-call evaluation on the GPU),
+      (c) the batched sampler pt_control_batched on the drop-in modules (tests/fortran/drive_rfinv mode 1).
+    Same trajectory in all three: the eleven model / histogram / mean files byte-identical, rslt/likelihood to 1e-11."""
+    import sys
+
+    if not all(os.path.exists(x) for x in (REF_OWN, DROPIN_LAPACK, RFINV)):
+        pytest.skip("oracle/_ref mains not built (no Fortran compiler / reference tree / MKL at build time)")
+    runs = {"reference": [REF_OWN, "params.in"], "dropin": [DROPIN_LAPACK, "params.in"],
+            "batched": [RFINV, "params.in", "0", "100", "1", "out"]}
+    for tag, cmd in runs.items():
+        work = tmp_path / tag
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "shape_run.py"), shape, "8", str(work), "2"],
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout + r.stderr
+        r = subprocess.run(cmd, cwd=work, env=dict(os.environ), capture_output=True, text=True, timeout=1800)
+        assert r.returncode == 0, (tag, r.stdout[-1500:] + r.stderr[-1500:])
+    lk = {t: np.loadtxt(tmp_path / t / "rslt" / "likelihood") for t in runs}
+    assert lk["reference"].shape == (100, 2) and np.isfinite(lk["reference"]).all()
+    for t in ("dropin", "batched"):
+        for name in RESULT_FILES:
+            if name == "likelihood":
+                continue
+            a = open(tmp_path / "reference" / "rslt" / name, "rb").read()
+            assert a == open(tmp_path / t / "rslt" / name, "rb").read(), (shape, t, name)
+        rel = np.abs(lk[t][:, 1] - lk["reference"][:, 1]) / np.abs(lk["reference"][:, 1])
+        assert rel.max() <= 1e-11, (shape, t, rel.max())
+    print(f"{shape} shape, 8 chains x 100 iterations: rslt/likelihood against the reference's own run: per-call drop-in "
+          f"{(np.abs(lk['dropin'][:, 1] - lk['reference'][:, 1]) / np.abs(lk['reference'][:, 1])).max():.2e}, batched sampler "
+          f"{(np.abs(lk['batched'][:, 1] - lk['reference'][:, 1]) / np.abs(lk['reference'][:, 1])).max():.2e}")
