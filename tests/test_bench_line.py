@@ -78,3 +78,21 @@ def test_nan_never_reaches_the_line():
     s = bench.headline_line(full, None)
     assert "NaN" not in s
     assert json.loads(s)["roofline"]["frac_at_clock"] is None
+
+
+def test_headline_of_the_round_5_record_carries_the_reference_baseline():
+    """The committed round-5 record (profiles/r05_bench_n1_detail.json -> profiles/r05_bench_n1.json): the compact line
+    built from the full record equals the line the run printed, carries `cpu_baseline.reference` (the reference's own
+    calc_likelihood timed on one core) and stays far below 4 KB."""
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_n1_detail.json")))
+    printed = open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")).read().strip()
+    assert "\n" not in printed and len(printed) < 4096
+    d = json.loads(printed)
+    again = json.loads(bench.headline_line(full, d["detail_file"]))
+    assert again == d
+    ref = d["cpu_baseline"]["reference"]
+    assert ref["kind"] == "reference" and ref["cores"] == 1 and 0.3 < ref["reference_over_port"] < 1.0
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    assert d["roofline"]["counters_file"] == "profiles/r05_counters.json" and d["roofline"]["frac"] is not None
+    assert d["parity_in_bench"]["n"] == d["config"]["walkers_per_gpu"] == 8192 and d["parity_in_bench"]["within_tolerance"]
+    assert set(d["also"]) == set(full["also"])
