@@ -2,7 +2,8 @@
 a synchronous round trip to the GPU per transform) be timed on ALL host cores at once?  P concurrent processes, one per
 core, with and without HSA settings that reduce the queues a process opens (HSA_ENABLE_SDMA=0, GPU_MAX_HW_QUEUES=1): more
 host processes than the GPU keeps queues mapped for are time-sliced, and the round trips then measure the slicing.
-usage: python tests/tools/reference_path_scaling.py [workload, default c4]"""
+usage: python tests/tools/reference_path_scaling.py [workload, default c4] [reps, default 2] [hold: the parent keeps an
+       engine context open on the GPU like bench.py does while it times its CPU leg]"""
 import copy
 import os
 import shutil
@@ -24,6 +25,8 @@ def main():
     from rf_inv_amd.make_syn import write_sac
 
     wl = sys.argv[1] if len(sys.argv) > 1 else "c4"
+    many = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+    hold = len(sys.argv) > 3 and sys.argv[3] == "hold"
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_path_time")
     p = bench.make_params(dict(bench.WORKLOADS[wl]))
     golden = os.path.join(ROOT, "tests", "golden", "sample_syn")
@@ -54,10 +57,21 @@ def main():
                 for arr in (m_z[i, :max(p.k_max - 1, 1)], m_dvp[i, :p.k_max], m_dvs[i, :p.k_max], np.full(p.ntrc, 0.01)):
                     fh.write(" ".join(repr(float(x)) for x in arr) + "\n")
         cores = bench.physical_cores()
+        eng = None
+        if hold:
+            import torch
+
+            from rf_inv_amd import RFEngine
+
+            eng = RFEngine(nfft=p.nfft, delta=p.delta, t_start=p.t_start, deconv_mode=p.deconv_mode, sdep=p.sdep, rayps=p.rayps,
+                           a_gus=p.a_gus, ipha=p.ipha, obs=obs[:, :p.nsmp].copy(), nsmp=p.nsmp, max_walkers=8192, nlay_max=p.k_max + 2)
+            x = torch.zeros(1 << 20, device="cuda")
+            torch.cuda.synchronize()
+            print("parent holds an engine context (8192 walkers) and a torch context", flush=True)
         for label, env in (("default", {}), ("HSA_ENABLE_SDMA=0", {"HSA_ENABLE_SDMA": "0"}),
                            ("HSA_ENABLE_SDMA=0 GPU_MAX_HW_QUEUES=1", {"HSA_ENABLE_SDMA": "0", "GPU_MAX_HW_QUEUES": "1"})):
             for procs in (1, 4, cores):
-                reps = 4 if procs == 1 else 2
+                reps = 2 * many if procs == 1 else many
                 t0 = time.perf_counter()
                 runs = [subprocess.Popen([exe, "params.in", "models.txt", f"ref_{i}.bin", str(reps)], cwd=work,
                                          stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, **env))
