@@ -358,13 +358,15 @@ def physical_cores():
 
 
 def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
-    """The CPU side of the comparison, on a bounded sample of the same workload: oracle/rf_oracle.c (a scalar fp64
-    restatement of the reference's arithmetic, kind "port") in its speed build (-O3 -march=native, same values as the
-    checker build), one OpenMP thread per PHYSICAL core, no allocation inside the evaluation loop.
-    Beside it, `reference`: the reference's OWN src/likelihood.f90 + src/forward.f90 + host modules, compiled unmodified,
-    timed on ONE core (reference_path_rate) with its ratio to the port's single-core rate on the same walkers.  (One core
-    only: its c2r goes through the drop-in module fftw on the GPU, and sixteen host processes sharing the GPU for those
-    round trips measure the GPU's time-slicing, not the CPU -- 5.9 evals/s per process against 106 alone.)
+    """The CPU side of the comparison, on a bounded sample of the same workload.
+    kind "reference" (when oracle/_ref/ref_path_time is there and runs): the reference's OWN src/likelihood.f90 +
+    src/forward.f90 + host modules, compiled unmodified (reference_path_rate), one process per physical core at once --
+    the reference's deployment, one MPI rank per core, no communication inside an evaluation -- with the port's figures
+    beside it under `port`.  Its c2r round trips to the GPU (the drop-in module fftw; six per evaluation at C4) are in the
+    time and contend when sixteen processes make them: the all-core figure is a LOWER bound of the reference's CPU-only
+    rate (`single_core` x cores is the upper bound).
+    kind "port" (otherwise): oracle/rf_oracle.c, a scalar fp64 restatement of the reference's arithmetic, in its speed
+    build (-O3 -march=native, same values as the checker build), one OpenMP thread per physical core.
     Returns (record, the port's logL on the sample, how many of the rank's walkers the sample covers)."""
     os.environ.setdefault("OMP_PROC_BIND", "spread")
     os.environ.setdefault("OMP_PLACES", "cores")
@@ -398,27 +400,32 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
             "sample": f"{n} evals = the rank's walker set cycled ({nb} walkers, mean {float(nlay.mean()):.1f} layers), "
                       f"oracle/rf_oracle.c (gcc {' '.join(orc.FAST_FLAGS)}, OpenMP x{cores} threads = physical cores, "
                       f"{dt:.1f} s wall); single-core rate on {n1} evals"}
-    # the reference's own forward + likelihood code on one core of this box (sigma 0.01 like `sig`), next to the port's
-    # single-core rate on the same walkers -- and its logL against the port's on them
+    # The reference's own forward + likelihood code on this box's cores (sigma 0.01 like `sig`): one process alone, then one
+    # per physical core at once -- the reference's deployment (one MPI rank per core).  When it runs, IT is the CPU
+    # baseline (kind "reference") and the port's figures move to `port`; otherwise the port stays the baseline.
     n24 = min(nb, 24)
     t0 = time.perf_counter()
-    ll24 = orc.eval_batch(cfg, obs, r_inv, nlay[:n24], layers[:n24], sig[:n24], p.nsmp, nthreads=1, fast=True)
+    orc.eval_batch(cfg, obs, r_inv, nlay[:n24], layers[:n24], sig[:n24], p.nsmp, nthreads=1, fast=True)
     port24 = n24 / (time.perf_counter() - t0)
     # (the reference reads its observed traces from SAC files: float32 samples -- the port is given the same here)
     obs32 = obs.astype(np.float32).astype(np.float64)
-    ref_rec, ll_ref = reference_path_rate(p, obs32, count=n24)
-    if ref_rec is not None:
+    one, ll_ref = reference_path_rate(p, obs32, budget_s=3.0, count=n24, procs=1)
+    full = reference_path_rate(p, obs32, budget_s=8.0, count=n24, procs=cores)[0] if one is not None and cores > 1 else one
+    if full is not None:
         ll24 = orc.eval_batch(cfg, obs32, r_inv, nlay[:n24], layers[:n24], sig[:n24], p.nsmp, nthreads=1, fast=True)
-        ref_rec["port_single_core_same_walkers"] = port24
-        ref_rec["reference_over_port"] = ref_rec["value"] / port24
-        # (R^-1 here comes from scipy's dgesvd, the reference's from MKL's: two SVDs of an ill-conditioned matrix)
-        ref_rec["max_rel_dlogl_port_vs_reference"] = float(np.max(np.abs(ll24 - ll_ref) / np.abs(ll_ref)))
-    base["reference"] = ref_rec
+        port = dict(base)
+        base = dict(full)
+        base["single_core"] = one["value"]
+        base["port"] = {k: port[k] for k in ("value", "unit", "cores", "kind", "per_core", "single_core", "sample")}
+        base["port"]["single_core_same_walkers"] = port24
+        base["reference_over_port"] = {"all_cores": full["value"] / port["value"], "single_core_same_walkers": one["value"] / port24}
+        # (R^-1 of the port comes from scipy's dgesvd, the reference's from MKL's: two SVDs of an ill-conditioned matrix)
+        base["max_rel_dlogl_port_vs_reference"] = float(np.max(np.abs(ll24 - ll_ref) / np.abs(ll_ref)))
     nuse = min(nb, n)
     return base, ll_all[:nuse], nuse
 
 
-def reference_path_rate(p, obs, budget_s=8.0, count=24):
+def reference_path_rate(p, obs, budget_s=8.0, count=24, procs=1):
     """The reference's OWN forward + likelihood code timed on one host core of this box: oracle/_ref/ref_path_time = the
     reference's src/likelihood.f90 + src/forward.f90 + model / params / mt19937 / sort / math / prior, all compiled
     unmodified (amdflang -O2 -ffp-contract=off; rf_inv_amd/fortran/Makefile, built where /root/reference exists and
@@ -426,6 +433,8 @@ def reference_path_rate(p, obs, budget_s=8.0, count=24):
     calc_likelihood(fwd_flag = .true.) (src/likelihood.f90:56-101: format_model, calc_rf, misfit, quadratic form, logL)
     over the first `count` of this workload's walkers.  The one thing in it that is not the reference's: calc_rf's c2r
     goes through the drop-in (a GPU round trip of ~0.1 ms per transform, counted in the time).
+    procs > 1: that many processes at once, one per host core, the way the reference runs (one MPI rank per core, no
+    communication inside an evaluation): the box's rate = all their evaluations / the slowest one's time.
     Returns (record or None, logL of the sample or None)."""
     import copy
     import shutil
@@ -459,27 +468,46 @@ def reference_path_rate(p, obs, budget_s=8.0, count=24):
                     fh.write(f"{int(m_k[i])}\n")
                     for arr in (m_z[i, :max(p.k_max - 1, 1)], m_dvp[i, :p.k_max], m_dvs[i, :p.k_max], np.full(p.ntrc, 0.01)):
                         fh.write(" ".join(repr(float(x)) for x in arr) + "\n")
-            secs, evals = None, 0
-            for reps in (1, None):       # one pass first (page-in, and its time sizes the second run to the budget)
-                if reps is None:
-                    reps = int(max(1, min(50, budget_s / max(secs, 1e-3))))
-                r = subprocess.run([exe, "params.in", "models.txt", "ref.bin", str(reps)], cwd=work, capture_output=True,
-                                   text=True, timeout=600)
-                line = [l for l in r.stdout.splitlines() if "ref_path_dump: seconds" in l]
-                if r.returncode != 0 or not line:
-                    return None, None
+            def parse(out):
+                line = [l for l in out.splitlines() if "ref_path_dump: seconds" in l]
+                if not line:
+                    raise ValueError("no timing line")
                 tok = line[0].split()
-                secs, evals = float(tok[2]), int(tok[4])
+                return float(tok[2]), int(tok[4])
+
+            # one pass first (page-in; its time sizes the timed run to the budget)
+            # The children's environment: WITHOUT the OpenMP binding this process set for the port's threads (inherited,
+            # OMP_PLACES=cores + OMP_PROC_BIND pin every child's main thread to the first core: sixteen processes on one
+            # core measured 5.9 evals/s each), and with one GPU queue per process and no SDMA queues (more host processes
+            # than the GPU keeps queues mapped for are time-sliced: 54 -> 69 evals/s per process at sixteen)
+            child_env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
+            child_env.update(HSA_ENABLE_SDMA="0", GPU_MAX_HW_QUEUES="1")
+            r = subprocess.run([exe, "params.in", "models.txt", "ref.bin", "1"], cwd=work, capture_output=True, text=True,
+                               timeout=600, env=child_env)
+            if r.returncode != 0:
+                return None, None
+            secs, evals = parse(r.stdout)
+            reps = int(max(1, min(50, budget_s / max(secs, 1e-3))))
+            runs = [subprocess.Popen([exe, "params.in", "models.txt", f"ref_{i}.bin", str(reps)], cwd=work, env=child_env,
+                                     stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
+            outs = [q.communicate(timeout=900)[0] for q in runs]
+            if any(q.returncode != 0 for q in runs):
+                return None, None
+            each = [parse(o) for o in outs]
+            secs, evals = max(e[0] for e in each), sum(e[1] for e in each)
             raw = open(os.path.join(work, "ref.bin"), "rb").read()
             nsmp = int(np.frombuffer(raw[8:12], dtype="<i4")[0])
             body = np.frombuffer(raw[20:], dtype="<f8")
             o = nsmp * nsmp * p.ntrc
             ll = body[o:o + n * (1 + p.nfft * p.ntrc)].reshape(n, 1 + p.nfft * p.ntrc)[:, 0].copy()
-        return ({"value": evals / secs, "unit": "evals/s", "cores": 1, "kind": "reference",
+        return ({"value": evals / secs, "unit": "evals/s", "cores": procs, "kind": "reference", "per_core": evals / secs / procs,
+                 "sample_short": f"{evals} calc_likelihood calls of the reference's own code, {procs} process(es) = cores, "
+                                 f"{secs:.1f} s; c2r via the drop-in module fftw (GPU round trips counted)",
                  "sample": f"{evals} calc_likelihood(fwd_flag = .true.) calls on {n} of this workload's walkers (mean "
-                           f"{float(np.mean(nlay)):.1f} layers), {secs:.1f} s on one core; src/likelihood.f90 + src/forward.f90 + "
-                           "host modules unmodified, amdflang -O2 -ffp-contract=off, dgesvd from MKL; c2r through the drop-in "
-                           "module fftw (GPU round trips included)"}, ll)
+                           f"{float(np.mean(nlay)):.1f} layers) by {procs} concurrent process(es), one per core, {secs:.1f} s (the "
+                           "slowest); src/likelihood.f90 + src/forward.f90 + host modules unmodified, amdflang -O2 "
+                           "-ffp-contract=off, dgesvd from MKL; c2r through the drop-in module fftw (GPU round trips included)"},
+                ll)
     except (OSError, subprocess.SubprocessError, ValueError, IndexError):
         return None, None
 
@@ -605,10 +633,11 @@ def headline_line(full, detail_file):
                             counters_file=(roof.get("counters") or {}).get("file"))
     line["roofline_hbm"] = pick(hbm, ("bound", "unit", "peak", "achieved", "frac"))
     if cpu:
-        line["cpu_baseline"] = dict(pick(cpu, ("value", "unit", "cores", "kind", "per_core")),
+        line["cpu_baseline"] = dict(pick(cpu, ("value", "unit", "cores", "kind", "per_core", "single_core")),
                                     sample=cpu.get("sample_short") or (cpu.get("sample") or "")[:120])
-        if cpu.get("reference"):        # the reference's own forward + likelihood code, one core (detail_file: the sample)
-            line["cpu_baseline"]["reference"] = pick(cpu["reference"], ("value", "unit", "cores", "kind", "reference_over_port"))
+        if cpu.get("port"):             # kind "reference": the C port's figures beside it
+            line["cpu_baseline"]["port"] = pick(cpu["port"], ("value", "cores", "per_core"))
+            line["cpu_baseline"]["reference_over_port"] = (cpu.get("reference_over_port") or {}).get("all_cores")
     if par:
         line["parity_in_bench"] = pick(par, ("n", "max_abs_dlogl", "max_rel_dlogl", "within_tolerance",
                                              "n_used_kappa_allowance"))
