@@ -82,17 +82,18 @@ def test_nan_never_reaches_the_line():
 
 def test_headline_of_the_round_5_record_carries_the_reference_baseline():
     """The committed round-5 record (profiles/r05_bench_n1_detail.json -> profiles/r05_bench_n1.json): the compact line
-    built from the full record equals the line the run printed, carries `cpu_baseline.reference` (the reference's own
-    calc_likelihood timed on one core) and stays far below 4 KB."""
+    built from the full record equals the line the run printed, carries a `cpu_baseline` of kind "reference" (the
+    reference's own calc_likelihood on every host core) with the C port's figures beside it, and stays far below 4 KB."""
     full = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_n1_detail.json")))
     printed = open(os.path.join(ROOT, "profiles", "r05_bench_n1.json")).read().strip()
     assert "\n" not in printed and len(printed) < 4096
     d = json.loads(printed)
     again = json.loads(bench.headline_line(full, d["detail_file"]))
     assert again == d
-    ref = d["cpu_baseline"]["reference"]
-    assert ref["kind"] == "reference" and ref["cores"] == 1 and 0.3 < ref["reference_over_port"] < 1.0
-    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["cores"] >= 1 and c["value"] > 0 and "reference's own code" in c["sample"]
+    assert c["per_core"] <= c["single_core"] * 1.05                  # sixteen processes at once are never faster per core than one alone
+    assert c["port"]["cores"] == c["cores"] and 0.1 < c["reference_over_port"] < 1.0
     assert d["roofline"]["counters_file"] == "profiles/r05_counters.json" and d["roofline"]["frac"] is not None
     assert d["parity_in_bench"]["n"] == d["config"]["walkers_per_gpu"] == 8192 and d["parity_in_bench"]["within_tolerance"]
     assert set(d["also"]) == set(full["also"])

@@ -42,12 +42,14 @@ def main():
             print(row(k, v))
     c = d.get("cpu_baseline") or {}
     print()
-    print(f"cpu_baseline: {c.get('value', 0):.0f} evals/s on {c.get('cores')} cores (kind {c.get('kind')}, {c.get('per_core', 0):.0f} per core)", end="")
-    r = c.get("reference")
-    if r:
-        print(f"; reference's own calc_likelihood on one core: {r['value']:.1f} evals/s = {r['reference_over_port']:.2f} of the port's "
-              f"{r['port_single_core_same_walkers']:.0f}/s on the same walkers; max relative |dlogL| port vs reference "
-              f"{r['max_rel_dlogl_port_vs_reference']:.2e}")
+    print(f"cpu_baseline: {c.get('value', 0):.0f} evals/s on {c.get('cores')} cores (kind {c.get('kind')}, {c.get('per_core', 0):.1f} per core, "
+          f"{c.get('single_core', 0):.1f} on one core alone)", end="")
+    q = c.get("port")
+    if q:
+        r = c.get("reference_over_port") or {}
+        print(f"; the C port beside it: {q['value']:.0f} evals/s on {q['cores']} cores ({q['per_core']:.0f} per core; {q.get('single_core_same_walkers', 0):.0f} on "
+              f"one core on the reference's sample); reference / port: {r.get('all_cores', 0):.2f} on all cores, {r.get('single_core_same_walkers', 0):.2f} "
+              f"on one; max relative |dlogL| port vs reference {c.get('max_rel_dlogl_port_vs_reference', 0):.2e}")
     else:
         print()
     p = d.get("parity_in_bench") or {}
