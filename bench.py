@@ -490,7 +490,13 @@ def reference_path_rate(p, obs, budget_s=8.0, count=24, procs=1):
             reps = int(max(1, min(50, budget_s / max(secs, 1e-3))))
             runs = [subprocess.Popen([exe, "params.in", "models.txt", f"ref_{i}.bin", str(reps)], cwd=work, env=child_env,
                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
-            outs = [q.communicate(timeout=900)[0] for q in runs]
+            try:
+                outs = [q.communicate(timeout=180)[0] for q in runs]
+            finally:
+                for q in runs:              # (a child that outlives its time must not keep the cores busy under the GPU runs)
+                    if q.poll() is None:
+                        q.kill()
+                        q.wait()
             if any(q.returncode != 0 for q in runs):
                 return None, None
             each = [parse(o) for o in outs]
