@@ -375,7 +375,8 @@ def test_bench_two_ranks_on_one_gpu_swap_matches_serial_replay(tmp_path, launche
     line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == steps
-    assert abs(d["value"] - 2 * nb * steps / (d["ms_per_step"] * 1e-3 * steps)) < 1e-6 * d["value"]
+    # (the line carries 6 significant digits of each number)
+    assert abs(d["value"] - 2 * nb * steps / (d["ms_per_step"] * 1e-3 * steps)) < 1e-4 * d["value"]
     assert d["config"]["parallelism"] == "walkers sharded x2"
     assert d["config"]["rccl"]["ranks"] == 0 and d["config"]["rccl"]["transport"] == "process_group"
     assert len(line) < 4096 and line == r.stdout.splitlines()[-1]          # one compact line, the last of stdout
