@@ -428,7 +428,7 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
 def reference_path_rate(p, obs, budget_s=8.0, count=24, procs=1):
     """The reference's OWN forward + likelihood code timed on one host core of this box: oracle/_ref/ref_path_time = the
     reference's src/likelihood.f90 + src/forward.f90 + model / params / mt19937 / sort / math / prior, all compiled
-    unmodified (amdflang -O2 -ffp-contract=off; rf_inv_amd/fortran/Makefile, built where /root/reference exists and
+    unmodified (amdflang -O2 -ffp-contract=off; oracle/Makefile.ref, built where /root/reference exists and
     shipped prebuilt), LAPACK's dgesvd from the Intel MKL of the image, on the drop-in module fftw -- looping
     calc_likelihood(fwd_flag = .true.) (src/likelihood.f90:56-101: format_model, calc_rf, misfit, quadratic form, logL)
     over the first `count` of this workload's walkers.  The one thing in it that is not the reference's: calc_rf's c2r

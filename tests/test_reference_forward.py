@@ -1,7 +1,7 @@
 """The reference's OWN forward module on the drop-in `module fftw`.
 
-oracle/_ref/ref_forward_dump = /root/reference/src/forward.f90 compiled unmodified (-O0 -ffp-contract=off, the class of
-the reference Makefile's default flags) + the reference's params.f90 + OUR module fftw (rf_inv_amd/fortran/fftw.f90),
+oracle/_ref/ref_forward_dump (recipe: oracle/Makefile.ref) = /root/reference/src/forward.f90 compiled unmodified (-O0
+-ffp-contract=off, the class of the reference Makefile's default flags) + the reference's params.f90 + OUR module fftw (rf_inv_amd/fortran/fftw.f90),
 whose `dfftw_execute(ifft)` -- called by calc_rf itself, src/forward.f90:172,200 -- runs the c2r on the GPU as the
 transform's definition (rf_fft_c2r).  It is first of all the test of the drop-in against its real consumer.  And since
 everything but the inverse transform in those traces is the reference's own code and arithmetic -- init_filter,
