@@ -931,9 +931,26 @@ def main():
         # again, which costs nothing, right before the timed region.)
         eng.profile_enable(0 if args.no_kernel_events else every)
         scratch = []
+        first = None
+        if world > 1:
+            # the FIRST steps across ranks (the first collectives of the exchange on the device): a rank whose stream has not
+            # drained after --comm-init-timeout seconds says so and leaves (exit code 4) instead of hanging the job
+            import threading
+
+            def _stuck_step():
+                print(f"bench.py: rank {rank}: the first steps with the temperature exchange did not finish within "
+                      f"{args.comm_init_timeout:.0f} s (transport: {'librfgpu RCCL' if over_rccl else 'process group'}): giving up "
+                      "(exit code 4)", file=sys.stderr, flush=True)
+                os._exit(4)
+
+            first = threading.Timer(args.comm_init_timeout, _stuck_step)
+            first.daemon = True
+            first.start()
         for i in range(8):
             timed_step(i, scratch)
         torch.cuda.synchronize(dev)
+        if first is not None:
+            first.cancel()
         eng.profile_enable(False)
         eng.profile_read()
         t_pre = time.perf_counter()
