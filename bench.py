@@ -83,6 +83,25 @@ WORKLOADS = {
                     "walkers/GPU x 4 traces (P .06, P .08, S .10, S .12) x nfft 4096 x ocean layer (sdep 2 km) x <=31 "
                     "layers, PT swap (BASELINE's 'buried station' has no reference behaviour: the borehole branch of "
                     "forward.f90:289-338 is commented out)"),
+    # water-level deconvolution (deconv_mode 1, src/forward.f90:148-153,447-470) at the multi-trace shapes
+    "c4d": dict(walkers=8192, nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], k_max=30, sdep=0.0, deconv=1,
+                temps=8,
+                desc="c4d: c4 with water-level deconvolution (deconv_mode 1; P: R/V, S: V/R): 8192 walkers/GPU x 3 traces "
+                     "x nfft 4096 x <=30 layers, PT swap"),
+    "c5d": dict(walkers=32768, nfft=4096, rayps=[0.06, 0.08, 0.10, 0.12], ipha=[1, 1, -1, -1], k_max=30, sdep=2.0,
+                deconv=1, temps=16,
+                desc="c5d: c5 with water-level deconvolution (deconv_mode 1): 32768 walkers/GPU x 4 traces x nfft 4096 x "
+                     "ocean layer x <=31 layers, PT swap"),
+    # BASELINE configs[3] / configs[4] at their FULL size on ONE GPU (the 8-GPU job's walkers all resident here)
+    "c4full": dict(walkers=65536, nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], k_max=30, sdep=0.0, deconv=0,
+                   temps=8,
+                   desc="c4full: ALL of BASELINE configs[3] on one GPU: 65536 walkers (8192 chains x 8 temperatures) x 3 "
+                        "traces x nfft 4096 x <=30 layers, PT swap; 12.9 GB of double-buffered resident traces"),
+    "c5full": dict(walkers=262144, nfft=4096, rayps=[0.06, 0.08, 0.10, 0.12], ipha=[1, 1, -1, -1], k_max=30, sdep=2.0,
+                   deconv=0, temps=16,
+                   desc="c5full: ALL of BASELINE configs[4] on one GPU: 262144 walkers (16384 chains x 16 temperatures) x 4 "
+                        "traces x nfft 4096 x ocean layer x <=31 layers, PT swap; 68.7 GB of double-buffered resident "
+                        "traces"),
     # real time windows: the reference takes any window up to npts_max = 2000 samples (src/params.f90:44) and its
     # quadratic form grows with nsmp^2 (src/likelihood.f90:92-93): the long-window plan (one FP64-MFMA GEMM per batch)
     "c4w20": dict(walkers=8192, nfft=4096, rayps=[0.06, 0.08, 0.10], ipha=[1, 1, -1], k_max=30, sdep=0.0, deconv=0,
@@ -131,16 +150,20 @@ def make_params(w):
     return p
 
 
-def draw_walkers(p, ref, first_id, count, seed=12345678, return_models=False):
+def draw_walkers(p, ref, first_id, count, seed=12345678, return_models=False, procs=0):
     """Walker models from the init_model prior (reference src/model.f90:66-95) conditioned on
     validity, with k uniform in [k_min, k_max), from a counter-based RNG
     keyed by seed + global walker id.  init_model rejects whole models, which makes deep
     stacks vanishingly rare (P(valid) ~ 0.68^nlay at dVs sigma 2.0); here k is drawn once and
     the rejection is applied per component (interface set until the thickness rules hold,
     each dVs until its layer passes the range rules) -- the same distribution as whole-model
-    rejection given k, since the validity rules factorise that way for vp_mode = 0."""
+    rejection given k, since the validity rules factorise that way for vp_mode = 0.
+    Every walker's model depends on seed + its global id only; 16384 walkers or more are drawn by child processes
+    (procs: 0 = one per physical core, 1 = in this process)."""
     from rf_inv_amd import format_model
 
+    if count >= 16384 and procs != 1:
+        return _draw_walkers_pool(p, ref, first_id, count, seed, return_models, procs)
     pad = p.k_max + 2
     layers = np.ones((count, 4, pad))
     nlay = np.zeros(count, dtype=np.int32)
@@ -159,10 +182,18 @@ def draw_walkers(p, ref, first_id, count, seed=12345678, return_models=False):
     for i in range(count):
         g = np.random.Generator(np.random.Philox(key=seed + first_id + i))
         k = p.k_min + int(g.random() * (p.k_max - p.k_min))
+        # rejection on the interface set, a block of tries at a time: the stream is consumed exactly as by one
+        # g.random(k) per try up to and including the accepted one (state restored, then that many doubles drawn)
         while True:
-            zs = np.sort(p.z_min + g.random(k) * (p.z_max - p.z_min))
-            th = np.diff(np.concatenate([[p.sdep], zs]))
-            if th[0] >= 0.125 * vp0 and np.all(th[1:] >= p.h_min):
+            st = g.bit_generator.state
+            blk = np.sort(p.z_min + g.random((64, k)) * (p.z_max - p.z_min), axis=1)
+            th = np.diff(np.concatenate([np.full((64, 1), p.sdep), blk], axis=1), axis=1)
+            good = (th[:, 0] >= 0.125 * vp0) & np.all(th[:, 1:] >= p.h_min, axis=1)
+            if good.any():
+                j = int(np.argmax(good))
+                zs = blk[j]
+                g.bit_generator.state = st
+                g.random((j + 1) * k)
                 break
         z = np.zeros(max(p.k_max - 1, 1)); dvp = np.zeros(p.k_max); dvs = np.zeros(p.k_max)
         z[:k] = g.permutation(zs)
@@ -177,6 +208,51 @@ def draw_walkers(p, ref, first_id, count, seed=12345678, return_models=False):
     if return_models:
         return nlay, layers, (m_k, m_z, m_dvp, m_dvs)
     return nlay, layers
+
+
+def _draw_walkers_pool(p, ref, first_id, count, seed, return_models, procs):
+    """draw_walkers over child processes (`python bench.py --draw-worker job.pkl`, started like any other child program:
+    fresh interpreters that never touch the GPU), one contiguous block of walker ids each."""
+    import pickle
+    import subprocess
+    import tempfile
+
+    procs = procs or max(1, min(physical_cores(), 32))
+    chunk = -(-count // procs)
+    with tempfile.TemporaryDirectory() as work:
+        jobs = []
+        for j, a in enumerate(range(0, count, chunk)):
+            job = os.path.join(work, f"job{j}.pkl")
+            with open(job, "wb") as fh:
+                pickle.dump((p, ref, first_id + a, min(chunk, count - a), seed, os.path.join(work, f"out{j}.npz")), fh)
+            env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
+            env.update(OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
+            jobs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), "--draw-worker", job], env=env,
+                                          stdout=subprocess.DEVNULL), os.path.join(work, f"out{j}.npz")))
+        parts = []
+        try:
+            for q, out in jobs:
+                if q.wait(timeout=1800) != 0:
+                    raise RuntimeError("bench.py: a --draw-worker child failed")
+                with np.load(out) as z:
+                    parts.append([z[n] for n in ("nlay", "layers", "k", "z", "dvp", "dvs")])
+        finally:
+            for q, _ in jobs:
+                if q.poll() is None:
+                    q.kill()
+                    q.wait()
+    nlay, layers = np.concatenate([q[0] for q in parts]), np.concatenate([q[1] for q in parts])
+    models = tuple(np.concatenate([q[j] for q in parts]) for j in range(2, 6))
+    return (nlay, layers, models) if return_models else (nlay, layers)
+
+
+def _draw_worker(job):
+    import pickle
+
+    with open(job, "rb") as fh:
+        p, ref, first_id, count, seed, out = pickle.load(fh)
+    nlay, layers, (k, z, dvp, dvs) = draw_walkers(p, ref, first_id, count, seed=seed, return_models=True, procs=1)
+    np.savez(out, nlay=nlay, layers=layers, k=k, z=z, dvp=dvp, dvs=dvs)
 
 
 def run_host_boundary(workload, steps, device, prewarm_s=1.0, warmup=5):
@@ -1288,4 +1364,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) == 3 and sys.argv[1] == "--draw-worker":
+        _draw_worker(sys.argv[2])
+    else:
+        main()

@@ -1,0 +1,199 @@
+"""Generate tests/golden/ref/*.npz: inputs and outputs of the reference's OWN code, run on the CPU (test infrastructure).
+
+    make -C oracle -f Makefile.cpuref        # the whole reference, unmodified, + MKL's FFTW3 interface / LAPACK; no GPU
+    python oracle/gen_golden.py              # needs /root/reference (the build) -- runs HERE only; the fixtures travel
+
+Every number in a fixture's outputs comes out of oracle/_ref/cpu_o0/ref_forward_dump or ref_path_dump (the reference
+Makefile's default -O0 class; `*_o2` fields: the same run through the -O2 build, i.e. the reference's own spread between
+two builds of itself).  No product code and no oracle code computes anything here: rf_inv_amd's Python host mirror only
+WRITES the input files the reference reads (params.in, SAC traces) and draws bench.py's walker models; the observed
+traces of the likelihood fixtures are the reference's own synthetic of bench.py's fixed three-interface model.
+
+  forward_<case>.npz   calc_rf (src/forward.f90:123-208) on hand-built layer stacks: the matrix of SURVEY.md section 8c
+                       (land / ocean x P / S x deconvolution 0 / 1 x common / separate rays x 2 .. 31 layers x nfft 256 ..
+                       4096, an odd length, the DC bin in every trace, an evanescent (NaN) trace, the scenario of the
+                       reference's own src/forward_test.f90)
+  path_<workload>.npz  calc_likelihood (src/likelihood.f90:56-101) with fwd_flag = .true. on bench.py's own walkers of
+                       that workload (the first ones, the deepest, the shallowest), and with fwd_flag = .false. on
+                       host-stored traces; format_model's layer stacks, the pseudo-inverse as init_r_inv forms it
+  MANIFEST.json        file list with sha256 (tests fail, not skip, on a missing or altered fixture)
+
+Consumers: tests/test_reference_fixtures.py (-m "not gpu": the oracle against the fixtures; -m gpu: the HIP path)."""
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+OUT = os.path.join(ROOT, "tests", "golden", "ref")
+
+# name -> (nfft, rayps, ipha, a_gus, deconv_mode, sdep, t_start)        [the cases of tests/test_reference_forward.py + more]
+FORWARD_CASES = {
+    "c1_ocean_2P_nfft256": (256, [0.06, 0.08], [1, 1], [4.0, 4.0], 0, 2.0, 0.0),
+    "land_S_nfft256_decon": (256, [0.09], [-1], [3.0], 1, 0.0, -1.0),
+    "c2_land_P": (4096, [0.06], [1], [4.0], 0, 0.0, 0.0),
+    "c2d_land_P_decon": (4096, [0.06], [1], [4.0], 1, 0.0, 0.0),
+    "c4_land_PPS": (4096, [0.06, 0.08, 0.10], [1, 1, -1], [4.0, 4.0, 4.0], 0, 0.0, 0.0),
+    "c4_land_PPS_decon_tstart": (4096, [0.06, 0.08, 0.10], [1, 1, -1], [4.0, 2.5, 4.0], 1, 0.0, -3.0),
+    "c5_ocean_PPSS": (4096, [0.06, 0.08, 0.10, 0.12], [1, 1, -1, -1], [4.0] * 4, 0, 2.0, 0.0),
+    "c5_ocean_PPSS_decon": (4096, [0.06, 0.08, 0.10, 0.12], [1, 1, -1, -1], [4.0] * 4, 1, 2.0, -1.0),
+    "c4common_land_3P_one_ray": (4096, [0.06, 0.06, 0.06], [1, 1, 1], [4.0, 2.5, 1.5], 0, 0.0, 0.0),
+    "common_ocean_3S_one_ray_nfft2048": (2048, [0.10, 0.10, 0.10], [-1, -1, -1], [4.0, 2.5, 1.5], 0, 2.0, -2.0),
+    "common_land_2S_decon_nfft512": (512, [0.07, 0.07], [-1, -1], [4.0, 2.0], 1, 0.0, -2.0),
+    "odd_length_nfft1000_S": (1000, [0.11], [-1], [3.0], 0, 0.0, 0.0),
+}
+PATH_WORKLOADS = {"c1": 40, "c2": 48, "c2d": 48, "c4": 56, "c4d": 48, "c4common": 40, "c5": 40, "c5d": 40, "c4w20": 20}
+N_FULL = 3          # models per path fixture whose whole rft(nfft, ntrc) is kept (all keep samples 1 .. nsmp)
+
+
+def forward_stacks(rng, ocean, sdep):
+    from helpers import random_stack
+
+    sizes = (3, 4, 7, 15, 20, 31) if ocean else (2, 3, 6, 15, 20, 30)
+    stacks = [random_stack(rng, n, ocean, sdep) for n in sizes]
+    # a soft surface layer on a fast half-space: spectra that dip below the water level (the level clips bins)
+    soft = (np.array([1.6, 6.0, 8.0]), np.array([0.2, 3.5, 4.5]), np.array([1.5, 2.7, 3.3]), np.array([0.5, 30.0, 999.0]))
+    if ocean:
+        soft = tuple(np.concatenate([[w], x]) for w, x in zip((1.5, -999.0, 1.0, sdep), soft))
+    return stacks + [soft]
+
+
+def forward_params(nfft, rayps, ipha, a_gus, deconv, sdep, t_start, t_end=5.0):
+    from helpers import DELTA
+    from rf_inv_amd import get_params
+    from rf_inv_amd.params import _nint
+
+    p = get_params(os.path.join(ROOT, "tests", "golden", "sample_syn", "params.in"))
+    n = len(rayps)
+    p.ntrc, p.nfft, p.deconv_mode, p.sdep, p.t_start, p.t_end, p.k_max = n, nfft, deconv, float(sdep), t_start, t_end, 31
+    p.rayps, p.a_gus, p.ipha = np.asarray(rayps, float), np.asarray(a_gus, float), np.asarray(ipha, dtype=np.int32)
+    p.sig_min = p.sig_max = np.full(n, 0.01)
+    p.delta = DELTA
+    p.nsmp = int(round((t_end - t_start) / DELTA)) + 1
+    assert p.nsmp == _nint(t_end / DELTA) - _nint(t_start / DELTA) + 1
+    return p
+
+
+def gen_forward(name, case, stacks=None):
+    from helpers import pack_layers
+    from oracle import refrun
+
+    nfft, rayps, ipha, a_gus, deconv, sdep, t_start = case
+    if stacks is None:
+        stacks = forward_stacks(np.random.default_rng(sum(map(ord, name))), sdep > 0, sdep)
+    p = forward_params(nfft, rayps, ipha, a_gus, deconv, sdep, t_start)
+    res = {}
+    for build in refrun.BUILDS:
+        with tempfile.TemporaryDirectory() as work:
+            text = refrun.write_run_dir(work, p, header=f"oracle/gen_golden.py: forward case {name}")
+            refrun.write_stacks(os.path.join(work, "stacks.txt"), stacks)
+            res[build] = refrun.run_forward(build, work, len(stacks), nfft, p.ntrc)
+    r0, r2 = res["cpu_o0"], res["cpu_o2"]
+    assert np.array_equal(r0["npre"], r2["npre"]) and np.array_equal(r0["flt"], r2["flt"])
+    nlay, layers = pack_layers(stacks, 33)
+    scale = np.nanmax(np.abs(r0["rft"]), axis=2, keepdims=True)
+    with np.errstate(invalid="ignore"):
+        spread = np.nanmax(np.abs(r2["rft"] - r0["rft"]) / scale, axis=2)
+    np.savez(os.path.join(OUT, f"forward_{name}.npz"), name=name, params_in=text, nfft=nfft, ntrc=p.ntrc, nsmp=p.nsmp,
+             delta=p.delta, t_start=t_start, t_end=p.t_end, deconv_mode=deconv, sdep=float(sdep), rayps=p.rayps, ipha=p.ipha,
+             a_gus=p.a_gus, nlay=nlay, layers=layers, flt=r0["flt"], rft=r0["rft"], tp=r0["tp"], npre=r0["npre"],
+             is_ray_common=r0["common"], o2_rel_trace_spread=spread, build="cpu_o0")
+    print(f"forward_{name}: {len(stacks)} stacks, -O2 against -O0 max rel trace difference {np.nanmax(spread):.2e}", flush=True)
+
+
+def gen_path(workload, count):
+    import bench
+    from oracle import refrun
+    from rf_inv_amd import read_ref_model
+
+    w = dict(bench.WORKLOADS[workload])
+    p = bench.make_params(w)
+    refm = read_ref_model(os.path.join(ROOT, "tests", "golden", "sample_syn", "model", "sample.velmod"))
+    nlay_b, _, (m_k, m_z, m_dvp, m_dvs) = bench.draw_walkers(p, refm, 0, 4 * count, return_models=True, procs=1)
+    pick = np.unique(np.concatenate([np.arange(count), np.argsort(nlay_b, kind="stable")[-6:], np.argsort(nlay_b, kind="stable")[:3]]))
+    m_k, m_z, m_dvp, m_dvs = m_k[pick], m_z[pick], m_dvp[pick], m_dvs[pick]
+    n = len(pick)
+    rng = np.random.default_rng(sum(map(ord, workload)) + 1)
+    sig = rng.uniform(0.01, 0.03, (n, p.ntrc))
+    sig[: n // 2] = 0.01                                   # half at bench.py's sigma, half spread
+    kz = max(p.k_max - 1, 1)
+    # pass 1: the reference's own synthetic of bench.py's fixed three-interface model = the observed traces
+    zt = np.zeros((1, p.k_max)); dvt = np.zeros((1, p.k_max)); dst = np.zeros((1, p.k_max))
+    zt[0, :3] = [3.1 + p.sdep, 7.7 + p.sdep, 14.2 + p.sdep]; dst[0, :3] = [-0.6, 0.2, 0.5]; dst[0, p.k_max - 1] = 0.9
+    with tempfile.TemporaryDirectory() as work:
+        refrun.write_run_dir(work, p)
+        refrun.write_models(os.path.join(work, "models.txt"), p.k_max, np.array([3]), zt, dvt, dst, np.full((1, p.ntrc), 0.01))
+        truth = refrun.run_path("cpu_o0", work, 1, p)
+    obs_full = truth["rft"][0]
+    # what the reference reads back from a SAC file: float32 samples
+    obs = np.stack([obs_full[t, :p.nsmp].astype(np.float32).astype(np.float64) for t in range(p.ntrc)])
+    res = {}
+    for build in refrun.BUILDS:
+        with tempfile.TemporaryDirectory() as work:
+            text = refrun.write_run_dir(work, p, obs=obs_full, header=f"oracle/gen_golden.py: bench.py workload {workload}")
+            refrun.write_models(os.path.join(work, "models.txt"), p.k_max, m_k, m_z, m_dvp, m_dvs, sig)
+            res[build] = refrun.run_path(build, work, n, p)
+    r0, r2 = res["cpu_o0"], res["cpu_o2"]
+    assert np.array_equal(r0["nlay"], r2["nlay"]) and np.array_equal(r0["npre"], r2["npre"]) and r0["valid"].all()
+    assert np.array_equal(r0["nlay"], nlay_b[pick]) and r0["nlay"].max() <= p.k_max + 2
+    pad = p.k_max + 2
+    # one stored matrix per distinct Gaussian parameter
+    a_unique, r_index = np.unique(p.a_gus, return_inverse=True)
+    r_inv = np.stack([r0["r_inv"][int(np.nonzero(r_index == j)[0][0])] for j in range(len(a_unique))])
+    for t in range(p.ntrc):
+        assert np.array_equal(r0["r_inv"][t], r_inv[r_index[t]])
+    m = len(r0["probe_logl"])
+    np.savez(os.path.join(OUT, f"path_{workload}.npz"), workload=workload, params_in=text, walker_ids=pick.astype(np.int32),
+             nfft=p.nfft, ntrc=p.ntrc, nsmp=p.nsmp, delta=p.delta, t_start=p.t_start, t_end=p.t_end, deconv_mode=p.deconv_mode,
+             sdep=p.sdep, rayps=p.rayps, ipha=p.ipha, a_gus=p.a_gus, k_max=p.k_max,
+             obs=obs, truth_nlay=truth["nlay"][0], truth_layers=truth["layers"][0][:, :pad],
+             k=m_k, z=m_z[:, :kz], dvp=m_dvp, dvs=m_dvs, sig=sig,
+             logl=r0["logl"], logl_o2=r2["logl"], nlay=r0["nlay"], layers=r0["layers"][:, :, :pad], tp=r0["tp"], npre=r0["npre"],
+             rft_window=r0["rft"][:, :, :p.nsmp], rft_full=r0["rft"][:N_FULL],
+             o2_rel_trace_spread=np.max(np.abs(r2["rft"] - r0["rft"]) / np.max(np.abs(r0["rft"]), axis=2, keepdims=True), axis=2),
+             r_inv=r_inv, r_index=r_index.astype(np.int32),
+             probe_logl=r0["probe_logl"], probe_window=r0["probe_trace"][:, :, :p.nsmp], probe_sig=r0["probe_sig"].reshape(m, p.ntrc),
+             build="cpu_o0")
+    d = np.abs(r2["logl"] - r0["logl"])
+    print(f"path_{workload}: {n} models (nlay {r0['nlay'].min()} .. {r0['nlay'].max()}), |logL| {np.abs(r0['logl']).min():.3g} .. "
+          f"{np.abs(r0['logl']).max():.3g}; the reference -O2 against -O0: max |dlogL| {d.max():.2e}, max rel "
+          f"{(d / np.abs(r0['logl'])).max():.2e}", flush=True)
+
+
+def main():
+    from oracle import refrun
+
+    if not (refrun.available("cpu_o0") and refrun.available("cpu_o2")):
+        raise SystemExit("oracle/gen_golden.py: build oracle/_ref/cpu_o0 and cpu_o2 first (make -C oracle -f Makefile.cpuref)")
+    os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])
+    for name, case in FORWARD_CASES.items():
+        if not only or f"forward_{name}" in only:
+            gen_forward(name, case)
+    # the scenario of the reference's own src/forward_test.f90:39-56 (a 20 km layer over a half-space, one S trace, a = 8)
+    if not only or "forward_reference_forward_test" in only:
+        gen_forward("reference_forward_test", (1024, [0.06], [-1], [8.0], 0, 0.0, -3.0),
+                    stacks=[(np.array([5.0, 8.0]), np.array([2.5, 4.0]), np.array([3.0, 3.3]), np.array([20.0, -10.0]))])
+    # an evanescent layer for the second ray (1 / v^2 < p^2: sqrt of a negative number, src/forward.f90:396-397): NaN trace
+    if not only or "forward_evanescent_nan" in only:
+        gen_forward("evanescent_nan", (256, [0.06, 0.30], [1, 1], [4.0, 4.0], 0, 0.0, 0.0),
+                    stacks=[(np.array([3.0, 6.0]), np.array([1.7, 3.4]), np.array([2.3, 2.8]), np.array([2.0, 999.0]))])
+    for workload, count in PATH_WORKLOADS.items():
+        if not only or f"path_{workload}" in only:
+            gen_path(workload, count)
+    files = sorted(f for f in os.listdir(OUT) if f.endswith(".npz"))
+    man = {f: {"sha256": hashlib.sha256(open(os.path.join(OUT, f), "rb").read()).hexdigest(),
+               "bytes": os.path.getsize(os.path.join(OUT, f))} for f in files}
+    with open(os.path.join(OUT, "MANIFEST.json"), "w") as fh:
+        json.dump({"generator": "oracle/gen_golden.py", "build": "oracle/Makefile.cpuref (cpu_o0; *_o2 fields: cpu_o2)",
+                   "files": man}, fh, indent=1, sort_keys=True)
+    print(f"{len(files)} fixtures, {sum(v['bytes'] for v in man.values()) / 1e6:.1f} MB")
+
+
+if __name__ == "__main__":
+    main()

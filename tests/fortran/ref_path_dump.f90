@@ -14,10 +14,17 @@
 !                     per model: real64 logL, rft(nfft, ntrc)          [calc_likelihood, fwd_flag = .true.]
 !                     per probe j = 1 .. m: real64 logL, trace(nfft, ntrc), sig(ntrc)   [fwd_flag = .false. on a trace
 !                                           this program stored in likelihood's public rft(:, :, 1)]
+!   optional 5th argument extras.bin (stream), per model: int32 nlay, valid; real64 alpha, beta, rho, h (nlay_max each)
+!   from the reference's own public format_model (src/model.f90:175-290); real64 tp(ntrc), int32 npre(ntrc) -- tp from
+!   its public direct_arrival under calc_rf's branch rule (src/forward.f90:148-163), npre by the expressions of
+!   :177 / :186 (calc_rf keeps both local: they are re-evaluated here)
 ! module likelihood keeps r_inv private: the matrix written to out.bin is formed here by the steps of init_r_inv
 ! (src/likelihood.f90:183-222: R(j, i) = r ** ((i - j) ** 2), dgesvd, reciprocals of the singular values above 1.0d-3,
 ! transpose(vt) . diag . transpose(u)) with the same LAPACK and the same intrinsic matmul; the probes check that it is
 ! the module's (their log-likelihoods are reproduced from it to rounding, tests/test_reference_forward.py).
+! Built twice: (1) oracle/Makefile.cpuref -- with the reference's OWN src/fftw.f90 on MKL's FFTW3 interface, CPU only, no
+! product object linked: the generator of tests/golden/ref/ (oracle/gen_golden.py) and bench.py's cpu_baseline;
+! (2) oracle/Makefile.ref -- on the drop-in module fftw as described above (the drop-in's own test, needs a GPU).
 ! Test infrastructure.
 !=======================================================================
 program ref_path_dump
@@ -30,7 +37,11 @@ program ref_path_dump
   implicit none
   integer, parameter :: m = 6
   character(clen_max) :: param_file, model_file, out_file
-  integer :: n, i, j, it, jt, u, v, pk, info, lw, reps, irep
+  integer :: n, i, j, it, jt, u, v, pk, info, lw, reps, irep, x, nl
+  integer(4), allocatable :: npre(:)
+  real(8), allocatable :: tp(:), fa(:), fb(:), fr(:), fh(:)
+  logical :: ok
+  character(clen_max) :: extra_file
   integer(8) :: c0, c1, crate
   character(32) :: arg
   integer, allocatable :: sk(:)
@@ -73,6 +84,13 @@ program ref_path_dump
   end do
 
   allocate(pz(k_max - 1), pdvp(k_max), pdvs(k_max), psig(ntrc), prft(nfft, ntrc))
+  allocate(tp(ntrc), npre(ntrc), fa(nlay_max), fb(nlay_max), fr(nlay_max), fh(nlay_max))
+  x = 0
+  if (command_argument_count() > 4) then
+     call get_command_argument(5, extra_file)
+     x = 73
+     open(x, file = trim(extra_file), status = "replace", access = "stream", form = "unformatted")
+  end if
   u = 71
   v = 72
   open(u, file = trim(model_file), status = "old")
@@ -90,6 +108,31 @@ program ref_path_dump
      call calc_likelihood(1, .true., pk, pz, pdvp, pdvs, psig, ll, prft)
      write(v) ll
      write(v) prft
+     if (x > 0) then
+        call format_model(pk, pz, pdvp, pdvs, nl, fa, fb, fr, fh, ok)
+        do jt = 1, ntrc
+           if (jt == 1 .or. .not. is_ray_common) then
+              if (deconv_mode == 1) then
+                 tp(jt) = 0.d0
+              else if (ipha(jt) == 1) then
+                 call direct_arrival(nl, fh(1:nl), fa(1:nl), rayps(jt), tp(jt))
+              else
+                 call direct_arrival(nl, fh(1:nl), fb(1:nl), rayps(jt), tp(jt))
+              end if
+           else
+              tp(jt) = tp(1)
+           end if
+           if (ipha(jt) == 1) then
+              npre(jt) = nint((-t_start - tp(jt)) / delta)
+           else
+              npre(jt) = nint((-t_start + tp(jt)) / delta)
+           end if
+        end do
+        write(x) int(nl, 4), int(merge(1, 0, ok), 4)
+        write(x) fa, fb, fr, fh
+        write(x) tp
+        write(x) npre
+     end if
      sk(i) = pk;  sz(:, i) = pz;  sdvp(:, i) = pdvp;  sdvs(:, i) = pdvs;  ssig(:, i) = psig
   end do
   close(u)
@@ -123,5 +166,6 @@ program ref_path_dump
      write(v) psig
   end do
   close(v)
+  if (x > 0) close(x)
   write(*,*) "ref_path_dump: ok", n, m
 end program ref_path_dump
