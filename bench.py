@@ -54,7 +54,8 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6   # MI355X FP64 vector == matrix peak (datasheet)
 ALSO_NOMINAL_MS = {"c1": 0.03, "c2": 0.075, "c2d": 0.08, "c3": 0.45, "c4": 1.9, "c4common": 0.95, "c5": 13.0,
-                   "c4w20": 2.2, "c4w60": 4.0, "c4win": 1.8, "c5win": 12.5}   # ms per step
+                   "c4w20": 2.2, "c4w60": 4.0, "c4win": 1.8, "c5win": 12.5, "c4d": 1.9, "c5d": 13.0, "c4full": 15.0,
+                   "c5full": 100.0}   # ms per step
 SPEC_CLOCK_GHZ = 2.4      # the engine clock 78.6 TF is quoted at (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4e9)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
 ENV_ALLOWED = {"RFGPU_BENCH_BACKEND"}   # "gloo": functional test of the N > 1 path on one GPU
@@ -158,11 +159,11 @@ def draw_walkers(p, ref, first_id, count, seed=12345678, return_models=False, pr
     the rejection is applied per component (interface set until the thickness rules hold,
     each dVs until its layer passes the range rules) -- the same distribution as whole-model
     rejection given k, since the validity rules factorise that way for vp_mode = 0.
-    Every walker's model depends on seed + its global id only; 16384 walkers or more are drawn by child processes
+    Every walker's model depends on seed + its global id only; 65536 walkers or more are drawn by child processes
     (procs: 0 = one per physical core, 1 = in this process)."""
     from rf_inv_amd import format_model
 
-    if count >= 16384 and procs != 1:
+    if count >= 65536 and procs != 1:
         return _draw_walkers_pool(p, ref, first_id, count, seed, return_models, procs)
     pad = p.k_max + 2
     layers = np.ones((count, 4, pad))
@@ -225,7 +226,9 @@ def _draw_walkers_pool(p, ref, first_id, count, seed, return_models, procs):
             job = os.path.join(work, f"job{j}.pkl")
             with open(job, "wb") as fh:
                 pickle.dump((p, ref, first_id + a, min(chunk, count - a), seed, os.path.join(work, f"out{j}.npz")), fh)
-            env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
+            # (no OpenMP binding of this process, and no profiler preload: the children are plain numpy programs)
+            env = {k: v for k, v in os.environ.items()
+                   if not (k.startswith("OMP_") or k.startswith("ROCP") or k.startswith("ROCPROF") or k == "LD_PRELOAD")}
             env.update(OMP_NUM_THREADS="1", MKL_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1")
             jobs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), "--draw-worker", job], env=env,
                                           stdout=subprocess.DEVNULL), os.path.join(work, f"out{j}.npz")))
@@ -435,12 +438,11 @@ def physical_cores():
 
 def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
     """The CPU side of the comparison, on a bounded sample of the same workload.
-    kind "reference" (when oracle/_ref/ref_path_time is there and runs): the reference's OWN src/likelihood.f90 +
-    src/forward.f90 + host modules, compiled unmodified (reference_path_rate), one process per physical core at once --
-    the reference's deployment, one MPI rank per core, no communication inside an evaluation -- with the port's figures
-    beside it under `port`.  Its c2r round trips to the GPU (the drop-in module fftw; six per evaluation at C4) are in the
-    time and contend when sixteen processes make them: the all-core figure is a LOWER bound of the reference's CPU-only
-    rate (`single_core` x cores is the upper bound).
+    kind "reference" (when oracle/_ref/cpu_o2/ref_path_dump is there and runs): ALL of the reference's own sources compiled
+    unmodified and run on the host cores only -- its own module fftw on the FFTW3 interface of the image's Intel MKL, dgesvd
+    from MKL, no GPU (reference_path_rate) --, one process per physical core at once: the reference's deployment, one MPI
+    rank per core, no communication inside an evaluation.  `o0`: the same with the reference Makefile's default -O0
+    class.  The port's figures sit beside it under `port`.
     kind "port" (otherwise): oracle/rf_oracle.c, a scalar fp64 restatement of the reference's arithmetic, in its speed
     build (-O3 -march=native, same values as the checker build), one OpenMP thread per physical core.
     Returns (record, the port's logL on the sample, how many of the rank's walkers the sample covers)."""
@@ -485,13 +487,19 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
     port24 = n24 / (time.perf_counter() - t0)
     # (the reference reads its observed traces from SAC files: float32 samples -- the port is given the same here)
     obs32 = obs.astype(np.float32).astype(np.float64)
-    one, ll_ref = reference_path_rate(p, obs32, budget_s=3.0, count=n24, procs=1)
-    full = reference_path_rate(p, obs32, budget_s=8.0, count=n24, procs=cores)[0] if one is not None and cores > 1 else one
+    one, ll_ref = reference_path_rate(p, obs32, budget_s=2.5, count=n24, procs=1)
+    full = reference_path_rate(p, obs32, budget_s=6.0, count=n24, procs=cores)[0] if one is not None and cores > 1 else one
     if full is not None:
         ll24 = orc.eval_batch(cfg, obs32, r_inv, nlay[:n24], layers[:n24], sig[:n24], p.nsmp, nthreads=1, fast=True)
         port = dict(base)
         base = dict(full)
         base["single_core"] = one["value"]
+        # the reference Makefile's default class (-O0, Makefile:11-13) beside the optimised build
+        one0 = reference_path_rate(p, obs32, budget_s=2.0, count=n24, procs=1, build="cpu_o0")[0]
+        full0 = reference_path_rate(p, obs32, budget_s=4.0, count=n24, procs=cores, build="cpu_o0")[0] if one0 and cores > 1 else one0
+        if full0 is not None:
+            base["o0"] = {"value": full0["value"], "cores": full0["cores"], "per_core": full0["per_core"],
+                          "single_core": one0["value"], "build": "cpu_o0", "sample": full0["sample"]}
         base["port"] = {k: port[k] for k in ("value", "unit", "cores", "kind", "per_core", "single_core", "sample")}
         base["port"]["single_core_same_walkers"] = port24
         base["reference_over_port"] = {"all_cores": full["value"] / port["value"], "single_core_same_walkers": one["value"] / port24}
@@ -501,73 +509,41 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
     return base, ll_all[:nuse], nuse
 
 
-def reference_path_rate(p, obs, budget_s=8.0, count=24, procs=1):
-    """The reference's OWN forward + likelihood code timed on one host core of this box: oracle/_ref/ref_path_time = the
-    reference's src/likelihood.f90 + src/forward.f90 + model / params / mt19937 / sort / math / prior, all compiled
-    unmodified (amdflang -O2 -ffp-contract=off; oracle/Makefile.ref, built where /root/reference exists and
-    shipped prebuilt), LAPACK's dgesvd from the Intel MKL of the image, on the drop-in module fftw -- looping
-    calc_likelihood(fwd_flag = .true.) (src/likelihood.f90:56-101: format_model, calc_rf, misfit, quadratic form, logL)
-    over the first `count` of this workload's walkers.  The one thing in it that is not the reference's: calc_rf's c2r
-    goes through the drop-in (a GPU round trip of ~0.1 ms per transform, counted in the time).
+def reference_path_rate(p, obs, budget_s=8.0, count=24, procs=1, build="cpu_o2"):
+    """The reference's OWN forward + likelihood code timed on this box's HOST CORES ONLY: oracle/_ref/<build>/ref_path_dump
+    = all of the reference's sources compiled unmodified (oracle/Makefile.cpuref: amdflang, `cpu_o2` = -O2 -ffp-contract=off,
+    `cpu_o0` = the reference Makefile's default -O0 class), its own src/fftw.f90 on the FFTW3 interface of the image's Intel
+    MKL, dgesvd from the same MKL -- no product object linked, no GPU touched -- looping calc_likelihood(fwd_flag = .true.)
+    (src/likelihood.f90:56-101: format_model, calc_rf, misfit, quadratic form, logL) over the first `count` of this
+    workload's walkers.  The timed loop is inside the program (system_clock around the calls: start-up, init_r_inv's SVD
+    and file IO are outside).
     procs > 1: that many processes at once, one per host core, the way the reference runs (one MPI rank per core, no
     communication inside an evaluation): the box's rate = all their evaluations / the slowest one's time.
     Returns (record or None, logL of the sample or None)."""
-    import copy
-    import shutil
     import subprocess
     import tempfile
 
-    exe = os.path.join(ROOT, "oracle", "_ref", "ref_path_time")
-    if not os.path.exists(exe):
-        return None, None
-    from rf_inv_amd import read_ref_model, write_params
-    from rf_inv_amd.make_syn import write_sac
+    from oracle import refrun
 
-    golden = os.path.join(ROOT, "tests", "golden", "sample_syn")
-    ref = read_ref_model(os.path.join(golden, "model", "sample.velmod"))
-    nlay, _, (m_k, m_z, m_dvp, m_dvs) = draw_walkers(p, ref, 0, count, return_models=True)     # the rank-0 walkers again
+    if not refrun.available(build):
+        return None, None
+    from rf_inv_amd import read_ref_model
+
+    ref = read_ref_model(os.path.join(ROOT, "tests", "golden", "sample_syn", "model", "sample.velmod"))
+    nlay, _, (m_k, m_z, m_dvp, m_dvs) = draw_walkers(p, ref, 0, count, return_models=True, procs=1)   # the rank-0 walkers again
     n = count
     try:
         with tempfile.TemporaryDirectory() as work:
-            for d in ("data", "rslt", "model"):
-                os.makedirs(os.path.join(work, d))
-            shutil.copy(os.path.join(golden, "model", "sample.velmod"), os.path.join(work, "model", "sample.velmod"))
-            q = copy.copy(p)
-            q.out_dir, q.nchains, q.ncool, q.nburn, q.niter, q.dvs_prior = "./rslt", 1, 1, 0, 10, 0.3
-            q.vel_file, q.obs_files = "model/sample.velmod", [f"data/t{t + 1}.trc" for t in range(p.ntrc)]
-            for t, f in enumerate(q.obs_files):
-                write_sac(os.path.join(work, f), obs[t, :p.nsmp], p.delta, p.t_start, p.t_end)
-            write_params(os.path.join(work, "params.in"), q)
-            with open(os.path.join(work, "models.txt"), "w") as fh:
-                fh.write(f"{n}\n")
-                for i in range(n):
-                    fh.write(f"{int(m_k[i])}\n")
-                    for arr in (m_z[i, :max(p.k_max - 1, 1)], m_dvp[i, :p.k_max], m_dvs[i, :p.k_max], np.full(p.ntrc, 0.01)):
-                        fh.write(" ".join(repr(float(x)) for x in arr) + "\n")
-            def parse(out):
-                line = [l for l in out.splitlines() if "ref_path_dump: seconds" in l]
-                if not line:
-                    raise ValueError("no timing line")
-                tok = line[0].split()
-                return float(tok[2]), int(tok[4])
-
+            refrun.write_run_dir(work, p, obs=obs, header="bench.py cpu_baseline")
+            refrun.write_models(os.path.join(work, "models.txt"), p.k_max, m_k, m_z, m_dvp, m_dvs, np.full((n, p.ntrc), 0.01))
             # one pass first (page-in; its time sizes the timed run to the budget)
-            # The children's environment: WITHOUT the OpenMP binding this process set for the port's threads (inherited,
-            # OMP_PLACES=cores + OMP_PROC_BIND pin every child's main thread to the first core: sixteen processes on one
-            # core measured 5.9 evals/s each), and with one GPU queue per process and no SDMA queues (more host processes
-            # than the GPU keeps queues mapped for are time-sliced: 54 -> 69 evals/s per process at sixteen)
-            child_env = {k: v for k, v in os.environ.items() if not k.startswith("OMP_")}
-            child_env.update(HSA_ENABLE_SDMA="0", GPU_MAX_HW_QUEUES="1")
-            r = subprocess.run([exe, "params.in", "models.txt", "ref.bin", "1"], cwd=work, capture_output=True, text=True,
-                               timeout=600, env=child_env)
-            if r.returncode != 0:
-                return None, None
-            secs, evals = parse(r.stdout)
-            reps = int(max(1, min(50, budget_s / max(secs, 1e-3))))
-            runs = [subprocess.Popen([exe, "params.in", "models.txt", f"ref_{i}.bin", str(reps)], cwd=work, env=child_env,
+            first = refrun.run_path(build, work, n, p, reps=1)
+            reps = int(max(1, min(200, budget_s / max(first["seconds"], 1e-3))))
+            exe = refrun.exe(build, "ref_path_dump")
+            runs = [subprocess.Popen([exe, "params.in", "models.txt", f"ref_{i}.bin", str(reps)], cwd=work, env=refrun.clean_env(),
                                      stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for i in range(procs)]
             try:
-                outs = [q.communicate(timeout=180)[0] for q in runs]
+                outs = [q.communicate(timeout=300)[0] for q in runs]
             finally:
                 for q in runs:              # (a child that outlives its time must not keep the cores busy under the GPU runs)
                     if q.poll() is None:
@@ -575,22 +551,22 @@ def reference_path_rate(p, obs, budget_s=8.0, count=24, procs=1):
                         q.wait()
             if any(q.returncode != 0 for q in runs):
                 return None, None
-            each = [parse(o) for o in outs]
+            each = []
+            for o in outs:
+                tok = [l for l in o.splitlines() if "ref_path_dump: seconds" in l][0].split()
+                each.append((float(tok[2]), int(tok[4])))
             secs, evals = max(e[0] for e in each), sum(e[1] for e in each)
-            raw = open(os.path.join(work, "ref.bin"), "rb").read()
-            nsmp = int(np.frombuffer(raw[8:12], dtype="<i4")[0])
-            body = np.frombuffer(raw[20:], dtype="<f8")
-            o = nsmp * nsmp * p.ntrc
-            ll = body[o:o + n * (1 + p.nfft * p.ntrc)].reshape(n, 1 + p.nfft * p.ntrc)[:, 0].copy()
+        flags = "-O2 -ffp-contract=off" if build == "cpu_o2" else "-O0 -ffp-contract=off (the reference Makefile's default class)"
         return ({"value": evals / secs, "unit": "evals/s", "cores": procs, "kind": "reference", "per_core": evals / secs / procs,
-                 "sample_short": f"{evals} calc_likelihood calls of the reference's own code, {procs} process(es) = cores, "
-                                 f"{secs:.1f} s; c2r via the drop-in module fftw (GPU round trips counted)",
+                 "build": build,
+                 "sample_short": f"{evals} calc_likelihood calls of the reference's own code ({build}) on host cores only, "
+                                 f"{procs} process(es) = cores, {secs:.1f} s",
                  "sample": f"{evals} calc_likelihood(fwd_flag = .true.) calls on {n} of this workload's walkers (mean "
                            f"{float(np.mean(nlay)):.1f} layers) by {procs} concurrent process(es), one per core, {secs:.1f} s (the "
-                           "slowest); src/likelihood.f90 + src/forward.f90 + host modules unmodified, amdflang -O2 "
-                           "-ffp-contract=off, dgesvd from MKL; c2r through the drop-in module fftw (GPU round trips included)"},
-                ll)
-    except (OSError, subprocess.SubprocessError, ValueError, IndexError):
+                           f"slowest); all of the reference's sources unmodified, amdflang {flags}, its own module fftw on the "
+                           "FFTW3 interface of Intel MKL, dgesvd from MKL; no GPU involved"},
+                first["logl"])
+    except (OSError, subprocess.SubprocessError, ValueError, IndexError, RuntimeError, AssertionError):
         return None, None
 
 
@@ -633,6 +609,9 @@ def spawn_ranks(n, argv):
     port = sk.getsockname()[1]
     sk.close()
     procs = []
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver supports only dmabuf IPC; with the legacy mode RCCL's (and torch's)
+    # cross-process device-memory handles fail with `hipIpcGetMemHandle: invalid argument`.  The image exports it already
+    # (here and on the GPU boxes); it is repeated so that ranks started from a scrubbed environment still get it.
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
@@ -715,14 +694,16 @@ def headline_line(full, detail_file):
                             counters_file=(roof.get("counters") or {}).get("file"))
     line["roofline_hbm"] = pick(hbm, ("bound", "unit", "peak", "achieved", "frac"))
     if cpu:
-        line["cpu_baseline"] = dict(pick(cpu, ("value", "unit", "cores", "kind", "per_core", "single_core")),
+        line["cpu_baseline"] = dict(pick(cpu, ("value", "unit", "cores", "kind", "per_core", "single_core", "build")),
                                     sample=cpu.get("sample_short") or (cpu.get("sample") or "")[:120])
+        if cpu.get("o0"):               # the reference Makefile's default -O0 class beside the -O2 build
+            line["cpu_baseline"]["o0"] = pick(cpu["o0"], ("value", "cores", "per_core", "single_core"))
         if cpu.get("port"):             # kind "reference": the C port's figures beside it
             line["cpu_baseline"]["port"] = pick(cpu["port"], ("value", "cores", "per_core"))
             line["cpu_baseline"]["reference_over_port"] = (cpu.get("reference_over_port") or {}).get("all_cores")
     if par:
         line["parity_in_bench"] = pick(par, ("n", "max_abs_dlogl", "max_rel_dlogl", "within_tolerance",
-                                             "n_used_kappa_allowance"))
+                                             "n_used_kappa_allowance", "within_kappa_rule"))
     for k in ("swap_replay_ok", "cross_rank_swaps", "cpu_leg_error"):
         if k in full:
             line[k] = full[k]
@@ -788,7 +769,7 @@ def main():
                          "reference's one pair per iteration via send/recv")
     ap.add_argument("--also", default=None,
                     help="comma list of extra workloads measured briefly into 'also' (default at N = 1: "
-                         "c2,c2d,c3,c5,c4common,c4w20,c4w60,c4win,c5win,c4stale,c4host; '' for none; <name>host = that workload "
+                         "c2,c2d,c3,c5,c4common,c4d,c5d,c4w20,c4w60,c4win,c5win,c4stale,c4host,c4full,c5full; '' for none; <name>host = that workload "
                          "handed over from pinned host arrays every step, the PCIe-inclusive boundary)")
     ap.add_argument("--prewarm-seconds", type=float, default=1.0,
                     help="untimed steps run for at least this long before --warmup (clock ramp; independent of --warmup)")
@@ -832,6 +813,34 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    # N > 1: a run that dies in the rendezvous, in librfgpu's RCCL bootstrap or in the first steps must still say so in ONE
+    # JSON line on rank 0's stdout ("value": null, "error", how far it got) before the non-zero exit -- a plain exit,
+    # never a re-exec.  `progress` is what the line reports.
+    progress = {"stage": "start", "rccl": {"control_plane": None, "init_s": None, "transport": None, "version": None}}
+    line_done = [False]
+
+    def failure_line(error):
+        if line_done[0] or int(os.environ.get("RANK", "0")) != 0:
+            return
+        line_done[0] = True
+        rec = {"metric": METRIC, "value": None, "unit": "evals/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+               "data": "synthetic", "error": str(error)[:400], "reached": progress["stage"],
+               "config": {"workload": WORKLOADS[args.workload]["desc"][:200], "rccl": progress["rccl"]}}
+        try:
+            os.write(real_stdout, (json.dumps(rec, separators=(",", ":")) + "\n").encode())
+        except OSError:
+            pass
+
+    if args.gpus > 1:
+        import signal
+
+        def _terminated(signum, frame):       # the launcher takes the ranks down when one of them failed
+            failure_line(f"rank 0 received signal {signum} at stage '{progress['stage']}' (another rank failed, or the launcher timed out)")
+            os._exit(6)
+
+        signal.signal(signal.SIGTERM, _terminated)
+
     stray = sorted(k for k in os.environ if k.startswith("RFGPU_") and k not in ENV_ALLOWED)
     if stray:
         raise SystemExit(f"bench.py: refusing to run with {stray} in the environment: librfgpu reads no environment "
@@ -871,14 +880,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost"):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # one node: never resolve the container's host name
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
-                                    timeout=datetime.timedelta(seconds=300))
-        else:
-            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+        progress["stage"], progress["rccl"]["control_plane"] = "process_group_init", backend
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=300))
+            else:
+                dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+        except Exception as e:      # noqa: BLE001
+            failure_line(f"process group ({backend}) rendezvous failed: {type(e).__name__}: {e}")
+            raise
+        progress["stage"] = "process_group_formed"
     if not torch.cuda.is_available():
+        failure_line("no GPU visible: the hot path has no CPU fallback")
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
     if not shared and world > torch.cuda.device_count():
+        failure_line(f"{world} ranks but {torch.cuda.device_count()} visible GPU(s): one GPU per rank")
         raise SystemExit(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible GPU(s): one GPU per rank")
     if shared:
         local_rank = local_rank % torch.cuda.device_count()
@@ -936,15 +953,20 @@ def main():
             def _stuck():
                 print(f"bench.py: rank {rank}: librfgpu's RCCL bootstrap (rf_comm_init, {world} ranks) did not finish "
                       f"within {args.comm_init_timeout:.0f} s: giving up (exit code 4)", file=sys.stderr, flush=True)
+                failure_line(f"rf_comm_init ({world} ranks) did not finish within {args.comm_init_timeout:.0f} s")
                 os._exit(4)
 
             dog = threading.Timer(args.comm_init_timeout, _stuck)
             dog.daemon = True
             dog.start()
             t_boot = time.perf_counter()
+            progress["stage"] = "rf_comm_init"
             over_rccl = open_exchange(eng, dist, shared_gpu_ok=bool(args.rccl_library))
             dog.cancel()
             comm_boot_s[0] = time.perf_counter() - t_boot
+            progress["stage"] = "communicator_formed"
+            progress["rccl"].update(init_s=comm_boot_s[0], transport="rccl_allgather" if over_rccl else "process_group",
+                                    version=eng.comm_info()["rccl_version"])
         swap = (PTSwap(eng, nb, w["temps"], dev, seed=1234, t_high=15.0, mode=args.swap, rccl=over_rccl)
                 if w["temps"] > 1 else None)
         # --perturb-nlay: NV pre-built depth vectors cycled through, so that the timed loop does nothing extra
@@ -1017,16 +1039,20 @@ def main():
                 print(f"bench.py: rank {rank}: the first steps with the temperature exchange did not finish within "
                       f"{args.comm_init_timeout:.0f} s (transport: {'librfgpu RCCL' if over_rccl else 'process group'}): giving up "
                       "(exit code 4)", file=sys.stderr, flush=True)
+                failure_line(f"the first steps with the temperature exchange did not finish within {args.comm_init_timeout:.0f} s")
                 os._exit(4)
 
             first = threading.Timer(args.comm_init_timeout, _stuck_step)
             first.daemon = True
             first.start()
+        if world > 1:
+            progress["stage"] = "first_steps"
         for i in range(8):
             timed_step(i, scratch)
         torch.cuda.synchronize(dev)
         if first is not None:
             first.cancel()
+            progress["stage"] = "steps_running"
         eng.profile_enable(False)
         eng.profile_read()
         t_pre = time.perf_counter()
@@ -1276,9 +1302,14 @@ def main():
             else:
                 orc.build()
                 n = min(nb, parity_n)
-                ll_cpu = orc.eval_batch(cfg, obs, r_inv, nlay_eval[:n], layers[:n], sig[:n], p.nsmp, nthreads=nthr)   # the checker build
-            res["parity_in_bench"] = parity_report(orc, cfg, obs, r_inv, nlay_eval[:n], layers[:n], sig[:n], p.nsmp,
-                                                   ll_gpu[:n], ll_cpu, nthr)
+                ll_cpu = None
+            # the compared walkers: the first n, and (side workloads) the n // 4 highest walker ids of the rank as well
+            pidx = np.arange(n) if with_cpu or n == nb else np.unique(np.concatenate([np.arange(n - n // 4), np.arange(nb - n // 4, nb)]))
+            if ll_cpu is None:
+                ll_cpu = orc.eval_batch(cfg, obs, r_inv, nlay_eval[pidx], layers[pidx], sig[pidx], p.nsmp, nthreads=nthr)   # the checker build
+            res["parity_in_bench"] = parity_report(orc, cfg, obs, r_inv, nlay_eval[pidx], layers[pidx], sig[pidx], p.nsmp,
+                                                   ll_gpu[pidx], ll_cpu, nthr)
+            res["parity_in_bench"]["walker_id_range"] = [int(pidx.min()), int(pidx.max())]
           except Exception as e:      # noqa: BLE001  (the CPU side failing must not take the measured line with it)
             print(f"bench.py: the CPU leg (cpu_baseline / parity_in_bench) of {workload} failed: {type(e).__name__}: {e}",
                   file=sys.stderr)
@@ -1286,8 +1317,14 @@ def main():
         eng.close()
         return res
 
-    main_res = run(args.workload, args.steps, args.warmup, not args.no_cpu_baseline and world == 1)
-    also_list = args.also if args.also is not None else ("c2,c2d,c3,c5,c4common,c4w20,c4w60,c4win,c5win,c4stale,c4host" if world == 1 else "")
+    try:
+        main_res = run(args.workload, args.steps, args.warmup, not args.no_cpu_baseline and world == 1)
+    except BaseException as e:      # noqa: BLE001  (N > 1: the failure still gets its JSON line; then the error as it was)
+        if world > 1 and not isinstance(e, KeyboardInterrupt):
+            failure_line(f"{type(e).__name__}: {e}")
+        raise
+    progress["stage"] = "measured"
+    also_list = args.also if args.also is not None else ("c2,c2d,c3,c5,c4common,c4d,c5d,c4w20,c4w60,c4win,c5win,c4stale,c4host,c4full,c5full" if world == 1 else "")
     also = {}
     keep = ("value", "ms_per_step", "ms_per_step_median", "steps", "config", "roofline", "kernel_ms", "parity_in_bench",
             "quadratic_form_gemm")
@@ -1312,6 +1349,8 @@ def main():
             return rec
         # long enough that one host hiccup does not show: about 0.4 s of steps for the small shapes
         n_also = max(30, min(200, args.steps))
+        if wl.endswith("full"):      # the whole 8-GPU job on one GPU: 15 / 100 ms per step
+            n_also = min(n_also, 60)
         if args.steps >= 10:     # (the counter passes of tools/collect_counters.sh ask for 3 steps and get them)
             n_also = max(n_also, min(6000, int(400.0 / ALSO_NOMINAL_MS.get(wl, 2.0))))
         r = run(wl, n_also, max(5, min(20, args.warmup)), False)
@@ -1353,6 +1392,15 @@ def main():
                                                        "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
                               | {"config": {"workload": (out.get("config") or {}).get("workload")}})
         os.write(real_stdout, (line + "\n").encode())
+        line_done[0] = True
+    # parity of the headline workload: the line is printed either way; a run whose checker leg died, or whose walkers are
+    # outside both the tolerance and the conditioning rule, ends with exit code 5
+    par = main_res.get("parity_in_bench")
+    parity_failed = rank == 0 and world == 1 and (
+        "cpu_leg_error" in main_res or (par is not None and not (par["within_tolerance"] or par["within_kappa_rule"])))
+    if parity_failed:
+        print("bench.py: parity of the headline workload is NOT established (cpu_leg_error, or walkers outside the tolerance "
+              "and the conditioning rule): exit code 5 -- the JSON line above carries the details", file=sys.stderr)
     failed = rank == 0 and main_res.get("swap_replay_ok") is False
     if failed:
         print("bench.py: the final temperatures do NOT equal the serial replay of the swap schedule: the temperature "
@@ -1361,6 +1409,8 @@ def main():
         dist.destroy_process_group()
     if failed:
         raise SystemExit(3)
+    if parity_failed:
+        raise SystemExit(5)
 
 
 if __name__ == "__main__":

@@ -443,6 +443,7 @@ static int alloc_traces(rf_ctx *c, int len)
     c->ws.rft = (double *)p;
     c->ws.trace_len = len;
     HIP_TRY(hipMemset(p, 0, sizeof(double) * elems));
+    HIP_TRY(hipDeviceSynchronize());   // (a memset of device memory may return early; c->stream is non-blocking: nothing else orders it)
     return 0;
 }
 
@@ -755,6 +756,8 @@ extern "C" int rf_ctx_create(const rf_config *cfg, rf_ctx **ctx_out)
                         fused8_lds_bytes(lnsmp, cfg->nlay_max) <= 80 * 1024;
     default_plan(c);
     if (!c->fused && !c->fusedc && ensure_spec(c)) return cleanup(1);
+    // the creation-time memsets above went to the NULL stream and may return early; the context's stream is non-blocking
+    if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail("rf_ctx_create: hipDeviceSynchronize failed"));
     *ctx_out = c;
     return 0;
 }
@@ -1210,7 +1213,10 @@ extern "C" int rf_set_r_inv(rf_ctx *c, const double *r_inv)
     // The cached quadratic forms of the stored traces (what a sigma-only proposal re-uses, src/likelihood.f90:81) belong
     // to the OLD matrix: they become NaN, so that such a proposal fails loudly until the chain has been re-evaluated and
     // committed (set the matrix before the first evaluation, as the Fortran shim does).
-    HIP_TRY(hipMemset(c->ws.phi, 0xFF, sizeof(double) * 2 * (size_t)c->nslots * (size_t)c->cfg.ntrc));
+    // (on the context's own stream and waited for: c->stream is non-blocking, a NULL-stream memset would not be ordered
+    // against the evaluation or commit the caller issues next)
+    HIP_TRY(hipMemsetAsync(c->ws.phi, 0xFF, sizeof(double) * 2 * (size_t)c->nslots * (size_t)c->cfg.ntrc, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 

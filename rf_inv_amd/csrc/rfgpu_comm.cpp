@@ -80,7 +80,10 @@ Rccl *rccl()
 struct rfgpu::CommState {
     ncclComm_t comm = nullptr;
     int rank = 0, nranks = 1;
-    double *d_buf = nullptr;     // [8] staging: [0..2] outgoing (T, logL, log u), [4..6] incoming
+    // staging, three disjoint areas of 8 doubles (the host-value exchanges run on the communicator's own stream, the merge on
+    // the evaluation stream: no two entry points share a word): [0..7] rf_pt_swap_exchange ([0..2] outgoing (T, logL,
+    // log u), [4..6] incoming), [8..15] rf_comm_bcast_i32, [16..23] rf_comm_post_reduce
+    double *d_buf = nullptr;
     double *h_buf = nullptr;     // pinned mirror
     double *d_gather = nullptr;  // [2][nranks * nchains]: every rank's T, then every rank's logL, by global walker id
     size_t gather_doubles = 0;
@@ -180,8 +183,8 @@ extern "C" int rf_comm_init(rf_ctx *c, const uint8_t *id, int32_t rank, int32_t 
         return comm_fail(std::string("rf_comm_init: ncclCommInitRank: ") + (R->GetErrorString ? R->GetErrorString(r) : "error") +
                          " (one rank per GPU is required: RCCL refuses two ranks on one device)");
     }
-    if (hipMalloc((void **)&s->d_buf, sizeof(double) * 8) != hipSuccess ||
-        hipHostMalloc((void **)&s->h_buf, sizeof(double) * 8, hipHostMallocDefault) != hipSuccess ||
+    if (hipMalloc((void **)&s->d_buf, sizeof(double) * 24) != hipSuccess ||
+        hipHostMalloc((void **)&s->h_buf, sizeof(double) * 24, hipHostMallocDefault) != hipSuccess ||
         hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) != hipSuccess) {
         R->CommDestroy(s->comm);
         if (s->d_buf) (void)hipFree(s->d_buf);
@@ -223,7 +226,7 @@ extern "C" int rf_comm_bcast_i32(rf_ctx *c, int32_t *buf, int32_t n, int32_t roo
     Rccl *R = rccl();
     hipStream_t st = s->stream;
     HIPC_TRY(hipSetDevice(ctx_device(c)));
-    int32_t *hb = reinterpret_cast<int32_t *>(s->h_buf), *db = reinterpret_cast<int32_t *>(s->d_buf);
+    int32_t *hb = reinterpret_cast<int32_t *>(s->h_buf + 8), *db = reinterpret_cast<int32_t *>(s->d_buf + 8);
     if (s->rank == root) {
         std::memcpy(hb, buf, sizeof(int32_t) * n);
         HIPC_TRY(hipMemcpyAsync(db, hb, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
@@ -377,9 +380,7 @@ extern "C" int rf_comm_post_reduce(rf_ctx *c, int32_t root, int32_t *nmod_sum)
         {p->vpvs_mean, nz, ncclDouble},
         {p->amp_oor, 1, ncclInt64},
     };
-    // (d_buf / h_buf also serve the host-value exchanges on the communicator's stream: those are synchronous, so
-    // nothing of theirs is in flight here)
-    int32_t *d_nmod = reinterpret_cast<int32_t *>(s->d_buf), *h_nmod = reinterpret_cast<int32_t *>(s->h_buf);
+    int32_t *d_nmod = reinterpret_cast<int32_t *>(s->d_buf + 16), *h_nmod = reinterpret_cast<int32_t *>(s->h_buf + 16);
     // one group of twelve reductions (one launch); rf_comm_set_option("sequential_reduce", 1): twelve plain calls, one
     // after the other on the stream -- the same sums, for an RCCL build that mishandles in-place reductions in a group
     if (!s->sequential_reduce) RCCL_TRY(R->GroupStart());

@@ -56,7 +56,7 @@ def _workload(name, walkers=None):
     return w, p, cfg, obs, r_inv, nlay, layers
 
 
-def _run_config(name, expect_defer, nsample, extra_check=None, walkers=None):
+def _run_config(name, expect_defer, nsample, extra_check=None, walkers=None, oracle_sample=None):
     import torch
 
     from oracle import rf_oracle as oracle
@@ -136,22 +136,31 @@ def _run_config(name, expect_defer, nsample, extra_check=None, walkers=None):
         # (4) EVERY walker of the batch against the oracle, conditioning accounted for (the rule above
         # test_randomised_contexts_against_oracle): an item may exceed the plain tolerance only if kappa >= KAPPA_MIN
         # and must then stay within tolerance * kappa / KAPPA_SCALE; items below KAPPA_MIN get no allowance
-        ref, kap = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, nsmp, nthreads=oracle.max_threads(),
-                                     want_kappa=True)
-        d = np.abs(ll - ref)
-        tol = logl_tol(ref)
+        # (oracle_sample: the whole-job-on-one-GPU sizes compare that many walkers -- the first, the last and a random
+        # draw -- and mark the others as conditioned well enough not to be looked at)
+        if oracle_sample and oracle_sample < nb:
+            cmp_idx = np.unique(np.concatenate([np.arange(oracle_sample // 4), np.arange(nb - oracle_sample // 4, nb),
+                                                rng.choice(nb, oracle_sample // 2, replace=False)]))
+        else:
+            cmp_idx = np.arange(nb)
+        ref_c, kap_c = oracle.eval_batch(cfg, obs, r_inv, nlay[cmp_idx], layers[cmp_idx], sig[cmp_idx], nsmp,
+                                         nthreads=oracle.max_threads(), want_kappa=True)
+        ref, kap = np.full(nb, np.nan), np.ones(nb)
+        ref[cmp_idx], kap[cmp_idx] = ref_c, kap_c
+        d = np.abs(ll[cmp_idx] - ref_c)
+        tol = logl_tol(ref_c)
         over = np.nonzero(~(d <= tol))[0]
         for i in over:
-            assert kap[i] >= KAPPA_MIN, (name, int(i), "well-conditioned walker off tolerance", ll[i], ref[i], kap[i])
-            assert d[i] <= tol[i] * kap[i] / KAPPA_SCALE, (name, int(i), ll[i], ref[i], kap[i])
-        assert len(over) <= max(2, nb // 100), (name, len(over))
+            assert kap_c[i] >= KAPPA_MIN, (name, int(cmp_idx[i]), "well-conditioned walker off tolerance", ll[cmp_idx[i]], ref_c[i], kap_c[i])
+            assert d[i] <= tol[i] * kap_c[i] / KAPPA_SCALE, (name, int(cmp_idx[i]), ll[cmp_idx[i]], ref_c[i], kap_c[i])
+        assert len(over) <= max(2, len(cmp_idx) // 100), (name, len(over))
         worst = int(np.argmax(d / tol))
-        report = {"config": name, "walkers": int(nb), "compared": int(nb), "n_kappa_ge_100": int(np.sum(kap >= KAPPA_MIN)),
-                  "n_used_kappa_allowance": int(len(over)), "max_rel_dlogl": float((d / np.abs(ref)).max()),
-                  "max_abs_dlogl": float(d.max()),
-                  "worst": {"walker": worst, "nlay": int(nlay[worst]), "logl": float(ref[worst]), "abs": float(d[worst]),
-                            "rel": float(d[worst] / abs(ref[worst])), "tolerance_used": float(d[worst] / tol[worst]),
-                            "kappa": float(kap[worst])}}
+        report = {"config": name, "walkers": int(nb), "compared": int(len(cmp_idx)), "n_kappa_ge_100": int(np.sum(kap_c >= KAPPA_MIN)),
+                  "n_used_kappa_allowance": int(len(over)), "max_rel_dlogl": float((d / np.abs(ref_c)).max()),
+                  "max_abs_dlogl": float(d.max()), "highest_walker_compared": int(cmp_idx.max()),
+                  "worst": {"walker": int(cmp_idx[worst]), "nlay": int(nlay[cmp_idx[worst]]), "logl": float(ref_c[worst]),
+                            "abs": float(d[worst]), "rel": float(d[worst] / abs(ref_c[worst])),
+                            "tolerance_used": float(d[worst] / tol[worst]), "kappa": float(kap_c[worst])}}
         print("full-batch parity:", report)
         out_dir = os.path.join(ROOT, "gpurun_out")
         if os.path.isdir(out_dir):
@@ -162,8 +171,11 @@ def _run_config(name, expect_defer, nsample, extra_check=None, walkers=None):
         # traces of sampled walkers (the deepest, the true model, the highest walker ids -- at C5 beyond the 4 GiB
         # mark of the trace array -- and the worst-conditioned ones)
         deep = np.argsort(nlay)[-4:]
-        idx = np.unique(np.concatenate([rng.choice(nb, nsample, replace=False), deep, [nb - 1, nb - 2, nb - 3],
+        idx = np.unique(np.concatenate([rng.choice(cmp_idx, nsample, replace=False), deep, [nb - 1, nb - 2, nb - 3],
                                         np.argsort(kap)[-2:], np.arange(nb - 1, nb // 2, -(nb // 16))]))
+        if len(cmp_idx) < nb:               # (the conditioning of walkers outside the compared sample)
+            kap[idx] = oracle.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], nsmp, nthreads=oracle.max_threads(),
+                                         want_kappa=True)[1]
         _, ref_rft = oracle.eval_batch(cfg, obs, r_inv, nlay[idx], layers[idx], sig[idx], nsmp, want_rft=True,
                                        nthreads=oracle.max_threads())
         eng.eval_batch(np.arange(nb), nlay, layers, sig)                        # proposals = the compared batch again
@@ -226,6 +238,31 @@ def test_c5_default_plan_full_batch():
             assert np.abs(got - ref_rft[i]).max() <= 1e-12 * np.abs(ref_rft[i]).max(), i
 
     _run_config("c5", expect_defer=True, nsample=64, extra_check=land_in_ocean_context)
+
+
+def test_c4d_default_plan_full_batch():
+    """C4 with water-level deconvolution (deconv_mode 1: P traces R / V, the S trace V / R, src/forward.f90:148-153,
+    447-470; the 256-thread kernel's in-place water level): every one of the 8192 walkers x 3 traces."""
+    _run_config("c4d", expect_defer=True, nsample=36)
+
+
+def test_c5d_default_plan_full_batch():
+    """C5 with water-level deconvolution: 32768 walkers x (P, P, S, S) under the ocean layer, every walker."""
+    _run_config("c5d", expect_defer=True, nsample=48)
+
+
+def test_c4full_all_of_configs3_on_one_gpu():
+    """ALL of BASELINE configs[3] on one GPU: 65536 walkers x 3 traces (12.9 GB of double-buffered traces).  The
+    size-independent properties and the swap replay at full size; every walker against the oracle."""
+    _run_config("c4full", expect_defer=True, nsample=48)
+
+
+def test_c5full_all_of_configs4_on_one_gpu():
+    """ALL of BASELINE configs[4] on one GPU: 262144 walkers x 4 traces under the ocean layer, 68.7 GB of
+    double-buffered traces (byte offsets to 2^36).  The size-independent properties (permutation invariance bit for bit,
+    sigma scaling, the true model at the last walker id, the swap replay) on all 262144; logL of 32768 walkers -- the
+    first, the LAST 8192 ids and a random draw -- and traces incl. the highest ids against the oracle."""
+    _run_config("c5full", expect_defer=True, nsample=48, oracle_sample=32768)
 
 
 def test_c4_20s_window_full_batch():
