@@ -725,7 +725,7 @@ def headline_line(full, detail_file):
     return s
 
 
-KAPPA_MIN, KAPPA_SCALE = 100.0, 10.0      # the conditioning rule of tests/test_gpu_configs.py
+KAPPA_MIN, KAPPA_SCALE = 1000.0, 1000.0      # the conditioning rule of tests/test_gpu_configs.py
 
 
 def parity_report(orc, cfg, obs, r_inv, nlay, layers, sig, nsmp, ll_gpu, ll_cpu, nthreads=1):
@@ -734,7 +734,8 @@ def parity_report(orc, cfg, obs, r_inv, nlay, layers, sig, nsmp, ll_gpu, ll_cpu,
     filtered vertical trace (forward.f90:201-202); kappa = max|rx| / |maxval(rx)| says how much of that trace's
     scale cancels in the divisor -- its rounding, in any double evaluation including the reference's, is amplified
     kappa-fold in every sample and 2 kappa-fold in logL.  An item may exceed the plain tolerance only if its kappa
-    (from the oracle's own vertical trace) is >= 100, and must then stay within tolerance * kappa / 10."""
+    (from the oracle's own vertical trace) is >= 1000, and must then stay within tolerance * kappa / 1000 (the scale the reference's own spread supports:
+    profiles/r06_kappa_reference_spread.json, tests/helpers.py)."""
     d = np.abs(ll_gpu - ll_cpu)
     tol = np.maximum(1e-9, 1e-12 * np.abs(ll_cpu))
     rel = d / np.abs(ll_cpu)

@@ -407,8 +407,12 @@ __device__ __forceinline__ void sincos_cw(double x, double &sn, double &cs)
     const bool sw = q & 1;
     double ss = sw ? c1 : s1;
     double cc = sw ? s1 : c1;
-    sn = (q & 2) ? -ss : ss;
-    cs = ((q + 1) & 2) ? -cc : cc;
+    // (the sign flips as integer work on the high word -- bit 1 of q resp. q + 1 moved to the sign bit and xor-ed in: three
+    // VALU instructions each instead of the compare / negate / select four; the same bits, NaN included)
+    const unsigned fs = ((unsigned)q << 30) & 0x80000000u;
+    const unsigned fc = ((unsigned)(q + 1) << 30) & 0x80000000u;
+    sn = __hiloint2double(__double2hiint(ss) ^ (int)fs, __double2loint(ss));
+    cs = __hiloint2double(__double2hiint(cc) ^ (int)fc, __double2loint(cc));
 }
 
 // Wave-uniform constants read straight from stage_kernel's global image go through the SCALAR data path
@@ -866,6 +870,9 @@ __device__ __forceinline__ void spectra_chunk_chain(const SpectraParams &P, CP c
             sincos_cw(ax0, sx, cx);
             sincos_cw(ae0, se, ce);
             apply_layer_trig_unit<NCOL>(st[0], c, sx, cx, se, ce);
+            // (round 6: testing it0 == 0 first -- wave-uniform, only that chunk holds the DC bin -- so that the other
+            // waves skip these eight selects was measured: C4 -0.5 %, but C2 +5.5 % and C3 +1 % (the eight-wave kernels'
+            // register assignment shifts) and 29 instead of 19 spills in the ocean chain; profiles/EXPERIMENTS.md)
             cEx = dc ? 1.0 : fma(sx, ex0, cx);
             sEx = dc ? 0.0 : fma(-cx, ex0, sx);
             cEe = dc ? 1.0 : fma(se, ee0, ce);

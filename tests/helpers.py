@@ -56,13 +56,21 @@ def logl_tol(ref):
     return np.maximum(1e-9, 1e-12 * np.abs(ref))
 
 
-KAPPA_MIN, KAPPA_SCALE = 100.0, 10.0
+KAPPA_MIN, KAPPA_SCALE = 1000.0, 1000.0      # backed by profiles/r06_kappa_reference_spread.json, see assert_logl_parity
 
 
 def assert_logl_parity(got, ref, kappa, what=""):
     """|dlogL| <= logl_tol for every item; an item may exceed it only under the conditioning rule of
     tests/test_gpu_configs.py: kappa = max|rx| / |maxval(rx)| of the oracle's own vertical trace
-    >= 100, and then within tolerance * kappa / 10.  Items below kappa = 100 get no allowance."""
+    >= 1000, and then within tolerance * kappa / 1000.  Items below kappa = 1000 get no allowance.
+    Why that scale (round 6, profiles/r06_kappa_reference_spread.json: all 103 items that needed an allowance in three
+    randomised sweeps, re-evaluated on the CPU): the divisor maxval(rx) carries an absolute rounding error of c * 1.1e-16 *
+    max|rx|, i.e. a relative error c * 1.1e-16 * kappa, twice that in logL = 2.2e-4 * c * kappa in units of the 1e-12
+    relative tolerance.  Measured: the HIP path against the reference's own -O0 build <= 2.7e-4 kappa; the oracle with its
+    FFT against the oracle with the O(n^2) definition of the SAME transform <= 2.6e-4 kappa (86 of the 103 items beyond the
+    plain tolerance: two correct inverse transforms -- the reference links an unpinned FFTW -- already disagree by that
+    much); two builds of the reference itself (-O0 / -O2, same MKL transform) <= 1.5e-5 kappa (10 items beyond the plain
+    tolerance).  kappa / 1000 leaves c <= 4.5; rounds 3-5 used kappa / 10, a hundred times looser than anything seen."""
     got, ref, kappa = np.asarray(got), np.asarray(ref), np.asarray(kappa)
     d = np.abs(got - ref)
     tol = logl_tol(ref)

@@ -21,7 +21,7 @@ if ROOT not in sys.path:
 
 pytestmark = pytest.mark.gpu
 
-KAPPA_MIN, KAPPA_SCALE = 100.0, 10.0      # the conditioning rule (see above test_randomised_contexts_against_oracle)
+KAPPA_MIN, KAPPA_SCALE = 1000.0, 1000.0      # the conditioning rule (see above test_randomised_contexts_against_oracle)
 
 
 def _workload(name, walkers=None):
@@ -155,7 +155,7 @@ def _run_config(name, expect_defer, nsample, extra_check=None, walkers=None, ora
             assert d[i] <= tol[i] * kap_c[i] / KAPPA_SCALE, (name, int(cmp_idx[i]), ll[cmp_idx[i]], ref_c[i], kap_c[i])
         assert len(over) <= max(2, len(cmp_idx) // 100), (name, len(over))
         worst = int(np.argmax(d / tol))
-        report = {"config": name, "walkers": int(nb), "compared": int(len(cmp_idx)), "n_kappa_ge_100": int(np.sum(kap_c >= KAPPA_MIN)),
+        report = {"config": name, "walkers": int(nb), "compared": int(len(cmp_idx)), "n_kappa_ge_1000": int(np.sum(kap_c >= KAPPA_MIN)),
                   "n_used_kappa_allowance": int(len(over)), "max_rel_dlogl": float((d / np.abs(ref_c)).max()),
                   "max_abs_dlogl": float(d.max()), "highest_walker_compared": int(cmp_idx.max()),
                   "worst": {"walker": int(cmp_idx[worst]), "nlay": int(nlay[cmp_idx[worst]]), "logl": float(ref_c[worst]),

@@ -1,18 +1,16 @@
-"""The reference's OWN forward module on the drop-in `module fftw`.
+"""The drop-in `module fftw` under its real consumer: the reference's OWN forward / likelihood modules on OUR transform.
 
-oracle/_ref/ref_forward_dump (recipe: oracle/Makefile.ref) = /root/reference/src/forward.f90 compiled unmodified (-O0
--ffp-contract=off, the class of the reference Makefile's default flags) + the reference's params.f90 + OUR module fftw (rf_inv_amd/fortran/fftw.f90),
-whose `dfftw_execute(ifft)` -- called by calc_rf itself, src/forward.f90:172,200 -- runs the c2r on the GPU as the
-transform's definition (rf_fft_c2r).  It is first of all the test of the drop-in against its real consumer.  And since
-everything but the inverse transform in those traces is the reference's own code and arithmetic -- init_filter,
-e_inverse, layer_matrix_sol / _liq, the propagator chain, land and ocean boundary conditions, P and S spectra,
-water_level_decon, direct_arrival, the shift maps, the normalisation -- the traces are known answers for branches no
-reference-held vector covers: S phase, deconvolution, sea floor, nfft 4096, common rays, 2 .. 31 layers.  The CPU
-oracle (oracle/rf_oracle.c) and the HIP path (rf_calc_rf / rf_eval_batch through the C ABI) must both reproduce them.
+oracle/_ref/ref_forward_dump, ref_path_dump (recipe: oracle/Makefile.ref) = /root/reference/src/forward.f90 and
+likelihood.f90 compiled unmodified (-O0 -ffp-contract=off) + the reference's host modules + OUR module fftw
+(rf_inv_amd/fortran/fftw.f90), whose `dfftw_execute(ifft)` -- called by calc_rf itself, src/forward.f90:172,200 -- runs
+the c2r on the GPU as the transform's definition (rf_fft_c2r); dgesvd from the image's MKL.  This is the TEST OF THE
+DROP-IN MODULE (and of rf_fft_c2r against a consumer that depends on every sample of it); the oracle (oracle/rf_oracle.c)
+and the HIP path are compared with what comes out.
 
-What this is NOT: a build of the reference's whole path (likelihood.f90 needs LAPACK, which the image lacks), nor a
-reference FFT (the c2r is ours; it is checked against the long-double O(n^2) definition in
-tests/test_gpu_parity.py::test_fftw_plans_on_the_gpu).  Needs a GPU (the drop-in has no CPU transform)."""
+It is NOT the pin of the oracle any more (round 6): that is tests/test_reference_fixtures.py -- the whole reference built
+on the CPU with MKL's FFTW3 interface, no product code linked, fixtures committed -- which covers the same branches
+without a GPU and without our transform.  Needs a GPU (the drop-in has no CPU transform); skips where the binaries were
+not built."""
 import os
 import subprocess
 
@@ -231,7 +229,7 @@ def test_benchmark_walkers_against_the_reference_forward_code(oracle, tmp_path, 
         st = tuple(layers[i, r, :nlay[i]] for r in range(4))
         scale = np.abs(ref[i]).max(axis=1, keepdims=True)
         kap = float(kaps[i])
-        allow = 1e-12 * max(1.0, kap / 10.0 if kap >= 100.0 else 1.0)
+        allow = 1e-12 * max(1.0, kap / 1000.0 if kap >= 1000.0 else 1.0)
         eo = (np.abs(oracle.calc_rf(cfg, *st) - ref[i]) / scale).max()
         eh = (np.abs(got_all[i] - ref[i]) / scale).max()
         assert eo <= allow and eh <= allow, (workload, int(pick[i]), int(nlay[i]), eo, eh, kap)
@@ -351,11 +349,11 @@ def test_reference_likelihood_code_vs_oracle_and_hip(oracle, tmp_path, workload,
         d = np.abs(ll - ll_ref)
         tol = logl_tol(ll_ref)
         for i in np.nonzero(~(d <= tol))[0]:
-            assert kaps[i] >= 100.0 and d[i] <= tol[i] * kaps[i] / 10.0, (workload, name, int(pick[i]), ll[i], ll_ref[i], kaps[i])
+            assert kaps[i] >= 1000.0 and d[i] <= tol[i] * kaps[i] / 1000.0, (workload, name, int(pick[i]), ll[i], ll_ref[i], kaps[i])
         worst[name] = float((d / tol).max())
         assert np.sum(~(d <= tol)) <= max(1, n // 50)
     scale = np.abs(rft_ref).max(axis=2, keepdims=True)
-    ok_tr = np.abs(got - rft_ref) <= 1e-12 * scale * np.maximum(1.0, np.where(kaps >= 100.0, kaps / 10.0, 1.0))[:, None, None]
+    ok_tr = np.abs(got - rft_ref) <= 1e-12 * scale * np.maximum(1.0, np.where(kaps >= 1000.0, kaps / 1000.0, 1.0))[:, None, None]
     assert ok_tr.all()
     print(f"{workload}: {n} models, |logL| {np.abs(ll_ref).min():.3g} .. {np.abs(ll_ref).max():.3g}: |dlogL| / tolerance against the "
           f"reference's calc_likelihood: oracle {worst['oracle']:.3f}, HIP {worst['hip']:.3f}; "
@@ -370,4 +368,4 @@ def test_reference_likelihood_code_vs_oracle_and_hip(oracle, tmp_path, workload,
                        "worst_fraction_of_tolerance_hip": worst["hip"],
                        "max_abs_dlogl_hip": float(np.abs(ll_hip - ll_ref).max()),
                        "max_rel_dlogl_hip": float((np.abs(ll_hip - ll_ref) / np.abs(ll_ref)).max()),
-                       "n_kappa_ge_100": int(np.sum(kaps >= 100.0))}, fh)
+                       "n_kappa_ge_1000": int(np.sum(kaps >= 1000.0))}, fh)
