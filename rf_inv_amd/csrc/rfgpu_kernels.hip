@@ -29,7 +29,17 @@
 #define RFGPU_ABLATE_DO(n, stmt) if (P.ablate == (n)) stmt
 #define RFGPU_ABLATE_IS(n) (P.ablate == (n))
 #define RFGPU_ABLATE_COPY(dst) (dst).ablate = P.ablate
+// "ablate" 100 + X (results stay VALID): every other block -- by a hash of its index -- idles X microseconds before it
+// starts, so that the blocks sharing a CU run out of phase (one propagates while the other transforms): the experiment of
+// profiles/EXPERIMENTS.md round 6.  1000 + X: only blocks of the first 512 (the first round of resident blocks).
+#define RFGPU_STAGGER(bid)                                                                                       \
+    do {                                                                                                         \
+        const int st_ = P.ablate >= 1000 ? P.ablate - 1000 : P.ablate - 100;                                     \
+        if (P.ablate >= 100 && (P.ablate < 1000 || (bid) < 512) && (((unsigned)(bid) * 2654435761u) >> 16 & 1u)) \
+            for (int i_ = 0; i_ < st_; ++i_) __builtin_amdgcn_s_sleep(32);   /* ~1 us each */                                   \
+    } while (0)
 #else
+#define RFGPU_STAGGER(bid) do { } while (0)
 #define RFGPU_ABLATE_AT(n, ret) do { } while (0)
 #define RFGPU_ABLATE_DO(n, stmt)
 #define RFGPU_ABLATE_IS(n) false
@@ -2420,6 +2430,7 @@ __global__ __launch_bounds__(TRACE_THREADS, 2) void fused_kernel(FusedParams F)
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
+    RFGPU_STAGGER(bid);
     if (F.order_next && bid == P.b.nb * t.ntrc) {
         // Longest-first dispatch order for the next launch of this batch shape, computed by one extra
         // block instead of a separate kernel in front of every launch.  It is the LAST block: it takes the
@@ -2797,6 +2808,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fused8_kernel(FusedParams F)
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
+    RFGPU_STAGGER(bid);
     if (F.order_next && bid == P.b.nb * t.ntrc) {
         // the dispatch order of the next launch (see fused_kernel)
         int *w = reinterpret_cast<int *>(lds2);
@@ -2943,6 +2955,7 @@ __global__ __launch_bounds__(W8_THREADS, 4) void fusedc_kernel(FusedParams F)
 
     const int tid = threadIdx.x;
     const int bid = blockIdx.x;
+    RFGPU_STAGGER(bid);
     if (F.order_next && bid == P.b.nb) {
         // the dispatch order of the next launch (see fused_kernel)
         int *w = reinterpret_cast<int *>(lds2);
