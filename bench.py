@@ -603,6 +603,11 @@ def spawn_ranks(n, argv):
     if have < n and not shared:
         print(f"bench.py: --gpus {n} needs {n} visible GPUs, this node shows {have}: refusing to report a {n}-GPU "
               "number from fewer devices (RCCL needs one GPU per rank)", file=sys.stderr)
+        # (the one JSON line of a failed run: value null, what happened, how far it got)
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "evals/s", "n_gpus": n, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                          "error": f"--gpus {n} needs {n} visible GPUs, this node shows {have}", "reached": "launcher",
+                          "config": {"workload": None, "rccl": {"ranks": 0, "transport": None}}}, separators=(",", ":")), flush=True)
         return 2
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))

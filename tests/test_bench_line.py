@@ -98,3 +98,37 @@ def test_headline_of_the_round_5_record_carries_the_reference_baseline():
     assert d["roofline"]["counters_file"] == "profiles/r05_counters.json" and d["roofline"]["frac"] is not None
     assert d["parity_in_bench"]["n"] == d["config"]["walkers_per_gpu"] == 8192 and d["parity_in_bench"]["within_tolerance"]
     assert set(d["also"]) == set(full["also"])
+
+
+def test_a_failed_multi_rank_run_still_prints_one_json_line(tmp_path):
+    """N > 1: whatever stops the run -- here: two ranks under a launcher's environment on a machine without a GPU -- rank 0
+    prints ONE JSON line (value null, error, how far it got, what of config.rccl was known) before the non-zero exit; the
+    bare `--gpus 2` form (bench.py as its own launcher) says so from the launcher."""
+    import socket
+    import subprocess
+    import sys
+
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU (the failure it provokes is 'no GPU visible')")
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--also", ""],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=str(tmp_path)))
+    outs = [q.communicate(timeout=300)[0] for q in procs]
+    assert all(q.returncode != 0 for q in procs)
+    lines = [l for l in outs[0].splitlines() if l.strip()]
+    assert len(lines) == 1 and outs[1].strip() == ""                 # rank 0 alone speaks, once
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 2 and "no GPU" in d["error"] and d["reached"] == "process_group_formed"
+    assert d["config"]["rccl"]["control_plane"] == "gloo" and d["metric"] == bench.METRIC
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       cwd=str(tmp_path), timeout=120)
+    d = json.loads(r.stdout.strip())
+    assert r.returncode == 2 and d["value"] is None and d["reached"] == "launcher" and "visible GPUs" in d["error"]
