@@ -16,6 +16,9 @@ traces of the likelihood fixtures are the reference's own synthetic of bench.py'
   path_<workload>.npz  calc_likelihood (src/likelihood.f90:56-101) with fwd_flag = .true. on bench.py's own walkers of
                        that workload (the first ones, the deepest, the shallowest), and with fwd_flag = .false. on
                        host-stored traces; format_model's layer stacks, the pseudo-inverse as init_r_inv forms it
+  run_sample_syn.npz   the reference's main program rf_inv on the shipped sample_syn directory (60 + 240 iterations x 5 chains;
+                       1 and 2 MPI ranks; and 1 rank at the shipped full length 3000 + 8000): sha256 of each of the
+                       eleven model / histogram / mean files it writes and the whole rslt/likelihood table
   MANIFEST.json        file list with sha256 (tests fail, not skip, on a missing or altered fixture)
 
 Consumers: tests/test_reference_fixtures.py (-m "not gpu": the oracle against the fixtures; -m gpu: the HIP path)."""
@@ -165,6 +168,48 @@ def gen_path(workload, count):
           f"{(d / np.abs(r0['logl'])).max():.2e}", flush=True)
 
 
+RUN_FILES = ["all_models", "num_interface.ppd", "syn_trace.ppd", "interface_depth.ppd", "sigma.ppd", "vs_z.ppd", "vp_z.ppd",
+             "vpvs_z.ppd", "vs_z.mean", "vp_z.mean", "vpvs_z.mean"]
+RUNS = [(1, 60, 240), (2, 60, 240), (1, 3000, 8000)]         # (MPI ranks, N_BURN, N_ITER)
+
+
+def gen_runs():
+    """The reference's main program end to end on tests/golden/sample_syn (params.in with the iteration counts replaced)."""
+    import shutil
+    import subprocess
+
+    from oracle import refrun
+
+    out = {}
+    for nranks, nburn, niter in RUNS:
+        tag = f"np{nranks}_{nburn}_{niter}"
+        res = {}
+        for build in refrun.BUILDS:
+            with tempfile.TemporaryDirectory() as tmp:
+                work = os.path.join(tmp, "run")
+                shutil.copytree(os.path.join(ROOT, "tests", "golden", "sample_syn"), work)
+                os.makedirs(os.path.join(work, "rslt"))
+                lines = open(os.path.join(work, "params.in")).read().split("\n")
+                i = next(j for j, l in enumerate(lines) if l.startswith("# N_BURN"))
+                assert lines[i + 1].strip() == "3000" and lines[i + 3].strip() == "8000"
+                lines[i + 1], lines[i + 3] = str(nburn), str(niter)
+                open(os.path.join(work, "params.in"), "w").write("\n".join(lines))
+                r = subprocess.run(["/opt/conda/bin/mpiexec", "-np", str(nranks), refrun.exe(build, "rf_inv"), "params.in"], cwd=work,
+                                   env=refrun.clean_env(), capture_output=True, text=True, timeout=3600)
+                assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+                res[build] = ({f: hashlib.sha256(open(os.path.join(work, "rslt", f), "rb").read()).hexdigest() for f in RUN_FILES},
+                              np.loadtxt(os.path.join(work, "rslt", "likelihood")))
+        (h0, l0), (h2, l2) = res["cpu_o0"], res["cpu_o2"]
+        same = h0 == h2
+        out[f"{tag}_sha256"] = np.array([h0[f] for f in RUN_FILES])
+        out[f"{tag}_likelihood"] = l0
+        out[f"{tag}_o2_same_files"] = same
+        out[f"{tag}_o2_max_rel_dlikelihood"] = float(np.max(np.abs(l2[:, 1] - l0[:, 1]) / np.abs(l0[:, 1])))
+        print(f"run_sample_syn {tag}: rslt/likelihood[0] = {l0[0, 1]!r}; the -O2 build writes the same eleven files: {same}, "
+              f"its likelihood column within {out[f'{tag}_o2_max_rel_dlikelihood']:.1e}", flush=True)
+    np.savez(os.path.join(OUT, "run_sample_syn.npz"), files=np.array(RUN_FILES), build="cpu_o0", **out)
+
+
 def main():
     from oracle import refrun
 
@@ -186,6 +231,8 @@ def main():
     for workload, count in PATH_WORKLOADS.items():
         if not only or f"path_{workload}" in only:
             gen_path(workload, count)
+    if not only or "run_sample_syn" in only:
+        gen_runs()
     files = sorted(f for f in os.listdir(OUT) if f.endswith(".npz"))
     man = {f: {"sha256": hashlib.sha256(open(os.path.join(OUT, f), "rb").read()).hexdigest(),
                "bytes": os.path.getsize(os.path.join(OUT, f))} for f in files}

@@ -353,7 +353,9 @@ def test_the_reference_make_syn_runs_unmodified_on_the_dropin_modules(golden_dir
     assert np.array_equal(np.loadtxt(work / "test_vel"), np.loadtxt(tmp_path / "python" / "test_vel"))
 
 
-REF_OWN = os.path.join(ROOT, "oracle", "_ref", "rf_inv_reference")
+# the WHOLE reference on the CPU (oracle/Makefile.cpuref: all twelve sources unmodified, its own module fftw on MKL's FFTW3
+# interface, dgesvd from MKL; no product code, no GPU) -- round 5 ran the reference's modules on the drop-in module fftw here
+REF_OWN = os.path.join(ROOT, "oracle", "_ref", "cpu_o2", "rf_inv")
 DROPIN_LAPACK = os.path.join(ROOT, "oracle", "_ref", "rf_inv_lapack")
 
 
@@ -362,8 +364,8 @@ DROPIN_LAPACK = os.path.join(ROOT, "oracle", "_ref", "rf_inv_lapack")
 def test_dropin_run_equals_the_run_of_the_reference_on_its_own_modules(golden_dir, tmp_path, nranks, nburn, niter):
     """The whole program, end to end, three ways on the shipped sample_syn directory (iteration counts reduced, and --
     one rank -- the shipped example at its full length: 3000 + 8000 iterations x 5 chains, 55 000 evaluations):
-      reference : src/rf_inv.f90 + pt_mcmc + mcmc_out + model ... on the reference's OWN src/forward.f90 and
-                  src/likelihood.f90 (all unmodified; c2r through the drop-in module fftw, dgesvd from the image's MKL)
+      reference : the reference itself, all twelve sources unmodified, on the host CPU (oracle/_ref/cpu_o2/rf_inv: its own
+                  module fftw on MKL's FFTW3 interface, dgesvd from MKL; no product code in it)
       drop-in   : the same main program and host modules on module forward / likelihood of rf_inv_amd/fortran (the HIP
                   kernels; R^-1 by librfgpu's own SVD)
       drop-in + LAPACK : the drop-in built with -DRFGPU_USE_LAPACK (R^-1 by the host's dgesvd, as the reference forms it)
@@ -401,13 +403,13 @@ def test_dropin_run_equals_the_run_of_the_reference_on_its_own_modules(golden_di
 
 @pytest.mark.gpu
 def test_make_syn_on_the_dropin_modules_equals_make_syn_on_the_reference_modules(golden_dir, tmp_path):
-    """`program make_syn` (src/make_syn.f90, unmodified) twice: on the reference's OWN forward / likelihood modules
-    (oracle/_ref/make_syn_reference) and on the drop-in modules (oracle/_ref/make_syn).  Same random stream, same model,
+    """`program make_syn` (src/make_syn.f90, unmodified) twice: the reference itself on the CPU (oracle/_ref/cpu_o2/make_syn:
+    every source the reference's, FFTW3 interface and LAPACK from MKL) and on the drop-in modules (oracle/_ref/make_syn).  Same random stream, same model,
     same noise: the SAC files -- float32 samples of chain 1's synthetic trace, with and without noise -- are byte-identical
     (the CPU and the GPU traces agree to 1e-14 of their scale), test_vel line for line."""
-    ref_exe = os.path.join(ROOT, "oracle", "_ref", "make_syn_reference")
+    ref_exe = os.path.join(ROOT, "oracle", "_ref", "cpu_o2", "make_syn")
     if not (os.path.exists(ref_exe) and os.path.exists(REF_MAKESYN)):
-        pytest.skip("oracle/_ref/make_syn_reference not built (no Fortran compiler / reference tree / MKL at build time)")
+        pytest.skip("oracle/_ref/cpu_o2/make_syn not built (no Fortran compiler / reference tree / MKL at build time)")
     outs = {}
     for tag, exe in (("reference", ref_exe), ("dropin", REF_MAKESYN)):
         work = tmp_path / tag
@@ -428,7 +430,7 @@ def test_dropin_runs_equal_the_reference_run_at_the_benchmark_shapes(tmp_path, s
     """End to end at the north-star geometry, not only on the shipped nfft-256 example: run directories with the shape of
     BASELINE configs 4 and 5 (tests/tools/shape_run.py: nfft 4096; c4 = traces P .06 / P .08 / S .10, k_max 30; c5 = 2 km
     of water, traces P / P / S / S; 8 chains, 2 of them at T = 1, 100 iterations) through
-      (a) the reference's main program on its OWN forward / likelihood modules (oracle/_ref/rf_inv_reference),
+      (a) the reference itself on the CPU (oracle/_ref/cpu_o2/rf_inv: all of its sources, MKL's FFTW3 interface and LAPACK),
       (b) the same main program on the drop-in modules (oracle/_ref/rf_inv_lapack: per-call evaluation on the GPU),
       (c) the batched sampler pt_control_batched on the drop-in modules (tests/fortran/drive_rfinv mode 1).
     Same trajectory in all three: the eleven model / histogram / mean files byte-identical, rslt/likelihood to 1e-11."""

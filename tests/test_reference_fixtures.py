@@ -79,7 +79,7 @@ def model_setup(f, tmp_path):
 # ---------------------------------------------------------------------------------------------------------------
 def test_fixture_set_is_complete_and_unaltered():
     man = json.load(open(os.path.join(REF, "MANIFEST.json")))["files"]
-    want = {f"forward_{n}.npz" for n in FORWARD} | {f"path_{n}.npz" for n in PATH}
+    want = {f"forward_{n}.npz" for n in FORWARD} | {f"path_{n}.npz" for n in PATH} | {"run_sample_syn.npz"}
     assert set(man) == want
     for name, rec in man.items():
         raw = open(os.path.join(REF, name), "rb").read()
@@ -229,3 +229,39 @@ def test_hip_calc_likelihood_against_the_reference_fixture(oracle, tmp_path, wor
             json.dump({"workload": workload, "models": int(n), "worst_fraction_of_tolerance_hip": worst,
                        "max_abs_dlogl_hip": float(np.abs(ll - f["logl"]).max()),
                        "max_rel_dlogl_hip": float((np.abs(ll - f["logl"]) / np.abs(f["logl"])).max())}, fh)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nranks,nburn,niter", [(1, 60, 240), (2, 60, 240), (1, 3000, 8000)])
+def test_dropin_main_program_reproduces_the_cpu_references_result_files(tmp_path, nranks, nburn, niter):
+    """The whole program against the whole reference: run_sample_syn.npz holds what the reference's rf_inv -- every source
+    its own, on the CPU -- wrote for the shipped sample_syn directory (sha256 of the eleven model / histogram / mean files,
+    the rslt/likelihood table).  The same main program linked against the drop-in modules (oracle/_ref/rf_inv: fftw /
+    forward / likelihood of rf_inv_amd/fortran, the HIP kernels) must take the same trajectory: the eleven files byte for
+    byte, rslt/likelihood (17 digits) to 1e-11 relative; 1 and 2 MPI ranks, and the shipped length (11 000 iterations)."""
+    import shutil
+    import subprocess
+
+    exe = os.path.join(ROOT, "oracle", "_ref", "rf_inv")
+    mpiexec = "/opt/conda/bin/mpiexec"
+    assert os.path.exists(exe) and os.path.exists(mpiexec), "oracle/_ref/rf_inv (build()) or mpiexec is missing on a GPU box"
+    f = load("run", "sample_syn")
+    tag = f"np{nranks}_{nburn}_{niter}"
+    work = tmp_path / "run"
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "sample_syn"), work)
+    os.makedirs(work / "rslt")
+    lines = open(work / "params.in").read().split("\n")
+    i = next(j for j, l in enumerate(lines) if l.startswith("# N_BURN"))
+    lines[i + 1], lines[i + 3] = str(nburn), str(niter)
+    open(work / "params.in", "w").write("\n".join(lines))
+    r = subprocess.run([mpiexec, "-np", str(nranks), exe, "params.in"], cwd=work, env=dict(os.environ), capture_output=True,
+                       text=True, timeout=1800)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    for name, want in zip(f["files"], f[f"{tag}_sha256"]):
+        got = hashlib.sha256(open(work / "rslt" / str(name), "rb").read()).hexdigest()
+        assert got == str(want), (tag, str(name))
+    lk, ref = np.loadtxt(work / "rslt" / "likelihood"), f[f"{tag}_likelihood"]
+    assert lk.shape == ref.shape == (nburn + niter, 2) and np.array_equal(lk[:, 0], ref[:, 0])
+    rel = np.abs(lk[:, 1] - ref[:, 1]) / np.abs(ref[:, 1])
+    assert rel.max() <= 1e-11, (tag, rel.max())
+    print(f"{tag}: eleven result files byte-identical to the CPU reference's; rslt/likelihood within {rel.max():.1e}")
