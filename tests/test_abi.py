@@ -251,7 +251,12 @@ def test_bench_refuses_a_rank_count_it_cannot_honour():
     if torch.cuda.device_count() < 2:
         r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300,
                            env=env, cwd=ROOT)
-        assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr and "{" not in r.stdout
+        assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr
+        # (round 6: a refused run says so in ONE JSON line -- value null, never a number)
+        import json
+
+        d = json.loads(r.stdout.strip())
+        assert d["value"] is None and d["n_gpus"] == 2 and "visible GPUs" in d["error"]
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1"], capture_output=True, text=True, timeout=300,
                        env=dict(env, WORLD_SIZE="3", RANK="0"), cwd=ROOT)
     assert r.returncode != 0 and "must agree" in r.stderr and "{" not in r.stdout
