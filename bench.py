@@ -365,16 +365,19 @@ def quad_flops_run(nsmp, plan):
     return 2.0 * 64.0 * rows
 
 
-def committed_counters(kernel, grid_threads, long_window=False):
+def committed_counters(kernel, grid_threads, long_window=False, decon=False):
     """Per-launch hardware counters of `kernel` at exactly this launch shape from the newest committed
     profile (profiles/rNN_counters.json, written by tools/collect_counters.sh from separate rocprofv3
     --pmc passes over THIS script; FETCH_SIZE doubled per the gfx950 correction of
     MI355X_MICROARCH.md).  bench.py itself cannot collect PMC counters.  None when no launch of that
-    kernel and grid is in the file.  The long-window workloads (c4w20, c4w60) launch the C4 fused kernel at C4's grid but
-    write different bytes: their counters live in files of their own (rNN_longwindow_counters.json, collected over
-    `--workload c4w60 --also c4w20`), which the other workloads' look-ups skip."""
+    kernel and grid is in the file.  Workloads that launch the same kernel at the same grid but execute different
+    instructions or write different bytes keep their counters in files of their own, which the other workloads' look-ups
+    skip: the long-window workloads (c4w20, c4w60: rNN_longwindow_counters.json, collected over `--workload c4w60 --also
+    c4w20`) and the water-level deconvolution workloads (c2d, c4d, c5d: rNN_decon_counters.json, collected over `--workload
+    c4d --also c2d,c5d`)."""
+    tag = "longwindow" if long_window else "decon" if decon else ""
     files = [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")), reverse=True)
-             if ("longwindow" in os.path.basename(f)) == bool(long_window)]
+             if (tag in os.path.basename(f) if tag else not any(t in os.path.basename(f) for t in ("longwindow", "decon")))]
     for f in files:
         try:
             d = json.load(open(f))
@@ -1157,7 +1160,8 @@ def main():
             grid_threads = bt * (nblk + (1 if (plan["lpt"] and plan["order_reuse"] and nb >= 512) else 0))
         else:
             grid_threads = None   # split path: matched by name only (nsplit decides the grid)
-        ctr = committed_counters(kname, grid_threads, long_window=plan["long_window_gemm"]) if grid_threads else None
+        ctr = (committed_counters(kname, grid_threads, long_window=plan["long_window_gemm"], decon=p.deconv_mode == 1)
+               if grid_threads else None)
         exe = executed_fp64_flops(ctr) if ctr else None
         t_k = kernel_ms * 1e-3 if kernel_ms else None
         # counters describe kernels: they are this build's if its gfx950 code objects (.hip_fatbin) are the ones they

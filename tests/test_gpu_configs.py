@@ -499,7 +499,7 @@ def test_bench_gpus_flag_is_honoured_or_refused(tmp_path):
     """`python bench.py --gpus 2` the way the driver's SCALE run may invoke it (no launcher, RCCL backend): on a node
     with two GPUs it must run two ranks over librfgpu's RCCL communicator (n_gpus == 2, config.rccl.ranks == 2, final
     temperatures == the serial replay); on a one-GPU box it must REFUSE with a non-zero exit code and a message --
-    never print a line that says n_gpus: 1.  And a launcher whose WORLD_SIZE disagrees with --gpus is refused too."""
+    never print a line that carries a rate.  And a launcher whose WORLD_SIZE disagrees with --gpus is refused too."""
     import json
     import subprocess
 
@@ -521,6 +521,10 @@ def test_bench_gpus_flag_is_honoured_or_refused(tmp_path):
         _replay_bench_state(dump, nb, ntemps, 2)
     else:
         assert r.returncode != 0
-        assert "needs 2 visible GPUs" in r.stderr and not any(x.startswith("{") for x in r.stdout.splitlines())
+        # (round 6: the refusal is also ONE JSON line on stdout -- value null, the error, never a rate)
+        lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+        assert "needs 2 visible GPUs" in r.stderr and len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["value"] is None and d["n_gpus"] == 2 and "visible GPUs" in d["error"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(env, WORLD_SIZE="3", RANK="0"), cwd=ROOT)
     assert r.returncode != 0 and "must agree" in r.stderr
