@@ -16,6 +16,9 @@ traces of the likelihood fixtures are the reference's own synthetic of bench.py'
   path_<workload>.npz  calc_likelihood (src/likelihood.f90:56-101) with fwd_flag = .true. on bench.py's own walkers of
                        that workload (the first ones, the deepest, the shallowest), and with fwd_flag = .false. on
                        host-stored traces; format_model's layer stacks, the pseudo-inverse as init_r_inv forms it
+  format_model.npz     format_model (src/model.f90:175-290) on 3 x 700 random proposals -- valid and invalid, with equal
+                       interface depths (the unstable quicksort's permutation), ocean, vp_mode 0 / 1, a NON-uniform
+                       reference velocity table: layer counts, verdicts and layer values
   run_sample_syn.npz   the reference's main program rf_inv on the shipped sample_syn directory (60 + 240 iterations x 5 chains;
                        1 and 2 MPI ranks; and 1 rank at the shipped full length 3000 + 8000): sha256 of each of the
                        eleven model / histogram / mean files it writes and the whole rslt/likelihood table
@@ -168,6 +171,52 @@ def gen_path(workload, count):
           f"{(d / np.abs(r0['logl'])).max():.2e}", flush=True)
 
 
+FORMAT_CASES = [(2.0, 0, 10, False), (0.0, 1, 30, False), (0.0, 0, 12, True)]      # (sdep, vp_mode, k_max, ties)
+
+
+def format_proposals(rng, p, nb, ties=False):
+    """Proposals as a chain may make them (tests/test_gpu_format_model.py draws the same way): some valid, some not."""
+    k = rng.integers(p.k_min, p.k_max, nb).astype(np.int32)
+    z = np.zeros((nb, p.k_max - 1)); dvp = np.zeros((nb, p.k_max)); dvs = np.zeros((nb, p.k_max))
+    for i in range(nb):
+        z[i, :k[i]] = rng.uniform(p.z_min + p.sdep, p.z_max, k[i])
+        if ties and k[i] >= 3:
+            z[i, 1] = z[i, 0]            # equal interface depths: the unstable quicksort's permutation matters
+        dvs[i, :k[i]] = rng.normal(0, 0.5, k[i]); dvs[i, -1] = rng.normal(0, 0.5)
+        dvp[i, :k[i]] = rng.normal(0, 0.3, k[i]); dvp[i, -1] = rng.normal(0, 0.3)
+        z[i, k[i]:] = rng.uniform(0, 20, p.k_max - 1 - k[i])   # stale entries beyond k must be ignored
+    return k, z, dvp, dvs
+
+
+def gen_format():
+    """format_model through the reference (ref_path_dump's extras: its public format_model on every model handed in)."""
+    from oracle import refrun
+
+    nref = 61
+    zr = 0.5 * np.arange(nref)
+    vp_ref, vs_ref = 5.0 + 0.03 * np.arange(nref), 2.8 + 0.02 * np.arange(nref)     # non-uniform: the iz look-ups matter
+    velmod = "".join(f"{zr[i]!r} {vp_ref[i]!r} {vs_ref[i]!r}\n" for i in range(nref))
+    out = {}
+    for ci, (sdep, vp_mode, k_max, ties) in enumerate(FORMAT_CASES):
+        p = forward_params(256, [0.06], [1], [4.0], 0, sdep, 0.0)
+        p.k_max, p.vp_mode, p.k_min = k_max, vp_mode, 1
+        p.z_min, p.z_max = 0.0 + sdep, 20.0 + sdep
+        k, z, dvp, dvs = format_proposals(np.random.default_rng(1000 + k_max), p, 700, ties)
+        with tempfile.TemporaryDirectory() as work:
+            text = refrun.write_run_dir(work, p, header=f"oracle/gen_golden.py: format_model case {ci}", velmod=velmod)
+            refrun.write_models(os.path.join(work, "models.txt"), k_max, k, np.pad(z, ((0, 0), (0, 1))), dvp, dvs,
+                                np.full((len(k), 1), 0.01))
+            r = refrun.run_path("cpu_o0", work, len(k), p)
+        pad = k_max + 2
+        assert r["nlay"].max() <= pad and 0 < r["valid"].sum() < len(k)
+        out.update({f"c{ci}_params_in": text, f"c{ci}_k": k, f"c{ci}_z": z, f"c{ci}_dvp": dvp, f"c{ci}_dvs": dvs,
+                    f"c{ci}_nlay": r["nlay"], f"c{ci}_valid": r["valid"], f"c{ci}_layers": r["layers"][:, :, :pad]})
+        print(f"format_model case {ci} (sdep {sdep}, vp_mode {vp_mode}, k_max {k_max}, ties {ties}): {len(k)} proposals, "
+              f"{int(r['valid'].sum())} valid, nlay {r['nlay'].min()} .. {r['nlay'].max()}", flush=True)
+    np.savez_compressed(os.path.join(OUT, "format_model.npz"), cases=np.array(FORMAT_CASES, dtype=float), velmod=velmod,
+                        z_ref=zr, vp_ref=vp_ref, vs_ref=vs_ref, build="cpu_o0", **out)
+
+
 RUN_FILES = ["all_models", "num_interface.ppd", "syn_trace.ppd", "interface_depth.ppd", "sigma.ppd", "vs_z.ppd", "vp_z.ppd",
              "vpvs_z.ppd", "vs_z.mean", "vp_z.mean", "vpvs_z.mean"]
 RUNS = [(1, 60, 240), (2, 60, 240), (1, 3000, 8000)]         # (MPI ranks, N_BURN, N_ITER)
@@ -231,6 +280,8 @@ def main():
     for workload, count in PATH_WORKLOADS.items():
         if not only or f"path_{workload}" in only:
             gen_path(workload, count)
+    if not only or "format_model" in only:
+        gen_format()
     if not only or "run_sample_syn" in only:
         gen_runs()
     files = sorted(f for f in os.listdir(OUT) if f.endswith(".npz"))

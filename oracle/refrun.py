@@ -41,18 +41,21 @@ def clean_env():
     return env
 
 
-def write_run_dir(work, p, obs=None, header="written by oracle/refrun.py", dvs_prior=0.3):
+def write_run_dir(work, p, obs=None, header="written by oracle/refrun.py", dvs_prior=0.3, velmod=None):
     """A run directory for the reference's programs: params.in for the geometry of `p` (an rf_inv_amd.params.Params),
     SAC files data/t<i>.trc holding obs[t, :nsmp] (zeros when obs is None), model/sample.velmod (the shipped reference
     model).  dvs_prior: init_model (src/model.f90:66-95, run by the dumper's init sequence) redraws whole models until one is
     valid; the narrow prior keeps that short and touches nothing calc_rf / calc_likelihood compute for GIVEN models.
-    Returns the text of params.in."""
+    velmod: text of another reference velocity table (rows "z vp vs").  Returns the text of params.in."""
     from rf_inv_amd import write_params
     from rf_inv_amd.make_syn import write_sac
 
     for d in ("data", "rslt", "model"):
         os.makedirs(os.path.join(work, d), exist_ok=True)
-    shutil.copy(os.path.join(GOLDEN, "model", "sample.velmod"), os.path.join(work, "model", "sample.velmod"))
+    if velmod is None:
+        shutil.copy(os.path.join(GOLDEN, "model", "sample.velmod"), os.path.join(work, "model", "sample.velmod"))
+    else:
+        open(os.path.join(work, "model", "sample.velmod"), "w").write(velmod)
     q = copy.copy(p)
     q.out_dir, q.nchains, q.ncool, q.nburn, q.niter, q.dvs_prior = "./rslt", 1, 1, 0, 10, dvs_prior
     q.vel_file, q.obs_files = "model/sample.velmod", [f"data/t{t + 1}.trc" for t in range(p.ntrc)]
