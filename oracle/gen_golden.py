@@ -195,7 +195,7 @@ def gen_format():
     nref = 61
     zr = 0.5 * np.arange(nref)
     vp_ref, vs_ref = 5.0 + 0.03 * np.arange(nref), 2.8 + 0.02 * np.arange(nref)     # non-uniform: the iz look-ups matter
-    velmod = "".join(f"{zr[i]!r} {vp_ref[i]!r} {vs_ref[i]!r}\n" for i in range(nref))
+    velmod = "".join(f"{float(zr[i])!r} {float(vp_ref[i])!r} {float(vs_ref[i])!r}\n" for i in range(nref))
     out = {}
     for ci, (sdep, vp_mode, k_max, ties) in enumerate(FORMAT_CASES):
         p = forward_params(256, [0.06], [1], [4.0], 0, sdep, 0.0)

@@ -79,7 +79,7 @@ def model_setup(f, tmp_path):
 # ---------------------------------------------------------------------------------------------------------------
 def test_fixture_set_is_complete_and_unaltered():
     man = json.load(open(os.path.join(REF, "MANIFEST.json")))["files"]
-    want = {f"forward_{n}.npz" for n in FORWARD} | {f"path_{n}.npz" for n in PATH} | {"run_sample_syn.npz"}
+    want = {f"forward_{n}.npz" for n in FORWARD} | {f"path_{n}.npz" for n in PATH} | {"run_sample_syn.npz", "format_model.npz"}
     assert set(man) == want
     for name, rec in man.items():
         raw = open(os.path.join(REF, name), "rb").read()
@@ -150,6 +150,42 @@ def test_oracle_calc_likelihood_against_the_reference_fixture(oracle, tmp_path, 
     for i in range(0, n, 7):
         st = tuple(layers[i, r, :nlay[i]] for r in range(4))
         assert np.array_equal(oracle.calc_rf(cfg, *st, want_stages=True)[1], f["npre"][i]), (workload, i)
+
+
+def format_cases(tmp_path):
+    """(p, refm, mcfg, arrays) of every case of format_model.npz; the reference velocity table is the fixture's (non-uniform)."""
+    from rf_inv_amd import get_params, read_ref_model
+
+    f = load("format", "model")
+    vel = tmp_path / "fixture.velmod"
+    vel.write_text(str(f["velmod"]))
+    refm = read_ref_model(str(vel))
+    assert np.array_equal(refm.vp_ref, f["vp_ref"]) and np.array_equal(refm.vs_ref, f["vs_ref"])
+    for ci in range(len(f["cases"])):
+        pin = tmp_path / f"params_{ci}.in"
+        pin.write_text(str(f[f"c{ci}_params_in"]))
+        p = get_params(str(pin))
+        assert (p.sdep, p.vp_mode, p.k_max) == (f["cases"][ci][0], int(f["cases"][ci][1]), int(f["cases"][ci][2]))
+        mcfg = dict(k_max=p.k_max, vp_mode=p.vp_mode, sdep=p.sdep, z_max=p.z_max, h_min=p.h_min, z_ref_min=refm.z_ref_min,
+                    dz_ref=refm.dz_ref, vp_min=p.vp_min, vp_max=p.vp_max, vs_min=p.vs_min, vs_max=p.vs_max,
+                    vpvs_min=p.vpvs_min, vpvs_max=p.vpvs_max, vp_ref=refm.vp_ref, vs_ref=refm.vs_ref)
+        yield ci, p, refm, mcfg, {k: f[f"c{ci}_{k}"] for k in ("k", "z", "dvp", "dvs", "nlay", "valid", "layers")}
+
+
+def test_oracle_format_model_against_the_reference_fixture(oracle, tmp_path):
+    """src/model.f90:175-290 through the reference itself on 3 x 700 proposals (valid and invalid, equal interface depths,
+    ocean, vp_mode 0 / 1, a non-uniform reference table): layer count, verdict and every layer value bit for bit."""
+    n_valid = 0
+    for ci, p, refm, mcfg, a in format_cases(tmp_path):
+        for i in range(len(a["k"])):
+            nl, al, be, rh, h, ok = oracle.format_model(mcfg, int(a["k"][i]), a["z"][i], a["dvp"][i], a["dvs"][i])
+            assert ok == bool(a["valid"][i]), (ci, i)
+            if ok:                                                   # (an invalid model's partial stack is never used)
+                assert nl == a["nlay"][i], (ci, i)
+                for row, arr in enumerate((al, be, rh, h)):
+                    assert np.array_equal(arr, a["layers"][i, row, :nl]), (ci, i, row)
+                n_valid += 1
+    assert n_valid > 900
 
 
 def check_path(f, workload, who, ll, rft, kap):
@@ -265,3 +301,32 @@ def test_dropin_main_program_reproduces_the_cpu_references_result_files(tmp_path
     rel = np.abs(lk[:, 1] - ref[:, 1]) / np.abs(ref[:, 1])
     assert rel.max() <= 1e-11, (tag, rel.max())
     print(f"{tag}: eleven result files byte-identical to the CPU reference's; rslt/likelihood within {rel.max():.1e}")
+
+
+@pytest.mark.gpu
+def test_hip_format_model_against_the_reference_fixture(tmp_path):
+    """format_model_kernel (rf_format_models_device) against the reference's own format_model: bit for bit."""
+    import torch
+
+    from rf_inv_amd import RFEngine
+
+    dev = torch.device("cuda", 0)
+    n_valid = 0
+    for ci, p, refm, mcfg, a in format_cases(tmp_path):
+        nb, pad = len(a["k"]), p.k_max + 2
+        with RFEngine(nfft=256, delta=float(np.float32(0.05)), t_start=0.0, deconv_mode=0, sdep=p.sdep, rayps=[0.06], a_gus=[4.0],
+                      ipha=[1], obs=np.zeros((1, 101)), nsmp=101, max_walkers=nb, nlay_max=pad) as eng:
+            eng.set_model(p, refm)
+            t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+            nlay = torch.zeros(nb, dtype=torch.int32, device=dev)
+            layers = torch.zeros((nb, 4, pad), dtype=torch.float64, device=dev)
+            valid = torch.zeros(nb, dtype=torch.int32, device=dev)
+            eng.format_models_device(t(a["k"].astype(np.int32)), t(a["z"]), t(a["dvp"]), t(a["dvs"]), nlay, layers, valid)
+            torch.cuda.synchronize()
+            nlay, layers, valid = nlay.cpu().numpy(), layers.cpu().numpy(), valid.cpu().numpy()
+        assert np.array_equal(valid != 0, a["valid"] != 0), ci
+        for i in np.nonzero(a["valid"])[0]:
+            nl = int(a["nlay"][i])
+            assert nlay[i] == nl and np.array_equal(layers[i, :, :nl], a["layers"][i, :, :nl]), (ci, int(i))
+            n_valid += 1
+    assert n_valid > 900
