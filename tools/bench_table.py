@@ -7,7 +7,10 @@ import sys
 NAMES = {"c4": "**C4 (default)**", "c2": "C2", "c2d": "C2, water-level deconvolution", "c3": "C3",
          "c5": "C5 (32768 walkers, ocean, 4 traces)", "c4common": "C4 common ray (single FWD)",
          "c4w20": "C4, 20 s window (nsmp 401)", "c4w60": "C4, 60 s window (nsmp 1201)", "c4win": "C4 with `trace_window`",
-         "c5win": "C5 with `trace_window`", "c4stale": "C4, depths changing every step"}
+         "c5win": "C5 with `trace_window`", "c4stale": "C4, depths changing every step",
+         "c4d": "C4, water-level deconvolution", "c5d": "C5, water-level deconvolution",
+         "c4full": "**ALL of BASELINE configs[3] on one GPU** (65 536 walkers x 3 traces)",
+         "c5full": "**ALL of BASELINE configs[4] on one GPU** (262 144 walkers x 4 traces, ocean; 68.7 GB of traces)"}
 
 
 def row(name, r):
