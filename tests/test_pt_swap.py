@@ -136,6 +136,62 @@ def test_rccl_exchange_entry_points_on_one_rank():
 
 
 @pytest.mark.gpu
+def test_rccl_two_stream_use_of_one_communicator_on_one_rank():
+    """The communicator is used from TWO streams: the host-value exchanges (rf_comm_bcast_i32, rf_pt_swap_exchange) on the
+    communicator's own stream, the all-gather swap on the evaluation stream -- a sampler makes the former while a segment's
+    evaluation kernels are in flight.  Real RCCL, one rank (all a one-GPU box can form): full-occupancy evaluation launches
+    queued on the evaluation stream, the exchanges issued from the host meanwhile, an all-gather swap between two
+    evaluations -- every value as if each had run alone.  (Across GPUs this interleaving has never run: DESIGN.md 7.)"""
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from helpers import make_cfg, pack_layers, random_stack
+
+    from rf_inv_amd import RFEngine
+    from rf_inv_amd.pt import PairSchedule, judge_pt
+
+    nb, nfft, nsmp = 2048, 4096, 101
+    delta = float(np.float32(0.05))
+    rng = np.random.default_rng(8)
+    stacks = [random_stack(rng, int(rng.integers(8, 16))) for _ in range(nb)]
+    nlay, layers = pack_layers(stacks, 17)
+    sig = np.full((nb, 1), 0.02)
+    obs = rng.normal(0, 0.05, (1, nsmp))
+    dev = torch.device("cuda", 0)
+    with RFEngine(nfft=nfft, delta=delta, t_start=0.0, deconv_mode=0, sdep=0.0, rayps=np.array([0.06]), a_gus=np.array([4.0]),
+                  ipha=np.array([1], dtype=np.int32), obs=obs, nsmp=nsmp, max_walkers=nb, nlay_max=17) as eng:
+        want = eng.eval_batch(np.arange(nb), nlay, layers, sig)                       # alone
+        eng.comm_init(RFEngine.comm_unique_id(), 0, 1)
+        stream = torch.cuda.Stream(device=dev)
+        d_ids = torch.arange(nb, dtype=torch.int32, device=dev)
+        d_nlay, d_layers, d_sig = (torch.from_numpy(x).to(dev) for x in (nlay, layers, sig))
+        d_l1, d_l2 = (torch.empty(nb, dtype=torch.float64, device=dev) for _ in range(2))
+        temps = np.exp(rng.random(nb) * np.log(15.0))
+        d_t = torch.from_numpy(temps.copy()).to(dev)
+        sched = PairSchedule(nb, 11, 64)
+        for rep in range(6):
+            pairs, logu = sched.draw()
+            d_p, d_u = torch.from_numpy(pairs).to(dev), torch.from_numpy(logu).to(dev)
+            with torch.cuda.stream(stream):
+                for _ in range(4):                                                     # ~1 ms of kernels in flight
+                    eng.eval_batch_device(d_ids, d_nlay, d_layers, d_sig, d_l1, stream=stream)
+                eng.pt_swap_allgather_device(d_p, d_u, d_t, d_l1, stream=stream)       # RCCL on the evaluation stream
+                eng.eval_batch_device(d_ids, d_nlay, d_layers, d_sig, d_l2, stream=stream)
+            # ... and meanwhile, from the host, RCCL on the communicator's own stream
+            for j in range(5):
+                assert list(eng.comm_bcast_i32([rep, j, 13, 17])) == [rep, j, 13, 17]
+                t_new, acc = eng.pt_swap_exchange(0, True, 2.5 + j, -10.0, np.log(0.3))
+                assert t_new == 2.5 + j and acc == judge_pt(2.5 + j, 2.5 + j, -10.0, -10.0, np.log(0.3))
+            stream.synchronize()
+            for (i1, i2), lu in zip(pairs, logu):
+                if judge_pt(temps[i1], temps[i2], want[i1], want[i2], lu):
+                    temps[i1], temps[i2] = temps[i2], temps[i1]
+            assert np.array_equal(d_l1.cpu().numpy(), want) and np.array_equal(d_l2.cpu().numpy(), want), rep
+            assert np.array_equal(d_t.cpu().numpy(), temps), rep
+        eng.comm_destroy()
+
+
+@pytest.mark.gpu
 def test_gathered_swap_kernel_as_three_ranks_on_one_gpu():
     """rf_pt_swap_gathered_device -- the ONE kernel of the multi-rank swap step -- driven as three ranks in turn on
     the one GPU: every "rank" reads the same gathered snapshot [3 * nchains] (global id = rank * nchains + chain,
