@@ -52,7 +52,12 @@ FORWARD_CASES = {
     "common_ocean_3S_one_ray_nfft2048": (2048, [0.10, 0.10, 0.10], [-1, -1, -1], [4.0, 2.5, 1.5], 0, 2.0, -2.0),
     "common_land_2S_decon_nfft512": (512, [0.07, 0.07], [-1, -1], [4.0, 2.0], 1, 0.0, -2.0),
     "odd_length_nfft1000_S": (1000, [0.11], [-1], [3.0], 0, 0.0, 0.0),
+    # the long-series plans of the library (row a12): a power of two beyond the in-LDS transform (four-step through HBM) and a
+    # length that is neither a power of two nor short (Bluestein); the reference's FFTW interface takes any length
+    "long_nfft8192_PS": (8192, [0.06, 0.10], [1, -1], [4.0, 2.5], 0, 0.0, -1.0),
+    "bluestein_nfft3000_ocean_P_decon": (3000, [0.07], [1], [4.0], 1, 2.0, 0.0),
 }
+FORWARD_FEWER_STACKS = {"long_nfft8192_PS": 4, "bluestein_nfft3000_ocean_P_decon": 4}      # (keeps the files small)
 PATH_WORKLOADS = {"c1": 40, "c2": 48, "c2d": 48, "c4": 56, "c4d": 48, "c4common": 40, "c5": 40, "c5d": 40, "c4w20": 20}
 N_FULL = 3          # models per path fixture whose whole rft(nfft, ntrc) is kept (all keep samples 1 .. nsmp)
 
@@ -92,6 +97,8 @@ def gen_forward(name, case, stacks=None):
     nfft, rayps, ipha, a_gus, deconv, sdep, t_start = case
     if stacks is None:
         stacks = forward_stacks(np.random.default_rng(sum(map(ord, name))), sdep > 0, sdep)
+        if name in FORWARD_FEWER_STACKS:
+            stacks = stacks[1:FORWARD_FEWER_STACKS[name]] + stacks[-1:]
     p = forward_params(nfft, rayps, ipha, a_gus, deconv, sdep, t_start)
     res = {}
     for build in refrun.BUILDS:

@@ -24,7 +24,7 @@ REF = os.path.join(ROOT, "tests", "golden", "ref")
 FORWARD = ["c1_ocean_2P_nfft256", "land_S_nfft256_decon", "c2_land_P", "c2d_land_P_decon", "c4_land_PPS",
            "c4_land_PPS_decon_tstart", "c5_ocean_PPSS", "c5_ocean_PPSS_decon", "c4common_land_3P_one_ray",
            "common_ocean_3S_one_ray_nfft2048", "common_land_2S_decon_nfft512", "odd_length_nfft1000_S",
-           "reference_forward_test", "evanescent_nan"]
+           "long_nfft8192_PS", "bluestein_nfft3000_ocean_P_decon", "reference_forward_test", "evanescent_nan"]
 PATH = ["c1", "c2", "c2d", "c4", "c4d", "c4common", "c5", "c5d", "c4w20"]
 TRACE_TOL = 1e-12            # of max|trace| per trace (tests/helpers.py)
 
