@@ -119,3 +119,93 @@ def test_hip_against_the_live_reference(oracle, tmp_path, seed):
                 assert (np.abs(one - r["rft"][i]) / scale).max() <= tol
             worst = max(worst, err)
     print(f"seed {seed}: {CASES_PER_SEED} random contexts x 6 stacks, HIP against the live reference: max |d trace| / scale {worst:.2e}")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# calc_likelihood (format_model + calc_rf + misfit + matmul(misfits, r_inv) + logL) against the live reference
+# ---------------------------------------------------------------------------------------------------------------
+def random_workload(rng):
+    ntrc = int(rng.integers(1, 4))
+    ocean = bool(rng.integers(0, 2))
+    ipha = [int(rng.choice([1, -1])) for _ in range(ntrc)]
+    rayps = [float(rng.uniform(0.04, 0.075)) if ph == 1 else float(rng.uniform(0.09, 0.12)) for ph in ipha]
+    if rng.integers(0, 4) == 0 and ntrc > 1:
+        rayps, ipha = [rayps[0]] * ntrc, [ipha[0]] * ntrc
+    return dict(walkers=16, nfft=int(rng.choice([256, 1024, 4096])), rayps=rayps, ipha=ipha,
+                a_gus=[float(rng.choice([2.5, 4.0])) for _ in range(ntrc)], k_max=int(rng.choice([6, 15, 30])),
+                sdep=2.0 if ocean else 0.0, deconv=int(rng.integers(0, 2)), temps=1, t_end=float(rng.choice([3.0, 5.0, 8.0])),
+                desc="random")
+
+
+def reference_likelihoods(w, seed, tmp_path):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import refrun
+    from rf_inv_amd import read_ref_model
+
+    if not refrun.available("cpu_o0"):
+        pytest.skip("oracle/_ref/cpu_o0 not built (no Fortran compiler / reference tree at build time)")
+    p = bench.make_params(w)
+    refm = read_ref_model(os.path.join(ROOT, "tests", "golden", "sample_syn", "model", "sample.velmod"))
+    nlay, layers, (m_k, m_z, m_dvp, m_dvs) = bench.draw_walkers(p, refm, 1000 * seed, w["walkers"], return_models=True, procs=1)
+    rng = np.random.default_rng(seed)
+    sig = rng.uniform(0.01, 0.05, (w["walkers"], p.ntrc))
+    # observed traces: the reference's own synthetic of the first model (so that one logL sits at its maximum), float32
+    work0, work = tmp_path / "truth", tmp_path / "run"
+    work0.mkdir(); work.mkdir()
+    refrun.write_run_dir(str(work0), p)
+    refrun.write_models(str(work0 / "models.txt"), p.k_max, m_k[:1], m_z[:1], m_dvp[:1], m_dvs[:1], sig[:1])
+    truth = refrun.run_path("cpu_o0", str(work0), 1, p)
+    refrun.write_run_dir(str(work), p, obs=truth["rft"][0])
+    refrun.write_models(str(work / "models.txt"), p.k_max, m_k, m_z, m_dvp, m_dvs, sig)
+    r = refrun.run_path("cpu_o0", str(work), w["walkers"], p)
+    obs = np.stack([truth["rft"][0][t, :p.nsmp].astype(np.float32).astype(np.float64) for t in range(p.ntrc)])
+    assert np.array_equal(r["nlay"], nlay) and r["valid"].all()
+    return p, refm, obs, sig, (m_k, m_z, m_dvp, m_dvs), nlay, layers, r
+
+
+@pytest.mark.parametrize("seed", [21, 22])
+def test_oracle_log_likelihood_against_the_live_reference(oracle, tmp_path, seed):
+    from helpers import logl_tol
+
+    rng = np.random.default_rng(seed)
+    for case in range(4):
+        w = random_workload(rng)
+        d = tmp_path / f"c{case}"
+        d.mkdir()
+        p, refm, obs, sig, models, nlay, layers, r = reference_likelihoods(w, seed + case, d)
+        cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep, rayps=p.rayps,
+                   a_gus=p.a_gus, ipha=p.ipha)
+        for i in range(len(nlay)):                              # format_model through the Python host mirror == the reference's
+            assert np.array_equal(layers[i, :, :nlay[i]], r["layers"][i, :, :nlay[i]]), (seed, case, i)
+        ll, kap = oracle.eval_batch(cfg, obs, r["r_inv"], nlay, layers, sig, p.nsmp, want_kappa=True)
+        slack = np.where(kap >= 1000.0, kap / 1000.0, 1.0)
+        assert (np.abs(ll - r["logl"]) <= logl_tol(r["logl"]) * slack).all(), (seed, case, w, np.abs(ll - r["logl"]) / logl_tol(r["logl"]))
+        assert abs(ll[0] + p.nsmp * np.log(sig[0]).sum()) < 1e-2          # the model that made the data: phi ~ 0 (float32 data)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [21, 22])
+def test_hip_log_likelihood_against_the_live_reference(oracle, tmp_path, seed):
+    from helpers import logl_tol
+    from rf_inv_amd import RFEngine
+
+    rng = np.random.default_rng(seed)
+    for case in range(4):
+        w = random_workload(rng)
+        d = tmp_path / f"c{case}"
+        d.mkdir()
+        p, refm, obs, sig, (m_k, m_z, m_dvp, m_dvs), nlay, layers, r = reference_likelihoods(w, seed + case, d)
+        cfg = dict(nfft=p.nfft, deconv_mode=p.deconv_mode, delta=p.delta, t_start=p.t_start, sdep=p.sdep, rayps=p.rayps,
+                   a_gus=p.a_gus, ipha=p.ipha)
+        n = w["walkers"]
+        ids = np.arange(n, dtype=np.int32)
+        with RFEngine(nfft=p.nfft, delta=p.delta, t_start=p.t_start, deconv_mode=p.deconv_mode, sdep=p.sdep, rayps=p.rayps,
+                      a_gus=p.a_gus, ipha=p.ipha, obs=obs, nsmp=p.nsmp, r_inv=r["r_inv"], max_walkers=n, nlay_max=p.k_max + 2) as eng:
+            eng.set_model(p, refm)
+            ll = eng.eval_models(ids, m_k, m_z[:, :max(p.k_max - 1, 1)], m_dvp, m_dvs, sig)
+        _, kap = oracle.eval_batch(cfg, obs, r["r_inv"], nlay, layers, sig, p.nsmp, want_kappa=True)
+        slack = np.where(kap >= 1000.0, kap / 1000.0, 1.0)
+        assert (np.abs(ll - r["logl"]) <= logl_tol(r["logl"]) * slack).all(), (seed, case, w, np.abs(ll - r["logl"]) / logl_tol(r["logl"]))
