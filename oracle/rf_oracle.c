@@ -31,23 +31,22 @@
  *     to this file; oracle/rf_oracle.py builds it with LAPACK dgesvd through
  *     scipy exactly as src/likelihood.f90:168-222 does.
  *
- * PARITY PINNING.  The reference's likelihood module cannot be compiled in
- * this image (LAPACK is absent and writing a stand-in is not allowed), nor
- * its fftw module (FFTW3 header + library are absent).  Pins:
- *   (0) [round 5] the reference's OWN src/forward.f90, compiled unmodified
- *       into oracle/_ref/ref_forward_dump on the PRODUCT's drop-in `module
- *       fftw` (rf_inv_amd/fortran/fftw.f90 -- the reference's main programs
- *       need that module anyway; its c2r is rf_fft_c2r on the GPU, the
- *       transform's definition): tests/test_reference_forward.py (needs a
- *       GPU) compares every trace of 10 configurations (P / S, deconvolution,
- *       sea floor, common rays, nfft 256 .. 4096, t_start < 0) x 7 stacks of
- *       2 .. 31 layers, and of bench.py's own C4 / C5 / c2d / c4common
- *       walkers, with this file: agreement 7e-16 of the trace scale.  Everything
- *       in those traces except the inverse transform is the reference's code.
- *       The same for the likelihood: oracle/_ref/ref_path_dump adds the
- *       reference's own src/likelihood.f90 (unmodified; dgesvd from the Intel
- *       MKL the image ships) -- calc_likelihood end to end on bench.py's
- *       walkers: this file's logL within 0.016 of max(1e-9, 1e-12 |logL|).
+ * PARITY PINNING.
+ *   (0) [round 6] THE WHOLE REFERENCE, BUILT ON THE CPU.  The image holds FFTW3's Fortran interface and LAPACK (Intel MKL
+ *       under /opt/conda/lib: dfftw_plan_dft_c2r_1d_, dfftw_plan_dft_r2c_1d_, dfftw_execute_, dgesvd_), so all twelve of
+ *       the reference's sources -- src/fftw.f90, forward.f90, likelihood.f90 included -- compile unmodified and run without
+ *       a GPU and without any product code (oracle/Makefile.cpuref -> oracle/_ref/cpu_o0, cpu_o2).  oracle/gen_golden.py
+ *       freezes their outputs as committed fixtures (tests/golden/ref/): calc_rf on the matrix of SURVEY.md section 8c
+ *       (P / S, deconvolution, sea floor, common rays, nfft 256 .. 8192 and odd lengths, 2 .. 31 layers, the DC bin, a NaN
+ *       trace), calc_likelihood with fwd_flag true and false on bench.py's own walkers of nine workloads, format_model on
+ *       2100 proposals, the npre shifts, R^-1 as init_r_inv forms it, the main program's result files.
+ *       tests/test_reference_fixtures.py checks THIS FILE against them in the CPU suite (traces <= 8e-15 of their scale,
+ *       logL <= 0.026 of max(1e-9, 1e-12 |logL|), layer stacks / shifts bit for bit); tests/test_reference_live.py runs
+ *       fresh random contexts through the same build at test time.  The one thing that build does not take from the
+ *       image is FFTW3's header file (src/fftw.f90:31 includes it): oracle/fftw3_include/fftw3.f supplies the single
+ *       constant read from it, a stand-in for a header -- which is why these fixtures are supplementary evidence and the
+ *       FORMAL pin stays (1) below.  (Round 5 had run the reference's forward / likelihood modules on the product's GPU
+ *       transform instead; that build is now the drop-in module's own test, tests/test_reference_forward.py.)
  * and, on the CPU, the reference's own fixtures (tests/test_oracle_kat.py):
  *   (1) sample_syn/true/true.velmod + sample_syn/params.in geometry (land)
  *       -> sample_syn/data/sample_{1,2}.trc, to float32 quantisation
@@ -69,9 +68,9 @@
  *       surveyor's probe build (FFT/LAPACK link shims), not from a fixture the
  *       reference ships.
  * Branches with no reference-SHIPPED known answers: S-phase traces, water-level
- * deconvolution, the sea floor beyond (3).  On a GPU box pin (0) covers them with
- * the reference's own code; on the CPU (no GPU transform for the drop-in) they
- * are pinned by an INDEPENDENT formulation (tests/analytic_layered.py,
+ * deconvolution, the sea floor beyond (3).  Pin (0) covers them with the
+ * reference's own code, on the CPU; independently of the reference's code they
+ * are also checked against another FORMULATION (tests/analytic_layered.py,
  * tests/test_analytic_pins.py):
  * the receiver function of a layer stack by the reflectivity method --
  * scattering matrices from numerically solved boundary conditions, Kennett's
@@ -85,8 +84,8 @@
  * case (layer_matrix_liq and the sea-floor rows, forward.f90:276-287,
  * 424-442) -- which therefore no longer rests on (3) alone.  Also kept: an
  * independent numpy restatement (calc_seis_numpy) and the half-space
- * apparent-angle relations (tests/test_oracle_kat.py).  On the CPU the
- * likelihood's quadratic form + logL rest on (3); on a GPU box on (0).
+ * apparent-angle relations (tests/test_oracle_kat.py).  The likelihood's
+ * quadratic form + logL rest on (0) and (3).
  */
 #include <math.h>
 #include <stdlib.h>
