@@ -514,7 +514,7 @@ def cpu_baseline(p, obs, r_inv, nlay, layers, sig, budget_s=15.0):
 
 def reference_path_rate(p, obs, budget_s=8.0, count=24, procs=1, build="cpu_o2"):
     """The reference's OWN forward + likelihood code timed on this box's HOST CORES ONLY: oracle/_ref/<build>/ref_path_dump
-    = all of the reference's sources compiled unmodified (oracle/Makefile.cpuref: amdflang, `cpu_o2` = -O2 -ffp-contract=off,
+    = all of the reference's sources compiled unmodified (oracle/Makefile.ref: amdflang, `cpu_o2` = -O2 -ffp-contract=off,
     `cpu_o0` = the reference Makefile's default -O0 class), its own src/fftw.f90 on the FFTW3 interface of the image's Intel
     MKL, dgesvd from the same MKL -- no product object linked, no GPU touched -- looping calc_likelihood(fwd_flag = .true.)
     (src/likelihood.f90:56-101: format_model, calc_rf, misfit, quadratic form, logL) over the first `count` of this

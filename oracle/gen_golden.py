@@ -1,6 +1,6 @@
 """Generate tests/golden/ref/*.npz: inputs and outputs of the reference's OWN code, run on the CPU (test infrastructure).
 
-    make -C oracle -f Makefile.cpuref        # the whole reference, unmodified, + MKL's FFTW3 interface / LAPACK; no GPU
+    make -C oracle -f Makefile.ref        # the whole reference, unmodified, + MKL's FFTW3 interface / LAPACK; no GPU
     python oracle/gen_golden.py              # needs /root/reference (the build) -- runs HERE only; the fixtures travel
 
 Every number in a fixture's outputs comes out of oracle/_ref/cpu_o0/ref_forward_dump or ref_path_dump (the reference
@@ -270,7 +270,7 @@ def main():
     from oracle import refrun
 
     if not (refrun.available("cpu_o0") and refrun.available("cpu_o2")):
-        raise SystemExit("oracle/gen_golden.py: build oracle/_ref/cpu_o0 and cpu_o2 first (make -C oracle -f Makefile.cpuref)")
+        raise SystemExit("oracle/gen_golden.py: build oracle/_ref/cpu_o0 and cpu_o2 first (make -C oracle -f Makefile.ref)")
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for name, case in FORWARD_CASES.items():
@@ -295,7 +295,7 @@ def main():
     man = {f: {"sha256": hashlib.sha256(open(os.path.join(OUT, f), "rb").read()).hexdigest(),
                "bytes": os.path.getsize(os.path.join(OUT, f))} for f in files}
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as fh:
-        json.dump({"generator": "oracle/gen_golden.py", "build": "oracle/Makefile.cpuref (cpu_o0; *_o2 fields: cpu_o2)",
+        json.dump({"generator": "oracle/gen_golden.py", "build": "oracle/Makefile.ref (cpu_o0; *_o2 fields: cpu_o2)",
                    "files": man}, fh, indent=1, sort_keys=True)
     print(f"{len(files)} fixtures, {sum(v['bytes'] for v in man.values()) / 1e6:.1f} MB")
 

@@ -1,6 +1,6 @@
 """Run the reference's OWN code on the CPU (test infrastructure; never imported by rf_inv_amd/).
 
-The builds of oracle/Makefile.cpuref -- all twelve /root/reference/src/*.f90 compiled unmodified, FFTW3's Fortran
+The builds of oracle/Makefile.ref -- all twelve /root/reference/src/*.f90 compiled unmodified, FFTW3's Fortran
 interface and LAPACK from the image's Intel MKL, no product object on any link line, no GPU -- driven through the two
 dumpers tests/fortran/ref_forward_dump.f90 (calc_rf, src/forward.f90:123-208) and ref_path_dump.f90 (calc_likelihood,
 src/likelihood.f90:56-101).  This module writes their run directories (params.in in the reference's positional format,
@@ -23,7 +23,7 @@ REF_NLAY_MAX = 200          # src/params.f90:44
 
 
 def exe(build, name):
-    """Path of a program of oracle/Makefile.cpuref's build `build` ("cpu_o0" = the reference Makefile's default -O0
+    """Path of a program of oracle/Makefile.ref's build `build` ("cpu_o0" = the reference Makefile's default -O0
     class, "cpu_o2" = optimised, no value-changing flags)."""
     assert build in BUILDS
     return os.path.join(ROOT, "oracle", "_ref", build, name)

@@ -35,7 +35,7 @@
  *   (0) [round 6] THE WHOLE REFERENCE, BUILT ON THE CPU.  The image holds FFTW3's Fortran interface and LAPACK (Intel MKL
  *       under /opt/conda/lib: dfftw_plan_dft_c2r_1d_, dfftw_plan_dft_r2c_1d_, dfftw_execute_, dgesvd_), so all twelve of
  *       the reference's sources -- src/fftw.f90, forward.f90, likelihood.f90 included -- compile unmodified and run without
- *       a GPU and without any product code (oracle/Makefile.cpuref -> oracle/_ref/cpu_o0, cpu_o2).  oracle/gen_golden.py
+ *       a GPU and without any product code (oracle/Makefile.ref -> oracle/_ref/cpu_o0, cpu_o2).  oracle/gen_golden.py
  *       freezes their outputs as committed fixtures (tests/golden/ref/): calc_rf on the matrix of SURVEY.md section 8c
  *       (P / S, deconvolution, sea floor, common rays, nfft 256 .. 8192 and odd lengths, 2 .. 31 layers, the DC bin, a NaN
  *       trace), calc_likelihood with fwd_flag true and false on bench.py's own walkers of nine workloads, format_model on

@@ -13,8 +13,8 @@
 !   optional 5th argument extras.bin (stream), per stack: real64 tp(ntrc), int32 npre(ntrc) -- tp from the reference's
 !   own public direct_arrival under calc_rf's branch rule (src/forward.f90:148-163; 0 with deconvolution; common rays
 !   reuse trace 1's), npre by the expressions of :177 / :186 (calc_rf keeps both local: they are re-evaluated here)
-! Built twice: (1) oracle/Makefile.cpuref -- with the reference's OWN src/fftw.f90 on MKL's FFTW3 interface, CPU only, no
-! product object linked: the generator of tests/golden/ref/ (oracle/gen_golden.py); (2) oracle/Makefile.ref -- on the
+! Built twice: (1) oracle/Makefile.ref -- with the reference's OWN src/fftw.f90 on MKL's FFTW3 interface, CPU only, no
+! product object linked: the generator of tests/golden/ref/ (oracle/gen_golden.py); (2) oracle/Makefile.dropin -- on the
 ! drop-in module fftw as described above (the drop-in's own test, needs a GPU).
 ! Test infrastructure (tests/test_reference_fixtures.py, tests/test_reference_forward.py).
 !=======================================================================

@@ -22,9 +22,9 @@
 ! (src/likelihood.f90:183-222: R(j, i) = r ** ((i - j) ** 2), dgesvd, reciprocals of the singular values above 1.0d-3,
 ! transpose(vt) . diag . transpose(u)) with the same LAPACK and the same intrinsic matmul; the probes check that it is
 ! the module's (their log-likelihoods are reproduced from it to rounding, tests/test_reference_forward.py).
-! Built twice: (1) oracle/Makefile.cpuref -- with the reference's OWN src/fftw.f90 on MKL's FFTW3 interface, CPU only, no
+! Built twice: (1) oracle/Makefile.ref -- with the reference's OWN src/fftw.f90 on MKL's FFTW3 interface, CPU only, no
 ! product object linked: the generator of tests/golden/ref/ (oracle/gen_golden.py) and bench.py's cpu_baseline;
-! (2) oracle/Makefile.ref -- on the drop-in module fftw as described above (the drop-in's own test, needs a GPU).
+! (2) oracle/Makefile.dropin -- on the drop-in module fftw as described above (the drop-in's own test, needs a GPU).
 ! Test infrastructure.
 !=======================================================================
 program ref_path_dump

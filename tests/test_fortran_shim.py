@@ -353,7 +353,7 @@ def test_the_reference_make_syn_runs_unmodified_on_the_dropin_modules(golden_dir
     assert np.array_equal(np.loadtxt(work / "test_vel"), np.loadtxt(tmp_path / "python" / "test_vel"))
 
 
-# the WHOLE reference on the CPU (oracle/Makefile.cpuref: all twelve sources unmodified, its own module fftw on MKL's FFTW3
+# the WHOLE reference on the CPU (oracle/Makefile.ref: all twelve sources unmodified, its own module fftw on MKL's FFTW3
 # interface, dgesvd from MKL; no product code, no GPU) -- round 5 ran the reference's modules on the drop-in module fftw here
 REF_OWN = os.path.join(ROOT, "oracle", "_ref", "cpu_o2", "rf_inv")
 DROPIN_LAPACK = os.path.join(ROOT, "oracle", "_ref", "rf_inv_lapack")

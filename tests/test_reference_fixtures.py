@@ -2,7 +2,7 @@
 
 Every output in them was computed by the reference's OWN twelve source files, compiled unmodified and run on the CPU --
 FFTW3's Fortran interface and LAPACK from the image's Intel MKL, no product object on any link line, no GPU
-(oracle/Makefile.cpuref; the one stand-in is the two-line include file oracle/fftw3_include/fftw3.f, so the formal pin
+(oracle/Makefile.ref; the one stand-in is the two-line include file oracle/fftw3_include/fftw3.f, so the formal pin
 of the oracle stays tests/test_oracle_kat.py's reference-held vectors and these are supplementary: DESIGN.md section 5).
 
   -m "not gpu":  the CPU oracle (oracle/rf_oracle.c) against the fixtures -- the oracle checked against the reference
@@ -87,9 +87,9 @@ def test_fixture_set_is_complete_and_unaltered():
 
 
 def test_the_cpu_reference_recipe_links_no_product_code():
-    """oracle/Makefile.cpuref: every source compiled comes from $(REF) (or is one of the two dumpers), and no compile or
+    """oracle/Makefile.ref: every source compiled comes from $(REF) (or is one of the two dumpers), and no compile or
     link line names the product (librfgpu, rf_inv_amd/, the drop-in Fortran modules)."""
-    lines = [l for l in open(os.path.join(ROOT, "oracle", "Makefile.cpuref")).read().splitlines() if not l.lstrip().startswith("#")]
+    lines = [l for l in open(os.path.join(ROOT, "oracle", "Makefile.ref")).read().splitlines() if not l.lstrip().startswith("#")]
     body = "\n".join(lines)
     assert "rfgpu" not in body and "rf_inv_amd" not in body and "-lrf" not in body
     assert "$(REF)/$$m.f90" in body and "$(REF)/$$p.f90" in body and "-lmkl_gf_lp64" in body

@@ -1,6 +1,6 @@
 """The drop-in `module fftw` under its real consumer: the reference's OWN forward / likelihood modules on OUR transform.
 
-oracle/_ref/ref_forward_dump, ref_path_dump (recipe: oracle/Makefile.ref) = /root/reference/src/forward.f90 and
+oracle/_ref/ref_forward_dump, ref_path_dump (recipe: oracle/Makefile.dropin) = /root/reference/src/forward.f90 and
 likelihood.f90 compiled unmodified (-O0 -ffp-contract=off) + the reference's host modules + OUR module fftw
 (rf_inv_amd/fortran/fftw.f90), whose `dfftw_execute(ifft)` -- called by calc_rf itself, src/forward.f90:172,200 -- runs
 the c2r on the GPU as the transform's definition (rf_fft_c2r); dgesvd from the image's MKL.  This is the TEST OF THE

@@ -1,6 +1,6 @@
 """Randomised contexts against the reference ITSELF, run live on the host CPU.
 
-oracle/_ref/cpu_o0/ref_forward_dump = the whole reference built on the CPU (oracle/Makefile.cpuref: all of its sources
+oracle/_ref/cpu_o0/ref_forward_dump = the whole reference built on the CPU (oracle/Makefile.ref: all of its sources
 unmodified, MKL's FFTW3 interface; no product code linked, no GPU).  The committed fixtures (tests/golden/ref/) freeze its
 outputs on a fixed matrix; here fresh seeded random contexts -- nfft 256 .. 4096 and odd lengths, 1 .. 4 traces, P / S,
 ocean, water-level deconvolution, common rays, windows, stacks of 2 .. 31 layers -- go through it at test time:

@@ -7,7 +7,7 @@ vertical trace the reference divides by, src/forward.f90:197-202).
 
 For exactly those items this evaluates the trace with
   (a) the reference's own code, built -O0 and built -O2 (oracle/_ref/cpu_o0, cpu_o2: all of the reference's sources
-      unmodified, MKL's FFTW3 interface; oracle/Makefile.cpuref) -- two builds of the SAME program,
+      unmodified, MKL's FFTW3 interface; oracle/Makefile.ref) -- two builds of the SAME program,
   (b) the CPU oracle with its two inverse transforms (the O(n^2) definition in long double and its FFT),
 forms logL from each trace set with one and the same quadratic form (the oracle's log_likelihood on the item's observed
 traces, R^-1 and sigma: the spread is in the traces, the quadratic form is well conditioned) and reports, per item, in
@@ -62,7 +62,7 @@ def oracle_rft_two_transforms(cfg, stack):
 def main():
     seeds = [int(a) for a in sys.argv[1:]] or [101, 102, 103]
     oracle.build()
-    assert refrun.available("cpu_o0") and refrun.available("cpu_o2"), "make -C oracle -f Makefile.cpuref first"
+    assert refrun.available("cpu_o0") and refrun.available("cpu_o2"), "make -C oracle -f Makefile.ref first"
     items = []
     for seed in seeds:
         z = np.load(os.path.join(ROOT, "gpurun_out", f"fuzz_allowance_items_seed{seed}.npz"))

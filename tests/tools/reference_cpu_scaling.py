@@ -1,5 +1,5 @@
 """The reference's own calc_likelihood on the host cores: evaluations/s per process with 1, 4 and <cores> processes at once,
-for the -O2 and the -O0 build of oracle/Makefile.cpuref (the WHOLE reference, unmodified, MKL's FFTW3 interface + LAPACK; no
+for the -O2 and the -O0 build of oracle/Makefile.ref (the WHOLE reference, unmodified, MKL's FFTW3 interface + LAPACK; no
 GPU anywhere).  bench.py's cpu_baseline is the <cores> row of the -O2 table; this tool shows that the per-core rate at
 <cores> is the per-core rate at 1 (round 5's baseline ran its transforms on the GPU and was shaped by GPU queueing).
 usage: python tests/tools/reference_cpu_scaling.py [workload, default c4] [seconds per point, default 4]"""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Whole-box CPU baseline of the SAMPLER ("mpiexec -np <physical cores> of rf_inv on the same
 # params.in"): the reference itself -- all twelve sources unmodified, its own module fftw on the FFTW3 interface of the
-# image's Intel MKL, dgesvd from MKL; oracle/_ref/cpu_o2/rf_inv (oracle/Makefile.cpuref), NO GPU involved -- one MPI rank
+# image's Intel MKL, dgesvd from MKL; oracle/_ref/cpu_o2/rf_inv (oracle/Makefile.ref), NO GPU involved -- one MPI rank
 # per core, on a run directory with the shape of a BASELINE config (tests/tools/shape_run.py).  The rate is that of the
 # sampler's LOOP: the program is run with N1 and with N2 iterations and the difference of the two wall times is divided by
 # the difference of the iteration counts (start-up -- reading, init_model's rejection loop, the SVD of init_r_inv -- and
@@ -12,7 +12,7 @@ SHAPE=${1:-c4}; NCH=${2:-8}; NP=${3:-16}; N1=${4:-100}; N2=${5:-400}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 MPIEXEC=${MPIEXEC:-/opt/conda/bin/mpiexec}
 EXE=$R/oracle/_ref/cpu_o2/rf_inv
-[ -x $EXE ] || { echo "$EXE not built (make -C oracle -f Makefile.cpuref)"; exit 1; }
+[ -x $EXE ] || { echo "$EXE not built (make -C oracle -f Makefile.ref)"; exit 1; }
 W=$(mktemp -d)
 python3 $R/tests/tools/shape_run.py $SHAPE $NCH $W > /dev/null || { echo "shape_run failed"; exit 1; }
 run() {  # iterations -> seconds of the whole program
