@@ -569,7 +569,7 @@ def reference_path_rate(p, obs, budget_s=8.0, count=24, procs=1, build="cpu_o2")
                            f"slowest); all of the reference's sources unmodified, amdflang {flags}, its own module fftw on the "
                            "FFTW3 interface of Intel MKL, dgesvd from MKL; no GPU involved"},
                 first["logl"])
-    except (OSError, subprocess.SubprocessError, ValueError, IndexError, RuntimeError, AssertionError):
+    except (OSError, subprocess.SubprocessError, ValueError, IndexError, RuntimeError, AssertionError, TypeError, KeyError):
         return None, None
 
 
