@@ -77,3 +77,23 @@ def assert_logl_parity(got, ref, kappa, what=""):
     for i in np.nonzero(~(d <= tol))[0]:
         assert kappa[i] >= KAPPA_MIN, (what, int(i), "well-conditioned item off tolerance", got[i], ref[i], kappa[i])
         assert d[i] <= tol[i] * kappa[i] / KAPPA_SCALE, (what, int(i), got[i], ref[i], kappa[i])
+
+
+def mkl_fftw3_c2r(spec, nfft):
+    """The c2r plan of the reference's CPU build (oracle/Makefile.ref): FFTW3's Fortran interface as the image's Intel MKL
+    exports it -- dfftw_plan_dft_c2r_1d_ / dfftw_execute_, the calls of src/fftw.f90:44 and src/forward.f90:172 -- on
+    cx(1:nfft) = (spec, 0 ...).  None when that MKL is not there."""
+    import ctypes as C
+
+    path = "/opt/conda/lib/libmkl_rt.so"
+    if not os.path.exists(path):
+        return None
+    mkl = C.CDLL(path)
+    cx = np.zeros(nfft, dtype=np.complex128)
+    cx[:len(spec)] = spec
+    rx = np.zeros(nfft)
+    plan, n, flags = C.c_int64(0), C.c_int(nfft), C.c_int(64)          # FFTW_ESTIMATE
+    mkl.dfftw_plan_dft_c2r_1d_(C.byref(plan), C.byref(n), cx.ctypes.data_as(C.c_void_p), rx.ctypes.data_as(C.c_void_p),
+                               C.byref(flags))
+    mkl.dfftw_execute_(C.byref(plan))
+    return rx

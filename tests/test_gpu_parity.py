@@ -1265,6 +1265,12 @@ def test_fftw_plans_on_the_gpu(oracle, nfft):
     scale = np.abs(want).max()
     assert np.abs(got - want).max() <= (2e-15 if nfft <= 4099 else 2e-14) * scale * max(1.0, np.log2(nfft) / 8)
     assert np.array_equal(got, fft_c2r(clean, nfft))                               # Im of DC / Nyquist: ignored
+    # ... and the third-party transform of the reference's CPU build (MKL's FFTW3 interface, called as src/fftw.f90:44 does)
+    from helpers import mkl_fftw3_c2r
+
+    mkl = mkl_fftw3_c2r(spec, nfft)
+    if mkl is not None:
+        assert np.abs(got - mkl).max() <= 2e-14 * scale * max(1.0, np.log2(nfft) / 8)
     x = rng.normal(0, 1, nfft)
     back = fft_r2c(x)
     ref = np.fft.rfft(x)

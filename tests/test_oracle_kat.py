@@ -241,3 +241,22 @@ def test_speed_build_of_the_oracle_returns_identical_values(oracle):
         a, ra = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, 101, want_rft=True)
         b, rb = oracle.eval_batch(cfg, obs, r_inv, nlay, layers, sig, 101, want_rft=True, nthreads=2, fast=True)
         assert np.array_equal(a, b) and np.array_equal(ra, rb)
+
+
+@pytest.mark.parametrize("nfft", [8, 250, 256, 1000, 4096])
+def test_oracle_c2r_against_the_fftw3_interface_the_reference_build_uses(oracle, nfft):
+    """rfo_c2r (this oracle's transform) and rfo_c2r_naive (the O(n^2) long-double definition) against the third-party
+    transform of the reference's CPU build: MKL's FFTW3 interface, called exactly as src/fftw.f90:44 / src/forward.f90:172
+    call it.  Im of the DC and Nyquist bins must be ignored by all three."""
+    from helpers import mkl_fftw3_c2r
+
+    rng = np.random.default_rng(nfft)
+    nh = nfft // 2 + 1
+    spec = rng.normal(0, 1, nh) + 1j * rng.normal(0, 1, nh)
+    want = mkl_fftw3_c2r(spec, nfft)
+    if want is None:
+        pytest.skip("no /opt/conda/lib/libmkl_rt.so here")
+    full = np.concatenate([spec, np.zeros(nfft - nh)])
+    for naive in (False, True):
+        got = oracle.c2r(full, nfft, naive=naive)
+        assert np.abs(got - want).max() <= 4e-15 * np.abs(want).max() * max(1.0, np.log2(nfft) / 4), (nfft, naive)
