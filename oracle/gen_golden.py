@@ -263,6 +263,29 @@ def gen_runs():
         out[f"{tag}_o2_max_rel_dlikelihood"] = float(np.max(np.abs(l2[:, 1] - l0[:, 1]) / np.abs(l0[:, 1])))
         print(f"run_sample_syn {tag}: rslt/likelihood[0] = {l0[0, 1]!r}; the -O2 build writes the same eleven files: {same}, "
               f"its likelihood column within {out[f'{tag}_o2_max_rel_dlikelihood']:.1e}", flush=True)
+    # BASELINE.json configs[0]: the shipped params.in with ONE P trace, 4 chains per rank (1 at T = 1), -np 8 = "8 x 4"
+    from rf_inv_amd import get_params, write_params
+
+    tag = "configs0_np8"
+    res = {}
+    for build in refrun.BUILDS:
+        with tempfile.TemporaryDirectory() as tmp:
+            work = os.path.join(tmp, "run")
+            shutil.copytree(os.path.join(ROOT, "tests", "golden", "sample_syn"), work)
+            os.makedirs(os.path.join(work, "rslt"))
+            p = get_params(os.path.join(work, "params.in"))
+            p.ntrc, p.nchains, p.ncool, p.nburn, p.niter = 1, 4, 1, 60, 240
+            write_params(os.path.join(work, "params.in"), p, header="BASELINE configs[0] (oracle/gen_golden.py)")
+            text = open(os.path.join(work, "params.in")).read()
+            r = subprocess.run(["/opt/conda/bin/mpiexec", "-np", "8", refrun.exe(build, "rf_inv"), "params.in"], cwd=work,
+                               env=refrun.clean_env(), capture_output=True, text=True, timeout=3600)
+            assert r.returncode == 0, r.stdout[-800:] + r.stderr[-800:]
+            res[build] = ({f: hashlib.sha256(open(os.path.join(work, "rslt", f), "rb").read()).hexdigest() for f in RUN_FILES},
+                          np.loadtxt(os.path.join(work, "rslt", "likelihood")))
+    (h0, l0), (h2, l2) = res["cpu_o0"], res["cpu_o2"]
+    out[f"{tag}_sha256"], out[f"{tag}_likelihood"], out[f"{tag}_params_in"] = np.array([h0[f] for f in RUN_FILES]), l0, text
+    out[f"{tag}_o2_same_files"] = h0 == h2
+    print(f"run_sample_syn {tag}: rslt/likelihood[0] = {l0[0, 1]!r}; the -O2 build writes the same eleven files: {h0 == h2}", flush=True)
     np.savez(os.path.join(OUT, "run_sample_syn.npz"), files=np.array(RUN_FILES), build="cpu_o0", **out)
 
 

@@ -330,3 +330,29 @@ def test_hip_format_model_against_the_reference_fixture(tmp_path):
             assert nlay[i] == nl and np.array_equal(layers[i, :, :nl], a["layers"][i, :, :nl]), (ci, int(i))
             n_valid += 1
     assert n_valid > 900
+
+
+@pytest.mark.gpu
+def test_baseline_configs0_on_the_dropin_modules(tmp_path):
+    """BASELINE.json configs[0] -- the shipped params.in with one P trace, 8 MPI ranks x 4 chains (one of them at T = 1) --
+    through the reference's main program on the drop-in modules (eight ranks share the one GPU, each with its own context;
+    the swap is the reference's own MPI exchange): the eleven result files of the reference itself (CPU build, fixture)
+    byte for byte, rslt/likelihood to 1e-11."""
+    import shutil
+    import subprocess
+
+    exe, mpiexec = os.path.join(ROOT, "oracle", "_ref", "rf_inv"), "/opt/conda/bin/mpiexec"
+    assert os.path.exists(exe) and os.path.exists(mpiexec), "oracle/_ref/rf_inv (build()) or mpiexec is missing on a GPU box"
+    f = load("run", "sample_syn")
+    work = tmp_path / "run"
+    shutil.copytree(os.path.join(ROOT, "tests", "golden", "sample_syn"), work)
+    os.makedirs(work / "rslt")
+    (work / "params.in").write_text(str(f["configs0_np8_params_in"]))
+    r = subprocess.run([mpiexec, "-np", "8", exe, "params.in"], cwd=work, env=dict(os.environ), capture_output=True, text=True,
+                       timeout=1800)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    for name, want in zip(f["files"], f["configs0_np8_sha256"]):
+        assert hashlib.sha256(open(work / "rslt" / str(name), "rb").read()).hexdigest() == str(want), str(name)
+    lk, ref = np.loadtxt(work / "rslt" / "likelihood"), f["configs0_np8_likelihood"]
+    assert lk.shape == ref.shape == (300, 2)
+    assert (np.abs(lk[:, 1] - ref[:, 1]) / np.abs(ref[:, 1])).max() <= 1e-11
